@@ -1,0 +1,115 @@
+/*
+ * bscgpu.h — thin C ABI between libbsc-style host code and the MI355X (gfx950) HIP kernels.
+ *
+ * This is the drop-in boundary for the reference's GPU plug points.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference tree, libbsc 3.3.5):
+ *
+ *   bscgpu_create / bscgpu_destroy   <->  libcubwt_allocate_device_storage / libcubwt_free_device_storage
+ *                                         (libbsc/bwt/libcubwt/libcubwt.cuh:60-71; called from bwt.cpp:92-115)
+ *   bscgpu_bwt                       <->  libcubwt_bwt      (libcubwt.cuh:73-80,  bwt.cpp:148-162)
+ *   bscgpu_bwt_aux                   <->  libcubwt_bwt_aux  (libcubwt.cuh:82-89,  bwt.cpp:104-118)
+ *   bscgpu_st_encode                 <->  bsc_st_encode_cuda (libbsc/st/st.cuh:57, st.cpp:998-1002)
+ *
+ * Like the reference hooks these take HOST pointers, do their own H2D/D2H and are synchronous on
+ * return.  The *_device variants take DEVICE pointers (input already resident in HBM) and are what
+ * bench.py times; they have no counterpart in the reference (its coder never leaves the CPU).
+ *
+ * Plain C, plain pointers and sizes.  Return values follow libbsc.h:41-51 (>= 0 ok, < 0 error code;
+ * -7 GPU_ERROR, -8 GPU_NOT_SUPPORTED, -9 GPU_NOT_ENOUGH_MEMORY, -1 BAD_PARAMETER).
+ */
+#ifndef BSCGPU_H
+#define BSCGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define BSCGPU_API __attribute__((visibility("default")))
+#else
+#define BSCGPU_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bscgpu_ctx bscgpu_ctx;
+
+/* Number of visible HIP devices (0 when there is no usable GPU). */
+BSCGPU_API int bscgpu_device_count(void);
+
+/* Create a per-device context with an HBM arena large enough for blocks of up to max_n bytes.
+ * One context per GPU (one process per GPU in the multi-GPU driver); a context is not re-entrant:
+ * serialise calls on it (the reference serialises on one global lock, bwt.cpp:50-52). */
+BSCGPU_API int  bscgpu_create(bscgpu_ctx** ctx, int device, int64_t max_n);
+BSCGPU_API void bscgpu_destroy(bscgpu_ctx* ctx);
+
+/* Bytes of device memory held by the context's arena. */
+BSCGPU_API int64_t bscgpu_arena_bytes(const bscgpu_ctx* ctx);
+
+/* ---- forward BWT ------------------------------------------------------------------------- */
+/* L may alias T.  Returns the primary index (1..n) like libcubwt_bwt, or a negative error. */
+BSCGPU_API int64_t bscgpu_bwt(bscgpu_ctx* ctx, const uint8_t* T, uint8_t* L, int64_t n);
+/* As above plus auxiliary indexes: r is a power of two, I[0..(n-1)/r] receives 1-based ranks
+ * (I[0] = primary index), exactly libsais_bwt_aux / libcubwt_bwt_aux semantics.  Returns 0. */
+BSCGPU_API int64_t bscgpu_bwt_aux(bscgpu_ctx* ctx, const uint8_t* T, uint8_t* L, int64_t n, int64_t r, uint32_t* I);
+/* Device-resident variant: dT, dL are device pointers (may alias); I is a HOST array or NULL
+ * (r ignored when I is NULL).  Returns the primary index. */
+BSCGPU_API int64_t bscgpu_bwt_device(bscgpu_ctx* ctx, const void* dT, void* dL, int64_t n, int64_t r, uint32_t* I);
+
+/* ---- Sort Transform (order k = 3..8) ----------------------------------------------------- */
+/* In place on host T[0..n).  Returns the 0-based primary index like bsc_st_encode (st.cpp:990). */
+BSCGPU_API int bscgpu_st_encode(bscgpu_ctx* ctx, uint8_t* T, int n, int k);
+BSCGPU_API int bscgpu_st_encode_device(bscgpu_ctx* ctx, const void* dT, void* dOut, int n, int k);
+
+/* ---- Adler-32 of a device buffer (adler32.cpp:82) ---------------------------------------- */
+BSCGPU_API int bscgpu_adler32_device(bscgpu_ctx* ctx, const void* dT, int64_t n, uint32_t* out);
+
+/* ---- LSD radix sort primitive (the kernel the roofline is measured on) -------------------- */
+/* Stable sort of n (u64 key, u32 value) records on key bits [begin_bit, end_bit), 8-bit digits.
+ * All pointers are device pointers; *_alt are same-sized scratch (ping-pong).  vals may be NULL
+ * (keys-only).  On return *result_in_alt is 1 when the sorted data lives in the *_alt buffers. */
+BSCGPU_API int bscgpu_radix_sort_u64(bscgpu_ctx* ctx, void* keys, void* keys_alt, void* vals, void* vals_alt,
+                          int64_t n, int begin_bit, int end_bit, int* result_in_alt);
+
+/* ---- full block compression with the BWT/ST + coder split across GPU and host ------------- */
+/* bsc_compress semantics (libbsc.cpp:213) for input already in HBM: Adler-32 + sort transform on
+ * the GPU, QLFC coder on host threads.  output is a HOST buffer of n + 28 bytes. */
+BSCGPU_API int bscgpu_compress_device(bscgpu_ctx* ctx, const void* dInput, uint8_t* output, int n,
+                           int blockSorter, int coder, int features);
+
+/* ---- profiling --------------------------------------------------------------------------- */
+/* When enabled every kernel launch is bracketed by HIP events on the context's stream (the stream
+ * the kernels run on) and accumulated per kernel class. */
+enum {
+    BSCGPU_K_RADIX_SCATTER = 0, /* the graded kernel: one LSD digit pass (read + scatter) */
+    BSCGPU_K_RADIX_HIST    = 1, /* per-chunk digit histogram of the next pass */
+    BSCGPU_K_RADIX_SCAN    = 2,
+    BSCGPU_K_PACK          = 3, /* key packing (BWT prefix keys / ST context keys) */
+    BSCGPU_K_SEG           = 4, /* head flags, rank scans, compaction */
+    BSCGPU_K_GATHER        = 5, /* ISA[SA+h] gathers */
+    BSCGPU_K_EMIT          = 6, /* BWT / ST output byte emit */
+    BSCGPU_K_MISC          = 7,
+    BSCGPU_K_COUNT         = 8
+};
+typedef struct bscgpu_kstat {
+    double   ms;        /* accumulated HIP-event time */
+    uint64_t launches;
+    uint64_t bytes;     /* algorithmic bytes moved (per kernel) */
+    uint64_t records;   /* records processed (radix kernels) */
+} bscgpu_kstat;
+BSCGPU_API void bscgpu_profile_enable(bscgpu_ctx* ctx, int on);
+BSCGPU_API void bscgpu_profile_reset(bscgpu_ctx* ctx);
+BSCGPU_API int  bscgpu_profile_get(bscgpu_ctx* ctx, bscgpu_kstat* stats /* [BSCGPU_K_COUNT] */);
+/* Per-launch durations (ms) of the most recent radix scatter launches, newest last; returns count. */
+BSCGPU_API int  bscgpu_profile_scatter_launches(bscgpu_ctx* ctx, double* ms, uint64_t* records, int max);
+/* Stage wall times (ms) of the last bscgpu_compress_device call: [0] adler, [1] sort transform,
+ * [2] D2H, [3] host coder, [4] total; plus doubling rounds in [5]. */
+BSCGPU_API int  bscgpu_last_stage_ms(bscgpu_ctx* ctx, double* out6);
+
+BSCGPU_API const char* bscgpu_last_error(const bscgpu_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSCGPU_H */

@@ -1,0 +1,97 @@
+"""Build the native library: hand-written HIP kernels (gfx950) + the C++ host side, one shared object.
+
+    python -m libbsc_amd.build            # incremental
+    python -m libbsc_amd.build --force
+
+Output: libbsc_amd/lib/libbsc_mi355x.so (git-ignored; travels to the GPU box with gpurun).
+hipcc cross-compiles for gfx950 without a GPU present.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "lib", "obj")
+LIB = os.path.join(HERE, "lib", "libbsc_mi355x.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+ARCH = "gfx950"
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-result"]
+DEVFLAGS = [f"--offload-arch={ARCH}"]
+
+
+def _sources():
+    out = []
+    for sub in ("device", "host"):
+        d = os.path.join(CSRC, sub)
+        if not os.path.isdir(d):
+            continue
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".cpp")):
+                out.append(os.path.join(d, f))
+    return out
+
+
+def _deps_hash(src):
+    """hash of the source plus every header under csrc/ and include/ (coarse but safe)."""
+    h = hashlib.sha1()
+    files = [src]
+    for root in (CSRC, INCLUDE):
+        for dp, _, fs in os.walk(root):
+            for f in fs:
+                if f.endswith((".h", ".hpp", ".inc")):
+                    files.append(os.path.join(dp, f))
+    for f in sorted(set(files)):
+        with open(f, "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    h.update(" ".join(COMMON + DEVFLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src, force):
+    name = os.path.splitext(os.path.basename(src))[0]
+    obj = os.path.join(OBJ, name + ".o")
+    stamp = obj + ".sha1"
+    want = _deps_hash(src)
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
+        return obj, False
+    cmd = [HIPCC] + COMMON
+    if src.endswith(".hip"):
+        cmd += DEVFLAGS
+    else:
+        cmd += ["-x", "c++"]            # host-only translation units: plain C++ through hipcc's clang
+    cmd += ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("compile failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    with open(stamp, "w") as fh:
+        fh.write(want)
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in res]
+    changed = any(c for _, c in res)
+    if changed or force or not os.path.exists(LIB):
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-Wl,-Bsymbolic"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if verbose:
+            print(f"[libbsc_amd.build] linked {LIB} ({len(objs)} objects)")
+    elif verbose:
+        print(f"[libbsc_amd.build] up to date: {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,383 @@
+// bwt.hip — forward Burrows-Wheeler transform of one block on MI355X: suffix sort by prefix doubling on
+// the LSD radix engine (radix_sort.hip), then the BWT byte gather.
+//
+// Result contract (what bsc_bwt_encode returns, bwt.cpp:178-231, via libsais_bwt_aux, libsais.c:6704):
+//   SA  = suffixes of T[0..n) in lexicographic order, a proper prefix sorting first;
+//   L   = [T[n-1]] ++ [T[SA[j]-1] for j = 0..n-1 if SA[j] != 0];  primary index = ISA[0] + 1;
+//   aux = I[t] = ISA[t*r] + 1 for t = 0..(n-1)/r  (I[0] is the primary index).
+// The reference GPU path (libcubwt.cu:2031-2223: DC3 2/3 sample + 64-bit prefix sort + segmented sort
+// + merge) is NOT followed; this is a different algorithm with the same result:
+//
+//   1. bwt_pack:   key[s] = big-endian T[i..i+8) (zero padded), value = i.  The <= 7 "tail" suffixes
+//                  whose 8-byte window crosses the block end are placed FIRST in input order,
+//                  shortest first; the LSD sort is stable, so inside a group of equal padded keys
+//                  they come out first and already in final order ("proper prefix is smaller"),
+//                  and seg marks each of them as a finished singleton.
+//   2. 8 radix passes over (u64 key, u32 suffix) -> order by 8-byte prefix.
+//   3. seg (reduce / scan / apply): group heads, rank = position of the group head (so ranks are valid
+//      SA slots and only ever grow under refinement), ISA scatter, and stream compaction of every
+//      suffix still sharing its rank ("unsorted").
+//   4. doubling round h = 8, 16, ...: key = (rank << 32) | (ISA[sa+h]+1, or 0 when sa+h == n),
+//      radix-sort the compacted set on the used bits only, seg again (new heads where the 64-bit
+//      key changes), write SA/ISA back through the saved slot list, compact again.  One 4-byte
+//      D2H + stream sync per round for the loop test (libcubwt does the same, libcubwt.cu:1383).
+//   5. bwt_emit:   L from SA/T, aux indexes from ISA.
+#include "dev_common.h"
+
+constexpr int SEG_ITEMS = 8;
+constexpr int SEG_TILE  = WG * SEG_ITEMS;      // 2048 records per tile, 8 consecutive per thread
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void bwt_pack_kernel(const u8* __restrict__ T, u32 n, u32 tc,
+                                                      u64* __restrict__ keys, u32* __restrict__ vals)
+{
+    const u32 i0 = 4u * (blockIdx.x * WG + threadIdx.x);
+    if (i0 >= n) return;
+    const u32* T32 = reinterpret_cast<const u32*>(T + i0);      // T is 16-B aligned, zero padded past n
+    const u32 a = __builtin_bswap32(T32[0]);
+    const u32 b = __builtin_bswap32(T32[1]);
+    const u32 c = __builtin_bswap32(T32[2]);
+    const u64 hi = ((u64)a << 32) | b;                            // bytes i0 .. i0+7, big endian
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+        const u32 i = i0 + j;
+        if (i < n) {
+            const u64 key = (j == 0) ? hi : ((hi << (8 * j)) | (u64)(c >> (32 - 8 * j)));
+            const bool tail = (u64)i + 8 > (u64)n;
+            const u32 slot = tail ? (n - 1 - i) : (i + tc);
+            keys[slot] = key;
+            vals[slot] = i;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// seg phase A: head / unsorted flags + per-chunk summaries.
+//   head(x)  = x == 0 || key[x] != key[x-1] || (INITIAL && (tail(sa[x]) || tail(sa[x-1])))
+//   uns(x)   = !(head(x) && head(x+1)), head(m) = 1
+//   flags[x] = head | uns << 1
+// ---------------------------------------------------------------------------------------------
+template <bool INITIAL>
+__global__ __launch_bounds__(WG) void seg_reduce_kernel(const u64* __restrict__ keys, const u32* __restrict__ sa,
+                                                        u32 m, u32 n, u32 chunk_tiles, u32 num_tiles,
+                                                        u8* __restrict__ flags, u32* __restrict__ segsum /*[2][MAX_CHUNKS]*/)
+{
+    __shared__ u32 scr[8];
+    const u32 t = threadIdx.x;
+    const u32 tile0 = blockIdx.x * chunk_tiles;
+    u32 tile1 = tile0 + chunk_tiles; if (tile1 > num_tiles) tile1 = num_tiles;
+    const u32 tail_lo = (n >= 8) ? (n - 7) : 0;      // suffix i is a tail iff i >= tail_lo
+
+    u32 cnt = 0, last1 = 0;
+    for (u32 tile = tile0; tile < tile1; ++tile) {
+        const u32 j = tile * SEG_TILE + t * SEG_ITEMS;
+        if (j >= m) continue;
+        u64 k[SEG_ITEMS + 2];          // keys j-1 .. j+8
+        u32 s[SEG_ITEMS + 2];
+        const bool full = (j + SEG_ITEMS <= m);
+        if (full) {
+#pragma unroll
+            for (int q = 0; q < SEG_ITEMS; q += 2) {
+                const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(keys + j + q);
+                k[1 + q] = kk.x; k[2 + q] = kk.y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < SEG_ITEMS; ++q) k[1 + q] = (j + q < m) ? keys[j + q] : 0;
+        }
+        k[0] = (j > 0) ? keys[j - 1] : 0;
+        k[SEG_ITEMS + 1] = (j + SEG_ITEMS < m) ? keys[j + SEG_ITEMS] : 0;
+        if (INITIAL) {
+#pragma unroll
+            for (int q = 0; q < SEG_ITEMS + 2; ++q) {
+                const long long x = (long long)j - 1 + q;
+                s[q] = (x >= 0 && x < (long long)m) ? sa[x] : 0;
+            }
+        }
+        u32 h[SEG_ITEMS + 1];
+#pragma unroll
+        for (int q = 0; q <= SEG_ITEMS; ++q) {
+            const u32 x = j + q;
+            bool hd;
+            if (x == 0 || x >= m) hd = true;
+            else {
+                hd = (k[q + 1] != k[q]);
+                if (INITIAL) hd = hd || (s[q + 1] >= tail_lo) || (s[q] >= tail_lo);
+            }
+            h[q] = hd ? 1u : 0u;
+        }
+        u64 packed = 0;
+#pragma unroll
+        for (int q = 0; q < SEG_ITEMS; ++q) {
+            const u32 x = j + q;
+            if (x < m) {
+                const u32 uns = (h[q] & h[q + 1]) ^ 1u;
+                packed |= (u64)(h[q] | (uns << 1)) << (8 * q);
+                cnt += uns;
+                if (h[q]) last1 = x + 1;
+            }
+        }
+        if (full) *reinterpret_cast<u64*>(flags + j) = packed;
+        else {
+#pragma unroll
+            for (int q = 0; q < SEG_ITEMS; ++q) if (j + q < m) flags[j + q] = (u8)(packed >> (8 * q));
+        }
+    }
+    u32 tot, mx;
+    block_excl_sum(cnt, scr, &tot);
+    block_incl_max(last1, scr, &mx);
+    if (t == 0) { segsum[blockIdx.x] = tot; segsum[MAX_CHUNKS + blockIdx.x] = mx; }
+}
+
+// seg phase B: one workgroup scans the <= 1024 chunk summaries.
+//   segoff[c]            = exclusive sum of unsorted counts
+//   segoff[MAX_CHUNKS+c] = max(last head + 1) over chunks < c
+//   dscal[0]             = total unsorted
+__global__ __launch_bounds__(WG) void seg_scan_kernel(const u32* __restrict__ segsum, u32 num_chunks,
+                                                      u32* __restrict__ segoff, u32* __restrict__ dscal)
+{
+    __shared__ u32 scr[8];
+    __shared__ u32 smax[WG];
+    u32 carry = 0, carrymax = 0;
+    for (u32 base = 0; base < num_chunks; base += WG) {
+        const u32 i = base + threadIdx.x;
+        const u32 v  = (i < num_chunks) ? segsum[i] : 0u;
+        const u32 mx = (i < num_chunks) ? segsum[MAX_CHUNKS + i] : 0u;
+        u32 tot, totmax;
+        const u32 ex = block_excl_sum(v, scr, &tot);
+        const u32 im = block_incl_max(mx, scr, &totmax);
+        __syncthreads();
+        smax[threadIdx.x] = im;
+        __syncthreads();
+        const u32 exmax = (threadIdx.x > 0) ? smax[threadIdx.x - 1] : 0u;
+        if (i < num_chunks) {
+            segoff[i] = carry + ex;
+            segoff[MAX_CHUNKS + i] = (carrymax > exmax) ? carrymax : exmax;
+        }
+        carry += tot;
+        carrymax = (carrymax > totmax) ? carrymax : totmax;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dscal[0] = carry;
+}
+
+// seg phase C: ranks (position of the group head), SA / ISA write-back, compaction of unsorted records.
+template <bool INITIAL>
+__global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ flags, const u32* __restrict__ sa_sorted,
+                                                       const u32* __restrict__ cpos_in, u32 m,
+                                                       u32 chunk_tiles, u32 num_tiles, const u32* __restrict__ segoff,
+                                                       u32* __restrict__ SA, u32* __restrict__ ISA,
+                                                       u32* __restrict__ cpos_out, u32* __restrict__ csa_out,
+                                                       u32* __restrict__ cgrp_out)
+{
+    __shared__ u32 scr[8];
+    __shared__ u32 sprev[WG];
+    const u32 t = threadIdx.x;
+    const u32 tile0 = blockIdx.x * chunk_tiles;
+    u32 tile1 = tile0 + chunk_tiles; if (tile1 > num_tiles) tile1 = num_tiles;
+    u32 off   = segoff[blockIdx.x];                 // next compacted slot
+    u32 carry = segoff[MAX_CHUNKS + blockIdx.x];    // (head position + 1) carried in from the left
+
+    for (u32 tile = tile0; tile < tile1; ++tile) {
+        const u32 j = tile * SEG_TILE + t * SEG_ITEMS;
+        u32 f[SEG_ITEMS], pos[SEG_ITEMS], s[SEG_ITEMS];
+        u32 lmax = 0, lcnt = 0;
+#pragma unroll
+        for (int q = 0; q < SEG_ITEMS; ++q) {
+            const u32 x = j + q;
+            if (x < m) {
+                f[q]   = flags[x];
+                pos[q] = INITIAL ? x : cpos_in[x];
+                s[q]   = sa_sorted[x];
+                if (f[q] & 1u) lmax = pos[q] + 1;
+                lcnt += (f[q] >> 1) & 1u;
+            } else { f[q] = 0; pos[q] = 0; s[q] = 0; }
+        }
+        u32 totmax, totcnt;
+        const u32 imax = block_incl_max(lmax, scr, &totmax);
+        __syncthreads();
+        sprev[t] = imax;
+        __syncthreads();
+        u32 run = (t > 0) ? sprev[t - 1] : 0u;       // exclusive max over lower threads
+        if (carry > run) run = carry;
+        u32 kslot = off + block_excl_sum(lcnt, scr, &totcnt);
+#pragma unroll
+        for (int q = 0; q < SEG_ITEMS; ++q) {
+            const u32 x = j + q;
+            if (x < m) {
+                if (f[q] & 1u) run = pos[q] + 1;
+                const u32 rank = run - 1;
+                SA[pos[q]] = s[q];
+                ISA[s[q]]  = rank;
+                if (f[q] & 2u) {
+                    cpos_out[kslot] = pos[q];
+                    csa_out[kslot]  = s[q];
+                    cgrp_out[kslot] = rank;
+                    ++kslot;
+                }
+            }
+        }
+        carry = (carry > totmax) ? carry : totmax;
+        off += totcnt;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// doubling round key build: key = rank << 32 | (ISA[sa + h] + 1, 0 when sa + h == n)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void bwt_gather_kernel(const u32* __restrict__ csa, const u32* __restrict__ cgrp,
+                                                        const u32* __restrict__ ISA, u32 U, u64 h, u64 n,
+                                                        u64* __restrict__ keys, u32* __restrict__ vals)
+{
+    const u32 stride = gridDim.x * WG;
+    for (u32 k = blockIdx.x * WG + threadIdx.x; k < U; k += stride) {
+        const u32 s = csa[k];
+        const u64 p = (u64)s + h;
+        const u32 nxt = (p < n) ? (ISA[p] + 1u) : 0u;
+        keys[k] = ((u64)cgrp[k] << 32) | nxt;
+        vals[k] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// L[0] = T[n-1]; L[o] = T[SA[j]-1] with j = o-1 for o <= ISA[0], j = o for o > ISA[0].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void bwt_emit_kernel(const u8* __restrict__ T, const u32* __restrict__ SA,
+                                                      const u32* __restrict__ ISA, u32 n, u8* __restrict__ L,
+                                                      u32* __restrict__ dscal)
+{
+    const u32 o0 = 4u * (blockIdx.x * WG + threadIdx.x);
+    if (o0 >= n) return;
+    const u32 p = ISA[0];
+    if (o0 == 0) dscal[1] = p + 1;
+    u32 word = 0;
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+        const u32 o = o0 + q;
+        u32 byte = 0;
+        if (o < n) {
+            if (o == 0) byte = T[n - 1];
+            else {
+                const u32 j = (o <= p) ? (o - 1) : o;
+                byte = T[SA[j] - 1];
+            }
+        }
+        word |= byte << (8 * q);
+    }
+    if (o0 + 4 <= n) *reinterpret_cast<u32*>(L + o0) = word;
+    else for (u32 q = 0; o0 + q < n; ++q) L[o0 + q] = (u8)(word >> (8 * q));
+}
+
+__global__ void bwt_aux_kernel(const u32* __restrict__ ISA, u32 n, u32 r, u32 cnt, u32* __restrict__ I)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < cnt) I[t] = ISA[(u64)t * r] + 1u;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int bit_length(u64 x) { int b = 0; while (x) { ++b; x >>= 1; } return b; }
+
+template <bool INITIAL>
+static int run_seg(bscgpu_ctx* c, const u64* keys, const u32* sa_sorted, const u32* cpos_in, u32 m, u32 n,
+                   u32* cpos_out, u32* csa_out, u32* cgrp_out, u32* U_out)
+{
+    const Chunking ch = make_chunking(m, SEG_TILE);
+    prof_begin(c, BSCGPU_K_SEG, (u64)m * (8 + (INITIAL ? 4 : 0) + 1), m);
+    hipLaunchKernelGGL(seg_reduce_kernel<INITIAL>, dim3(ch.num_chunks), dim3(WG), 0, c->stream,
+                       keys, sa_sorted, m, n, ch.chunk_tiles, ch.num_tiles, c->flags, c->segsum);
+    prof_end(c);
+    prof_begin(c, BSCGPU_K_SEG, 0, 0);
+    hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(WG), 0, c->stream, c->segsum, ch.num_chunks, c->segoff, c->dscal);
+    prof_end(c);
+    prof_begin(c, BSCGPU_K_SEG, (u64)m * (1 + 4 + (INITIAL ? 0 : 4) + 4 + 4), m);
+    hipLaunchKernelGGL(seg_apply_kernel<INITIAL>, dim3(ch.num_chunks), dim3(WG), 0, c->stream,
+                       c->flags, sa_sorted, cpos_in, m, ch.chunk_tiles, ch.num_tiles, c->segoff,
+                       c->SA, c->ISA, cpos_out, csa_out, cgrp_out);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->hscal, c->dscal, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    *U_out = c->hscal[0];
+    return BSC_NO_ERROR;
+}
+
+int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64_t r, u32* I_host, int64_t* primary_out)
+{
+    if (n64 < 0 || n64 > c->max_n || n64 >= 0x7fffffffll) return BSC_BAD_PARAMETER;
+    if (n64 == 0) { *primary_out = 0; return BSC_NO_ERROR; }
+    const u32 n = (u32)n64;
+    int rc;
+
+    // private, padded copy of the text (emit may overwrite the user's buffer when dL aliases dT)
+    HIP_TRY(c, hipMemcpyAsync(c->dT, dT_user, n, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dT + n, 0, 32, c->stream));
+
+    const u32 tc = n < 7 ? n : 7;
+    prof_begin(c, BSCGPU_K_PACK, (u64)n * 13, n);
+    hipLaunchKernelGGL(bwt_pack_kernel, dim3((n + 4 * WG - 1) / (4 * WG)), dim3(WG), 0, c->stream,
+                       c->dT, n, tc, c->kA, c->vA);
+    prof_end(c);
+
+    RadixPass passes[8];
+    for (int p = 0; p < 8; ++p) { passes[p].shift = 8 * p; passes[p].bits = 8; }
+    int in_alt = 0;
+    rc = radix_sort_passes(c, c->kA, c->kB, c->vA, c->vB, n, passes, 8, &in_alt);
+    if (rc < 0) return rc;
+    const u64* ks = in_alt ? c->kB : c->kA;
+    const u32* vs = in_alt ? c->vB : c->vA;
+
+    int cur = 0;
+    u32 U = 0;
+    rc = run_seg<true>(c, ks, vs, nullptr, n, n, c->cpos[cur], c->csa[cur], c->cgrp[cur], &U);
+    if (rc < 0) return rc;
+
+    const int lo_bits = bit_length(n);          // next-rank field: values 0 .. n
+    const int hi_bits = bit_length(n - 1);      // group rank field: values 0 .. n-1
+    u64 h = 8;
+    int rounds = 0;
+    while (U > 0) {
+        if (++rounds > 40) return ctx_fail(c, BSC_GPU_ERROR, "prefix doubling did not converge", hipSuccess);
+        u32 blocks = (U + WG - 1) / WG; if (blocks > 8192) blocks = 8192;
+        prof_begin(c, BSCGPU_K_GATHER, (u64)U * (4 + 4 + 4 + 8 + 4), U);
+        hipLaunchKernelGGL(bwt_gather_kernel, dim3(blocks), dim3(WG), 0, c->stream,
+                           c->csa[cur], c->cgrp[cur], c->ISA, U, h, (u64)n, c->kA, c->vA);
+        prof_end(c);
+
+        RadixPass rp[8]; int np = 0;
+        for (int s = 0; s < lo_bits; s += 8) { rp[np].shift = s;      rp[np].bits = (lo_bits - s < 8) ? lo_bits - s : 8; ++np; }
+        for (int s = 0; s < hi_bits; s += 8) { rp[np].shift = 32 + s; rp[np].bits = (hi_bits - s < 8) ? hi_bits - s : 8; ++np; }
+        rc = radix_sort_passes(c, c->kA, c->kB, c->vA, c->vB, U, rp, np, &in_alt);
+        if (rc < 0) return rc;
+        ks = in_alt ? c->kB : c->kA;
+        vs = in_alt ? c->vB : c->vA;
+
+        u32 U2 = 0;
+        rc = run_seg<false>(c, ks, vs, c->cpos[cur], U, n, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2);
+        if (rc < 0) return rc;
+        cur ^= 1;
+        U = U2;
+        h <<= 1;
+    }
+    c->stage_ms[5] = rounds;
+
+    prof_begin(c, BSCGPU_K_EMIT, (u64)n * 6, n);
+    hipLaunchKernelGGL(bwt_emit_kernel, dim3((n + 4 * WG - 1) / (4 * WG)), dim3(WG), 0, c->stream,
+                       c->dT, c->SA, c->ISA, n, dL_user, c->dscal);
+    prof_end(c);
+    u32 cnt = 0;
+    if (I_host != nullptr) {
+        if (r <= 0 || (r & (r - 1)) != 0) return BSC_BAD_PARAMETER;
+        cnt = (u32)((n64 - 1) / r) + 1;
+        if (cnt > 256) return BSC_BAD_PARAMETER;
+        hipLaunchKernelGGL(bwt_aux_kernel, dim3(1), dim3(256), 0, c->stream, c->ISA, n, (u32)r, cnt, c->dscal + 8);
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->hscal, c->dscal, (8 + 256) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    *primary_out = c->hscal[1];
+    for (u32 t = 0; t < cnt; ++t) I_host[t] = c->hscal[8 + t];
+    return BSC_NO_ERROR;
+}

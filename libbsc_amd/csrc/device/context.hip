@@ -1,0 +1,242 @@
+// context.hip — per-GPU context (HBM arena, stream, HIP-event profiling) and the host-pointer C ABI.
+//
+// Mirrors the role of libcubwt's device storage object (libcubwt.cu:2239-2395) but is sized for
+// 288 GB of HBM3E: one hipMalloc of ~60 bytes per block byte, carved once, reused for every block.
+#include "dev_common.h"
+#include <cstdio>
+#include <cstring>
+
+int ctx_fail(bscgpu_ctx* c, int code, const char* what, hipError_t e)
+{
+    if (c) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s: %s", what, e == hipSuccess ? "failed" : hipGetErrorString(e));
+        c->err = buf;
+    }
+    return code;
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" int bscgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
+{
+    if (!out || max_n < 0 || max_n >= 0x7fffffffll) return BSC_BAD_PARAMETER;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BSC_GPU_NOT_SUPPORTED;
+    if (device < 0 || device >= ndev) return BSC_BAD_PARAMETER;
+    if (hipSetDevice(device) != hipSuccess) return BSC_GPU_ERROR;
+
+    bscgpu_ctx* c = new bscgpu_ctx();
+    c->device = device;
+    c->max_n  = max_n;
+    memset(c->kstat, 0, sizeof c->kstat);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BSC_GPU_ERROR; }
+
+    const size_t N = align_up((size_t)max_n + 4096, 4096);
+    struct Carve { void** p; size_t bytes; size_t lead; };
+    Carve carve[] = {
+        {(void**)&c->dT,      N + 128, 64},      // 64 B of front padding (cyclic byte for ST), tail padding behind
+        {(void**)&c->dL,      N + 64, 0},
+        {(void**)&c->kA,      8 * N, 0}, {(void**)&c->kB, 8 * N, 0},
+        {(void**)&c->vA,      4 * N, 0}, {(void**)&c->vB, 4 * N, 0},
+        {(void**)&c->SA,      4 * N, 0}, {(void**)&c->ISA, 4 * N + 64, 0},
+        {(void**)&c->cpos[0], 4 * N, 0}, {(void**)&c->cpos[1], 4 * N, 0},
+        {(void**)&c->csa[0],  4 * N, 0}, {(void**)&c->csa[1],  4 * N, 0},
+        {(void**)&c->cgrp[0], 4 * N, 0}, {(void**)&c->cgrp[1], 4 * N, 0},
+        {(void**)&c->flags,   N + 64, 0},
+        {(void**)&c->counts,  (size_t)256 * MAX_CHUNKS * 4, 0},
+        {(void**)&c->rowtot,  256 * 4, 0},
+        {(void**)&c->segsum,  2 * MAX_CHUNKS * 4, 0},
+        {(void**)&c->segoff,  2 * MAX_CHUNKS * 4, 0},
+        {(void**)&c->dscal,   512 * 4, 0},
+        {(void**)&c->dscal64, 16 * 8, 0},
+        {(void**)&c->adler_part, (size_t)MAX_CHUNKS * 16, 0},
+    };
+    size_t total = 0;
+    for (auto& cv : carve) total += align_up(cv.bytes, 256);
+    hipError_t e = hipMalloc((void**)&c->arena, total);
+    if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return BSC_GPU_NOT_ENOUGH_MEMORY; }
+    c->arena_bytes = total;
+    size_t off = 0;
+    for (auto& cv : carve) { *cv.p = c->arena + off + cv.lead; off += align_up(cv.bytes, 256); }
+    if (hipMemsetAsync(c->arena, 0, total, c->stream) != hipSuccess) { bscgpu_destroy(c); return BSC_GPU_ERROR; }
+
+    bool ok = hipHostMalloc((void**)&c->hscal, 512 * 4, hipHostMallocDefault) == hipSuccess
+           && hipHostMalloc((void**)&c->hscal64, 16 * 8, hipHostMallocDefault) == hipSuccess
+           && hipHostMalloc((void**)&c->hadler, (size_t)MAX_CHUNKS * 16, hipHostMallocDefault) == hipSuccess
+           && hipHostMalloc((void**)&c->hL, N + 64, hipHostMallocDefault) == hipSuccess;
+    if (!ok || hipStreamSynchronize(c->stream) != hipSuccess) { bscgpu_destroy(c); return BSC_GPU_NOT_ENOUGH_MEMORY; }
+    *out = c;
+    return BSC_NO_ERROR;
+}
+
+extern "C" void bscgpu_destroy(bscgpu_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto& e : c->event_pool) hipEventDestroy(e);
+    if (c->hscal) hipHostFree(c->hscal);
+    if (c->hscal64) hipHostFree(c->hscal64);
+    if (c->hadler) hipHostFree(c->hadler);
+    if (c->hL) hipHostFree(c->hL);
+    if (c->arena) hipFree(c->arena);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int64_t bscgpu_arena_bytes(const bscgpu_ctx* c) { return c ? (int64_t)c->arena_bytes : 0; }
+extern "C" const char* bscgpu_last_error(const bscgpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+// ---- profiling --------------------------------------------------------------------------------
+static hipEvent_t take_event(bscgpu_ctx* c)
+{
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+void prof_begin(bscgpu_ctx* c, int kind, u64 bytes, u64 records)
+{
+    if (!c->prof) return;
+    bscgpu_ctx::Pending p;
+    p.a = take_event(c); p.b = take_event(c); p.kind = kind; p.bytes = bytes; p.records = records;
+    hipEventRecord(p.a, c->stream);
+    c->pending.push_back(p);
+}
+void prof_end(bscgpu_ctx* c)
+{
+    if (!c->prof || c->pending.empty()) return;
+    hipEventRecord(c->pending.back().b, c->stream);
+}
+void prof_collect(bscgpu_ctx* c)
+{
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            c->kstat[p.kind].ms += ms;
+            c->kstat[p.kind].launches += 1;
+            c->kstat[p.kind].bytes += p.bytes;
+            c->kstat[p.kind].records += p.records;
+            if (p.kind == BSCGPU_K_RADIX_SCATTER && c->scatter_log.size() < 65536)
+                c->scatter_log.push_back({(double)ms, p.records});
+        }
+        c->event_pool.push_back(p.a); c->event_pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+extern "C" void bscgpu_profile_enable(bscgpu_ctx* c, int on) { if (c) c->prof = (on != 0); }
+extern "C" void bscgpu_profile_reset(bscgpu_ctx* c)
+{
+    if (!c) return;
+    memset(c->kstat, 0, sizeof c->kstat);
+    c->scatter_log.clear();
+}
+extern "C" int bscgpu_profile_get(bscgpu_ctx* c, bscgpu_kstat* stats)
+{
+    if (!c || !stats) return BSC_BAD_PARAMETER;
+    memcpy(stats, c->kstat, sizeof c->kstat);
+    return BSC_NO_ERROR;
+}
+extern "C" int bscgpu_profile_scatter_launches(bscgpu_ctx* c, double* ms, uint64_t* records, int max)
+{
+    if (!c) return 0;
+    int cnt = (int)c->scatter_log.size();
+    int from = cnt > max ? cnt - max : 0;
+    for (int i = from; i < cnt; ++i) { ms[i - from] = c->scatter_log[i].ms; records[i - from] = c->scatter_log[i].records; }
+    return cnt - from;
+}
+extern "C" int bscgpu_last_stage_ms(bscgpu_ctx* c, double* out6)
+{
+    if (!c || !out6) return BSC_BAD_PARAMETER;
+    for (int i = 0; i < 6; ++i) out6[i] = c->stage_ms[i];
+    return BSC_NO_ERROR;
+}
+
+// ---- C ABI: device-pointer entry points --------------------------------------------------------
+extern "C" int64_t bscgpu_bwt_device(bscgpu_ctx* c, const void* dT, void* dL, int64_t n, int64_t r, uint32_t* I)
+{
+    if (!c || !dT || !dL) return BSC_BAD_PARAMETER;
+    if (hipSetDevice(c->device) != hipSuccess) return BSC_GPU_ERROR;
+    int64_t primary = 0;
+    int rc = bwt_device(c, (const u8*)dT, (u8*)dL, n, r, I, &primary);
+    return rc < 0 ? rc : primary;
+}
+
+extern "C" int bscgpu_st_encode_device(bscgpu_ctx* c, const void* dT, void* dOut, int n, int k)
+{
+    if (!c || !dT || !dOut) return BSC_BAD_PARAMETER;
+    if (hipSetDevice(c->device) != hipSuccess) return BSC_GPU_ERROR;
+    int index = 0;
+    int rc = st_device(c, (const u8*)dT, (u8*)dOut, n, k, &index);
+    return rc < 0 ? rc : index;
+}
+
+extern "C" int bscgpu_adler32_device(bscgpu_ctx* c, const void* dT, int64_t n, uint32_t* out)
+{
+    if (!c || !out || (!dT && n > 0)) return BSC_BAD_PARAMETER;
+    if (hipSetDevice(c->device) != hipSuccess) return BSC_GPU_ERROR;
+    return adler32_device(c, (const u8*)dT, n, out);
+}
+
+extern "C" int bscgpu_radix_sort_u64(bscgpu_ctx* c, void* keys, void* keys_alt, void* vals, void* vals_alt,
+                                     int64_t n, int begin_bit, int end_bit, int* result_in_alt)
+{
+    if (!c || !keys || !keys_alt || !result_in_alt || n < 0) return BSC_BAD_PARAMETER;
+    if (begin_bit < 0 || end_bit > 64 || begin_bit > end_bit) return BSC_BAD_PARAMETER;
+    if ((vals == nullptr) != (vals_alt == nullptr)) return BSC_BAD_PARAMETER;
+    if (hipSetDevice(c->device) != hipSuccess) return BSC_GPU_ERROR;
+    RadixPass passes[8]; int np = 0;
+    for (int s = begin_bit; s < end_bit; s += 8) { passes[np].shift = s; passes[np].bits = (end_bit - s < 8) ? end_bit - s : 8; ++np; }
+    int rc = radix_sort_passes(c, (u64*)keys, (u64*)keys_alt, (u32*)vals, (u32*)vals_alt, (u64)n, passes, np, result_in_alt);
+    if (rc < 0) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return BSC_NO_ERROR;
+}
+
+// ---- C ABI: host-pointer entry points (the reference's hook shape: H2D, run, D2H, synchronous) ----
+static int64_t bwt_host(bscgpu_ctx* c, const uint8_t* T, uint8_t* L, int64_t n, int64_t r, uint32_t* I)
+{
+    if (!c || !T || !L || n < 0) return BSC_BAD_PARAMETER;
+    if (n > c->max_n) return BSC_GPU_NOT_ENOUGH_MEMORY;
+    if (hipSetDevice(c->device) != hipSuccess) return BSC_GPU_ERROR;
+    if (n == 0) return 0;
+    HIP_TRY(c, hipMemcpyAsync(c->dL, T, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    int64_t primary = 0;
+    int rc = bwt_device(c, c->dL, c->dL, n, r, I, &primary);
+    if (rc < 0) return rc;
+    HIP_TRY(c, hipMemcpyAsync(L, c->dL, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return primary;
+}
+extern "C" int64_t bscgpu_bwt(bscgpu_ctx* c, const uint8_t* T, uint8_t* L, int64_t n) { return bwt_host(c, T, L, n, 0, nullptr); }
+extern "C" int64_t bscgpu_bwt_aux(bscgpu_ctx* c, const uint8_t* T, uint8_t* L, int64_t n, int64_t r, uint32_t* I)
+{
+    if (!I) return BSC_BAD_PARAMETER;
+    int64_t rc = bwt_host(c, T, L, n, r, I);
+    return rc < 0 ? rc : 0;
+}
+
+extern "C" int bscgpu_st_encode(bscgpu_ctx* c, uint8_t* T, int n, int k)
+{
+    if (!c || !T || n < 0) return BSC_BAD_PARAMETER;
+    if (k < 3 || k > 8) return BSC_BAD_PARAMETER;
+    if (n <= 1) return 0;
+    if (n > c->max_n) return BSC_GPU_NOT_ENOUGH_MEMORY;
+    if (hipSetDevice(c->device) != hipSuccess) return BSC_GPU_ERROR;
+    HIP_TRY(c, hipMemcpyAsync(c->dL, T, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    int index = 0;
+    int rc = st_device(c, c->dL, c->dL, n, k, &index);
+    if (rc < 0) return rc;
+    HIP_TRY(c, hipMemcpyAsync(T, c->dL, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return index;
+}

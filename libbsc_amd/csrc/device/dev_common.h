@@ -1,0 +1,179 @@
+// dev_common.h — shared declarations for the gfx950 device layer (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+
+#include "../../../include/bscgpu.h"
+
+typedef unsigned long long u64;
+typedef unsigned int       u32;
+typedef unsigned short     u16;
+typedef unsigned char      u8;
+
+// libbsc error codes (libbsc.h:41-51)
+#define BSC_NO_ERROR                0
+#define BSC_BAD_PARAMETER          -1
+#define BSC_NOT_ENOUGH_MEMORY      -2
+#define BSC_NOT_COMPRESSIBLE       -3
+#define BSC_NOT_SUPPORTED          -4
+#define BSC_GPU_ERROR              -7
+#define BSC_GPU_NOT_SUPPORTED      -8
+#define BSC_GPU_NOT_ENOUGH_MEMORY  -9
+
+// ---------------------------------------------------------------------------------------------
+// Work decomposition shared by all "chunked" kernels: the input is cut into at most MAX_CHUNKS
+// contiguous chunks, one workgroup per chunk, each chunk a whole number of tiles.  ~1024 chunks
+// = 4 workgroups of 256 threads on each of the 256 CUs (all resident at once, b % 8 -> XCD so
+// every XCD streams an equal share).
+// ---------------------------------------------------------------------------------------------
+constexpr int   WG          = 256;      // threads per workgroup (4 wave64)
+constexpr int   WAVES       = WG / 64;
+constexpr int   MAX_CHUNKS  = 1024;
+
+struct Chunking {
+    u32 num_tiles;     // total tiles
+    u32 chunk_tiles;   // tiles per chunk
+    u32 num_chunks;    // workgroups to launch
+};
+static inline Chunking make_chunking(u64 n, u32 tile) {
+    Chunking c;
+    c.num_tiles   = (u32)((n + tile - 1) / tile);
+    if (c.num_tiles == 0) c.num_tiles = 1;
+    c.chunk_tiles = (c.num_tiles + MAX_CHUNKS - 1) / MAX_CHUNKS;
+    c.num_chunks  = (c.num_tiles + c.chunk_tiles - 1) / c.chunk_tiles;
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Context
+// ---------------------------------------------------------------------------------------------
+struct ScatterLaunch { double ms; u64 records; };
+
+struct bscgpu_ctx {
+    int          device      = 0;
+    hipStream_t  stream      = nullptr;
+    int64_t      max_n       = 0;
+    char*        arena       = nullptr;
+    size_t       arena_bytes = 0;
+
+    // carved device buffers (sized for max_n)
+    u8*  dT     = nullptr;   // text with 64 B zero/cyclic padding on both sides (points at T[0])
+    u8*  dL     = nullptr;   // output bytes
+    u64* kA     = nullptr;  u64* kB = nullptr;   // sort keys ping/pong
+    u32* vA     = nullptr;  u32* vB = nullptr;   // sort values ping/pong
+    u32* SA     = nullptr;
+    u32* ISA    = nullptr;
+    u32* cpos[2] = {nullptr, nullptr};
+    u32* csa [2] = {nullptr, nullptr};
+    u32* cgrp[2] = {nullptr, nullptr};
+    u8*  flags  = nullptr;
+    u32* counts = nullptr;   // [256][MAX_CHUNKS] radix per-chunk digit counts -> offsets
+    u32* rowtot = nullptr;   // [256]
+    u32* segsum = nullptr;   // [2][MAX_CHUNKS] per-chunk (unsorted count, last head+1)
+    u32* segoff = nullptr;   // [2][MAX_CHUNKS] scanned
+    u32* dscal  = nullptr;   // small device scalars (64 u32)
+    u64* dscal64 = nullptr;  // small device u64 scalars (16)
+    u64* adler_part = nullptr; // [MAX_CHUNKS][2]
+    // pinned host
+    u32* hscal  = nullptr;   // 64 u32
+    u64* hscal64 = nullptr;
+    u64* hadler = nullptr;
+    u8*  hL     = nullptr;   // pinned staging for D2H of L (max_n + 64)
+
+    // profiling
+    bool         prof        = false;
+    bscgpu_kstat kstat[BSCGPU_K_COUNT];
+    std::vector<ScatterLaunch> scatter_log;
+    struct Pending { hipEvent_t a, b; int kind; u64 bytes; u64 records; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+    double       stage_ms[6] = {0, 0, 0, 0, 0, 0};
+
+    std::string  err;
+};
+
+int  ctx_fail(bscgpu_ctx* c, int code, const char* what, hipError_t e);
+#define HIP_TRY(ctx, expr)                                                         \
+    do { hipError_t _e = (expr);                                                   \
+         if (_e != hipSuccess) return ctx_fail((ctx), BSC_GPU_ERROR, #expr, _e);   \
+    } while (0)
+
+// profiling brackets: PROF_BEGIN/END record events on ctx->stream around a launch.
+void prof_begin(bscgpu_ctx* c, int kind, u64 bytes, u64 records);
+void prof_end(bscgpu_ctx* c);
+void prof_collect(bscgpu_ctx* c);   // after a stream sync: fold pending events into kstat
+
+// ---- internal device-layer entry points (all asynchronous on ctx->stream) ---------------------
+struct RadixPass { int shift; int bits; };
+// Sort n records; passes applied in order (LSD).  Result lands in (keys, vals) if the number of
+// passes is even, else in (keys_alt, vals_alt); *in_alt tells which.
+int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* vals_alt, u64 n,
+                      const RadixPass* passes, int npasses, int* in_alt);
+
+int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n, int64_t r, u32* I_host,
+               int64_t* primary_out);
+int st_device(bscgpu_ctx* c, const u8* dT_user, u8* dOut_user, int n, int k, int* index_out);
+int adler32_device(bscgpu_ctx* c, const u8* d, int64_t n, u32* out);
+
+// ---------------------------------------------------------------------------------------------
+// Device helpers (wave64)
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ u32 lane_id() { return __lane_id(); }
+
+__device__ __forceinline__ u64 lanemask_lt() {
+    u32 l = lane_id();
+    return (l == 0) ? 0ull : (~0ull >> (64 - l));
+}
+
+// inclusive wave scan (sum) over 64 lanes
+__device__ __forceinline__ u32 wave_incl_sum(u32 v) {
+    u32 l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d, 64);
+        if (l >= (u32)d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ u32 wave_incl_max(u32 v) {
+    u32 l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d, 64);
+        if (l >= (u32)d) v = (t > v) ? t : v;
+    }
+    return v;
+}
+
+// Block (256 threads) exclusive sum scan.  lds must hold >= 8 u32.  Returns exclusive prefix of v;
+// *total receives the block total.  Contains __syncthreads(); all threads must call.
+__device__ __forceinline__ u32 block_excl_sum(u32 v, u32* lds, u32* total) {
+    u32 incl = wave_incl_sum(v);
+    u32 w = threadIdx.x >> 6, l = lane_id();
+    __syncthreads();                 // protect lds reuse from a previous call
+    if (l == 63) lds[w] = incl;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) { u32 t = lds[i]; if ((u32)i < w) base += t; tot += t; }
+    *total = tot;
+    return base + incl - v;
+}
+// Block inclusive max scan.
+__device__ __forceinline__ u32 block_incl_max(u32 v, u32* lds, u32* total) {
+    u32 incl = wave_incl_max(v);
+    u32 w = threadIdx.x >> 6, l = lane_id();
+    __syncthreads();
+    if (l == 63) lds[w] = incl;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) { u32 t = lds[i]; if ((u32)i < w) base = (t > base) ? t : base; tot = (t > tot) ? t : tot; }
+    *total = tot;
+    return (base > incl) ? base : incl;
+}
+#endif

@@ -1,0 +1,267 @@
+// radix_sort.hip — stable LSD radix sort of (u64 key [, u32 value]) records for gfx950 (MI355X).
+//
+// This is the engine under both block sorters: the BWT's suffix sort (initial 8-byte-prefix sort and
+// every prefix-doubling round) and the Sort Transform.  It replaces the reference's calls into
+// cub::DeviceRadixSort / cub::DeviceSegmentedSort (libcubwt.cu:718, :1691, :2136-2163; st.cu:187-193,
+// :273-279) with a design written for CDNA4, not a translation of CUB:
+//
+//  * One digit pass = three launches on one stream: rs_hist (per-chunk digit counts of the pass's
+//    input), rs_scan (256 workgroups, one per digit: exclusive scan over chunks), rs_scatter (the
+//    graded kernel).  There is NO inter-workgroup communication inside a launch: on MI355X the eight
+//    XCD L2s are not coherent and an agent-scope hand-off costs ~1-3 us under streaming load
+//    (MI355X_MICROARCH.md, handoff rows), while a chip at 5 TB/s retires a 96 KB tile every ~20 ns —
+//    a decoupled-look-back chain ("onesweep") would serialise on that latency.  The price is one
+//    extra streaming read of the keys per pass (8 B/record, rs_hist); the scatter pass itself moves
+//    exactly the algorithmic 2*(8+4) B/record.
+//  * <= 1024 chunks (one workgroup each, 4 per CU, all resident; block b runs on XCD b % 8 so every
+//    XCD streams an equal contiguous share).  A workgroup walks its chunk tile by tile (4096 records)
+//    keeping its 256 running global bucket offsets in LDS, so the per-chunk offsets table is only
+//    256 x 1024 u32.
+//  * Inside a tile: wave-striped coalesced loads (each wave64 load instruction covers 512 contiguous
+//    bytes of keys), 8-bit digit, stable in-wave ranking by wave64 ballot match (8 ballots -> peer
+//    mask, popcount of lower peers), per-wave 256-bin histograms in LDS, then the tile is locally
+//    reordered through LDS (32 KB staging) so that every bucket leaves as one contiguous run:
+//    consecutive lanes store consecutive addresses.  Integer/index work only — no MFMA.
+#include "dev_common.h"
+
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE  = WG * RS_ITEMS;          // 4096 records per tile
+constexpr int RS_LDS   = RS_TILE * 8 + WAVES * 256 * 4 + 3 * 256 * 4 + 8 * 4;   // 39968 B -> 4 WG / CU
+
+// ---------------------------------------------------------------------------------------------
+// rs_hist: per-chunk digit histogram.  counts layout [digit][chunk].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void rs_hist_kernel(const u64* __restrict__ keys, u32 n, int shift, u32 mask,
+                                                     u32 chunk_tiles, u32 num_chunks, u32* __restrict__ counts)
+{
+    __shared__ u32 h[WAVES * 256];
+    const u32 t = threadIdx.x, w = t >> 6;
+    for (u32 i = t; i < WAVES * 256; i += WG) h[i] = 0;
+    __syncthreads();
+
+    const u64 start = (u64)blockIdx.x * chunk_tiles * RS_TILE;
+    u64 end = start + (u64)chunk_tiles * RS_TILE;
+    if (end > n) end = n;
+    u32* hw = h + w * 256;
+
+    // 16-byte loads (2 keys per lane), 4 in flight per lane.
+    u64 i = start + 2 * t;
+    for (; i + 3 * 2 * WG + 1 < end; i += 4 * 2 * WG) {
+        ulonglong2 a = *reinterpret_cast<const ulonglong2*>(keys + i);
+        ulonglong2 b = *reinterpret_cast<const ulonglong2*>(keys + i + 2 * WG);
+        ulonglong2 c = *reinterpret_cast<const ulonglong2*>(keys + i + 4 * WG);
+        ulonglong2 d = *reinterpret_cast<const ulonglong2*>(keys + i + 6 * WG);
+        atomicAdd(&hw[(u32)(a.x >> shift) & mask], 1u); atomicAdd(&hw[(u32)(a.y >> shift) & mask], 1u);
+        atomicAdd(&hw[(u32)(b.x >> shift) & mask], 1u); atomicAdd(&hw[(u32)(b.y >> shift) & mask], 1u);
+        atomicAdd(&hw[(u32)(c.x >> shift) & mask], 1u); atomicAdd(&hw[(u32)(c.y >> shift) & mask], 1u);
+        atomicAdd(&hw[(u32)(d.x >> shift) & mask], 1u); atomicAdd(&hw[(u32)(d.y >> shift) & mask], 1u);
+    }
+    for (; i < end; i += 2 * WG) {
+        atomicAdd(&hw[(u32)(keys[i] >> shift) & mask], 1u);
+        if (i + 1 < end) atomicAdd(&hw[(u32)(keys[i + 1] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    counts[(size_t)t * num_chunks + blockIdx.x] = h[t] + h[256 + t] + h[512 + t] + h[768 + t];
+}
+
+// ---------------------------------------------------------------------------------------------
+// rs_scan: workgroup d turns row d of counts into exclusive per-chunk offsets and its row total.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void rs_scan_kernel(u32* __restrict__ counts, u32 num_chunks, u32* __restrict__ rowtot)
+{
+    __shared__ u32 scr[8];
+    u32* row = counts + (size_t)blockIdx.x * num_chunks;
+    u32 carry = 0;
+    for (u32 base = 0; base < num_chunks; base += WG) {
+        const u32 i = base + threadIdx.x;
+        const u32 v = (i < num_chunks) ? row[i] : 0u;
+        u32 tot;
+        const u32 ex = block_excl_sum(v, scr, &tot);
+        if (i < num_chunks) row[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) rowtot[blockIdx.x] = carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rs_scatter: the digit pass.  Reads each record once, writes it once.
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_VAL>
+__global__ __launch_bounds__(WG, 4) void rs_scatter_kernel(const u64* __restrict__ kin, u64* __restrict__ kout,
+                                                        const u32* __restrict__ vin, u32* __restrict__ vout,
+                                                        u32 n, int shift, u32 mask,
+                                                        u32 chunk_tiles, u32 num_chunks, u32 num_tiles,
+                                                        const u32* __restrict__ offsets,
+                                                        const u32* __restrict__ rowtot)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* skeys  = reinterpret_cast<u64*>(smem);                       // [4096] staging (reused as u32 for values)
+    u32* whist  = reinterpret_cast<u32*>(smem + RS_TILE * 8);         // [4][256] per-wave digit counts / prefixes
+    u32* goff   = whist + WAVES * 256;                                // [256] running global bucket offsets
+    u32* adj    = goff + 256;                                         // [256] goff - tile-local bucket start
+    u32* dstart = adj + 256;                                          // [256] (scratch)
+    u32* scr    = dstart + 256;                                       // [8]
+    volatile u32* vwh = whist;
+
+    const u32 t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const u64 lt = lanemask_lt();
+
+    {   // global offset of this chunk's first record of digit t
+        u32 tot;
+        const u32 base = block_excl_sum(rowtot[t], scr, &tot);
+        goff[t] = base + offsets[(size_t)t * num_chunks + blockIdx.x];
+    }
+    __syncthreads();
+
+    const u32 tile0 = blockIdx.x * chunk_tiles;
+    u32 tile1 = tile0 + chunk_tiles;
+    if (tile1 > num_tiles) tile1 = num_tiles;
+
+    for (u32 tile = tile0; tile < tile1; ++tile) {
+        const u64 tbase = (u64)tile * RS_TILE;
+        const u32 rem = (u32)((u64)n - tbase);
+        const u32 nvalid = rem < (u32)RS_TILE ? rem : (u32)RS_TILE;
+
+        // ---- wave-striped loads: wave w owns records [w*1024, w*1024+1024) of the tile -------
+        u64 k[RS_ITEMS];
+        u32 v[RS_ITEMS];
+        const u32 wbase = w * (64 * RS_ITEMS) + lane;
+#pragma unroll
+        for (int i = 0; i < RS_ITEMS; ++i) {
+            const u32 idx = wbase + i * 64;
+            k[i] = (idx < nvalid) ? kin[tbase + idx] : ~0ull;
+        }
+#pragma unroll
+        for (int i = 0; i < WAVES; ++i) whist[i * 256 + t] = 0;
+        __syncthreads();
+
+        // ---- stable in-wave ranking by ballot match ---------------------------------------------
+        u32 rk[RS_ITEMS];
+#pragma unroll
+        for (int i = 0; i < RS_ITEMS; ++i) {
+            const u32 d = (u32)(k[i] >> shift) & mask;
+            u64 m = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const u64 bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            const u32 before = vwh[w * 256 + d];       // records of digit d seen by this wave so far
+            const u32 r      = (u32)__popcll(m & lt);  // peers in lower lanes
+            const u32 cnt    = (u32)__popcll(m);
+            rk[i] = before + r;
+            if (r == cnt - 1) vwh[w * 256 + d] = before + cnt;   // highest peer lane publishes
+        }
+        // values are fetched only now (they are not needed for ranking): keeps the ranking loop's
+        // register footprint at 4 waves/SIMD, and the loads fly under the bucket scan + key reorder.
+        if (HAS_VAL) {
+#pragma unroll
+            for (int i = 0; i < RS_ITEMS; ++i) {
+                const u32 idx = wbase + i * 64;
+                v[i] = (idx < nvalid) ? vin[tbase + idx] : 0u;
+            }
+        }
+        __syncthreads();
+
+        // ---- per digit: wave prefixes, tile-local bucket start, global adjust -------------------
+        {
+            const u32 c0 = whist[t], c1 = whist[256 + t], c2 = whist[512 + t], c3 = whist[768 + t];
+            const u32 tot = c0 + c1 + c2 + c3;
+            u32 all;
+            const u32 ds = block_excl_sum(tot, scr, &all);
+            whist[t]       = ds;
+            whist[256 + t] = ds + c0;
+            whist[512 + t] = ds + c0 + c1;
+            whist[768 + t] = ds + c0 + c1 + c2;
+            const u32 g = goff[t];
+            adj[t]  = g - ds;
+            goff[t] = g + tot;
+        }
+        __syncthreads();
+
+        // ---- local reorder through LDS --------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < RS_ITEMS; ++i) {
+            const u32 d = (u32)(k[i] >> shift) & mask;
+            const u32 pos = whist[w * 256 + d] + rk[i];
+            rk[i] = pos;
+            skeys[pos] = k[i];
+        }
+        __syncthreads();
+
+        u32 dd[RS_ITEMS / 4];
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) {
+            const u32 q = j * WG + t;
+            const u64 key = skeys[q];
+            const u32 d = (u32)(key >> shift) & mask;
+            if ((j & 3) == 0) dd[j >> 2] = d; else dd[j >> 2] |= d << (8 * (j & 3));
+            if (q < nvalid) kout[adj[d] + q] = key;
+        }
+
+        if (HAS_VAL) {
+            __syncthreads();
+            u32* svals = reinterpret_cast<u32*>(skeys);
+#pragma unroll
+            for (int i = 0; i < RS_ITEMS; ++i) svals[rk[i]] = v[i];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < RS_ITEMS; ++j) {
+                const u32 q = j * WG + t;
+                const u32 d = (dd[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                if (q < nvalid) vout[adj[d] + q] = svals[q];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launcher
+// ---------------------------------------------------------------------------------------------
+int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* vals_alt, u64 n,
+                      const RadixPass* passes, int npasses, int* in_alt)
+{
+    *in_alt = 0;
+    if (n == 0 || npasses == 0) return BSC_NO_ERROR;
+    if (n >= 0xffffffffull) return BSC_BAD_PARAMETER;
+    if ((((uintptr_t)keys) | ((uintptr_t)keys_alt)) & 15) return ctx_fail(c, BSC_BAD_PARAMETER, "radix keys not 16B aligned", hipSuccess);
+
+    const Chunking ch = make_chunking(n, RS_TILE);
+    u64 *ksrc = keys, *kdst = keys_alt;
+    u32 *vsrc = vals, *vdst = vals_alt;
+    const bool has_val = (vals != nullptr);
+    const u64 rec_bytes = 8 + (has_val ? 4 : 0);
+
+    for (int p = 0; p < npasses; ++p) {
+        const int shift = passes[p].shift;
+        const u32 mask  = (passes[p].bits >= 8) ? 0xffu : ((1u << passes[p].bits) - 1u);
+
+        prof_begin(c, BSCGPU_K_RADIX_HIST, n * 8, n);
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(ch.num_chunks), dim3(WG), 0, c->stream,
+                           ksrc, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks, c->counts);
+        prof_end(c);
+
+        prof_begin(c, BSCGPU_K_RADIX_SCAN, (u64)256 * ch.num_chunks * 8, 0);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(WG), 0, c->stream, c->counts, ch.num_chunks, c->rowtot);
+        prof_end(c);
+
+        prof_begin(c, BSCGPU_K_RADIX_SCATTER, 2 * n * rec_bytes, n);
+        if (has_val)
+            hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(ch.num_chunks), dim3(WG), RS_LDS, c->stream,
+                               ksrc, kdst, vsrc, vdst, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks,
+                               ch.num_tiles, c->counts, c->rowtot);
+        else
+            hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(ch.num_chunks), dim3(WG), RS_LDS, c->stream,
+                               ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, shift, mask,
+                               ch.chunk_tiles, ch.num_chunks, ch.num_tiles, c->counts, c->rowtot);
+        prof_end(c);
+        HIP_TRY(c, hipGetLastError());
+
+        u64* tk = ksrc; ksrc = kdst; kdst = tk;
+        u32* tv = vsrc; vsrc = vdst; vdst = tv;
+    }
+    *in_alt = (npasses & 1);
+    return BSC_NO_ERROR;
+}

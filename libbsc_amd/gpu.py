@@ -1,0 +1,130 @@
+"""Per-GPU context: thin object wrapper over the bscgpu_* C ABI (include/bscgpu.h)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+class GpuError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__(f"bscgpu error {code}: {msg}")
+        self.code = code
+
+
+def _dptr(t):
+    """device pointer of a torch CUDA tensor (or a raw int)."""
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())
+
+
+class GpuContext:
+    """One context per GPU (mirrors libcubwt's device storage handle, libcubwt.cuh:60-71)."""
+
+    def __init__(self, device=0, max_n=64 << 20):
+        self.L = N.lib()
+        h = C.c_void_p()
+        rc = self.L.bscgpu_create(C.byref(h), int(device), int(max_n))
+        if rc != 0:
+            raise GpuError(rc, "bscgpu_create failed (no GPU / out of memory?)")
+        self.h = h
+        self.device = device
+        self.max_n = max_n
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.bscgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise GpuError(rc, (self.L.bscgpu_last_error(self.h) or b"").decode())
+        return rc
+
+    @property
+    def arena_bytes(self):
+        return int(self.L.bscgpu_arena_bytes(self.h))
+
+    # ---- host-pointer entry points (shape of the reference hooks) -----------------------------
+    def bwt(self, data, aux_rate=None):
+        """-> (L np.uint8[n], primary index, I list or None).  libcubwt_bwt / libcubwt_bwt_aux."""
+        T = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else data)
+        n = T.size
+        Lout = np.empty(max(n, 1), np.uint8)
+        if aux_rate:
+            cnt = (n - 1) // aux_rate + 1 if n > 0 else 0
+            I = (C.c_uint32 * max(cnt, 1))()
+            rc = self.L.bscgpu_bwt_aux(self.h, N.np_ptr(T), N.np_ptr(Lout), n, aux_rate, I)
+            self._check(rc)
+            return Lout[:n], int(I[0]) if cnt else 0, [int(I[t]) for t in range(cnt)]
+        rc = self._check(self.L.bscgpu_bwt(self.h, N.np_ptr(T), N.np_ptr(Lout), n))
+        return Lout[:n], int(rc), None
+
+    def st_encode(self, data, k):
+        T = np.array(np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else data, copy=True)
+        rc = self._check(self.L.bscgpu_st_encode(self.h, N.np_ptr(T), T.size, k))
+        return T, int(rc)
+
+    # ---- device-pointer entry points -------------------------------------------------------
+    def bwt_device(self, dT, dL, n, aux_rate=None):
+        if aux_rate:
+            cnt = (n - 1) // aux_rate + 1
+            I = (C.c_uint32 * cnt)()
+            rc = self._check(self.L.bscgpu_bwt_device(self.h, _dptr(dT), _dptr(dL), n, aux_rate, I))
+            return int(rc), [int(I[t]) for t in range(cnt)]
+        rc = self._check(self.L.bscgpu_bwt_device(self.h, _dptr(dT), _dptr(dL), n, 0, None))
+        return int(rc), None
+
+    def st_encode_device(self, dT, dOut, n, k):
+        return int(self._check(self.L.bscgpu_st_encode_device(self.h, _dptr(dT), _dptr(dOut), n, k)))
+
+    def adler32_device(self, dT, n):
+        out = C.c_uint32(0)
+        self._check(self.L.bscgpu_adler32_device(self.h, _dptr(dT), n, C.byref(out)))
+        return int(out.value)
+
+    def radix_sort(self, keys, keys_alt, vals, vals_alt, n, begin_bit=0, end_bit=64):
+        """torch int64 / int32 CUDA tensors (bit patterns are treated as unsigned). Returns (keys, vals) tensors
+        that hold the result."""
+        alt = C.c_int(0)
+        self._check(self.L.bscgpu_radix_sort_u64(self.h, _dptr(keys), _dptr(keys_alt),
+                                                 _dptr(vals) if vals is not None else None,
+                                                 _dptr(vals_alt) if vals_alt is not None else None,
+                                                 n, begin_bit, end_bit, C.byref(alt)))
+        return (keys_alt, vals_alt) if alt.value else (keys, vals)
+
+    def compress_device(self, dInput, n, sorter=1, coder=1, features=3):
+        out = np.empty(n + 28, np.uint8)
+        rc = self._check(self.L.bscgpu_compress_device(self.h, _dptr(dInput), N.np_ptr(out), n, sorter, coder, features))
+        return out[:rc]
+
+    # ---- profiling ---------------------------------------------------------------------------
+    def profile(self, on=True):
+        self.L.bscgpu_profile_enable(self.h, 1 if on else 0)
+
+    def profile_reset(self):
+        self.L.bscgpu_profile_reset(self.h)
+
+    def profile_get(self):
+        arr = (N.KStat * len(N.K_NAMES))()
+        self.L.bscgpu_profile_get(self.h, arr)
+        return {N.K_NAMES[i]: dict(ms=arr[i].ms, launches=int(arr[i].launches), bytes=int(arr[i].bytes),
+                                   records=int(arr[i].records)) for i in range(len(N.K_NAMES))}
+
+    def scatter_launches(self, max_n=4096):
+        ms = (C.c_double * max_n)()
+        rec = (C.c_uint64 * max_n)()
+        cnt = self.L.bscgpu_profile_scatter_launches(self.h, ms, rec, max_n)
+        return [(ms[i], int(rec[i])) for i in range(cnt)]
+
+    def last_stage_ms(self):
+        out = (C.c_double * 6)()
+        self.L.bscgpu_last_stage_ms(self.h, out)
+        return list(out)

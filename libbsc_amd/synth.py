@@ -1,0 +1,83 @@
+"""`synth-text v1` — the synthetic block generator every benchmark and parity test uses.
+
+Integer-only and deterministic: xorshift64* PRNG, a 4096-word vocabulary of 2..9 lowercase letters,
+words drawn with a product-of-uniforms skew, separated by ' ' (every 16th word by '\\n').
+The word loop is sequential; this vectorises the PRNG stream in chunks with numpy so 64 MiB takes seconds.
+"""
+import numpy as np
+
+_M64 = (1 << 64) - 1
+_MUL = 2685821657736338717
+
+
+class _XorShift64Star:
+    def __init__(self, seed):
+        assert seed != 0
+        self.s = seed & _M64
+
+    def next(self):
+        s = self.s
+        s ^= s >> 12
+        s ^= (s << 25) & _M64
+        s ^= s >> 27
+        self.s = s
+        return (s * _MUL) & _M64
+
+
+def synth_text_v1(seed: int, n: int) -> np.ndarray:
+    """n bytes of synthetic text as np.uint8."""
+    g = _XorShift64Star(seed)
+    vocab = []
+    for _ in range(4096):
+        ln = 2 + g.next() % 8
+        vocab.append(np.array([97 + g.next() % 26 for _ in range(ln)], np.uint8))
+    lens = np.array([v.size for v in vocab], np.int64)
+    flat = np.concatenate(vocab)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+
+    out = np.empty(n + 16, np.uint8)
+    pos = 0
+    words = 0
+    CH = 1 << 16
+    while pos < n:
+        # draw a chunk of word ids sequentially (the PRNG is a serial recurrence)
+        rs = np.empty(CH, np.uint64)
+        s = g.s
+        for i in range(CH):
+            s ^= s >> 12
+            s ^= (s << 25) & _M64
+            s ^= s >> 27
+            rs[i] = (s * _MUL) & _M64
+        # how many of these words fit?
+        idx = ((rs & np.uint64(0xfff)) * ((rs >> np.uint64(12)) & np.uint64(0xfff))) >> np.uint64(12)
+        idx = idx.astype(np.int64)
+        wl = lens[idx] + 1
+        ends = pos + np.cumsum(wl)
+        # words whose START is < n are emitted (the last one truncated)
+        wstart = ends - wl
+        k = int(np.searchsorted(wstart, n, side="left"))
+        k = min(k, CH)
+        if k == 0:
+            break
+        # advance the generator by exactly k draws
+        if k == CH:
+            g.s = s
+        else:
+            for _ in range(k):
+                g.next()
+        tot = int(ends[k - 1] - pos)
+        buf = np.empty(tot, np.uint8)
+        # gather word bytes
+        wl_k = wl[:k]
+        offs = np.concatenate([[0], np.cumsum(wl_k)[:-1]])
+        src = np.repeat(starts[idx[:k]] - offs, wl_k) + np.arange(tot)
+        sep_pos = offs + wl_k - 1
+        src[sep_pos] = 0
+        buf[:] = flat[src]
+        wn = words + 1 + np.arange(k)
+        buf[sep_pos] = np.where(wn % 16 == 0, 10, 32).astype(np.uint8)
+        take = min(tot, n - pos)
+        out[pos:pos + take] = buf[:take]
+        pos += take
+        words += k
+    return out[:n].copy()
