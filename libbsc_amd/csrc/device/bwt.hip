@@ -23,6 +23,8 @@
 //      D2H + stream sync per round for the loop test (libcubwt does the same, libcubwt.cu:1383).
 //   5. bwt_emit:   L from SA/T, aux indexes from ISA.
 #include "dev_common.h"
+#include <cstdio>
+#include <cstdlib>
 
 constexpr int SEG_ITEMS = 8;
 constexpr int SEG_TILE  = WG * SEG_ITEMS;      // 2048 records per tile, 8 consecutive per thread
@@ -176,7 +178,8 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
     const u32 tile0 = blockIdx.x * chunk_tiles;
     u32 tile1 = tile0 + chunk_tiles; if (tile1 > num_tiles) tile1 = num_tiles;
     u32 off   = segoff[blockIdx.x];                 // next compacted slot
-    u32 carry = segoff[MAX_CHUNKS + blockIdx.x];    // (head position + 1) carried in from the left
+    u32 carry = segoff[MAX_CHUNKS + blockIdx.x];    // (head index + 1) carried in from the left
+    if (!INITIAL && carry) carry = cpos_in[carry - 1] + 1;   // compacted index -> SA slot of that head
 
     for (u32 tile = tile0; tile < tile1; ++tile) {
         const u32 j = tile * SEG_TILE + t * SEG_ITEMS;
@@ -337,6 +340,8 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
     const int hi_bits = bit_length(n - 1);      // group rank field: values 0 .. n-1
     u64 h = 8;
     int rounds = 0;
+    const bool dbg = getenv("BSCGPU_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[bwt] n=%u initial unsorted=%u\n", n, U);
     while (U > 0) {
         if (++rounds > 40) return ctx_fail(c, BSC_GPU_ERROR, "prefix doubling did not converge", hipSuccess);
         u32 blocks = (U + WG - 1) / WG; if (blocks > 8192) blocks = 8192;
@@ -357,6 +362,7 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
         rc = run_seg<false>(c, ks, vs, c->cpos[cur], U, n, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2);
         if (rc < 0) return rc;
         cur ^= 1;
+        if (dbg) fprintf(stderr, "[bwt] round %d h=%llu U %u -> %u (passes %d)\n", rounds, h, U, U2, np);
         U = U2;
         h <<= 1;
     }

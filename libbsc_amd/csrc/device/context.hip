@@ -189,7 +189,9 @@ extern "C" int bscgpu_adler32_device(bscgpu_ctx* c, const void* dT, int64_t n, u
 extern "C" int bscgpu_radix_sort_u64(bscgpu_ctx* c, void* keys, void* keys_alt, void* vals, void* vals_alt,
                                      int64_t n, int begin_bit, int end_bit, int* result_in_alt)
 {
-    if (!c || !keys || !keys_alt || !result_in_alt || n < 0) return BSC_BAD_PARAMETER;
+    if (!c || !result_in_alt || n < 0) return BSC_BAD_PARAMETER;
+    if (n == 0) { *result_in_alt = 0; return BSC_NO_ERROR; }
+    if (!keys || !keys_alt) return BSC_BAD_PARAMETER;
     if (begin_bit < 0 || end_bit > 64 || begin_bit > end_bit) return BSC_BAD_PARAMETER;
     if ((vals == nullptr) != (vals_alt == nullptr)) return BSC_BAD_PARAMETER;
     if (hipSetDevice(c->device) != hipSuccess) return BSC_GPU_ERROR;
