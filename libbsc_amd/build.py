@@ -20,6 +20,7 @@ LIB = os.path.join(HERE, "lib", "libbsc_mi355x.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 ARCH = "gfx950"
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-result"]
 DEVFLAGS = [f"--offload-arch={ARCH}"]
@@ -64,7 +65,8 @@ def _compile(src, force):
     if src.endswith(".hip"):
         cmd += DEVFLAGS
     else:
-        cmd += ["-x", "c++"]            # host-only translation units: plain C++ through hipcc's clang
+        # host-only translation units: plain C++ through hipcc's clang (HIP runtime API headers only)
+        cmd += ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROCM, "include")]
     cmd += ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -1,0 +1,321 @@
+// block.cpp — the libbsc block container and public C API on top of the GPU sorters and the host coder.
+//
+// Follows the container semantics of libbsc/libbsc/libbsc.cpp: bsc_store :68-81, bsc_compress :213-338
+// (in-place twin :83-211), bsc_block_info :340-418, bsc_decompress :522-617; header layout
+// [0]blockSize [4]dataSize [8]mode [12]index [16]adler(data) [20]adler(payload) [24]adler(header[0..24)),
+// trailer = indexes[num] + num byte.  Stage entry points mirror bwt.cpp:178, st.cpp:990, coder.cpp:244.
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <mutex>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "../../../include/libbsc.h"
+#include "../../../include/bscgpu.h"
+#include "../device/dev_common.h"
+#include "qlfc.h"
+
+using namespace bschost;
+
+// ---- allocator hooks (platform.cpp:173-190) ---------------------------------------------------------
+static void* (*g_malloc)(size_t) = nullptr;
+static void* (*g_zero_malloc)(size_t) = nullptr;
+static void  (*g_free)(void*) = nullptr;
+static void* bsc_malloc(size_t n) { return g_malloc ? g_malloc(n) : malloc(n); }
+static void  bsc_free(void* p) { if (g_free) g_free(p); else free(p); }
+
+// ---- process-wide default GPU context for the host-pointer stage API -------------------------------
+// (the reference keeps one cached arena behind one lock, bwt.cpp:50-52; multi-GPU drivers create their
+// own bscgpu_ctx per device instead of going through this)
+static std::mutex   g_gpu_lock;
+static bscgpu_ctx*  g_gpu = nullptr;
+static int64_t      g_gpu_cap = 0;
+
+static int default_gpu(int64_t n, bscgpu_ctx** out)
+{
+    if (g_gpu && g_gpu_cap >= n) { *out = g_gpu; return LIBBSC_NO_ERROR; }
+    if (g_gpu) { bscgpu_destroy(g_gpu); g_gpu = nullptr; g_gpu_cap = 0; }
+    int dev = 0;
+    if (const char* e = getenv("BSC_GPU_DEVICE")) dev = atoi(e);
+    const int64_t cap = n + n / 32 + 4096;                    // headroom like bwt.cpp:106
+    int rc = bscgpu_create(&g_gpu, dev, cap);
+    if (rc != LIBBSC_NO_ERROR) { g_gpu = nullptr; return rc; }
+    g_gpu_cap = cap;
+    *out = g_gpu;
+    return LIBBSC_NO_ERROR;
+}
+
+static inline void put_i32(unsigned char* p, int v) { memcpy(p, &v, 4); }
+static inline int  get_i32(const unsigned char* p) { int v; memcpy(&v, p, 4); return v; }
+
+static int aux_rate(int n)          // largest power of two <= n / 8 (>= 1), bwt.cpp:192-197
+{
+    int mod = n / 8;
+    mod |= mod >> 1; mod |= mod >> 2; mod |= mod >> 4; mod |= mod >> 8; mod |= mod >> 16; mod >>= 1;
+    return mod + 1;
+}
+
+extern "C" {
+
+int bsc_init_full(int features, void* (*malloc_fn)(size_t), void* (*zero_malloc_fn)(size_t), void (*free_fn)(void*))
+{
+    (void)features;
+    g_malloc = malloc_fn; g_zero_malloc = zero_malloc_fn; g_free = free_fn;
+    (void)qlfc_tables();
+    return LIBBSC_NO_ERROR;
+}
+int bsc_init(int features) { return bsc_init_full(features, nullptr, nullptr, nullptr); }
+int bsc_bwt_init(int) { return LIBBSC_NO_ERROR; }
+int bsc_st_init(int) { return LIBBSC_NO_ERROR; }
+int bsc_coder_init(int) { (void)qlfc_tables(); return LIBBSC_NO_ERROR; }
+
+unsigned int bsc_adler32(const unsigned char* T, int n, int) { return adler32(T, n < 0 ? 0 : (size_t)n); }
+
+int bsc_coder_compress(const unsigned char* in, unsigned char* out, int n, int coder, int features)
+{ return coder_compress(in, out, n, coder, features); }
+int bsc_coder_decompress(const unsigned char* in, unsigned char* out, int coder, int features)
+{ return coder_decompress(in, out, coder, features); }
+int bsc_qlfc_encode_block(const unsigned char* in, unsigned char* out, int inSize, int outSize, int coder)
+{ return qlfc_encode_block(in, out, inSize, outSize, coder); }
+int bsc_qlfc_decode_block(const unsigned char* in, unsigned char* out, int coder)
+{ return qlfc_decode_block(in, out, coder); }
+int bsc_qlfc_ranks(const unsigned char* in, int n, unsigned char* ranks, unsigned char* firstSeen, int* pK)
+{
+    QlfcRuns R;
+    qlfc_runs(in, n, R);
+    memcpy(ranks, R.rank.data(), R.rank.size());
+    memcpy(firstSeen, R.first_seen, (size_t)R.nsym);
+    if (pK) *pK = R.nsym;
+    return (int)R.rank.size();
+}
+
+// ---- sorters: GPU only ---------------------------------------------------------------------------------
+int bsc_bwt_encode(unsigned char* T, int n, unsigned char* num_indexes, int* indexes, int features)
+{
+    (void)features;
+    if (T == nullptr || n < 0) return LIBBSC_BAD_PARAMETER;
+    if (n == 0) { if (num_indexes) *num_indexes = 0; return 0; }
+    std::lock_guard<std::mutex> g(g_gpu_lock);
+    bscgpu_ctx* c = nullptr;
+    int rc = default_gpu(n, &c);
+    if (rc != LIBBSC_NO_ERROR) return rc;
+    if (num_indexes != nullptr && indexes != nullptr) {
+        const int r = aux_rate(n);
+        if (r < 2) return LIBBSC_BAD_PARAMETER;               // libsais_bwt_aux rejects r < 2 (libsais.c:6711)
+        uint32_t I[256];
+        const int cnt = (n - 1) / r;
+        if (cnt + 1 > 256) return LIBBSC_BAD_PARAMETER;
+        int64_t res = bscgpu_bwt_aux(c, T, T, n, r, I);
+        if (res < 0) return (int)res;
+        *num_indexes = (unsigned char)cnt;
+        for (int t = 0; t < cnt; ++t) indexes[t] = (int)I[t + 1] - 1;     // bwt.cpp:205-209
+        return (int)I[0];
+    }
+    return (int)bscgpu_bwt(c, T, T, n);
+}
+
+int bsc_st_encode(unsigned char* T, int n, int k, int features)
+{
+    (void)features;
+    if (T == nullptr || n < 0) return LIBBSC_BAD_PARAMETER;
+    if (k < 3 || k > 8) return LIBBSC_BAD_PARAMETER;
+    if (n <= 1) return 0;
+    std::lock_guard<std::mutex> g(g_gpu_lock);
+    bscgpu_ctx* c = nullptr;
+    int rc = default_gpu(n, &c);
+    if (rc != LIBBSC_NO_ERROR) return rc;
+    return bscgpu_st_encode(c, T, n, k);
+}
+
+// ---- container ---------------------------------------------------------------------------------------------
+int bsc_store(const unsigned char* input, unsigned char* output, int n, int)
+{
+    const unsigned a = adler32(input, (size_t)n);
+    memmove(output + LIBBSC_HEADER_SIZE, input, (size_t)n);
+    put_i32(output + 0, n + LIBBSC_HEADER_SIZE);
+    put_i32(output + 4, n);
+    put_i32(output + 8, 0);
+    put_i32(output + 12, 0);
+    put_i32(output + 16, (int)a);
+    put_i32(output + 20, (int)a);
+    put_i32(output + 24, (int)adler32(output, 24));
+    return n + LIBBSC_HEADER_SIZE;
+}
+
+static int make_mode(int sorter, int coder, int lzpHashSize, int lzpMinLen, int* mode_out)
+{
+    int mode;
+    if (sorter == LIBBSC_BLOCKSORTER_BWT || (sorter >= LIBBSC_BLOCKSORTER_ST3 && sorter <= LIBBSC_BLOCKSORTER_ST8)) mode = sorter;
+    else return LIBBSC_BAD_PARAMETER;
+    if (coder < LIBBSC_CODER_QLFC_STATIC || coder > LIBBSC_CODER_QLFC_FAST) return LIBBSC_BAD_PARAMETER;
+    mode += coder << 5;
+    if (lzpMinLen != 0 || lzpHashSize != 0) {
+        if (lzpMinLen < 4 || lzpMinLen > 255) return LIBBSC_BAD_PARAMETER;
+        if (lzpHashSize < 10 || lzpHashSize > 28) return LIBBSC_BAD_PARAMETER;
+        return LIBBSC_NOT_SUPPORTED;       // LZP is outside the hot-path scope
+    }
+    *mode_out = mode;
+    return LIBBSC_NO_ERROR;
+}
+
+// Shared tail of bsc_compress: `sorted` holds the sorter output (lzSize bytes) at output[0..), finish the block.
+static int finish_block(const unsigned char* input, unsigned adler_data, unsigned char* output, int n, int mode, int index,
+                        int num_indexes, const int* indexes, int coder, int features, bool inplace)
+{
+    unsigned char* buffer = (unsigned char*)bsc_malloc((size_t)n + 4096);
+    if (!buffer) return LIBBSC_NOT_ENOUGH_MEMORY;
+    int result = coder_compress(output, buffer, n, coder, features);
+    if (result >= LIBBSC_NO_ERROR) memcpy(output + LIBBSC_HEADER_SIZE, buffer, (size_t)result);
+    bsc_free(buffer);
+    if (result < LIBBSC_NO_ERROR || result + 1 + 4 * num_indexes >= n) {
+        if (inplace) return LIBBSC_NOT_COMPRESSIBLE;          // libbsc.cpp:188-191
+        return bsc_store(input, output, n, features);         // libbsc.cpp:315-318
+    }
+    if (num_indexes > 0) memcpy(output + LIBBSC_HEADER_SIZE + result, indexes, (size_t)4 * num_indexes);
+    output[LIBBSC_HEADER_SIZE + result + 4 * num_indexes] = (unsigned char)num_indexes;
+    result += 1 + 4 * num_indexes;
+    put_i32(output + 0, result + LIBBSC_HEADER_SIZE);
+    put_i32(output + 4, n);
+    put_i32(output + 8, mode);
+    put_i32(output + 12, index);
+    put_i32(output + 16, (int)adler_data);
+    put_i32(output + 20, (int)adler32(output + LIBBSC_HEADER_SIZE, (size_t)result));
+    put_i32(output + 24, (int)adler32(output, 24));
+    return result + LIBBSC_HEADER_SIZE;
+}
+
+int bsc_compress(const unsigned char* input, unsigned char* output, int n, int lzpHashSize, int lzpMinLen,
+                 int blockSorter, int coder, int features)
+{
+    const bool inplace = (input == output);
+    int mode = 0;
+    int rc = make_mode(blockSorter, coder, lzpHashSize, lzpMinLen, &mode);
+    if (rc != LIBBSC_NO_ERROR) return rc;
+    if (n < 0 || n > (inplace ? 2146435072 : 1073741824)) return LIBBSC_BAD_PARAMETER;
+    if (n <= LIBBSC_HEADER_SIZE) return bsc_store(input, output, n, features);
+
+    const unsigned adler_data = adler32(input, (size_t)n);
+    if (!inplace) memcpy(output, input, (size_t)n);
+
+    int indexes[256];
+    unsigned char num_indexes = 0;
+    int index;
+    if (blockSorter == LIBBSC_BLOCKSORTER_BWT) index = bsc_bwt_encode(output, n, &num_indexes, indexes, features);
+    else                                       index = bsc_st_encode(output, n, blockSorter, features);
+    if (n < 64 * 1024) num_indexes = 0;                       // libbsc.cpp:176
+    if (index < LIBBSC_NO_ERROR) return index;
+    return finish_block(input, adler_data, output, n, mode, index, num_indexes, indexes, coder, features, inplace);
+}
+
+int bsc_block_info(const unsigned char* hdr, int headerSize, int* pBlockSize, int* pDataSize, int)
+{
+    if (headerSize < LIBBSC_HEADER_SIZE) return LIBBSC_UNEXPECTED_EOB;
+    if ((unsigned)get_i32(hdr + 24) != adler32(hdr, 24)) return LIBBSC_DATA_CORRUPT;
+    const int blockSize = get_i32(hdr + 0), dataSize = get_i32(hdr + 4), mode = get_i32(hdr + 8), index = get_i32(hdr + 12);
+    const int lzpHashSize = (mode >> 16) & 0xff, lzpMinLen = (mode >> 8) & 0xff, coder = (mode >> 5) & 0x7, sorter = mode & 0x1f;
+
+    int test = 0;
+    if (sorter == LIBBSC_BLOCKSORTER_BWT || (sorter >= LIBBSC_BLOCKSORTER_ST3 && sorter <= LIBBSC_BLOCKSORTER_ST8)) test = sorter;
+    else if (sorter > 0) return LIBBSC_DATA_CORRUPT;
+    if (coder >= LIBBSC_CODER_QLFC_STATIC && coder <= LIBBSC_CODER_QLFC_FAST) test += coder << 5;
+    else if (coder > 0) return LIBBSC_DATA_CORRUPT;
+    if (lzpMinLen != 0 || lzpHashSize != 0) {
+        if (lzpMinLen < 4 || lzpMinLen > 255) return LIBBSC_DATA_CORRUPT;
+        if (lzpHashSize < 10 || lzpHashSize > 28) return LIBBSC_DATA_CORRUPT;
+        test += (lzpMinLen << 8) + (lzpHashSize << 16);
+    }
+    if (test != mode) return LIBBSC_DATA_CORRUPT;
+    if (blockSize < LIBBSC_HEADER_SIZE || blockSize > LIBBSC_HEADER_SIZE + dataSize) return LIBBSC_DATA_CORRUPT;
+    if (index < 0 || index > dataSize) return LIBBSC_DATA_CORRUPT;
+    if (pBlockSize) *pBlockSize = blockSize;
+    if (pDataSize) *pDataSize = dataSize;
+    return LIBBSC_NO_ERROR;
+}
+
+// ---- GPU-resident compress: Adler-32 + sorter on the device, QLFC on host threads --------------------
+int bscgpu_compress_device(bscgpu_ctx* c, const void* dInput, uint8_t* output, int n, int blockSorter, int coder, int features)
+{
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    if (!c || !dInput || !output) return LIBBSC_BAD_PARAMETER;
+    int mode = 0;
+    int rc = make_mode(blockSorter, coder, 0, 0, &mode);
+    if (rc != LIBBSC_NO_ERROR) return rc;
+    if (n < 0 || n > c->max_n) return LIBBSC_BAD_PARAMETER;
+    if (hipSetDevice(c->device) != hipSuccess) return LIBBSC_GPU_ERROR;
+    const auto t_all = clk::now();
+    if (n <= LIBBSC_HEADER_SIZE) {
+        unsigned char tmp[LIBBSC_HEADER_SIZE + 1];
+        if (n > 0 && hipMemcpy(tmp, dInput, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return LIBBSC_GPU_ERROR;
+        return bsc_store(tmp, output, n, features);
+    }
+    auto t0 = clk::now();
+    uint32_t adler_data = 0;
+    rc = adler32_device(c, (const u8*)dInput, n, &adler_data);
+    if (rc < 0) return rc;
+    c->stage_ms[0] = ms_since(t0);
+
+    t0 = clk::now();
+    int index = 0, num_indexes = 0, indexes[256];
+    if (blockSorter == LIBBSC_BLOCKSORTER_BWT) {
+        const int r = aux_rate(n);
+        uint32_t I[256];
+        int64_t primary = 0;
+        rc = bwt_device(c, (const u8*)dInput, c->dL, n, r, I, &primary);
+        if (rc < 0) return rc;
+        index = (int)primary;
+        num_indexes = (n - 1) / r;
+        for (int t = 0; t < num_indexes; ++t) indexes[t] = (int)I[t + 1] - 1;
+    } else {
+        rc = st_device(c, (const u8*)dInput, c->dL, n, blockSorter, &index);
+        if (rc < 0) return rc;
+    }
+    if (n < 64 * 1024) num_indexes = 0;
+    c->stage_ms[1] = ms_since(t0);
+
+    t0 = clk::now();
+    if (hipMemcpyAsync(output, c->dL, (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return LIBBSC_GPU_ERROR;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return LIBBSC_GPU_ERROR;
+    c->stage_ms[2] = ms_since(t0);
+
+    t0 = clk::now();
+    int res = finish_block(nullptr, adler_data, output, n, mode, index, num_indexes, indexes, coder, features, true);
+    if (res == LIBBSC_NOT_COMPRESSIBLE) {                     // store path needs the original bytes back
+        if (hipMemcpy(output + LIBBSC_HEADER_SIZE, dInput, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return LIBBSC_GPU_ERROR;
+        put_i32(output + 0, n + LIBBSC_HEADER_SIZE); put_i32(output + 4, n); put_i32(output + 8, 0); put_i32(output + 12, 0);
+        put_i32(output + 16, (int)adler_data); put_i32(output + 20, (int)adler_data);
+        put_i32(output + 24, (int)adler32(output, 24));
+        res = n + LIBBSC_HEADER_SIZE;
+    }
+    c->stage_ms[3] = ms_since(t0);
+    c->stage_ms[4] = ms_since(t_all);
+    return res;
+}
+
+// ---- `synth-text v1` -----------------------------------------------------------------
+int bsc_synth_text_v1(unsigned long long seed, unsigned char* out, long long n)
+{
+    if (seed == 0 || !out || n < 0) return LIBBSC_BAD_PARAMETER;
+    unsigned long long s = seed;
+    auto next = [&]() { s ^= s >> 12; s ^= s << 25; s ^= s >> 27; return s * 2685821657736338717ull; };
+    static thread_local unsigned char vocab[4096][10];
+    static thread_local unsigned char vlen[4096];
+    for (int w = 0; w < 4096; ++w) {
+        const int len = 2 + (int)(next() % 8);
+        vlen[w] = (unsigned char)len;
+        for (int i = 0; i < len; ++i) vocab[w][i] = (unsigned char)('a' + next() % 26);
+    }
+    long long pos = 0, words = 0;
+    while (pos < n) {
+        const unsigned long long r = next();
+        const unsigned idx = (unsigned)(((r & 0xfff) * ((r >> 12) & 0xfff)) >> 12);
+        for (int i = 0; i < vlen[idx] && pos < n; ++i) out[pos++] = vocab[idx][i];
+        ++words;
+        if (pos < n) out[pos++] = (words % 16 == 0) ? '\n' : ' ';
+    }
+    return LIBBSC_NO_ERROR;
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+// coder.cpp — block-level coder: split a sorted block into 1/2/4/8 sub-blocks at run boundaries, code each
+// independently (one host thread per sub-block), frame them.  Wire format and split rule are the
+// reference's (coder.cpp:52-59 counts, :70-109 split, :111-155 serial framing, :159-240 parallel framing).
+#include "qlfc.h"
+
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace bschost {
+
+enum { FEATURE_MULTITHREADING = 2 };
+
+int coder_num_blocks(int n)
+{
+    if (n < 256 * 1024)       return 1;
+    if (n < 4 * 1024 * 1024)  return 2;
+    if (n < 16 * 1024 * 1024) return 4;
+    return 8;
+}
+
+// Sub-block boundaries: sample every 32nd position (1, 33, 65, ...), count the sampled positions that
+// start a run, cut whenever the running count reaches total / nblocks, at that sampled position.
+void coder_split_blocks(const uint8_t* in, int n, int nblocks, int* start, int* size)
+{
+    int changes = 0;
+    for (int i = 1; i < n; i += 32) changes += (in[i] != in[i - 1]);
+
+    if (changes > nblocks) {
+        const int per_block = changes / nblocks;
+        int id = 0, seen = 0;
+        start[0] = 0;
+        for (int i = 1; i < n && id < nblocks - 1; i += 32) {
+            if (in[i] != in[i - 1] && ++seen == per_block) {
+                seen = 0;
+                size[id] = i - start[id];
+                start[++id] = i;
+            }
+        }
+        size[nblocks - 1] = n - start[nblocks - 1];
+    } else {
+        const int each = n / nblocks;
+        for (int p = 0; p < nblocks; ++p) {
+            start[p] = each * p;
+            size[p]  = (p != nblocks - 1) ? each : n - each * (nblocks - 1);
+        }
+    }
+}
+
+static inline void put_i32(uint8_t* p, int v) { memcpy(p, &v, 4); }
+static inline int  get_i32(const uint8_t* p) { int v; memcpy(&v, p, 4); return v; }
+
+static int compress_serial(const uint8_t* in, uint8_t* out, int n, int coder)
+{
+    const int nblocks = coder_num_blocks(n);
+    if (nblocks == 1) {
+        const int r = qlfc_encode_block(in, out + 1, n, n - 1, coder);
+        if (r < 0) return r;
+        out[0] = 1;
+        return r + 1;
+    }
+    int start[8], size[8];
+    coder_split_blocks(in, n, nblocks, start, size);
+    out[0] = (uint8_t)nblocks;
+    int optr = 1 + 8 * nblocks;
+    for (int b = 0; b < nblocks; ++b) {
+        int room = size[b];
+        if (room > n - optr) room = n - optr;
+        int r = qlfc_encode_block(in + start[b], out + optr, size[b], room, coder);
+        if (r < 0) {                                         // stored raw (coder.cpp:136-140)
+            if (optr + size[b] >= n) return NOT_COMPRESSIBLE;
+            r = size[b];
+            memcpy(out + optr, in + start[b], (size_t)size[b]);
+        }
+        put_i32(out + 1 + 8 * b, size[b]);
+        put_i32(out + 1 + 8 * b + 4, r);
+        optr += r;
+    }
+    return optr;
+}
+
+static int compress_parallel(const uint8_t* in, uint8_t* out, int n, int coder)
+{
+    const int nblocks = coder_num_blocks(n);
+    int start[8], size[8], res[8];
+    coder_split_blocks(in, n, nblocks, start, size);
+    std::vector<uint8_t> scratch((size_t)n + 64);
+    {
+        std::vector<std::thread> pool;
+        for (int b = 0; b < nblocks; ++b)
+            pool.emplace_back([&, b] {
+                int r = qlfc_encode_block(in + start[b], scratch.data() + start[b], size[b], size[b], coder);
+                res[b] = (r < 0) ? size[b] : r;             // failed sub-block is stored raw (coder.cpp:194)
+            });
+        for (auto& t : pool) t.join();
+    }
+    int total = 1 + 8 * nblocks;
+    for (int b = 0; b < nblocks; ++b) total += res[b];
+    if (total >= n) return NOT_COMPRESSIBLE;
+
+    out[0] = (uint8_t)nblocks;
+    int optr = 1 + 8 * nblocks;
+    for (int b = 0; b < nblocks; ++b) {
+        put_i32(out + 1 + 8 * b, size[b]);
+        put_i32(out + 1 + 8 * b + 4, res[b]);
+        memcpy(out + optr, (res[b] != size[b] ? scratch.data() : in) + start[b], (size_t)res[b]);
+        optr += res[b];
+    }
+    return total;
+}
+
+int coder_compress(const uint8_t* in, uint8_t* out, int n, int coder, int features)
+{
+    if (coder != CODER_STATIC && coder != CODER_ADAPTIVE && coder != CODER_FAST) return BAD_PARAMETER;
+    if (coder_num_blocks(n) != 1 && (features & FEATURE_MULTITHREADING)) return compress_parallel(in, out, n, coder);
+    return compress_serial(in, out, n, coder);
+}
+
+int coder_decompress(const uint8_t* in, uint8_t* out, int coder, int features)
+{
+    if (coder != CODER_STATIC && coder != CODER_ADAPTIVE && coder != CODER_FAST) return BAD_PARAMETER;
+    const int nblocks = in[0];
+    if (nblocks == 1) return qlfc_decode_block(in + 1, out, coder);
+    if (nblocks < 1 || nblocks > 8) return DATA_CORRUPT;   // the format never writes more than 8 (coder.cpp:52-59)
+
+    int res[8], iptr[8], optr[8], isz[8], osz[8];
+    int ip = 1 + 8 * nblocks, op = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        osz[b] = get_i32(in + 1 + 8 * b);
+        isz[b] = get_i32(in + 1 + 8 * b + 4);
+        iptr[b] = ip; optr[b] = op;
+        ip += isz[b]; op += osz[b];
+    }
+    auto one = [&](int b) {
+        if (isz[b] != osz[b]) res[b] = qlfc_decode_block(in + iptr[b], out + optr[b], coder);
+        else { res[b] = isz[b]; memcpy(out + optr[b], in + iptr[b], (size_t)isz[b]); }
+    };
+    if (features & FEATURE_MULTITHREADING) {
+        std::vector<std::thread> pool;
+        for (int b = 0; b < nblocks; ++b) pool.emplace_back(one, b);
+        for (auto& t : pool) t.join();
+    } else {
+        for (int b = 0; b < nblocks; ++b) one(b);
+    }
+    int total = 0, err = OK;
+    for (int b = 0; b < nblocks; ++b) { if (res[b] < 0) err = res[b]; total += res[b]; }
+    return err == OK ? total : err;
+}
+
+// Adler-32 (adler32.cpp:82-204): s1 = 1 + sum, s2 = sum of s1, mod 65521; deferred modulo every 5552 bytes.
+uint32_t adler32(const uint8_t* p, size_t n)
+{
+    uint32_t s1 = 1, s2 = 0;
+    while (n > 0) {
+        size_t k = n < 5552 ? n : 5552;
+        n -= k;
+        while (k >= 8) {
+            s1 += p[0]; s2 += s1; s1 += p[1]; s2 += s1; s1 += p[2]; s2 += s1; s1 += p[3]; s2 += s1;
+            s1 += p[4]; s2 += s1; s1 += p[5]; s2 += s1; s1 += p[6]; s2 += s1; s1 += p[7]; s2 += s1;
+            p += 8; k -= 8;
+        }
+        while (k--) { s1 += *p++; s2 += s1; }
+        s1 %= 65521u; s2 %= 65521u;
+    }
+    return s1 | (s2 << 16);
+}
+
+}  // namespace bschost

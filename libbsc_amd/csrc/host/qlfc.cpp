@@ -1,0 +1,427 @@
+// qlfc.cpp — host-side QLFC encoders (static -e1, adaptive -e2, fast -e0), bit-exact with libbsc 3.3.5.
+//
+// Stream definition followed (reference file:line): header word + alphabet bits qlfc.cpp:852-891 (static),
+// :486-525 (adaptive), :1146-1183 (fast); per-run decision tree :896-1126 / :530-820 / :1186-1331;
+// counter update predictor.h:53-61; mixer predictor.h:121-183; range coder rangecoder.h:83-177.
+// The organisation (flat run arrays -> templated decision walker -> range encoder) is ours.
+#include "qlfc.h"
+
+#include <cstring>
+#include <memory>
+#include <algorithm>
+
+#include "qlfc_data.inc"
+
+namespace bschost {
+
+// ------------------------------------------------------------------------------------------------
+// tables
+// ------------------------------------------------------------------------------------------------
+static const QlfcTables* build_tables()
+{
+    QlfcTables* t = new QlfcTables();
+    for (int i = 0; i < 4097; ++i) {
+        t->stretch[i] = (short)((kStretchPacked[i >> 2] >> (16 * (i & 3))) & 0xffff);
+        t->squash[i]  = (short)((kSquashPacked[i >> 2] >> (16 * (i & 3))) & 0xffff);
+    }
+    for (int i = 0; i < 32768; ++i) t->rank_state[i] = (uint8_t)(kRankStatePacked[i >> 3] >> (8 * (i & 7)));
+    for (int i = 0; i < 8192; ++i)  t->run_state[i]  = (uint8_t)(kRunStatePacked[i >> 3] >> (8 * (i & 7)));
+    return t;
+}
+const QlfcTables& qlfc_tables()
+{
+    static const QlfcTables* t = build_tables();
+    return *t;
+}
+
+static inline int bsr32(unsigned x) { return x ? 31 - __builtin_clz(x) : 0; }
+
+// ------------------------------------------------------------------------------------------------
+// run / rank front end
+// ------------------------------------------------------------------------------------------------
+void qlfc_runs(const uint8_t* in, int n, QlfcRuns& out)
+{
+    out.sym.clear(); out.rank.clear(); out.len.clear(); out.nsym = 0;
+    if (n <= 0) return;
+    // pass 1: maximal runs
+    {
+        size_t guess = (size_t)n / 2 + 16;
+        out.sym.reserve(guess); out.len.reserve(guess);
+        int i = 0;
+        while (i < n) {
+            const uint8_t c = in[i];
+            int j = i + 1;
+            // word-at-a-time scan for long runs
+            if (j + 8 <= n) {
+                const uint64_t pat = 0x0101010101010101ull * c;
+                while (j + 8 <= n) {
+                    uint64_t w; memcpy(&w, in + j, 8);
+                    const uint64_t x = w ^ pat;
+                    if (x) { j += __builtin_ctzll(x) >> 3; goto done; }
+                    j += 8;
+                }
+            }
+            while (j < n && in[j] == c) ++j;
+        done:
+            out.sym.push_back(c);
+            out.len.push_back((uint32_t)(j - i));
+            i = j;
+        }
+    }
+    // pass 2: the rank of a run is the move-to-front position its symbol has when it is seen NEXT
+    const size_t m = out.sym.size();
+    out.rank.assign(m, 0);
+    uint8_t mtf[256];
+    int     pos_of_last[256];
+    int     nseen = 0;
+    for (int c = 0; c < 256; ++c) pos_of_last[c] = -1;
+    for (size_t j = 0; j < m; ++j) {
+        const uint8_t c = out.sym[j];
+        const int prev = pos_of_last[c];
+        if (prev < 0) {
+            out.first_seen[out.nsym++] = c;
+            memmove(mtf + 1, mtf, (size_t)nseen);
+            mtf[0] = c; ++nseen;
+        } else {
+            int p = 1;                              // mtf[0] is the previous run's symbol, never c
+            while (mtf[p] != c) ++p;
+            out.rank[(size_t)prev] = (uint8_t)p;
+            memmove(mtf + 1, mtf, (size_t)p);
+            mtf[0] = c;
+        }
+        pos_of_last[c] = (int)j;
+    }
+    for (int p = 0; p < nseen; ++p) out.rank[(size_t)pos_of_last[mtf[p]]] = (uint8_t)p;   // last occurrences
+    out.rank[m - 1] = 1;                                                                  // qlfc.cpp:249/449
+}
+
+// ------------------------------------------------------------------------------------------------
+// range encoder: 32-bit range, 64-bit low (bit 32 = carry), 16-bit little-endian output units
+// ------------------------------------------------------------------------------------------------
+class RangeEncoder {
+public:
+    void init(uint8_t* out, int out_size)
+    {
+        begin_ = out_ = out;
+        limit_ = (ptrdiff_t)out_size - 16;          // rangecoder.h:127 (EOB margin)
+        low_ = 0; range_ = 0xffffffffu; cache_ = 0; held_ = 0;
+    }
+    bool full() const { return (out_ - begin_) >= limit_; }
+
+    template <int P> inline void encode(unsigned bit, int p)
+    {
+        if (range_ < 0x10000u) { shift(); range_ <<= 16; }
+        const uint32_t r = (range_ >> P) * (uint32_t)p;
+        if (bit) { low_ += r; range_ -= r; } else range_ = r;
+    }
+    inline void encode_half(unsigned bit) { encode<12>(bit, 2048); }     // rangecoder.h:179-182
+    void encode_word(uint32_t w) { for (int b = 31; b >= 0; --b) encode_half((w >> b) & 1u); }
+
+    int finish()
+    {
+        if (range_ < 0x10000u) shift();
+        shift(); shift(); shift();
+        return (int)(out_ - begin_);
+    }
+
+private:
+    inline void put16(uint32_t v) { out_[0] = (uint8_t)v; out_[1] = (uint8_t)(v >> 8); out_ += 2; }
+    void shift()
+    {
+        const uint32_t low32 = (uint32_t)low_;
+        const uint32_t carry = (uint32_t)(low_ >> 32);
+        if (low32 < 0xffff0000u || carry) {
+            put16(cache_ + carry);
+            for (; held_; --held_) put16(carry - 1u);     // 0xffff without carry, 0x0000 after one
+            cache_ = low32 >> 16;
+        } else {
+            ++held_;
+        }
+        low_ = (uint64_t)(uint32_t)(low32 << 16);
+    }
+
+    uint64_t low_; uint32_t range_, cache_, held_;
+    uint8_t *out_, *begin_; ptrdiff_t limit_;
+};
+
+// ------------------------------------------------------------------------------------------------
+// model state
+// ------------------------------------------------------------------------------------------------
+enum { RANK_FIRST = 0, RANK_EXP, RANK_MANT, RANK_ESC, RUN_FIRST, RUN_EXP, RUN_MANT };
+
+struct Mixer {                       // predictor.h:74-213
+    int   w0, w1, w2;
+    short map[17];
+    void init(const QlfcTables& T)
+    {
+        w0 = w1 = 2048 << 5; w2 = 0;
+        for (int p = 0; p < 17; ++p) map[p] = T.squash[2048 + (p - 8) * 256];
+    }
+};
+
+static inline void bump(short& p, unsigned bit, int th0, int ar0, int th1, int ar1)
+{
+    // predictor.h:53-61 (the four-argument form at :44-50 is algebraically the same map)
+    if (bit) p = (short)(p - (((p - th1) * ar1) >> 12));
+    else     p = (short)(p + (((4096 - th0 - p) * ar0) >> 12));
+}
+
+struct Counters1 {
+    // rank side
+    short rT_stat, rT_state[256], rT_chr[256];
+    short rE_stat[8], rE_state[256][8], rE_chr[256][8];
+    short rM_stat[8][256], rM_state[8][256][256], rM_chr[8][256][256];
+    short rP_stat[256], rP_state[256][256], rP_chr[256][256];
+    // run side
+    short nT_stat, nT_state[256], nT_chr[256];
+    short nE_stat[32], nE_state[256][32], nE_chr[256][32];
+    short nM_stat[32][32], nM_state[32][256][32], nM_chr[32][256][32];
+};
+struct Mixers1 {
+    Mixer rank[256], rank_exp[8][8], rank_mant[8], rank_esc[256], run[256], run_exp[32][32], run_mant[32];
+};
+
+static void fill_shorts(void* p, size_t bytes, short v)
+{
+    short* s = (short*)p;
+    std::fill(s, s + bytes / 2, v);
+}
+
+// One binary decision of class CLS: three counters (+ mixer), update, code.
+template <int CLS, bool ADAPT>
+static inline void decide(RangeEncoder& rc, const QlfcTables& T, unsigned bit, short& st, short& ch, short& sp, Mixer* mx)
+{
+    constexpr const short* P = ADAPT ? kAdaptiveParams[CLS] : kStaticParams[CLS];
+    const int p0 = ch, p1 = st, p2 = sp;
+    bump(st, bit, P[0], P[1], P[2],  P[3]);
+    bump(ch, bit, P[4], P[5], P[6],  P[7]);
+    bump(sp, bit, P[8], P[9], P[10], P[11]);
+    int p;
+    if (!ADAPT) {
+        p = (p0 * P[16] + p1 * P[17] + p2 * P[18]) >> 5;
+    } else {
+        const int s0 = T.stretch[p0], s1 = T.stretch[p1], s2 = T.stretch[p2];
+        short sp16 = (short)((s0 * mx->w0 + s1 * mx->w1 + s2 * mx->w2) >> 17);
+        if (sp16 < -2047) sp16 = -2047;
+        if (sp16 >  2047) sp16 =  2047;
+        const int frac = sp16 & 255;
+        const int idx  = (sp16 + 2048) >> 8;
+        const int sq   = T.squash[2048 + sp16];
+        const int mapped = mx->map[idx] + (((mx->map[idx + 1] - mx->map[idx]) * frac) >> 8);
+        p = (3 * sq + mapped) >> 2;
+        bump(mx->map[idx],     bit, P[12], P[13], P[14], P[15]);
+        bump(mx->map[idx + 1], bit, P[12], P[13], P[14], P[15]);
+        const int eps = p - (bit ? 1 : 4095);
+        mx->w0 -= (P[16] * eps * s0) >> 16;
+        mx->w1 -= (P[17] * eps * s1) >> 16;
+        mx->w2 -= (P[18] * eps * s2) >> 16;
+    }
+    rc.encode<12>(bit, p);
+}
+
+// Alphabet header shared by the three coders: for every symbol in order of first appearance emit only
+// the bits not implied by the set of still-possible symbols; a repeated symbol terminates the list.
+template <class EmitBit>
+static int encode_alphabet(const QlfcRuns& R, EmitBit&& emit)
+{
+    bool used[256] = {false};
+    int prev = -1;
+    int max_rank = 7;
+    for (int slot = 0; slot < 256; ++slot) {
+        const int cur = (slot < R.nsym) ? R.first_seen[slot] : R.first_seen[R.nsym - 1];
+        for (int bit = 7; bit >= 0; --bit) {
+            bool can0 = false, can1 = false;
+            for (int c = 0; c < 256 && !(can0 && can1); ++c) {
+                if ((c == prev || !used[c]) && (cur >> (bit + 1)) == (c >> (bit + 1))) {
+                    if (c & (1 << bit)) can1 = true; else can0 = true;
+                }
+            }
+            if (can0 && can1) emit((unsigned)((cur >> bit) & 1));
+        }
+        if (cur == prev) { max_rank = bsr32((unsigned)(slot - 1)); break; }
+        prev = cur; used[cur] = true;
+    }
+    return max_rank;
+}
+
+template <bool ADAPT>
+static int encode_model1(const uint8_t* in, uint8_t* out, int in_size, int out_size)
+{
+    const QlfcTables& T = qlfc_tables();
+    QlfcRuns R;
+    qlfc_runs(in, in_size, R);
+
+    std::unique_ptr<Counters1> Cn(new Counters1);
+    fill_shorts(Cn.get(), sizeof(Counters1), 2048);
+    std::unique_ptr<Mixers1> Mx;
+    if (ADAPT) {
+        Mx.reset(new Mixers1);
+        Mixer* all = reinterpret_cast<Mixer*>(Mx.get());
+        for (size_t i = 0; i < sizeof(Mixers1) / sizeof(Mixer); ++i) all[i].init(T);
+    }
+    Counters1& K = *Cn;
+    Mixers1* M = Mx.get();
+
+    RangeEncoder rc;
+    rc.init(out, out_size);
+    rc.encode_word((uint32_t)in_size);
+    const int max_rank = encode_alphabet(R, [&](unsigned b) { rc.encode_half(b); });
+
+    int ctx_rank0 = 0, ctx_rank4 = 0, ctx_run = 0, avg_rank = 0;
+    uint8_t rank_hist[256] = {0}, run_hist[256] = {0};
+
+    const size_t m = R.sym.size();
+    for (size_t j = 0; j < m; ++j) {
+        if (rc.full()) return NOT_COMPRESSIBLE;
+        const int c = R.sym[j];
+        int rank = R.rank[j];
+        const int run = (int)R.len[j];
+
+        // ---------------- rank ----------------
+        int hist = rank_hist[c];
+        int state = T.rank_state[(ctx_run << 11) | (ctx_rank4 << 3) | hist];
+        if (avg_rank < 32) {
+            decide<RANK_FIRST, ADAPT>(rc, T, rank != 1, K.rT_state[state], K.rT_chr[c], K.rT_stat, ADAPT ? &M->rank[c] : nullptr);
+            if (rank == 1) {
+                rank_hist[c] = 0;
+            } else {
+                const int bits = bsr32((unsigned)rank);
+                rank_hist[c] = (uint8_t)bits;
+                for (int b = 1; b < bits; ++b)
+                    decide<RANK_EXP, ADAPT>(rc, T, 1, K.rE_state[state][b - 1], K.rE_chr[c][b - 1], K.rE_stat[b - 1],
+                                            ADAPT ? &M->rank_exp[hist > b ? hist : b][b] : nullptr);
+                if (bits < max_rank)
+                    decide<RANK_EXP, ADAPT>(rc, T, 0, K.rE_state[state][bits - 1], K.rE_chr[c][bits - 1], K.rE_stat[bits - 1],
+                                            ADAPT ? &M->rank_exp[hist > bits ? hist : bits][bits] : nullptr);
+                short* ms = K.rM_state[bits][state]; short* mc = K.rM_chr[bits][c]; short* mp = K.rM_stat[bits];
+                for (int ctx = 1, b = bits - 1; b >= 0; --b) {
+                    const unsigned v = (unsigned)(rank >> b) & 1u;
+                    decide<RANK_MANT, ADAPT>(rc, T, v, ms[ctx], mc[ctx], mp[ctx], ADAPT ? &M->rank_mant[bits] : nullptr);
+                    ctx += ctx + (int)v;
+                }
+            }
+        } else {
+            rank_hist[c] = (uint8_t)bsr32((unsigned)rank);
+            short* es = K.rP_state[state]; short* ec = K.rP_chr[c]; short* ep = K.rP_stat;
+            for (int ctx = 1, b = max_rank; b >= 0; --b) {
+                const unsigned v = (unsigned)(rank >> b) & 1u;
+                decide<RANK_ESC, ADAPT>(rc, T, v, es[ctx], ec[ctx], ep[ctx], ADAPT ? &M->rank_esc[ctx] : nullptr);
+                ctx += ctx + (int)v;
+            }
+        }
+
+        // ---------------- run length ----------------
+        avg_rank = (avg_rank * 124 + rank * 4) >> 7;
+        rank -= 1;
+        hist = run_hist[c];
+        state = T.run_state[(ctx_rank0 << 10) | (ctx_run << 6) | ((rank < 7 ? rank : 7) << 3) | (hist < 7 ? hist : 7)];
+        decide<RUN_FIRST, ADAPT>(rc, T, run != 1, K.nT_state[state], K.nT_chr[c], K.nT_stat, ADAPT ? &M->run[c] : nullptr);
+        if (run == 1) {
+            run_hist[c] = (uint8_t)((run_hist[c] + 2) >> 2);
+        } else {
+            const int bits = bsr32((unsigned)run);
+            run_hist[c] = (uint8_t)((run_hist[c] + 3 * bits + 3) >> 2);
+            for (int b = 1; b < bits; ++b)
+                decide<RUN_EXP, ADAPT>(rc, T, 1, K.nE_state[state][b - 1], K.nE_chr[c][b - 1], K.nE_stat[b - 1],
+                                       ADAPT ? &M->run_exp[hist > b ? hist : b][b] : nullptr);
+            decide<RUN_EXP, ADAPT>(rc, T, 0, K.nE_state[state][bits - 1], K.nE_chr[c][bits - 1], K.nE_stat[bits - 1],
+                                   ADAPT ? &M->run_exp[hist > bits ? hist : bits][bits] : nullptr);
+            short* ms = K.nM_state[bits][state]; short* mc = K.nM_chr[bits][c]; short* mp = K.nM_stat[bits];
+            for (int ctx = 1, b = bits - 1; b >= 0; --b) {
+                const unsigned v = (unsigned)(run >> b) & 1u;
+                decide<RUN_MANT, ADAPT>(rc, T, v, ms[ctx], mc[ctx], mp[ctx], ADAPT ? &M->run_mant[bits] : nullptr);
+                ctx = (bits <= 5) ? (ctx + ctx + (int)v) : (ctx + 1);
+            }
+        }
+
+        ctx_rank0 = ((ctx_rank0 << 1) | (rank == 0 ? 1 : 0)) & 0x7;
+        ctx_rank4 = ((ctx_rank4 << 2) | (rank < 3 ? rank : 3)) & 0xff;
+        ctx_run   = ((ctx_run   << 1) | (run < 3 ? 1 : 0)) & 0xf;
+    }
+    return rc.finish();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fast coder (-e0): one counter per context, shift updates, 13-bit (rank) / 11-bit (run) precision
+// ------------------------------------------------------------------------------------------------
+struct Counters2 {
+    short r_exp[256][8];  short r_mant[256][8][256];
+    short n_exp[256][32]; short n_mant[256][32][32];
+};
+template <int R> static inline void nudge(short& p, int target) { p = (short)(p - ((p - target) >> R)); }
+
+static int encode_model2(const uint8_t* in, uint8_t* out, int in_size, int out_size)
+{
+    QlfcRuns R;
+    qlfc_runs(in, in_size, R);
+    std::unique_ptr<Counters2> Cn(new Counters2);
+    fill_shorts(Cn->r_exp, sizeof(Cn->r_exp) + sizeof(Cn->r_mant), 4096);      // qlfc_model.cpp:74
+    fill_shorts(Cn->n_exp, sizeof(Cn->n_exp) + sizeof(Cn->n_mant), 1024);      // qlfc_model.cpp:75
+    Counters2& K = *Cn;
+
+    RangeEncoder rc;
+    rc.init(out, out_size);
+    rc.encode_word((uint32_t)in_size);
+    encode_alphabet(R, [&](unsigned b) { rc.encode<1>(b, 1); });               // qlfc.cpp:1174
+
+    const size_t m = R.sym.size();
+    for (size_t j = 0; j < m; ++j) {
+        if (rc.full()) return NOT_COMPRESSIBLE;
+        const int c = R.sym[j];
+        const unsigned rank = R.rank[j];
+        const unsigned run = R.len[j];
+        {
+            short* e = K.r_exp[c];
+            if (rank == 1) { const int p = e[0]; nudge<4>(e[0], 8016); rc.encode<13>(0, p); }
+            else {
+                { const int p = e[0]; nudge<4>(e[0], 83); rc.encode<13>(1, p); }
+                const int bits = bsr32(rank);
+                for (int b = 1; b < bits; ++b) { const int p = e[b]; nudge<4>(e[b], 122); rc.encode<13>(1, p); }
+                if (bits < 7) { const int p = e[bits]; nudge<4>(e[bits], 8114); rc.encode<13>(0, p); }
+                short* mt = K.r_mant[c][bits];
+                for (int ctx = 1, b = bits - 1; b >= 0; --b) {
+                    const unsigned v = (rank >> b) & 1u;
+                    const int p = mt[ctx]; nudge<7>(mt[ctx], v ? 235 : 7999); rc.encode<13>(v, p);
+                    ctx += ctx + (int)v;
+                }
+            }
+        }
+        {
+            short* e = K.n_exp[c];
+            if (run == 1) { const int p = e[0]; nudge<5>(e[0], 2025); rc.encode<11>(0, p); }
+            else {
+                { const int p = e[0]; nudge<5>(e[0], 42); rc.encode<11>(1, p); }
+                const int bits = bsr32(run);
+                for (int b = 1; b < bits; ++b) { const int p = e[b]; nudge<4>(e[b], 142); rc.encode<11>(1, p); }
+                { const int p = e[bits]; nudge<4>(e[bits], 1962); rc.encode<11>(0, p); }
+                short* mt = K.n_mant[c][bits];
+                if (bits <= 5) {
+                    for (int ctx = 1, b = bits - 1; b >= 0; --b) {
+                        const unsigned v = (run >> b) & 1u;
+                        const int p = mt[ctx]; nudge<6>(mt[ctx], v ? 147 : 1951); rc.encode<11>(v, p);
+                        ctx += ctx + (int)v;
+                    }
+                } else {
+                    for (int ctx = 1, b = bits - 1; b >= 0; --b, ++ctx) {
+                        const unsigned v = (run >> b) & 1u;
+                        const int p = mt[ctx]; nudge<5>(mt[ctx], v ? 46 : 1987); rc.encode<11>(v, p);
+                    }
+                }
+            }
+        }
+    }
+    return rc.finish();
+}
+
+int qlfc_encode_block(const uint8_t* in, uint8_t* out, int in_size, int out_size, int coder)
+{
+    if (in_size <= 0) return BAD_PARAMETER;
+    switch (coder) {
+        case CODER_STATIC:   return encode_model1<false>(in, out, in_size, out_size);
+        case CODER_ADAPTIVE: return encode_model1<true>(in, out, in_size, out_size);
+        case CODER_FAST:     return encode_model2(in, out, in_size, out_size);
+    }
+    return BAD_PARAMETER;
+}
+
+}  // namespace bschost

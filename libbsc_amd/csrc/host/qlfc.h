@@ -1,0 +1,62 @@
+// qlfc.h — host-side QLFC entropy coder (bit-exact with libbsc 3.3.5's coder/qlfc), internal API.
+//
+// The bit stream is fixed by the reference (qlfc.cpp:463-1336 encoders, rangecoder.h:38-271,
+// predictor.h:40-213, qlfc_model.h); the code organisation here is ours:
+//   * a run/rank front end (`qlfc_runs`) that turns a sorted sub-block into three flat arrays
+//     (symbol, rank, run length) — the part that is data-parallel and is meant to move to the GPU;
+//   * one templated "model walker" that enumerates the binary decisions of a run with their context
+//     slots, shared by the static (-e1) and adaptive (-e2) coders, specialised at compile time per
+//     decision class so every threshold/rate is an immediate;
+//   * the 32-bit-range / 16-bit-unit range encoder.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <vector>
+
+namespace bschost {
+
+// libbsc.h error codes
+enum : int {
+    OK = 0, BAD_PARAMETER = -1, NOT_ENOUGH_MEMORY = -2, NOT_COMPRESSIBLE = -3, NOT_SUPPORTED = -4,
+    UNEXPECTED_EOB = -5, DATA_CORRUPT = -6, GPU_ERROR = -7, GPU_NOT_SUPPORTED = -8, GPU_NOT_ENOUGH_MEMORY = -9
+};
+enum : int { CODER_STATIC = 1, CODER_ADAPTIVE = 2, CODER_FAST = 3 };
+
+// Lookup tables (unpacked once from qlfc_data.inc).
+struct QlfcTables {
+    short   stretch[4097];
+    short   squash[4097];
+    uint8_t rank_state[32768];
+    uint8_t run_state[8192];
+};
+const QlfcTables& qlfc_tables();
+
+// Run decomposition of a sub-block + QLFC ranks.
+//   sym[j], len[j]  : the j-th maximal run;
+//   rank[j]         : the QLFC rank of run j (qlfc.cpp:398-455): number of distinct symbols between run j and
+//                     the next run of the same symbol, or — for the last run of a symbol — the number of distinct
+//                     symbols that still occur later; the rank of the final run is forced to 1;
+//   first_seen[0..k): distinct symbols in order of first appearance (the stream's alphabet header).
+struct QlfcRuns {
+    std::vector<uint8_t>  sym;
+    std::vector<uint8_t>  rank;
+    std::vector<uint32_t> len;
+    uint8_t  first_seen[256];
+    int      nsym = 0;
+};
+void qlfc_runs(const uint8_t* in, int n, QlfcRuns& out);
+
+// Encode one sub-block (what coder.cpp:61 dispatches to).  Returns bytes written or NOT_COMPRESSIBLE.
+int qlfc_encode_block(const uint8_t* in, uint8_t* out, int in_size, int out_size, int coder);
+// Decode one sub-block; returns the decoded size or an error.
+int qlfc_decode_block(const uint8_t* in, uint8_t* out, int coder);
+
+// Block-level coder (coder.cpp:244 / :273): split into 1/2/4/8 sub-blocks, encode, frame.
+int coder_compress(const uint8_t* in, uint8_t* out, int n, int coder, int features);
+int coder_decompress(const uint8_t* in, uint8_t* out, int coder, int features);
+int coder_num_blocks(int n);
+void coder_split_blocks(const uint8_t* in, int n, int nblocks, int* start, int* size);
+
+uint32_t adler32(const uint8_t* p, size_t n);
+
+}  // namespace bschost

@@ -1,0 +1,121 @@
+"""CPU tests: the product's host-side coder / container against the compiled reference (oracle/_ref).
+No GPU needed: inputs to the coder are produced by the reference's own BWT."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from libbsc_amd import api
+
+
+def _texts():
+    from libbsc_amd.synth import synth_text_v1
+    rng = np.random.default_rng(5)
+    out = [("text300k", synth_text_v1(3, 300_000)), ("text1m", synth_text_v1(1, 1 << 20))]
+    out.append(("rand16-200k", rng.integers(0, 16, 200_000, dtype=np.uint8)))
+    out.append(("rand256-100k", rng.integers(0, 256, 100_000, dtype=np.uint8)))
+    out.append(("zeros-70k", np.zeros(70_000, np.uint8)))
+    out.append(("one-run-then-text", np.concatenate([np.full(100_000, 65, np.uint8), synth_text_v1(9, 50_000)])))
+    long_runs = np.repeat(rng.integers(0, 200, 3000, dtype=np.uint8), rng.integers(1, 3000, 3000))
+    out.append(("long-runs", long_runs))
+    allsym = np.concatenate([np.arange(256, dtype=np.uint8), rng.integers(0, 256, 50_000, dtype=np.uint8) // 3])
+    out.append(("all-256-symbols", allsym))
+    for n in (1, 2, 3, 29, 100, 1000):
+        out.append((f"tiny{n}", rng.integers(97, 100, n, dtype=np.uint8)))
+    return out
+
+
+def test_synth_generators_agree_and_match_survey_md5():
+    from libbsc_amd.synth import synth_text_v1
+    a = synth_text_v1(1, 1 << 20)
+    b = api.synth_text_v1(1, 1 << 20)
+    assert np.array_equal(a, b)
+    assert hashlib.md5(a.tobytes()).hexdigest() == "7e493144d260fc285567cb4145cf4737"
+    assert np.array_equal(synth_text_v1(7, 12345), api.synth_text_v1(7, 12345))
+
+
+def test_adler32_matches_reference(ref):
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 24, 5551, 5552, 5553, 100_000, 1 << 20):
+        d = rng.integers(0, 256, n, dtype=np.uint8)
+        assert api.bsc_adler32(d) == ref.adler32(d)
+    d = np.full(1 << 20, 255, np.uint8)
+    assert api.bsc_adler32(d) == ref.adler32(d)
+
+
+def test_qlfc_ranks_match_reference_transform(ref):
+    for name, T in _texts():
+        L, _, _ = ref.bwt_encode(T, aux=False)
+        want_ranks, want_mtf = ref.qlfc_transform(L)
+        ranks, first = api.bsc_qlfc_ranks(L)
+        assert np.array_equal(ranks, want_ranks), name
+        k = first.size
+        assert np.array_equal(first, want_mtf[:k]), name          # MTFTable[0..K) = first-appearance order
+        if k < 256:
+            assert want_mtf[k] == want_mtf[k - 1], name          # terminator (qlfc.cpp:252)
+
+
+@pytest.mark.parametrize("coder", [1, 2, 3])
+def test_qlfc_encode_block_matches_reference(ref, coder):
+    for name, T in _texts():
+        L, _, _ = ref.bwt_encode(T, aux=False)
+        want = ref.qlfc_encode_block(L, coder)
+        got = api.bsc_qlfc_encode_block(L, coder)
+        assert got == want, (name, coder, got if isinstance(got, int) else len(got), want if isinstance(want, int) else len(want))
+
+
+@pytest.mark.parametrize("coder", [1, 2, 3])
+@pytest.mark.parametrize("features", [1, 3])
+def test_coder_compress_matches_reference(ref, coder, features):
+    from libbsc_amd.synth import synth_text_v1
+    cases = _texts() + [("text5m", synth_text_v1(4, 5 << 20))]        # 4 sub-blocks
+    for name, T in cases:
+        L, _, _ = ref.bwt_encode(T, aux=False)
+        want = ref.coder_compress(L, coder, features=features)
+        got = api.bsc_coder_compress(L, coder, features=features)
+        assert got == want, (name, coder, features)
+
+
+def test_store_and_block_info_match_reference(ref):
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 28, 29, 1000):
+        d = rng.integers(0, 256, n, dtype=np.uint8)
+        ours = api.bsc_store(d)
+        out = np.empty(n + 28, np.uint8)
+        import ctypes as C
+        from oracle.refbind import u8p
+        r = ref.L.ref_bsc_store(d.ctypes.data_as(u8p), out.ctypes.data_as(u8p), n, 3)
+        assert ours == out[:r].tobytes()
+        assert api.bsc_block_info(ours) == (0, n + 28, n)
+        assert api.bsc_decompress(ours) == d.tobytes()
+    bad = bytearray(api.bsc_store(b"hello world, hello world, hello"))
+    bad[5] ^= 1
+    assert api.bsc_block_info(bytes(bad))[0] == api.DATA_CORRUPT
+    assert api.bsc_block_info(b"short")[0] == api.UNEXPECTED_EOB
+
+
+def test_parameter_validation_matches_reference():
+    d = np.zeros(1000, np.uint8)
+    assert api.bsc_compress(d, sorter=2) == api.BAD_PARAMETER
+    assert api.bsc_compress(d, sorter=9) == api.BAD_PARAMETER
+    assert api.bsc_compress(d, coder=0) == api.BAD_PARAMETER
+    assert api.bsc_compress(d, coder=4) == api.BAD_PARAMETER
+    assert api.bsc_compress(d, lzp_hash=9, lzp_min=128) == api.BAD_PARAMETER
+    assert api.bsc_compress(d, lzp_hash=15, lzp_min=3) == api.BAD_PARAMETER
+    assert api.bsc_compress(d, lzp_hash=15, lzp_min=128) == api.NOT_SUPPORTED      # LZP out of scope
+    small = np.arange(20, dtype=np.uint8)
+    assert api.bsc_compress(small) == api.bsc_store(small)                         # n <= 28 -> stored (libbsc.cpp:259)
+
+
+def test_native_library_exports_every_declared_symbol():
+    import re, os
+    from libbsc_amd import _native as N
+    L = N.lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = []
+    for h in ("include/libbsc.h", "include/bscgpu.h"):
+        txt = open(os.path.join(root, h)).read()
+        names += re.findall(r"(?:LIBBSC_API|BSCGPU_API)[^;(]*?\b(bsc\w*)\s*\(", txt)
+    assert len(names) > 30
+    for nm in names:
+        assert hasattr(L, nm), nm
