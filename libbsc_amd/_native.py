@@ -26,6 +26,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; load it FIRST so that our DT_NEEDED "libamdhip64.so.7" binds to
+    # the same runtime instead of pulling a second HIP runtime (/opt/rocm) into the process, which leaves
+    # whichever loads second without a usable device.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - pure-C deployments have no torch; /opt/rocm's runtime is used
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"native library {LIB_PATH} is missing — build it with `python -m libbsc_amd.build` "

@@ -55,6 +55,10 @@ class Ref:
         L.ref_wtime.restype = C.c_double
         self.features = features
         assert L.ref_bsc_init(features) == 0
+        # The GPU box has 256 hardware threads; libgomp teams of that size are slow to start and can
+        # fail to spawn under the container's pid limit.  Cap the reference's OpenMP team (callers that
+        # time the reference set the count explicitly and report it).
+        L.ref_omp_set_threads(min(os.cpu_count() or 1, int(os.environ.get("BSC_REF_THREADS", "16"))))
 
     # --- block API -------------------------------------------------------
     def compress(self, data, sorter=1, coder=1, lzp_hash=0, lzp_min=0, features=None):

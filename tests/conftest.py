@@ -3,6 +3,7 @@ import sys
 
 import pytest
 
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # reference's libgomp workers must not spin between calls
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
