@@ -166,3 +166,76 @@ class Ref:
 
     def set_threads(self, t):
         self.L.ref_omp_set_threads(int(t))
+
+
+class Oracle:
+    """The plain-C restatement (oracle/bsc_oracle.c).  Same method names as Ref where they overlap."""
+
+    def __init__(self, path=PORT_SO):
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} missing: run `make -C oracle port`")
+        L = self.L = C.CDLL(path)
+        L.orc_adler32.argtypes = [u8p, C.c_int]
+        L.orc_adler32.restype = C.c_uint
+        L.orc_bwt.argtypes = [u8p, C.c_int, u8p, i32p]
+        L.orc_st.argtypes = [u8p, C.c_int, C.c_int]
+        L.orc_qlfc_transform.argtypes = [u8p, u8p, C.c_int, u8p]
+        L.orc_qlfc_encode.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int]
+        L.orc_coder_compress.argtypes = [u8p, u8p, C.c_int, C.c_int]
+        L.orc_store.argtypes = [u8p, u8p, C.c_int]
+        L.orc_compress.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int]
+
+    @staticmethod
+    def _np(data, copy=False):
+        import numpy as np
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        a = np.ascontiguousarray(a)
+        return a.copy() if copy else a
+
+    def adler32(self, data):
+        a = self._np(data)
+        return int(self.L.orc_adler32(a.ctypes.data_as(u8p), a.size))
+
+    def bwt_encode(self, data, aux=True):
+        T = self._np(data, copy=True)
+        num = C.c_ubyte(0)
+        idx = (C.c_int * 256)()
+        if aux:
+            r = self.L.orc_bwt(T.ctypes.data_as(u8p), T.size, C.cast(C.byref(num), u8p), idx)
+        else:
+            r = self.L.orc_bwt(T.ctypes.data_as(u8p), T.size, None, None)
+        return T, r, [idx[i] for i in range(num.value)]
+
+    def st_encode(self, data, k):
+        T = self._np(data, copy=True)
+        r = self.L.orc_st(T.ctypes.data_as(u8p), T.size, k)
+        return T, r
+
+    def qlfc_transform(self, data):
+        import numpy as np
+        a = self._np(data)
+        buf = np.empty(a.size + 16, np.uint8)
+        mtf = np.empty(256, np.uint8)
+        m = self.L.orc_qlfc_transform(a.ctypes.data_as(u8p), buf.ctypes.data_as(u8p), a.size, mtf.ctypes.data_as(u8p))
+        return buf[a.size - m:a.size].copy(), mtf
+
+    def qlfc_encode_block(self, data, coder=1, out_size=None):
+        import numpy as np
+        a = self._np(data)
+        out = np.empty(a.size + 4096, np.uint8)
+        r = self.L.orc_qlfc_encode(a.ctypes.data_as(u8p), out.ctypes.data_as(u8p), a.size, a.size if out_size is None else out_size, coder)
+        return out[:r].tobytes() if r >= 0 else r
+
+    def coder_compress(self, data, coder=1):
+        import numpy as np
+        a = self._np(data)
+        out = np.empty(a.size + 4096, np.uint8)
+        r = self.L.orc_coder_compress(a.ctypes.data_as(u8p), out.ctypes.data_as(u8p), a.size, coder)
+        return out[:r].tobytes() if r >= 0 else r
+
+    def compress(self, data, sorter=1, coder=1):
+        import numpy as np
+        a = self._np(data)
+        out = np.empty(a.size + 28 + 4096, np.uint8)
+        r = self.L.orc_compress(a.ctypes.data_as(u8p), out.ctypes.data_as(u8p), a.size, sorter, coder)
+        return out[:r].tobytes() if r >= 0 else r
