@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--block", type=int, default=BLOCK)
     ap.add_argument("--sorter", type=int, default=1)
     ap.add_argument("--coder", type=int, default=1)
+    ap.add_argument("--depth", type=int, default=2, help="blocks in flight per GPU (host coder of block i overlaps the GPU stage of block i+1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -67,11 +68,27 @@ def main():
     gather_buf = torch.empty(n + 64, dtype=torch.uint8, device=dev)
 
     from libbsc_amd.multigpu import gather_blocks_to_rank0
+    pipe = ctx.pipe(args.depth)
+    stage = np.zeros(6)
 
-    def step():
-        blk = ctx.compress_device(d_in, n, args.sorter, args.coder, 3)
+    def finish(ticket):
+        blk = pipe.wait(ticket)
         if world > 1:       # final concatenation on rank 0 over RCCL / xGMI (sizes all_gather + send/recv)
             gather_blocks_to_rank0(blk, rank, world, dev, staging=gather_buf)
+        return blk
+
+    def run(steps, record=False):
+        """`steps` blocks through the pipe: GPU stage of block i+1 overlaps the host coding of block i."""
+        nonlocal stage
+        tickets, blk = [], None
+        for _ in range(steps):
+            tickets.append(pipe.submit(d_in, n, args.sorter, args.coder, 3))
+            if record:
+                stage += np.array(ctx.last_stage_ms())
+            if len(tickets) >= args.depth:
+                blk = finish(tickets.pop(0))
+        while tickets:
+            blk = finish(tickets.pop(0))
         return blk
 
     def sync():
@@ -79,16 +96,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        blk = step()
+    blk = run(args.warmup)
     ctx.profile(True)
     ctx.profile_reset()
-    stage = np.zeros(6)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        blk = step()
-        stage += np.array(ctx.last_stage_ms())
+    blk = run(args.steps, record=True)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -127,14 +140,16 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{world} x {n >> 20} MiB synth-text-v1 block(s) per step (seed {'2' if world == 1 else '10..'+str(9+world)}), "
                                    f"bsc_compress(lzp off, sorter={args.sorter}, coder={args.coder}); input resident in HBM; "
-                                   "Adler-32 + BWT on GPU, QLFC on 8 host threads per GPU; output bit-identical to reference libbsc",
+                                   "Adler-32 + BWT + QLFC run/rank front end on GPU, QLFC modelling + range coding on 8 host threads per block, "
+                                   f"{args.depth} block(s) in flight per GPU; output bit-identical to reference libbsc",
                        "block_bytes": n, "blocks_per_step": world, "sorter": "BWT" if args.sorter == 1 else f"ST{args.sorter}",
                        "coder": {1: "QLFC static (-e1)", 2: "QLFC adaptive (-e2)", 3: "QLFC fast (-e0)"}[args.coder],
                        "parallelism": f"block-parallel x{world}", "compressed_bytes_rank0": int(blk.size)},
             "roofline": roofline,
             "stage_ms_per_step": {"adler32_gpu": round(stage[0] / args.steps, 2), "sort_transform_gpu": round(stage[1] / args.steps, 2),
-                                  "d2h": round(stage[2] / args.steps, 2), "qlfc_host": round(stage[3] / args.steps, 2),
-                                  "total": round(stage[4] / args.steps, 2), "doubling_rounds": stage[5] / args.steps},
+                                  "qlfc_front_gpu_and_d2h": round(stage[2] / args.steps, 2),
+                                  "gpu_stage_total": round((stage[0] + stage[1] + stage[2]) / args.steps, 2),
+                                  "doubling_rounds": stage[5] / args.steps, "pipeline_depth": args.depth},
             "sorter_only_MBps": round(n / 1e6 / max(stage[1] / args.steps / 1e3, 1e-9), 1),
             "kernels": per_kernel,
             "host": {"cpus": os.cpu_count()},

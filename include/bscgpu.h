@@ -78,6 +78,18 @@ BSCGPU_API int bscgpu_radix_sort_u64(bscgpu_ctx* ctx, void* keys, void* keys_alt
 BSCGPU_API int bscgpu_compress_device(bscgpu_ctx* ctx, const void* dInput, uint8_t* output, int n,
                            int blockSorter, int coder, int features);
 
+/* Pipelined variant: up to `depth` (<= 4) blocks in flight on one GPU.  submit() runs the GPU stage of a block
+ * (Adler-32, sort transform, QLFC front end, D2H of the run arrays) on the calling thread and hands the host stage
+ * (QLFC modelling + range coding on 8 threads, container) to a worker, so block i+1 sorts while block i is coded.
+ * dInput and output must stay valid until wait() returns for that ticket.  wait() returns what
+ * bscgpu_compress_device would have returned.  One submitting thread per pipe. */
+typedef struct bscgpu_pipe bscgpu_pipe;
+BSCGPU_API int  bscgpu_pipe_create(bscgpu_ctx* ctx, int depth, bscgpu_pipe** out);
+BSCGPU_API void bscgpu_pipe_destroy(bscgpu_pipe* pipe);
+BSCGPU_API int  bscgpu_pipe_submit(bscgpu_pipe* pipe, const void* dInput, uint8_t* output, int n,
+                                   int blockSorter, int coder, int features);       /* ticket >= 0 or error */
+BSCGPU_API int  bscgpu_pipe_wait(bscgpu_pipe* pipe, int ticket);
+
 /* ---- profiling --------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on the context's stream (the stream
  * the kernels run on) and accumulated per kernel class. */

@@ -64,6 +64,11 @@ def lib():
     L.bscgpu_last_stage_ms.argtypes = [vp, C.POINTER(C.c_double)]
     L.bscgpu_last_error.argtypes = [vp]
     L.bscgpu_last_error.restype = C.c_char_p
+    L.bscgpu_pipe_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.bscgpu_pipe_destroy.argtypes = [vp]
+    L.bscgpu_pipe_destroy.restype = None
+    L.bscgpu_pipe_submit.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.bscgpu_pipe_wait.argtypes = [vp, C.c_int]
     if hasattr(L, "bscgpu_compress_device"):
         L.bscgpu_compress_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
     _lib = L

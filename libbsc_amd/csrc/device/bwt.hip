@@ -278,6 +278,11 @@ __global__ void bwt_aux_kernel(const u32* __restrict__ ISA, u32 n, u32 r, u32 cn
     if (t < cnt) I[t] = ISA[(u64)t * r] + 1u;
 }
 
+void launch_seg_scan(bscgpu_ctx* c, u32 num_chunks)
+{
+    hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(WG), 0, c->stream, c->segsum, num_chunks, c->segoff, c->dscal);
+}
+
 // ---------------------------------------------------------------------------------------------
 static int bit_length(u64 x) { int b = 0; while (x) { ++b; x >>= 1; } return b; }
 

@@ -18,6 +18,21 @@ int ctx_fail(bscgpu_ctx* c, int code, const char* what, hipError_t e)
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+int ctx_ensure_slots(bscgpu_ctx* c, int count)
+{
+    if (count > MAX_SLOTS) return BSC_BAD_PARAMETER;
+    const size_t N = align_up((size_t)c->max_n + 4096, 4096);
+    for (; c->nslots < count; ++c->nslots) {
+        HostSlot& s = c->slots[c->nslots];
+        bool ok = hipHostMalloc((void**)&s.hsym, N, hipHostMallocDefault) == hipSuccess
+               && hipHostMalloc((void**)&s.hrank, N, hipHostMallocDefault) == hipSuccess
+               && hipHostMalloc((void**)&s.hstart, 4 * N, hipHostMallocDefault) == hipSuccess
+               && hipHostMalloc((void**)&s.hL, N + 64, hipHostMallocDefault) == hipSuccess;
+        if (!ok) return BSC_NOT_ENOUGH_MEMORY;
+    }
+    return BSC_NO_ERROR;
+}
+
 extern "C" int bscgpu_device_count(void)
 {
     int n = 0;
@@ -72,7 +87,8 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
     bool ok = hipHostMalloc((void**)&c->hscal, 512 * 4, hipHostMallocDefault) == hipSuccess
            && hipHostMalloc((void**)&c->hscal64, 16 * 8, hipHostMallocDefault) == hipSuccess
            && hipHostMalloc((void**)&c->hadler, (size_t)MAX_CHUNKS * 16, hipHostMallocDefault) == hipSuccess
-           && hipHostMalloc((void**)&c->hL, N + 64, hipHostMallocDefault) == hipSuccess;
+           && hipHostMalloc((void**)&c->hsplit, N / 256 + 64, hipHostMallocDefault) == hipSuccess
+           && ctx_ensure_slots(c, 1) == BSC_NO_ERROR;
     if (!ok || hipStreamSynchronize(c->stream) != hipSuccess) { bscgpu_destroy(c); return BSC_GPU_NOT_ENOUGH_MEMORY; }
     *out = c;
     return BSC_NO_ERROR;
@@ -88,7 +104,14 @@ extern "C" void bscgpu_destroy(bscgpu_ctx* c)
     if (c->hscal) hipHostFree(c->hscal);
     if (c->hscal64) hipHostFree(c->hscal64);
     if (c->hadler) hipHostFree(c->hadler);
-    if (c->hL) hipHostFree(c->hL);
+    if (c->hsplit) hipHostFree(c->hsplit);
+    for (int i = 0; i < MAX_SLOTS; ++i) {
+        HostSlot& s = c->slots[i];
+        if (s.hsym) hipHostFree(s.hsym);
+        if (s.hrank) hipHostFree(s.hrank);
+        if (s.hstart) hipHostFree(s.hstart);
+        if (s.hL) hipHostFree(s.hL);
+    }
     if (c->arena) hipFree(c->arena);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;

@@ -52,6 +52,15 @@ static inline Chunking make_chunking(u64 n, u32 tile) {
 // ---------------------------------------------------------------------------------------------
 struct ScatterLaunch { double ms; u64 records; };
 
+// Pinned host buffers one block's QLFC front-end output lands in (sized for max_n).
+struct HostSlot {
+    u8*  hsym   = nullptr;   // run symbols
+    u8*  hrank  = nullptr;   // QLFC ranks
+    u32* hstart = nullptr;   // run start positions
+    u8*  hL     = nullptr;   // the sorted block itself (only read if a sub-block must be stored raw)
+};
+constexpr int MAX_SLOTS = 4;
+
 struct bscgpu_ctx {
     int          device      = 0;
     hipStream_t  stream      = nullptr;
@@ -81,7 +90,9 @@ struct bscgpu_ctx {
     u32* hscal  = nullptr;   // 64 u32
     u64* hscal64 = nullptr;
     u64* hadler = nullptr;
-    u8*  hL     = nullptr;   // pinned staging for D2H of L (max_n + 64)
+    u64* hsplit = nullptr;   // pinned: split-flag words (max_n / 256 + 64 bytes)
+    HostSlot slots[MAX_SLOTS];   // pinned landing zones for the QLFC front end; >1 when blocks are pipelined
+    int      nslots = 0;
 
     // profiling
     bool         prof        = false;
@@ -117,6 +128,11 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n, int64_t
                int64_t* primary_out);
 int st_device(bscgpu_ctx* c, const u8* dT_user, u8* dOut_user, int n, int k, int* index_out);
 int adler32_device(bscgpu_ctx* c, const u8* d, int64_t n, u32* out);
+void launch_seg_scan(bscgpu_ctx* c, u32 num_chunks);
+int qlfc_front_split(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, int* start, int* size);
+int qlfc_front_runs(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, const int* start, u32* m_out, u32* run_first, u32* first_run_host,
+                    HostSlot& slot, bool copy_block);
+int ctx_ensure_slots(bscgpu_ctx* c, int count);
 
 // ---------------------------------------------------------------------------------------------
 // Device helpers (wave64)

@@ -1,0 +1,282 @@
+// qlfc_front.hip — the data-parallel front half of the QLFC coder on MI355X.
+//
+// What the reference does on the CPU per sub-block before any entropy coding (coder.cpp:70-109 split,
+// qlfc.cpp:177-255 / :398-455 run scan + backward move-to-front) is restated here as parallel kernels
+// over the whole sorted block L that stays resident in HBM after the BWT / ST:
+//
+//   qf_split_flags  bit q = (L[1+32q] != L[32q])            -> 2^21 bits for a 64 MiB block; the host picks the
+//                                                              <= 7 cut points from popcounts (coder.cpp:83-99)
+//   qf_reduce/apply run heads (forced at sub-block starts), stream compaction -> sym[j], start[j] per run,
+//                   first run index of every symbol per sub-block (alphabet order of the stream header)
+//   qf_tile_masks   256-bit "symbols present" set per 256 runs, and per 65536 runs
+//   qf_rank         rank[j] = number of distinct symbols between run j and the next run of the same symbol
+//                   (or to the end of the sub-block): one lane per run walks forward, OR-ing whole tile /
+//                   super-tile masks whenever they do not contain its symbol (SURVEY.md §4.3 restatement:
+//                   this is embarrassingly parallel, unlike the reference's backward MTF scan)
+//
+// The host coder then consumes (sym, rank, start) directly; L itself never crosses PCIe unless a sub-block turns
+// out incompressible and must be stored raw.
+#include "dev_common.h"
+
+constexpr int QF_BYTES = 16;                 // bytes per thread per tile
+constexpr int QF_TILE  = WG * QF_BYTES;      // 4096 bytes per tile
+
+struct QfSplit { u32 nblocks; u32 start[9]; };     // start[nblocks] = n
+
+__global__ __launch_bounds__(WG) void qf_split_flags_kernel(const u8* __restrict__ L, u32 n, u32 nq, u64* __restrict__ words)
+{
+    const u32 q = blockIdx.x * WG + threadIdx.x;
+    bool f = false;
+    if (q < nq) { const u32 i = 1u + 32u * q; f = L[i] != L[i - 1]; }
+    const u64 b = __ballot(f);
+    if ((threadIdx.x & 63) == 0 && (q >> 6) < ((nq + 63) >> 6)) words[q >> 6] = b;
+}
+
+__device__ __forceinline__ u32 qf_heads16(const u8* __restrict__ L, u32 i0, u32 n, const QfSplit& sp, uint4& bytes)
+{
+    // returns a 16-bit mask: bit p set iff position i0+p starts a run (and i0+p < n)
+    bytes = make_uint4(0, 0, 0, 0);
+    if (i0 + 16 <= n) bytes = *reinterpret_cast<const uint4*>(L + i0);
+    else { u8 tmp[16]; for (int p = 0; p < 16; ++p) tmp[p] = (i0 + p < n) ? L[i0 + p] : 0; bytes = *reinterpret_cast<uint4*>(tmp); }
+    const u32 prev = (i0 > 0) ? L[i0 - 1] : 0x100u;
+    const u32 w[4] = {bytes.x, bytes.y, bytes.z, bytes.w};
+    u32 mask = 0, last = prev;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const u32 c = (w[p >> 2] >> (8 * (p & 3))) & 0xffu;
+        if (c != last) mask |= 1u << p;
+        last = c;
+    }
+    if (i0 == 0) mask |= 1u;
+#pragma unroll
+    for (int b = 1; b < 8; ++b) {
+        if ((u32)b < sp.nblocks) { const u32 s = sp.start[b]; if (s >= i0 && s < i0 + 16) mask |= 1u << (s - i0); }
+    }
+    if (i0 + 16 > n) mask &= (n > i0) ? ((1u << (n - i0)) - 1u) : 0u;
+    return mask;
+}
+
+__global__ __launch_bounds__(WG) void qf_reduce_kernel(const u8* __restrict__ L, u32 n, QfSplit sp, u32 chunk_tiles, u32 num_tiles,
+                                                       u32* __restrict__ segsum)
+{
+    __shared__ u32 scr[8];
+    const u32 tile0 = blockIdx.x * chunk_tiles;
+    u32 tile1 = tile0 + chunk_tiles; if (tile1 > num_tiles) tile1 = num_tiles;
+    u32 cnt = 0;
+    for (u32 tile = tile0; tile < tile1; ++tile) {
+        const u32 i0 = tile * QF_TILE + threadIdx.x * QF_BYTES;
+        if (i0 >= n) continue;
+        uint4 bytes;
+        cnt += __popc(qf_heads16(L, i0, n, sp, bytes));
+    }
+    u32 tot;
+    block_excl_sum(cnt, scr, &tot);
+    if (threadIdx.x == 0) { segsum[blockIdx.x] = tot; segsum[MAX_CHUNKS + blockIdx.x] = 0; }
+}
+
+__global__ __launch_bounds__(WG) void qf_apply_kernel(const u8* __restrict__ L, u32 n, QfSplit sp, u32 chunk_tiles, u32 num_tiles,
+                                                      const u32* __restrict__ segoff, u8* __restrict__ sym, u32* __restrict__ start,
+                                                      u32* __restrict__ first_run /*[8][256]*/)
+{
+    __shared__ u32 scr[8];
+    const u32 tile0 = blockIdx.x * chunk_tiles;
+    u32 tile1 = tile0 + chunk_tiles; if (tile1 > num_tiles) tile1 = num_tiles;
+    u32 off = segoff[blockIdx.x];
+    for (u32 tile = tile0; tile < tile1; ++tile) {
+        const u32 i0 = tile * QF_TILE + threadIdx.x * QF_BYTES;
+        uint4 bytes = make_uint4(0, 0, 0, 0);
+        u32 mask = 0;
+        if (i0 < n) mask = qf_heads16(L, i0, n, sp, bytes);
+        u32 tot;
+        u32 j = off + block_excl_sum(__popc(mask), scr, &tot);
+        const u32 w[4] = {bytes.x, bytes.y, bytes.z, bytes.w};
+        while (mask) {
+            const u32 p = __ffs(mask) - 1; mask &= mask - 1;
+            const u32 c = (w[p >> 2] >> (8 * (p & 3))) & 0xffu;
+            const u32 pos = i0 + p;
+            sym[j] = (u8)c;
+            start[j] = pos;
+            u32 b = 0;
+#pragma unroll
+            for (int q = 1; q < 8; ++q) if ((u32)q < sp.nblocks && pos >= sp.start[q]) b = q;
+            u32* fr = first_run + b * 256 + c;
+            if (j < *reinterpret_cast<volatile u32*>(fr)) atomicMin(fr, j);
+            ++j;
+        }
+        off += tot;
+        __syncthreads();
+    }
+}
+
+// 256-bit symbol sets: masks[t][4] for runs [256 t, 256 t + 256)
+__global__ __launch_bounds__(WG) void qf_tile_masks_kernel(const u8* __restrict__ sym, u32 m, u64* __restrict__ masks)
+{
+    __shared__ u32 bits[8];
+    if (threadIdx.x < 8) bits[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 j = blockIdx.x * WG + threadIdx.x;
+    if (j < m) { const u32 c = sym[j]; atomicOr(&bits[c >> 5], 1u << (c & 31)); }
+    __syncthreads();
+    if (threadIdx.x < 4) masks[(size_t)blockIdx.x * 4 + threadIdx.x] = (u64)bits[2 * threadIdx.x] | ((u64)bits[2 * threadIdx.x + 1] << 32);
+}
+// super masks: OR of 256 tile masks (65536 runs)
+__global__ __launch_bounds__(WG) void qf_super_masks_kernel(const u64* __restrict__ masks, u32 ntiles, u64* __restrict__ super)
+{
+    __shared__ u64 red[4][WAVES];
+    const u32 t = blockIdx.x * WG + threadIdx.x;
+    u64 v[4] = {0, 0, 0, 0};
+    if (t < ntiles) { for (int k = 0; k < 4; ++k) v[k] = masks[(size_t)t * 4 + k]; }
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v[k] |= __shfl_xor(v[k], d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 4; ++k) red[k][threadIdx.x >> 6] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 4) { u64 r = 0; for (int w = 0; w < WAVES; ++w) r |= red[threadIdx.x][w]; super[(size_t)blockIdx.x * 4 + threadIdx.x] = r; }
+}
+
+struct QfRuns { u32 nblocks; u32 first[9]; };      // run index range of each sub-block; first[nblocks] = m
+
+__global__ __launch_bounds__(WG) void qf_rank_kernel(const u8* __restrict__ sym, u32 m, QfRuns rb,
+                                                     const u64* __restrict__ masks, const u64* __restrict__ super,
+                                                     u8* __restrict__ rank)
+{
+    const u32 j = blockIdx.x * WG + threadIdx.x;
+    if (j >= m) return;
+    u32 re = m;
+#pragma unroll
+    for (int b = 8; b >= 1; --b) if ((u32)b <= rb.nblocks && j < rb.first[b]) re = rb.first[b];
+    const u32 c = sym[j];
+    if (j + 1 == re) { rank[j] = 1; return; }                       // qlfc.cpp:249 / :449
+    u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    auto add = [&](u32 s) {
+        const u64 bit = 1ull << (s & 63);
+        const u32 w = s >> 6;
+        s0 |= (w == 0) ? bit : 0; s1 |= (w == 1) ? bit : 0; s2 |= (w == 2) ? bit : 0; s3 |= (w == 3) ? bit : 0;
+    };
+    const u32 cw = c >> 6; const u64 cbit = 1ull << (c & 63);
+    u32 i = j + 1;
+    bool found = false;
+    // phase 1: run by run to the next tile boundary
+    while (i < re && (i & 255u) != 0) { const u32 s = sym[i]; if (s == c) { found = true; break; } add(s); ++i; }
+    if (!found) {
+        // phase 2: whole tiles / super tiles that do not contain c
+        while (i + 256 <= re) {
+            if ((i & 65535u) == 0 && i + 65536 <= re) {
+                const u64* sm = super + (size_t)(i >> 16) * 4;
+                if (!(sm[cw] & cbit)) { s0 |= sm[0]; s1 |= sm[1]; s2 |= sm[2]; s3 |= sm[3]; i += 65536; continue; }
+            }
+            const u64* tm = masks + (size_t)(i >> 8) * 4;
+            if (tm[cw] & cbit) break;
+            s0 |= tm[0]; s1 |= tm[1]; s2 |= tm[2]; s3 |= tm[3];
+            i += 256;
+        }
+        // phase 3: inside the tile that holds the next occurrence (or the ragged end of the sub-block)
+        while (i < re) { const u32 s = sym[i]; if (s == c) break; add(s); ++i; }
+    }
+    rank[j] = (u8)(__popcll(s0) + __popcll(s1) + __popcll(s2) + __popcll(s3));
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side of the front end
+// -------------------------------------------------------------------------------------------------
+int qlfc_front_split(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, int* start, int* size)
+{
+    // coder.cpp:70-109
+    if (nblocks == 1) { start[0] = 0; size[0] = (int)n; return BSC_NO_ERROR; }
+    const u32 nq = (n >= 2) ? (n - 1 + 31) / 32 : 0;
+    const u32 nwords = (nq + 63) / 64;
+    u64* dwords = reinterpret_cast<u64*>(c->kA);          // scratch: the sort buffers are free after the BWT
+    prof_begin(c, BSCGPU_K_MISC, nq * 2, 0);
+    hipLaunchKernelGGL(qf_split_flags_kernel, dim3((nq + WG - 1) / WG), dim3(WG), 0, c->stream, dL, n, nq, dwords);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->hsplit, dwords, (size_t)nwords * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const u64* w = c->hsplit;
+    u64 changes = 0;
+    for (u32 k = 0; k < nwords; ++k) changes += (u64)__builtin_popcountll(w[k]);
+    if (changes > (u64)nblocks) {
+        const u64 per = changes / (u64)nblocks;
+        int id = 0; u64 seen = 0;
+        start[0] = 0;
+        for (u32 k = 0; k < nwords && id < nblocks - 1; ++k) {
+            u64 bits = w[k];
+            const u64 pc = (u64)__builtin_popcountll(bits);
+            if (seen + pc < per) { seen += pc; continue; }
+            while (bits && id < nblocks - 1) {
+                const int b = __builtin_ctzll(bits); bits &= bits - 1;
+                if (++seen == per) {
+                    seen = 0;
+                    const int i = 1 + 32 * (int)(k * 64 + (u32)b);
+                    size[id] = i - start[id];
+                    start[++id] = i;
+                }
+            }
+        }
+        size[nblocks - 1] = (int)n - start[nblocks - 1];
+    } else {
+        const int each = (int)n / nblocks;
+        for (int p = 0; p < nblocks; ++p) { start[p] = each * p; size[p] = (p != nblocks - 1) ? each : (int)n - each * (nblocks - 1); }
+    }
+    return BSC_NO_ERROR;
+}
+
+// Runs + ranks of all sub-blocks of dL.  Results in pinned host memory: c->hsym / c->hrank / c->hstart (m entries),
+// run_first[0..nblocks] (run index range per sub-block) and first_run[8][256].
+int qlfc_front_runs(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, const int* start, u32* m_out, u32* run_first /*[9]*/,
+                    u32* first_run_host /*[8*256]*/, HostSlot& slot, bool copy_block)
+{
+    QfSplit sp; sp.nblocks = (u32)nblocks;
+    for (int b = 0; b < 9; ++b) sp.start[b] = (b < nblocks) ? (u32)start[b] : n;
+    u8*  dsym   = reinterpret_cast<u8*>(c->vA);
+    u8*  drank  = reinterpret_cast<u8*>(c->vB);
+    u32* dstart = c->SA;                                   // SA / ISA are dead once L has been emitted
+    u32* dfirst = c->ISA;
+    u64* dmask  = c->kB;                                   // m / 8 bytes
+    u64* dsuper = reinterpret_cast<u64*>(c->cpos[0]);
+
+    const Chunking ch = make_chunking(n, QF_TILE);
+    HIP_TRY(c, hipMemsetAsync(dfirst, 0xff, 8 * 256 * 4, c->stream));
+    prof_begin(c, BSCGPU_K_SEG, n, 0);
+    hipLaunchKernelGGL(qf_reduce_kernel, dim3(ch.num_chunks), dim3(WG), 0, c->stream, dL, n, sp, ch.chunk_tiles, ch.num_tiles, c->segsum);
+    prof_end(c);
+    launch_seg_scan(c, ch.num_chunks);
+    prof_begin(c, BSCGPU_K_SEG, n, 0);
+    hipLaunchKernelGGL(qf_apply_kernel, dim3(ch.num_chunks), dim3(WG), 0, c->stream, dL, n, sp, ch.chunk_tiles, ch.num_tiles,
+                       c->segoff, dsym, dstart, dfirst);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->hscal, c->dscal, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(first_run_host, dfirst, 8 * 256 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const u32 m = c->hscal[0];
+    *m_out = m;
+
+    // run index range of every sub-block = smallest first_run of its symbols
+    QfRuns rb; rb.nblocks = (u32)nblocks;
+    for (int b = 0; b < nblocks; ++b) {
+        u32 lo = 0xffffffffu;
+        for (int s = 0; s < 256; ++s) if (first_run_host[b * 256 + s] < lo) lo = first_run_host[b * 256 + s];
+        rb.first[b] = lo;
+    }
+    for (int b = nblocks; b < 9; ++b) rb.first[b] = m;
+    for (int b = 0; b <= nblocks; ++b) run_first[b] = rb.first[b];
+
+    const u32 ntiles = (m + 255) / 256, nsuper = (ntiles + 255) / 256;
+    prof_begin(c, BSCGPU_K_MISC, m, 0);
+    hipLaunchKernelGGL(qf_tile_masks_kernel, dim3(ntiles), dim3(WG), 0, c->stream, dsym, m, dmask);
+    hipLaunchKernelGGL(qf_super_masks_kernel, dim3(nsuper), dim3(WG), 0, c->stream, dmask, ntiles, dsuper);
+    prof_end(c);
+    prof_begin(c, BSCGPU_K_GATHER, (u64)m * 2, m);
+    hipLaunchKernelGGL(qf_rank_kernel, dim3((m + WG - 1) / WG), dim3(WG), 0, c->stream, dsym, m, rb, dmask, dsuper, drank);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(slot.hsym, dsym, m, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(slot.hrank, drank, m, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(slot.hstart, dstart, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+    if (copy_block) HIP_TRY(c, hipMemcpyAsync(slot.hL, dL, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return BSC_NO_ERROR;
+}

@@ -8,7 +8,11 @@
 #include <cstring>
 #include <chrono>
 #include <mutex>
+#include <memory>
+#include <thread>
 #include <vector>
+#include <algorithm>
+#include <utility>
 
 #include <hip/hip_runtime.h>
 
@@ -86,8 +90,8 @@ int bsc_qlfc_ranks(const unsigned char* in, int n, unsigned char* ranks, unsigne
     QlfcRuns R;
     qlfc_runs(in, n, R);
     memcpy(ranks, R.rank.data(), R.rank.size());
-    memcpy(firstSeen, R.first_seen, (size_t)R.nsym);
-    if (pK) *pK = R.nsym;
+    memcpy(firstSeen, R.view.first_seen, (size_t)R.view.nsym);
+    if (pK) *pK = R.view.nsym;
     return (int)R.rank.size();
 }
 
@@ -234,64 +238,212 @@ int bsc_block_info(const unsigned char* hdr, int headerSize, int* pBlockSize, in
     return LIBBSC_NO_ERROR;
 }
 
-// ---- GPU-resident compress: Adler-32 + sorter on the device, QLFC on host threads --------------------
-int bscgpu_compress_device(bscgpu_ctx* c, const void* dInput, uint8_t* output, int n, int blockSorter, int coder, int features)
+// ---- GPU-resident compress: Adler-32 + sorter + QLFC front end on the device, QLFC coding on host threads ----
+// One block = a GPU stage (runs on the submitting thread, serialised per context) and a host stage (worker thread).
+struct BlockJob {
+    bscgpu_ctx* c = nullptr;
+    const void* dInput = nullptr;
+    uint8_t*    output = nullptr;
+    int n = 0, coder = 0, features = 0, mode = 0, index = 0, num_indexes = 0, nblocks = 0;
+    int indexes[256];
+    uint32_t adler_data = 0;
+    int start[8], size[8];
+    u32 run_first[9];
+    u32 first_run[8 * 256];
+    HostSlot slot;
+    bool stored_small = false;       // n <= header size: finished in the GPU stage
+    int  result = 0;
+};
+
+using clk = std::chrono::steady_clock;
+static double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+static int gpu_stage(BlockJob& J, int blockSorter)
 {
-    using clk = std::chrono::steady_clock;
-    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
-    if (!c || !dInput || !output) return LIBBSC_BAD_PARAMETER;
-    int mode = 0;
-    int rc = make_mode(blockSorter, coder, 0, 0, &mode);
-    if (rc != LIBBSC_NO_ERROR) return rc;
-    if (n < 0 || n > c->max_n) return LIBBSC_BAD_PARAMETER;
+    bscgpu_ctx* c = J.c;
+    const int n = J.n;
     if (hipSetDevice(c->device) != hipSuccess) return LIBBSC_GPU_ERROR;
-    const auto t_all = clk::now();
     if (n <= LIBBSC_HEADER_SIZE) {
         unsigned char tmp[LIBBSC_HEADER_SIZE + 1];
-        if (n > 0 && hipMemcpy(tmp, dInput, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return LIBBSC_GPU_ERROR;
-        return bsc_store(tmp, output, n, features);
+        if (n > 0 && hipMemcpy(tmp, J.dInput, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return LIBBSC_GPU_ERROR;
+        J.result = bsc_store(tmp, J.output, n, J.features);
+        J.stored_small = true;
+        return LIBBSC_NO_ERROR;
     }
     auto t0 = clk::now();
-    uint32_t adler_data = 0;
-    rc = adler32_device(c, (const u8*)dInput, n, &adler_data);
+    int rc = adler32_device(c, (const u8*)J.dInput, n, &J.adler_data);
     if (rc < 0) return rc;
     c->stage_ms[0] = ms_since(t0);
 
     t0 = clk::now();
-    int index = 0, num_indexes = 0, indexes[256];
+    J.num_indexes = 0;
     if (blockSorter == LIBBSC_BLOCKSORTER_BWT) {
         const int r = aux_rate(n);
         uint32_t I[256];
         int64_t primary = 0;
-        rc = bwt_device(c, (const u8*)dInput, c->dL, n, r, I, &primary);
+        rc = bwt_device(c, (const u8*)J.dInput, c->dL, n, r, I, &primary);
         if (rc < 0) return rc;
-        index = (int)primary;
-        num_indexes = (n - 1) / r;
-        for (int t = 0; t < num_indexes; ++t) indexes[t] = (int)I[t + 1] - 1;
+        J.index = (int)primary;
+        J.num_indexes = (n - 1) / r;
+        for (int t = 0; t < J.num_indexes; ++t) J.indexes[t] = (int)I[t + 1] - 1;
     } else {
-        rc = st_device(c, (const u8*)dInput, c->dL, n, blockSorter, &index);
+        rc = st_device(c, (const u8*)J.dInput, c->dL, n, blockSorter, &J.index);
         if (rc < 0) return rc;
     }
-    if (n < 64 * 1024) num_indexes = 0;
+    if (n < 64 * 1024) J.num_indexes = 0;
     c->stage_ms[1] = ms_since(t0);
 
+    // QLFC front half on the GPU (sub-block split, runs, ranks); only the run arrays (+ L for the rare raw
+    // sub-block) cross PCIe, into this job's pinned slot.
     t0 = clk::now();
-    if (hipMemcpyAsync(output, c->dL, (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return LIBBSC_GPU_ERROR;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return LIBBSC_GPU_ERROR;
+    J.nblocks = coder_num_blocks(n);
+    rc = qlfc_front_split(c, c->dL, (u32)n, J.nblocks, J.start, J.size);
+    if (rc < 0) return rc;
+    u32 m = 0;
+    rc = qlfc_front_runs(c, c->dL, (u32)n, J.nblocks, J.start, &m, J.run_first, J.first_run, J.slot, true);
+    if (rc < 0) return rc;
     c->stage_ms[2] = ms_since(t0);
+    return LIBBSC_NO_ERROR;
+}
 
-    t0 = clk::now();
-    int res = finish_block(nullptr, adler_data, output, n, mode, index, num_indexes, indexes, coder, features, true);
-    if (res == LIBBSC_NOT_COMPRESSIBLE) {                     // store path needs the original bytes back
-        if (hipMemcpy(output + LIBBSC_HEADER_SIZE, dInput, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return LIBBSC_GPU_ERROR;
-        put_i32(output + 0, n + LIBBSC_HEADER_SIZE); put_i32(output + 4, n); put_i32(output + 8, 0); put_i32(output + 12, 0);
-        put_i32(output + 16, (int)adler_data); put_i32(output + 20, (int)adler_data);
-        put_i32(output + 24, (int)adler32(output, 24));
-        res = n + LIBBSC_HEADER_SIZE;
+static void host_stage(BlockJob& J)
+{
+    if (J.stored_small) return;
+    const int n = J.n;
+    uint8_t* output = J.output;
+    RunView views[8];
+    for (int b = 0; b < J.nblocks; ++b) {
+        RunView& V = views[b];
+        V.sym = J.slot.hsym + J.run_first[b]; V.rank = J.slot.hrank + J.run_first[b]; V.start = J.slot.hstart + J.run_first[b];
+        V.count = J.run_first[b + 1] - J.run_first[b];
+        V.end = (u32)(J.start[b] + J.size[b]);
+        // alphabet in order of first appearance = symbols sorted by the index of their first run
+        std::pair<u32, int> order[256]; int k = 0;
+        for (int s = 0; s < 256; ++s) if (J.first_run[b * 256 + s] != 0xffffffffu) order[k++] = {J.first_run[b * 256 + s], s};
+        std::sort(order, order + k);
+        V.nsym = k;
+        for (int i = 0; i < k; ++i) V.first_seen[i] = (uint8_t)order[i].second;
     }
+    struct Fetch : RawFetch {
+        const uint8_t* L;
+        int operator()(int st, int sz, uint8_t* dst) override { memcpy(dst, L + st, (size_t)sz); return 0; }
+    } fetch; fetch.L = J.slot.hL;
+    int result;
+    {
+        unsigned char* buffer = (unsigned char*)bsc_malloc((size_t)n + 4096);
+        if (!buffer) { J.result = LIBBSC_NOT_ENOUGH_MEMORY; return; }
+        result = coder_compress_views(views, J.nblocks, J.start, J.size, n, buffer, J.coder, J.features, fetch);
+        if (result >= 0) memcpy(output + LIBBSC_HEADER_SIZE, buffer, (size_t)result);
+        bsc_free(buffer);
+    }
+    if (result < LIBBSC_NO_ERROR || result + 1 + 4 * J.num_indexes >= n) {       // store (libbsc.cpp:315-318)
+        if (hipSetDevice(J.c->device) != hipSuccess ||
+            hipMemcpy(output + LIBBSC_HEADER_SIZE, J.dInput, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) { J.result = LIBBSC_GPU_ERROR; return; }
+        put_i32(output + 0, n + LIBBSC_HEADER_SIZE); put_i32(output + 4, n); put_i32(output + 8, 0); put_i32(output + 12, 0);
+        put_i32(output + 16, (int)J.adler_data); put_i32(output + 20, (int)J.adler_data);
+        put_i32(output + 24, (int)adler32(output, 24));
+        J.result = n + LIBBSC_HEADER_SIZE;
+        return;
+    }
+    if (J.num_indexes > 0) memcpy(output + LIBBSC_HEADER_SIZE + result, J.indexes, (size_t)4 * J.num_indexes);
+    output[LIBBSC_HEADER_SIZE + result + 4 * J.num_indexes] = (unsigned char)J.num_indexes;
+    result += 1 + 4 * J.num_indexes;
+    put_i32(output + 0, result + LIBBSC_HEADER_SIZE);
+    put_i32(output + 4, n);
+    put_i32(output + 8, J.mode);
+    put_i32(output + 12, J.index);
+    put_i32(output + 16, (int)J.adler_data);
+    put_i32(output + 20, (int)adler32(output + LIBBSC_HEADER_SIZE, (size_t)result));
+    put_i32(output + 24, (int)adler32(output, 24));
+    J.result = result + LIBBSC_HEADER_SIZE;
+}
+
+static int prepare_job(BlockJob& J, bscgpu_ctx* c, const void* dInput, uint8_t* output, int n, int blockSorter, int coder, int features)
+{
+    if (!c || !dInput || !output) return LIBBSC_BAD_PARAMETER;
+    int rc = make_mode(blockSorter, coder, 0, 0, &J.mode);
+    if (rc != LIBBSC_NO_ERROR) return rc;
+    if (n < 0 || n > c->max_n) return LIBBSC_BAD_PARAMETER;
+    J.c = c; J.dInput = dInput; J.output = output; J.n = n; J.coder = coder; J.features = features;
+    J.stored_small = false; J.result = 0;
+    return LIBBSC_NO_ERROR;
+}
+
+int bscgpu_compress_device(bscgpu_ctx* c, const void* dInput, uint8_t* output, int n, int blockSorter, int coder, int features)
+{
+    const auto t_all = clk::now();
+    std::unique_ptr<BlockJob> J(new BlockJob);
+    int rc = prepare_job(*J, c, dInput, output, n, blockSorter, coder, features);
+    if (rc < 0) return rc;
+    J->slot = c->slots[0];
+    rc = gpu_stage(*J, blockSorter);
+    if (rc < 0) return rc;
+    const auto t0 = clk::now();
+    host_stage(*J);
     c->stage_ms[3] = ms_since(t0);
     c->stage_ms[4] = ms_since(t_all);
-    return res;
+    return J->result;
+}
+
+// ---- pipe: several blocks in flight ------------------------------------------------------------------------
+struct bscgpu_pipe {
+    bscgpu_ctx* c = nullptr;
+    int depth = 1;
+    int next_ticket = 0;
+    struct Lane { std::unique_ptr<BlockJob> job; std::thread worker; int ticket = -1; bool busy = false; int result = 0; };
+    Lane lanes[MAX_SLOTS];
+};
+
+static void lane_join(bscgpu_pipe::Lane& L)
+{
+    if (L.busy) { if (L.worker.joinable()) L.worker.join(); L.result = L.job->result; L.busy = false; }
+}
+
+int bscgpu_pipe_create(bscgpu_ctx* c, int depth, bscgpu_pipe** out)
+{
+    if (!c || !out || depth < 1 || depth > MAX_SLOTS) return LIBBSC_BAD_PARAMETER;
+    if (hipSetDevice(c->device) != hipSuccess) return LIBBSC_GPU_ERROR;
+    int rc = ctx_ensure_slots(c, depth);
+    if (rc < 0) return rc;
+    bscgpu_pipe* p = new bscgpu_pipe;
+    p->c = c; p->depth = depth;
+    for (int i = 0; i < depth; ++i) p->lanes[i].job.reset(new BlockJob);
+    *out = p;
+    return LIBBSC_NO_ERROR;
+}
+
+void bscgpu_pipe_destroy(bscgpu_pipe* p)
+{
+    if (!p) return;
+    for (int i = 0; i < p->depth; ++i) lane_join(p->lanes[i]);
+    delete p;
+}
+
+int bscgpu_pipe_submit(bscgpu_pipe* p, const void* dInput, uint8_t* output, int n, int blockSorter, int coder, int features)
+{
+    if (!p) return LIBBSC_BAD_PARAMETER;
+    const int ticket = p->next_ticket;
+    bscgpu_pipe::Lane& L = p->lanes[ticket % p->depth];
+    lane_join(L);                                   // the lane's previous block must have been waited for or is finished now
+    BlockJob& J = *L.job;
+    int rc = prepare_job(J, p->c, dInput, output, n, blockSorter, coder, features);
+    if (rc < 0) return rc;
+    J.slot = p->c->slots[ticket % p->depth];
+    rc = gpu_stage(J, blockSorter);
+    if (rc < 0) return rc;
+    L.ticket = ticket; L.busy = true;
+    L.worker = std::thread([&J] { host_stage(J); });
+    p->next_ticket = ticket + 1;
+    return ticket;
+}
+
+int bscgpu_pipe_wait(bscgpu_pipe* p, int ticket)
+{
+    if (!p || ticket < 0 || ticket >= p->next_ticket) return LIBBSC_BAD_PARAMETER;
+    bscgpu_pipe::Lane& L = p->lanes[ticket % p->depth];
+    if (L.ticket != ticket) return LIBBSC_BAD_PARAMETER;   // already overwritten by a later submit
+    lane_join(L);
+    return L.result;
 }
 
 // ---- `synth-text v1` -----------------------------------------------------------------

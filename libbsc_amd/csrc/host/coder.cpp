@@ -89,7 +89,7 @@ static int compress_parallel(const uint8_t* in, uint8_t* out, int n, int coder)
         std::vector<std::thread> pool;
         for (int b = 0; b < nblocks; ++b)
             pool.emplace_back([&, b] {
-                int r = qlfc_encode_block(in + start[b], scratch.data() + start[b], size[b], size[b], coder);
+                int r = qlfc_encode_block(in + start[b], scratch.data() + start[b], size[b], size[b], coder, true);
                 res[b] = (r < 0) ? size[b] : r;             // failed sub-block is stored raw (coder.cpp:194)
             });
         for (auto& t : pool) t.join();
@@ -107,6 +107,60 @@ static int compress_parallel(const uint8_t* in, uint8_t* out, int n, int coder)
         optr += res[b];
     }
     return total;
+}
+
+int coder_compress_views(const RunView* views, int nblocks, const int* start, const int* size, int n,
+                         uint8_t* out, int coder, int features, RawFetch& fetch_raw)
+{
+    if (coder != CODER_STATIC && coder != CODER_ADAPTIVE && coder != CODER_FAST) return BAD_PARAMETER;
+    if (nblocks == 1) {
+        const int r = qlfc_encode_runs(views[0], n, out + 1, n - 1, coder);
+        if (r < 0) return r;
+        out[0] = 1;
+        return r + 1;
+    }
+    out[0] = (uint8_t)nblocks;
+    if (features & FEATURE_MULTITHREADING) {               // coder.cpp:159-240
+        std::vector<std::vector<uint8_t>> scratch((size_t)nblocks);
+        int res[8];
+        {
+            std::vector<std::thread> pool;
+            for (int b = 0; b < nblocks; ++b)
+                pool.emplace_back([&, b] {
+                    scratch[(size_t)b].resize((size_t)size[b] + 64);
+                    int r = qlfc_encode_runs(views[b], size[b], scratch[(size_t)b].data(), size[b], coder, true);
+                    res[b] = (r < 0) ? size[b] : r;
+                });
+            for (auto& t : pool) t.join();
+        }
+        int total = 1 + 8 * nblocks;
+        for (int b = 0; b < nblocks; ++b) total += res[b];
+        if (total >= n) return NOT_COMPRESSIBLE;
+        int optr = 1 + 8 * nblocks;
+        for (int b = 0; b < nblocks; ++b) {
+            put_i32(out + 1 + 8 * b, size[b]);
+            put_i32(out + 1 + 8 * b + 4, res[b]);
+            if (res[b] != size[b]) memcpy(out + optr, scratch[(size_t)b].data(), (size_t)res[b]);
+            else { int rc = fetch_raw(start[b], size[b], out + optr); if (rc < 0) return rc; }
+            optr += res[b];
+        }
+        return total;
+    }
+    int optr = 1 + 8 * nblocks;                            // coder.cpp:111-155
+    for (int b = 0; b < nblocks; ++b) {
+        int room = size[b];
+        if (room > n - optr) room = n - optr;
+        int r = qlfc_encode_runs(views[b], size[b], out + optr, room, coder);
+        if (r < 0) {
+            if (optr + size[b] >= n) return NOT_COMPRESSIBLE;
+            r = size[b];
+            int rc = fetch_raw(start[b], size[b], out + optr); if (rc < 0) return rc;
+        }
+        put_i32(out + 1 + 8 * b, size[b]);
+        put_i32(out + 1 + 8 * b + 4, r);
+        optr += r;
+    }
+    return optr;
 }
 
 int coder_compress(const uint8_t* in, uint8_t* out, int n, int coder, int features)

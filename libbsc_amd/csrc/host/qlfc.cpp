@@ -7,8 +7,11 @@
 #include "qlfc.h"
 
 #include <cstring>
+#include <cstdlib>
 #include <memory>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 
 #include "qlfc_data.inc"
 
@@ -41,37 +44,34 @@ static inline int bsr32(unsigned x) { return x ? 31 - __builtin_clz(x) : 0; }
 // ------------------------------------------------------------------------------------------------
 void qlfc_runs(const uint8_t* in, int n, QlfcRuns& out)
 {
-    out.sym.clear(); out.rank.clear(); out.len.clear(); out.nsym = 0;
+    out.sym.clear(); out.rank.clear(); out.start.clear();
+    RunView& V = out.view;
+    V = RunView();
     if (n <= 0) return;
-    // pass 1: maximal runs
+    // pass 1: maximal runs (count first so the arrays are allocated once)
+    size_t m = 1;
+    for (int i = 1; i < n; ++i) m += (in[i] != in[i - 1]);
+    out.sym.resize(m); out.rank.resize(m); out.start.resize(m);
     {
-        size_t guess = (size_t)n / 2 + 16;
-        out.sym.reserve(guess); out.len.reserve(guess);
-        int i = 0;
+        size_t j = 0; int i = 0;
         while (i < n) {
             const uint8_t c = in[i];
-            int j = i + 1;
-            // word-at-a-time scan for long runs
-            if (j + 8 <= n) {
-                const uint64_t pat = 0x0101010101010101ull * c;
-                while (j + 8 <= n) {
-                    uint64_t w; memcpy(&w, in + j, 8);
-                    const uint64_t x = w ^ pat;
-                    if (x) { j += __builtin_ctzll(x) >> 3; goto done; }
-                    j += 8;
-                }
+            int e = i + 1;
+            const uint64_t pat = 0x0101010101010101ull * c;
+            while (e + 8 <= n) {                     // word-at-a-time scan for long runs
+                uint64_t w; memcpy(&w, in + e, 8);
+                const uint64_t x = w ^ pat;
+                if (x) { e += __builtin_ctzll(x) >> 3; goto done; }
+                e += 8;
             }
-            while (j < n && in[j] == c) ++j;
+            while (e < n && in[e] == c) ++e;
         done:
-            out.sym.push_back(c);
-            out.len.push_back((uint32_t)(j - i));
-            i = j;
+            out.sym[j] = c; out.start[j] = (uint32_t)i; ++j;
+            i = e;
         }
     }
     // pass 2: the rank of a run is the move-to-front position its symbol has when it is seen NEXT
-    const size_t m = out.sym.size();
-    out.rank.assign(m, 0);
-    uint8_t mtf[256];
+    uint8_t mtf[256 + 8];
     int     pos_of_last[256];
     int     nseen = 0;
     for (int c = 0; c < 256; ++c) pos_of_last[c] = -1;
@@ -79,20 +79,22 @@ void qlfc_runs(const uint8_t* in, int n, QlfcRuns& out)
         const uint8_t c = out.sym[j];
         const int prev = pos_of_last[c];
         if (prev < 0) {
-            out.first_seen[out.nsym++] = c;
-            memmove(mtf + 1, mtf, (size_t)nseen);
+            V.first_seen[V.nsym++] = c;
+            for (int p = nseen; p > 0; --p) mtf[p] = mtf[p - 1];
             mtf[0] = c; ++nseen;
         } else {
-            int p = 1;                              // mtf[0] is the previous run's symbol, never c
-            while (mtf[p] != c) ++p;
-            out.rank[(size_t)prev] = (uint8_t)p;
-            memmove(mtf + 1, mtf, (size_t)p);
+            uint8_t carry = mtf[0];                  // mtf[0] is the previous run's symbol, never c
+            int p = 1;
+            for (;; ++p) { const uint8_t t = mtf[p]; mtf[p] = carry; if (t == c) break; carry = t; }
             mtf[0] = c;
+            out.rank[(size_t)prev] = (uint8_t)p;
         }
         pos_of_last[c] = (int)j;
     }
     for (int p = 0; p < nseen; ++p) out.rank[(size_t)pos_of_last[mtf[p]]] = (uint8_t)p;   // last occurrences
     out.rank[m - 1] = 1;                                                                  // qlfc.cpp:249/449
+    V.sym = out.sym.data(); V.rank = out.rank.data(); V.start = out.start.data();
+    V.count = (uint32_t)m; V.end = (uint32_t)n;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -222,7 +224,7 @@ static inline void decide(RangeEncoder& rc, const QlfcTables& T, unsigned bit, s
 // Alphabet header shared by the three coders: for every symbol in order of first appearance emit only
 // the bits not implied by the set of still-possible symbols; a repeated symbol terminates the list.
 template <class EmitBit>
-static int encode_alphabet(const QlfcRuns& R, EmitBit&& emit)
+static int encode_alphabet(const RunView& R, EmitBit&& emit)
 {
     bool used[256] = {false};
     int prev = -1;
@@ -244,59 +246,43 @@ static int encode_alphabet(const QlfcRuns& R, EmitBit&& emit)
     return max_rank;
 }
 
-template <bool ADAPT>
-static int encode_model1(const uint8_t* in, uint8_t* out, int in_size, int out_size)
+// The decision walker: enumerates, run by run, every binary decision of the static / adaptive coders with the
+// three counter slots (state-, char- and position-indexed) and the mixer slot it uses.  All context indices are
+// pure functions of the run data, never of the coder state — which is what lets the policies below either code
+// directly or hand the three counter families to separate threads.  Returns false when the policy aborts.
+template <bool ADAPT, class Policy>
+static bool walk_model1(const RunView& R, const QlfcTables& T, const int max_rank, Counters1& K, Mixers1* M, Policy& pol)
 {
-    const QlfcTables& T = qlfc_tables();
-    QlfcRuns R;
-    qlfc_runs(in, in_size, R);
-
-    std::unique_ptr<Counters1> Cn(new Counters1);
-    fill_shorts(Cn.get(), sizeof(Counters1), 2048);
-    std::unique_ptr<Mixers1> Mx;
-    if (ADAPT) {
-        Mx.reset(new Mixers1);
-        Mixer* all = reinterpret_cast<Mixer*>(Mx.get());
-        for (size_t i = 0; i < sizeof(Mixers1) / sizeof(Mixer); ++i) all[i].init(T);
-    }
-    Counters1& K = *Cn;
-    Mixers1* M = Mx.get();
-
-    RangeEncoder rc;
-    rc.init(out, out_size);
-    rc.encode_word((uint32_t)in_size);
-    const int max_rank = encode_alphabet(R, [&](unsigned b) { rc.encode_half(b); });
-
     int ctx_rank0 = 0, ctx_rank4 = 0, ctx_run = 0, avg_rank = 0;
     uint8_t rank_hist[256] = {0}, run_hist[256] = {0};
 
-    const size_t m = R.sym.size();
-    for (size_t j = 0; j < m; ++j) {
-        if (rc.full()) return NOT_COMPRESSIBLE;
+    const uint32_t m = R.count;
+    for (uint32_t j = 0; j < m; ++j) {
+        if (!pol.begin_run()) return false;
         const int c = R.sym[j];
         int rank = R.rank[j];
-        const int run = (int)R.len[j];
+        const int run = (int)R.len(j);
 
         // ---------------- rank ----------------
         int hist = rank_hist[c];
         int state = T.rank_state[(ctx_run << 11) | (ctx_rank4 << 3) | hist];
         if (avg_rank < 32) {
-            decide<RANK_FIRST, ADAPT>(rc, T, rank != 1, K.rT_state[state], K.rT_chr[c], K.rT_stat, ADAPT ? &M->rank[c] : nullptr);
+            pol.template decide<RANK_FIRST>(rank != 1, K.rT_state[state], K.rT_chr[c], K.rT_stat, ADAPT ? &M->rank[c] : nullptr);
             if (rank == 1) {
                 rank_hist[c] = 0;
             } else {
                 const int bits = bsr32((unsigned)rank);
                 rank_hist[c] = (uint8_t)bits;
                 for (int b = 1; b < bits; ++b)
-                    decide<RANK_EXP, ADAPT>(rc, T, 1, K.rE_state[state][b - 1], K.rE_chr[c][b - 1], K.rE_stat[b - 1],
+                    pol.template decide<RANK_EXP>(1, K.rE_state[state][b - 1], K.rE_chr[c][b - 1], K.rE_stat[b - 1],
                                             ADAPT ? &M->rank_exp[hist > b ? hist : b][b] : nullptr);
                 if (bits < max_rank)
-                    decide<RANK_EXP, ADAPT>(rc, T, 0, K.rE_state[state][bits - 1], K.rE_chr[c][bits - 1], K.rE_stat[bits - 1],
+                    pol.template decide<RANK_EXP>(0, K.rE_state[state][bits - 1], K.rE_chr[c][bits - 1], K.rE_stat[bits - 1],
                                             ADAPT ? &M->rank_exp[hist > bits ? hist : bits][bits] : nullptr);
                 short* ms = K.rM_state[bits][state]; short* mc = K.rM_chr[bits][c]; short* mp = K.rM_stat[bits];
                 for (int ctx = 1, b = bits - 1; b >= 0; --b) {
                     const unsigned v = (unsigned)(rank >> b) & 1u;
-                    decide<RANK_MANT, ADAPT>(rc, T, v, ms[ctx], mc[ctx], mp[ctx], ADAPT ? &M->rank_mant[bits] : nullptr);
+                    pol.template decide<RANK_MANT>(v, ms[ctx], mc[ctx], mp[ctx], ADAPT ? &M->rank_mant[bits] : nullptr);
                     ctx += ctx + (int)v;
                 }
             }
@@ -305,7 +291,7 @@ static int encode_model1(const uint8_t* in, uint8_t* out, int in_size, int out_s
             short* es = K.rP_state[state]; short* ec = K.rP_chr[c]; short* ep = K.rP_stat;
             for (int ctx = 1, b = max_rank; b >= 0; --b) {
                 const unsigned v = (unsigned)(rank >> b) & 1u;
-                decide<RANK_ESC, ADAPT>(rc, T, v, es[ctx], ec[ctx], ep[ctx], ADAPT ? &M->rank_esc[ctx] : nullptr);
+                pol.template decide<RANK_ESC>(v, es[ctx], ec[ctx], ep[ctx], ADAPT ? &M->rank_esc[ctx] : nullptr);
                 ctx += ctx + (int)v;
             }
         }
@@ -315,21 +301,21 @@ static int encode_model1(const uint8_t* in, uint8_t* out, int in_size, int out_s
         rank -= 1;
         hist = run_hist[c];
         state = T.run_state[(ctx_rank0 << 10) | (ctx_run << 6) | ((rank < 7 ? rank : 7) << 3) | (hist < 7 ? hist : 7)];
-        decide<RUN_FIRST, ADAPT>(rc, T, run != 1, K.nT_state[state], K.nT_chr[c], K.nT_stat, ADAPT ? &M->run[c] : nullptr);
+        pol.template decide<RUN_FIRST>(run != 1, K.nT_state[state], K.nT_chr[c], K.nT_stat, ADAPT ? &M->run[c] : nullptr);
         if (run == 1) {
             run_hist[c] = (uint8_t)((run_hist[c] + 2) >> 2);
         } else {
             const int bits = bsr32((unsigned)run);
             run_hist[c] = (uint8_t)((run_hist[c] + 3 * bits + 3) >> 2);
             for (int b = 1; b < bits; ++b)
-                decide<RUN_EXP, ADAPT>(rc, T, 1, K.nE_state[state][b - 1], K.nE_chr[c][b - 1], K.nE_stat[b - 1],
+                pol.template decide<RUN_EXP>(1, K.nE_state[state][b - 1], K.nE_chr[c][b - 1], K.nE_stat[b - 1],
                                        ADAPT ? &M->run_exp[hist > b ? hist : b][b] : nullptr);
-            decide<RUN_EXP, ADAPT>(rc, T, 0, K.nE_state[state][bits - 1], K.nE_chr[c][bits - 1], K.nE_stat[bits - 1],
+            pol.template decide<RUN_EXP>(0, K.nE_state[state][bits - 1], K.nE_chr[c][bits - 1], K.nE_stat[bits - 1],
                                    ADAPT ? &M->run_exp[hist > bits ? hist : bits][bits] : nullptr);
             short* ms = K.nM_state[bits][state]; short* mc = K.nM_chr[bits][c]; short* mp = K.nM_stat[bits];
             for (int ctx = 1, b = bits - 1; b >= 0; --b) {
                 const unsigned v = (unsigned)(run >> b) & 1u;
-                decide<RUN_MANT, ADAPT>(rc, T, v, ms[ctx], mc[ctx], mp[ctx], ADAPT ? &M->run_mant[bits] : nullptr);
+                pol.template decide<RUN_MANT>(v, ms[ctx], mc[ctx], mp[ctx], ADAPT ? &M->run_mant[bits] : nullptr);
                 ctx = (bits <= 5) ? (ctx + ctx + (int)v) : (ctx + 1);
             }
         }
@@ -338,6 +324,159 @@ static int encode_model1(const uint8_t* in, uint8_t* out, int in_size, int out_s
         ctx_rank4 = ((ctx_rank4 << 2) | (rank < 3 ? rank : 3)) & 0xff;
         ctx_run   = ((ctx_run   << 1) | (run < 3 ? 1 : 0)) & 0xf;
     }
+    return true;
+}
+
+
+template <bool ADAPT>
+struct DirectPolicy {
+    RangeEncoder& rc; const QlfcTables& T;
+    inline bool begin_run() { return !rc.full(); }
+    template <int CLS> inline void decide(unsigned bit, short& st, short& ch, short& sp, Mixer* mx) { bschost::decide<CLS, ADAPT>(rc, T, bit, st, ch, sp, mx); }
+};
+
+static Counters1* new_counters()
+{
+    Counters1* k = new Counters1;
+    fill_shorts(k, sizeof(Counters1), 2048);
+    return k;
+}
+
+template <bool ADAPT>
+static int encode_model1(const RunView& R, uint8_t* out, int in_size, int out_size)
+{
+    const QlfcTables& T = qlfc_tables();
+    std::unique_ptr<Counters1> Cn(new_counters());
+    std::unique_ptr<Mixers1> Mx;
+    if (ADAPT) {
+        Mx.reset(new Mixers1);
+        Mixer* all = reinterpret_cast<Mixer*>(Mx.get());
+        for (size_t i = 0; i < sizeof(Mixers1) / sizeof(Mixer); ++i) all[i].init(T);
+    }
+    RangeEncoder rc;
+    rc.init(out, out_size);
+    rc.encode_word((uint32_t)in_size);
+    const int max_rank = encode_alphabet(R, [&](unsigned b) { rc.encode_half(b); });
+    DirectPolicy<ADAPT> pol{rc, T};
+    if (!walk_model1<ADAPT>(R, T, max_rank, *Cn, Mx.get(), pol)) return NOT_COMPRESSIBLE;
+    return rc.finish();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined static coder: the three counter families of the -e1 model are independent chains (each counter
+// only ever sees its own events, and which counter a decision touches is decided by the data alone), and the
+// range coder consumes nothing but (bit, probability) pairs.  So one sub-block is coded by four threads:
+//   family threads S / C / P : walk the decisions, update only their own counters, emit the counter value seen
+//                              by each decision into a single-producer single-consumer ring;
+//   coder thread             : pops the three values, forms p = (c*LR0 + s*LR1 + p*LR2) >> 5, range-codes.
+// Output is bit-identical to the single-threaded coder by construction (same values, same order).
+// ------------------------------------------------------------------------------------------------
+template <class Tv>
+class SpscRing {
+public:
+    explicit SpscRing(size_t cap_log2, std::atomic<bool>* abort) : buf_(new Tv[(size_t)1 << cap_log2]), mask_(((size_t)1 << cap_log2) - 1), abort_(abort) {}
+    inline void push(Tv v)
+    {
+        if (w_ - head_cache_ > mask_) {
+            flush();
+            for (unsigned spin = 0;; ++spin) {
+                head_cache_ = head_.load(std::memory_order_acquire);
+                if (w_ - head_cache_ <= mask_) break;
+                if (abort_->load(std::memory_order_relaxed)) return;
+                if (spin > 64) std::this_thread::yield(); else cpu_relax();
+            }
+        }
+        buf_[w_ & mask_] = v;
+        if ((++w_ & 2047) == 0) tail_.store(w_, std::memory_order_release);
+    }
+    inline void flush() { tail_.store(w_, std::memory_order_release); }
+    void close() { flush(); done_.store(true, std::memory_order_release); }
+    inline bool pop(Tv& v)
+    {
+        if (r_ == tail_cache_) {
+            head_.store(r_, std::memory_order_release);
+            for (unsigned spin = 0;; ++spin) {
+                tail_cache_ = tail_.load(std::memory_order_acquire);
+                if (tail_cache_ != r_) break;
+                if (done_.load(std::memory_order_acquire)) {
+                    tail_cache_ = tail_.load(std::memory_order_acquire);
+                    if (tail_cache_ != r_) break;
+                    return false;
+                }
+                if (abort_->load(std::memory_order_relaxed)) return false;
+                if (spin > 64) std::this_thread::yield(); else cpu_relax();
+            }
+        }
+        v = buf_[r_ & mask_];
+        if ((++r_ & 2047) == 0) head_.store(r_, std::memory_order_release);
+        return true;
+    }
+private:
+    static inline void cpu_relax() { __builtin_ia32_pause(); }
+    std::unique_ptr<Tv[]> buf_;
+    const size_t mask_;
+    std::atomic<bool>* abort_;
+    alignas(64) std::atomic<size_t> tail_{0};
+    alignas(64) std::atomic<size_t> head_{0};
+    alignas(64) std::atomic<bool> done_{false};
+    alignas(64) size_t w_ = 0; size_t head_cache_ = 0;
+    alignas(64) size_t r_ = 0; size_t tail_cache_ = 0;
+};
+
+enum { FAM_STATE = 0, FAM_CHAR = 1, FAM_POS = 2 };
+// the state family's ring also carries the decision's bit, class and a start-of-run mark
+static inline uint32_t pack_meta(short v, unsigned bit, int cls, unsigned first) { return (uint32_t)(uint16_t)v | (bit << 16) | ((uint32_t)cls << 17) | (first << 20); }
+
+template <int FAM, class Tv>
+struct FamilyPolicy {
+    SpscRing<Tv>& ring; std::atomic<bool>& abort; unsigned first = 0;
+    inline bool begin_run() { first = 1; return !abort.load(std::memory_order_relaxed); }
+    template <int CLS> inline void decide(unsigned bit, short& st, short& ch, short& sp, Mixer*)
+    {
+        constexpr const short* P = kStaticParams[CLS];
+        short& x = (FAM == FAM_STATE) ? st : (FAM == FAM_CHAR) ? ch : sp;
+        const short v = x;
+        bump(x, bit, P[4 * FAM + 0], P[4 * FAM + 1], P[4 * FAM + 2], P[4 * FAM + 3]);
+        if (FAM == FAM_STATE) { ring.push((Tv)pack_meta(v, bit, CLS, first)); first = 0; }
+        else ring.push((Tv)(uint16_t)v);
+    }
+};
+
+static int encode_static_pipelined(const RunView& R, uint8_t* out, int in_size, int out_size)
+{
+    const QlfcTables& T = qlfc_tables();
+    std::atomic<bool> abort{false};
+    SpscRing<uint32_t> ring_s(18, &abort);
+    SpscRing<uint16_t> ring_c(18, &abort), ring_p(18, &abort);
+    const int max_rank = encode_alphabet(R, [](unsigned) {});
+
+    auto producer_s = [&] { std::unique_ptr<Counters1> k(new_counters()); FamilyPolicy<FAM_STATE, uint32_t> pol{ring_s, abort};
+                            walk_model1<false>(R, T, max_rank, *k, nullptr, pol); ring_s.close(); };
+    auto producer_c = [&] { std::unique_ptr<Counters1> k(new_counters()); FamilyPolicy<FAM_CHAR, uint16_t> pol{ring_c, abort};
+                            walk_model1<false>(R, T, max_rank, *k, nullptr, pol); ring_c.close(); };
+    auto producer_p = [&] { std::unique_ptr<Counters1> k(new_counters()); FamilyPolicy<FAM_POS, uint16_t> pol{ring_p, abort};
+                            walk_model1<false>(R, T, max_rank, *k, nullptr, pol); ring_p.close(); };
+    std::thread ts(producer_s), tc(producer_c), tp(producer_p);
+
+    RangeEncoder rc;
+    rc.init(out, out_size);
+    rc.encode_word((uint32_t)in_size);
+    encode_alphabet(R, [&](unsigned b) { rc.encode_half(b); });
+    int lr0[7], lr1[7], lr2[7];
+    for (int k = 0; k < 7; ++k) { lr0[k] = kStaticParams[k][16]; lr1[k] = kStaticParams[k][17]; lr2[k] = kStaticParams[k][18]; }
+    int result = 0;
+    for (;;) {
+        uint32_t a; uint16_t b, c;
+        if (!ring_s.pop(a)) break;
+        if ((a >> 20) & 1u) { if (rc.full()) { result = NOT_COMPRESSIBLE; break; } }
+        if (!ring_c.pop(b) || !ring_p.pop(c)) { result = DATA_CORRUPT; break; }       // cannot happen: same decision count
+        const int cls = (int)((a >> 17) & 7u);
+        const int p = ((int)(short)b * lr0[cls] + (int)(short)(a & 0xffffu) * lr1[cls] + (int)(short)c * lr2[cls]) >> 5;
+        rc.encode<12>((a >> 16) & 1u, p);
+    }
+    if (result != 0) abort.store(true, std::memory_order_relaxed);
+    ts.join(); tc.join(); tp.join();
+    if (result != 0) return result;
     return rc.finish();
 }
 
@@ -350,10 +489,8 @@ struct Counters2 {
 };
 template <int R> static inline void nudge(short& p, int target) { p = (short)(p - ((p - target) >> R)); }
 
-static int encode_model2(const uint8_t* in, uint8_t* out, int in_size, int out_size)
+static int encode_model2(const RunView& R, uint8_t* out, int in_size, int out_size)
 {
-    QlfcRuns R;
-    qlfc_runs(in, in_size, R);
     std::unique_ptr<Counters2> Cn(new Counters2);
     fill_shorts(Cn->r_exp, sizeof(Cn->r_exp) + sizeof(Cn->r_mant), 4096);      // qlfc_model.cpp:74
     fill_shorts(Cn->n_exp, sizeof(Cn->n_exp) + sizeof(Cn->n_mant), 1024);      // qlfc_model.cpp:75
@@ -364,12 +501,12 @@ static int encode_model2(const uint8_t* in, uint8_t* out, int in_size, int out_s
     rc.encode_word((uint32_t)in_size);
     encode_alphabet(R, [&](unsigned b) { rc.encode<1>(b, 1); });               // qlfc.cpp:1174
 
-    const size_t m = R.sym.size();
-    for (size_t j = 0; j < m; ++j) {
+    const uint32_t m = R.count;
+    for (uint32_t j = 0; j < m; ++j) {
         if (rc.full()) return NOT_COMPRESSIBLE;
         const int c = R.sym[j];
         const unsigned rank = R.rank[j];
-        const unsigned run = R.len[j];
+        const unsigned run = R.len(j);
         {
             short* e = K.r_exp[c];
             if (rank == 1) { const int p = e[0]; nudge<4>(e[0], 8016); rc.encode<13>(0, p); }
@@ -413,15 +550,32 @@ static int encode_model2(const uint8_t* in, uint8_t* out, int in_size, int out_s
     return rc.finish();
 }
 
-int qlfc_encode_block(const uint8_t* in, uint8_t* out, int in_size, int out_size, int coder)
+static int g_pipeline = -1;      // BSC_QLFC_PIPELINE=0 disables the 4-thread static coder
+int qlfc_encode_runs(const RunView& R, int in_size, uint8_t* out, int out_size, int coder, bool allow_threads)
 {
-    if (in_size <= 0) return BAD_PARAMETER;
+    if (in_size <= 0 || R.count == 0) return BAD_PARAMETER;
+    // Measured on 2x EPYC 9575F (round 1): the 4-thread split does NOT pay — every family thread still walks the
+    // whole (branch-bound) decision structure: 132 ms vs 147 ms per 8 MiB stream when pinned to one CCD, 240 ms
+    // unpinned.  Kept as an opt-in experiment (BSC_QLFC_PIPELINE=1; =2 forces it), default off; throughput comes
+    // from keeping several blocks in flight instead (bscgpu_pipe_*).
+    if (g_pipeline < 0) { const char* e = getenv("BSC_QLFC_PIPELINE"); g_pipeline = e ? atoi(e) : 0; }
+    if (g_pipeline == 2) allow_threads = true;          // test hook: force the pipelined coder
     switch (coder) {
-        case CODER_STATIC:   return encode_model1<false>(in, out, in_size, out_size);
-        case CODER_ADAPTIVE: return encode_model1<true>(in, out, in_size, out_size);
-        case CODER_FAST:     return encode_model2(in, out, in_size, out_size);
+        case CODER_STATIC:
+            if (allow_threads && g_pipeline && R.count >= 65536) return encode_static_pipelined(R, out, in_size, out_size);
+            return encode_model1<false>(R, out, in_size, out_size);
+        case CODER_ADAPTIVE: return encode_model1<true>(R, out, in_size, out_size);
+        case CODER_FAST:     return encode_model2(R, out, in_size, out_size);
     }
     return BAD_PARAMETER;
+}
+
+int qlfc_encode_block(const uint8_t* in, uint8_t* out, int in_size, int out_size, int coder, bool allow_threads)
+{
+    if (in_size <= 0) return BAD_PARAMETER;
+    QlfcRuns R;
+    qlfc_runs(in, in_size, R);
+    return qlfc_encode_runs(R.view, in_size, out, out_size, coder, allow_threads);
 }
 
 }  // namespace bschost

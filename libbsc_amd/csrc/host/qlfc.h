@@ -31,23 +31,34 @@ struct QlfcTables {
 };
 const QlfcTables& qlfc_tables();
 
-// Run decomposition of a sub-block + QLFC ranks.
-//   sym[j], len[j]  : the j-th maximal run;
-//   rank[j]         : the QLFC rank of run j (qlfc.cpp:398-455): number of distinct symbols between run j and
-//                     the next run of the same symbol, or — for the last run of a symbol — the number of distinct
-//                     symbols that still occur later; the rank of the final run is forced to 1;
-//   first_seen[0..k): distinct symbols in order of first appearance (the stream's alphabet header).
-struct QlfcRuns {
-    std::vector<uint8_t>  sym;
-    std::vector<uint8_t>  rank;
-    std::vector<uint32_t> len;
+// Run decomposition of a sub-block + QLFC ranks, as flat arrays (the layout the GPU front end produces):
+//   sym[j], start[j] : symbol and start position of the j-th maximal run (length = start[j+1] - start[j], the
+//                      last run ends at `end`);
+//   rank[j]          : the QLFC rank of run j (qlfc.cpp:398-455): number of distinct symbols between run j and
+//                      the next run of the same symbol, or — for the last run of a symbol — the number of distinct
+//                      symbols that still occur later; the rank of the final run is forced to 1;
+//   first_seen[0..k) : distinct symbols in order of first appearance (the stream's alphabet header).
+struct RunView {
+    const uint8_t*  sym   = nullptr;
+    const uint8_t*  rank  = nullptr;
+    const uint32_t* start = nullptr;
+    uint32_t count = 0;
+    uint32_t end   = 0;
     uint8_t  first_seen[256];
     int      nsym = 0;
+    inline uint32_t len(uint32_t j) const { return (j + 1 < count ? start[j + 1] : end) - start[j]; }
+};
+struct QlfcRuns {                       // owning storage for the host-side front end
+    std::vector<uint8_t>  sym, rank;
+    std::vector<uint32_t> start;
+    RunView view;
 };
 void qlfc_runs(const uint8_t* in, int n, QlfcRuns& out);
 
+// Encode one sub-block from its run arrays.  Returns bytes written or NOT_COMPRESSIBLE.
+int qlfc_encode_runs(const RunView& R, int in_size, uint8_t* out, int out_size, int coder, bool allow_threads = false);
 // Encode one sub-block (what coder.cpp:61 dispatches to).  Returns bytes written or NOT_COMPRESSIBLE.
-int qlfc_encode_block(const uint8_t* in, uint8_t* out, int in_size, int out_size, int coder);
+int qlfc_encode_block(const uint8_t* in, uint8_t* out, int in_size, int out_size, int coder, bool allow_threads = false);
 // Decode one sub-block; returns the decoded size or an error.
 int qlfc_decode_block(const uint8_t* in, uint8_t* out, int coder);
 
@@ -55,6 +66,11 @@ int qlfc_decode_block(const uint8_t* in, uint8_t* out, int coder);
 int coder_compress(const uint8_t* in, uint8_t* out, int n, int coder, int features);
 int coder_decompress(const uint8_t* in, uint8_t* out, int coder, int features);
 int coder_num_blocks(int n);
+// Same framing, but the sub-blocks arrive as run arrays (GPU front end).  fetch_raw(start, size, dst) supplies the
+// original bytes of a sub-block that has to be stored raw.
+struct RawFetch { virtual int operator()(int start, int size, uint8_t* dst) = 0; virtual ~RawFetch() {} };
+int coder_compress_views(const RunView* views, int nblocks, const int* start, const int* size, int n,
+                         uint8_t* out, int coder, int features, RawFetch& fetch_raw);
 void coder_split_blocks(const uint8_t* in, int n, int nblocks, int* start, int* size);
 
 uint32_t adler32(const uint8_t* p, size_t n);

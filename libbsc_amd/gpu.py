@@ -105,6 +105,9 @@ class GpuContext:
         rc = self._check(self.L.bscgpu_compress_device(self.h, _dptr(dInput), N.np_ptr(out), n, sorter, coder, features))
         return out[:rc]
 
+    def pipe(self, depth=2):
+        return Pipe(self, depth)
+
     # ---- profiling ---------------------------------------------------------------------------
     def profile(self, on=True):
         self.L.bscgpu_profile_enable(self.h, 1 if on else 0)
@@ -128,3 +131,39 @@ class GpuContext:
         out = (C.c_double * 6)()
         self.L.bscgpu_last_stage_ms(self.h, out)
         return list(out)
+
+
+class Pipe:
+    """Several blocks in flight on one GPU (bscgpu_pipe_*): submit() runs the GPU stage, the host coder of that
+    block runs on worker threads while the next block is sorted."""
+
+    def __init__(self, ctx, depth=2):
+        self.ctx = ctx
+        self.L = ctx.L
+        h = C.c_void_p()
+        ctx._check(self.L.bscgpu_pipe_create(ctx.h, depth, C.byref(h)))
+        self.h = h
+        self.depth = depth
+        self._out = {}
+
+    def submit(self, dInput, n, sorter=1, coder=1, features=3):
+        out = np.empty(n + 28, np.uint8)
+        t = self.ctx._check(self.L.bscgpu_pipe_submit(self.h, _dptr(dInput), N.np_ptr(out), n, sorter, coder, features))
+        self._out[t] = (out, dInput)          # keep both alive until wait()
+        return t
+
+    def wait(self, ticket):
+        rc = self.ctx._check(self.L.bscgpu_pipe_wait(self.h, ticket))
+        out, _ = self._out.pop(ticket)
+        return out[:rc]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.bscgpu_pipe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

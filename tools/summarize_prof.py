@@ -1,0 +1,44 @@
+"""Condense rocprofv3 output directories into a small text summary (committed under profiles/)."""
+import csv, glob, os, sys, collections
+root = sys.argv[1]
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
+
+print("== rocprofv3 --kernel-trace --stats of: python bench.py --steps 3 --warmup 1 (4 blocks of 64 MiB incl. warm-up)")
+for f in find("*kernel_stats.csv"):
+    rows = list(csv.DictReader(open(f)))
+    print(f"-- {os.path.relpath(f, root)}")
+    print(f"{'kernel':70s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
+    for r in rows[:25]:
+        name = r.get("Name", "")[:70]
+        print(f"{name:70s} {r.get('Calls',''):>6s} {float(r.get('TotalDurationNs',0))/1e6:10.3f} {float(r.get('AverageNs',0))/1e3:10.2f} "
+              f"{float(r.get('MinNs',0))/1e3:9.2f} {float(r.get('MaxNs',0))/1e3:9.2f} {r.get('Percentage',''):>6s}")
+# per-launch durations of the scatter kernel on full-size passes from the raw trace
+for f in find("*kernel_trace.csv"):
+    if "pmc" in f:
+        continue
+    rows = list(csv.DictReader(open(f)))
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "rs_scatter_kernelILb1" in r["Kernel_Name"]]
+    if d:
+        d.sort(reverse=True)
+        big = [x for x in d if x > 300]
+        print(f"-- {os.path.relpath(f, root)}: rs_scatter<pairs> launches={len(d)}; launches > 300 us: {len(big)} avg {sum(big)/max(len(big),1):.1f} us")
+        if big:
+            print(f"   => full 64 Mi-record pass: 24 B x 67108864 / {sum(big)/len(big):.1f} us = {24*67108864/(sum(big)/len(big))/1e3:.0f} GB/s")
+print()
+print("== PMC passes (one 64 MiB BWT; counters per dispatch, summed per kernel; FETCH_SIZE/WRITE_SIZE in KiB units as reported)")
+for tag, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    for f in find("*counter_collection.csv"):
+        if tag not in f:
+            continue
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != cname:
+                continue
+            k = r["Kernel_Name"].split("(")[0][:60]
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])
+        print(f"-- {cname} ({os.path.relpath(f, root)})")
+        for k, (cnt, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
+            print(f"{k:62s} dispatches {cnt:4d}  sum {v:16.0f}  per-dispatch {v/cnt:14.0f}")
