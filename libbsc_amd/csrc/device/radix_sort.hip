@@ -23,26 +23,60 @@
 //    reordered through LDS (32 KB staging) so that every bucket leaves as one contiguous run:
 //    consecutive lanes store consecutive addresses.  Integer/index work only — no MFMA.
 #include "dev_common.h"
+#include <cstdlib>
 
+#ifndef RS_WG
+#define RS_WG 256      // measured: 512 threads / 8192-record tiles are 10-25 % slower (barrier stalls, spills)
+#endif
+constexpr int RS_WAVES = RS_WG / 64;
 constexpr int RS_ITEMS = 16;
-constexpr int RS_TILE  = WG * RS_ITEMS;          // 4096 records per tile
-constexpr int RS_LDS   = RS_TILE * 8 + WAVES * 256 * 4 + 3 * 256 * 4 + 8 * 4;   // 39968 B -> 4 WG / CU
+constexpr int RS_TILE  = RS_WG * RS_ITEMS;       // 4096 records per tile
+constexpr int RS_LDS   = RS_TILE * 8 + RS_WAVES * 256 * 4 + 3 * 256 * 4 + 16 * 4;   // 40,000 B -> 4 WG (16 waves) / CU
+constexpr int RS_MAX_CHUNKS = 256 * (1024 / RS_WG);       // all workgroups resident at once: 4 per CU
+
+static inline Chunking rs_chunking(u64 n) {
+    Chunking c;
+    c.num_tiles   = (u32)((n + RS_TILE - 1) / RS_TILE);
+    if (c.num_tiles == 0) c.num_tiles = 1;
+    c.chunk_tiles = (c.num_tiles + RS_MAX_CHUNKS - 1) / RS_MAX_CHUNKS;
+    c.num_chunks  = (c.num_tiles + c.chunk_tiles - 1) / c.chunk_tiles;
+    return c;
+}
+
+// Exclusive sum over the first 256 threads' values (one per digit); every thread of the workgroup calls it
+// (threads >= 256 pass 0).  scr: RS_WAVES u32.
+__device__ __forceinline__ u32 rs_digit_excl_sum(u32 v, u32* scr, u32* total) {
+    const u32 incl = wave_incl_sum(v);
+    const u32 w = threadIdx.x >> 6, l = lane_id();
+    __syncthreads();
+    if (l == 63) scr[w] = incl;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; ++i) { const u32 t = scr[i]; if ((u32)i < w) base += t; tot += t; }
+    *total = tot;
+    return base + incl - v;
+}
 
 // ---------------------------------------------------------------------------------------------
 // rs_hist: per-chunk digit histogram.  counts layout [digit][chunk].
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void rs_hist_kernel(const u64* __restrict__ keys, u32 n, int shift, u32 mask,
-                                                     u32 chunk_tiles, u32 num_chunks, u32* __restrict__ counts)
+__global__ __launch_bounds__(RS_WG) void rs_hist_kernel(const u64* __restrict__ keys, u32 n, int shift, u32 mask,
+                                                        u32 chunk_tiles, u32 num_chunks, u32* __restrict__ counts)
 {
-    __shared__ u32 h[WAVES * 256];
+    // BWT keys are text: a handful of digit values dominate, so a single 256-bin histogram per wave serialises its
+    // LDS atomics (measured 2.4 TB/s with every lane on one bin).  Each wave keeps HREP replicas selected by the
+    // low lane bits, which cuts the worst case from 64-way to 8-way conflicts; replicas are summed at the end.
+    constexpr int WG = RS_WG, WAVES = RS_WAVES, HREP = 8;
+    __shared__ u32 h[WAVES * HREP * 256];
     const u32 t = threadIdx.x, w = t >> 6;
-    for (u32 i = t; i < WAVES * 256; i += WG) h[i] = 0;
+    for (u32 i = t; i < WAVES * HREP * 256; i += WG) h[i] = 0;
     __syncthreads();
 
     const u64 start = (u64)blockIdx.x * chunk_tiles * RS_TILE;
     u64 end = start + (u64)chunk_tiles * RS_TILE;
     if (end > n) end = n;
-    u32* hw = h + w * 256;
+    u32* hw = h + (w * HREP + (t & (HREP - 1))) * 256;
 
     // 16-byte loads (2 keys per lane), 4 in flight per lane.
     u64 i = start + 2 * t;
@@ -61,7 +95,12 @@ __global__ __launch_bounds__(WG) void rs_hist_kernel(const u64* __restrict__ key
         if (i + 1 < end) atomicAdd(&hw[(u32)(keys[i + 1] >> shift) & mask], 1u);
     }
     __syncthreads();
-    counts[(size_t)t * num_chunks + blockIdx.x] = h[t] + h[256 + t] + h[512 + t] + h[768 + t];
+    if (t < 256) {
+        u32 sum = 0;
+#pragma unroll 8
+        for (int r = 0; r < WAVES * HREP; ++r) sum += h[r * 256 + t];
+        counts[(size_t)t * num_chunks + blockIdx.x] = sum;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -86,16 +125,17 @@ __global__ __launch_bounds__(WG) void rs_scan_kernel(u32* __restrict__ counts, u
 // ---------------------------------------------------------------------------------------------
 // rs_scatter: the digit pass.  Reads each record once, writes it once.
 // ---------------------------------------------------------------------------------------------
-template <bool HAS_VAL>
-__global__ __launch_bounds__(WG, 4) void rs_scatter_kernel(const u64* __restrict__ kin, u64* __restrict__ kout,
+template <bool HAS_VAL, int ABLATE = 0>
+__global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restrict__ kin, u64* __restrict__ kout,
                                                         const u32* __restrict__ vin, u32* __restrict__ vout,
                                                         u32 n, int shift, u32 mask,
                                                         u32 chunk_tiles, u32 num_chunks, u32 num_tiles,
                                                         const u32* __restrict__ offsets,
                                                         const u32* __restrict__ rowtot)
 {
+    constexpr int WG = RS_WG, WAVES = RS_WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* skeys  = reinterpret_cast<u64*>(smem);                       // [4096] staging (reused as u32 for values)
+    u64* skeys  = reinterpret_cast<u64*>(smem);                       // [RS_TILE] staging (reused as u32 for values)
     u32* whist  = reinterpret_cast<u32*>(smem + RS_TILE * 8);         // [4][256] per-wave digit counts / prefixes
     u32* goff   = whist + WAVES * 256;                                // [256] running global bucket offsets
     u32* adj    = goff + 256;                                         // [256] goff - tile-local bucket start
@@ -108,8 +148,8 @@ __global__ __launch_bounds__(WG, 4) void rs_scatter_kernel(const u64* __restrict
 
     {   // global offset of this chunk's first record of digit t
         u32 tot;
-        const u32 base = block_excl_sum(rowtot[t], scr, &tot);
-        goff[t] = base + offsets[(size_t)t * num_chunks + blockIdx.x];
+        const u32 base = rs_digit_excl_sum(t < 256 ? rowtot[t] : 0u, scr, &tot);
+        if (t < 256) goff[t] = base + offsets[(size_t)t * num_chunks + blockIdx.x];
     }
     __syncthreads();
 
@@ -131,25 +171,31 @@ __global__ __launch_bounds__(WG, 4) void rs_scatter_kernel(const u64* __restrict
             const u32 idx = wbase + i * 64;
             k[i] = (idx < nvalid) ? kin[tbase + idx] : ~0ull;
         }
-#pragma unroll
-        for (int i = 0; i < WAVES; ++i) whist[i * 256 + t] = 0;
+        for (u32 i = t; i < (u32)WAVES * 256; i += WG) whist[i] = 0;
         __syncthreads();
 
         // ---- stable in-wave ranking by ballot match ---------------------------------------------
+        // peers(lane) = lanes whose digit equals this lane's.  Per digit bit: nb = all-ones if this lane's bit is
+        // clear; the lanes agreeing with us on that bit are (ballot ^ nb), so the running mask is one 3-input
+        // boolean op per 32-bit half (v_bitop3 on gfx950).
         u32 rk[RS_ITEMS];
+        const u32 lt_lo = (u32)lt, lt_hi = (u32)(lt >> 32);
 #pragma unroll
         for (int i = 0; i < RS_ITEMS; ++i) {
             const u32 d = (u32)(k[i] >> shift) & mask;
-            u64 m = ~0ull;
+            if (ABLATE == 1) { rk[i] = atomicAdd(&whist[w * 256 + d], 1u); continue; }   // timing experiment only (unstable)
+            u32 mlo = ~0u, mhi = ~0u;
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const u64 bal = __ballot(bit);
-                m &= bit ? bal : ~bal;
+                const int bitm = __builtin_amdgcn_sbfe((int)d, b, 1);         // -1 if bit b set, else 0
+                const u64 bal = __ballot(bitm != 0);
+                const u32 nb = ~(u32)bitm;
+                mlo &= (u32)bal ^ nb;
+                mhi &= (u32)(bal >> 32) ^ nb;
             }
             const u32 before = vwh[w * 256 + d];       // records of digit d seen by this wave so far
-            const u32 r      = (u32)__popcll(m & lt);  // peers in lower lanes
-            const u32 cnt    = (u32)__popcll(m);
+            const u32 r      = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));   // peers in lower lanes
+            const u32 cnt    = (u32)(__popc(mlo) + __popc(mhi));
             rk[i] = before + r;
             if (r == cnt - 1) vwh[w * 256 + d] = before + cnt;   // highest peer lane publishes
         }
@@ -166,17 +212,22 @@ __global__ __launch_bounds__(WG, 4) void rs_scatter_kernel(const u64* __restrict
 
         // ---- per digit: wave prefixes, tile-local bucket start, global adjust -------------------
         {
-            const u32 c0 = whist[t], c1 = whist[256 + t], c2 = whist[512 + t], c3 = whist[768 + t];
-            const u32 tot = c0 + c1 + c2 + c3;
+            u32 c[WAVES];
+            u32 tot = 0;
+            if (t < 256) {
+#pragma unroll
+                for (int i = 0; i < WAVES; ++i) { c[i] = whist[i * 256 + t]; tot += c[i]; }
+            }
             u32 all;
-            const u32 ds = block_excl_sum(tot, scr, &all);
-            whist[t]       = ds;
-            whist[256 + t] = ds + c0;
-            whist[512 + t] = ds + c0 + c1;
-            whist[768 + t] = ds + c0 + c1 + c2;
-            const u32 g = goff[t];
-            adj[t]  = g - ds;
-            goff[t] = g + tot;
+            const u32 ds = rs_digit_excl_sum(tot, scr, &all);
+            if (t < 256) {
+                u32 run = ds;
+#pragma unroll
+                for (int i = 0; i < WAVES; ++i) { whist[i * 256 + t] = run; run += c[i]; }
+                const u32 g = goff[t];
+                adj[t]  = g - ds;
+                goff[t] = g + tot;
+            }
         }
         __syncthreads();
 
@@ -228,7 +279,7 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
     if (n >= 0xffffffffull) return BSC_BAD_PARAMETER;
     if ((((uintptr_t)keys) | ((uintptr_t)keys_alt)) & 15) return ctx_fail(c, BSC_BAD_PARAMETER, "radix keys not 16B aligned", hipSuccess);
 
-    const Chunking ch = make_chunking(n, RS_TILE);
+    const Chunking ch = rs_chunking(n);
     u64 *ksrc = keys, *kdst = keys_alt;
     u32 *vsrc = vals, *vdst = vals_alt;
     const bool has_val = (vals != nullptr);
@@ -239,7 +290,7 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
         const u32 mask  = (passes[p].bits >= 8) ? 0xffu : ((1u << passes[p].bits) - 1u);
 
         prof_begin(c, BSCGPU_K_RADIX_HIST, n * 8, n);
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(ch.num_chunks), dim3(WG), 0, c->stream,
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(ch.num_chunks), dim3(RS_WG), 0, c->stream,
                            ksrc, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks, c->counts);
         prof_end(c);
 
@@ -248,12 +299,17 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
         prof_end(c);
 
         prof_begin(c, BSCGPU_K_RADIX_SCATTER, 2 * n * rec_bytes, n);
-        if (has_val)
-            hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(ch.num_chunks), dim3(WG), RS_LDS, c->stream,
+        static const int ablate = getenv("BSCGPU_ABLATE") ? atoi(getenv("BSCGPU_ABLATE")) : 0;
+        if (has_val && ablate == 1)
+            hipLaunchKernelGGL((rs_scatter_kernel<true, 1>), dim3(ch.num_chunks), dim3(RS_WG), RS_LDS, c->stream,
+                               ksrc, kdst, vsrc, vdst, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks,
+                               ch.num_tiles, c->counts, c->rowtot);
+        else if (has_val)
+            hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(ch.num_chunks), dim3(RS_WG), RS_LDS, c->stream,
                                ksrc, kdst, vsrc, vdst, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks,
                                ch.num_tiles, c->counts, c->rowtot);
         else
-            hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(ch.num_chunks), dim3(WG), RS_LDS, c->stream,
+            hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(ch.num_chunks), dim3(RS_WG), RS_LDS, c->stream,
                                ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, shift, mask,
                                ch.chunk_tiles, ch.num_chunks, ch.num_tiles, c->counts, c->rowtot);
         prof_end(c);

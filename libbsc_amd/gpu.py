@@ -13,9 +13,13 @@ class GpuError(RuntimeError):
 
 
 def _dptr(t):
-    """device pointer of a torch CUDA tensor (or a raw int)."""
+    """device pointer of a torch CUDA tensor (or a raw int).  The context runs on its own non-blocking HIP stream,
+    so pending torch work that produces the tensor (an async clone / copy on torch's stream) must have finished:
+    synchronise torch's current stream before handing the pointer over."""
     if isinstance(t, int):
         return C.c_void_p(t)
+    import torch
+    torch.cuda.current_stream(t.device).synchronize()
     return C.c_void_p(t.data_ptr())
 
 

@@ -1,0 +1,97 @@
+// Microbenchmarks for the memory shapes used by the radix engine (not part of the product).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef unsigned long long u64; typedef unsigned int u32;
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ a, uint4* __restrict__ b, size_t n16) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) b[i] = a[i];
+}
+__global__ __launch_bounds__(256) void k_read16(const uint4* __restrict__ a, u32* __restrict__ out, size_t n16) {
+    u32 acc = 0;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) { uint4 v = a[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x12345) out[0] = acc;
+}
+// chunked: WG c owns a contiguous chunk and walks it tile by tile (4096 keys), wave-striped 8-B loads like rs_scatter
+template <int MODE>   // 0: read keys only; 1: read keys+vals; 2: copy keys+vals to same index; 3: read keys w/ LDS atomics (hist)
+__global__ __launch_bounds__(256) void k_chunked(const u64* __restrict__ kin, const u32* __restrict__ vin, u64* __restrict__ kout, u32* __restrict__ vout,
+                                                 u32 n, u32 chunk_tiles, u32* __restrict__ sink) {
+    __shared__ u32 h[1024];
+    const u32 t = threadIdx.x, w = t >> 6, lane = t & 63;
+    if (MODE == 3) { for (int i = t; i < 1024; i += 256) h[i] = 0; __syncthreads(); }
+    u64 acc = 0;
+    const u32 tile0 = blockIdx.x * chunk_tiles;
+    for (u32 tile = tile0; tile < tile0 + chunk_tiles; ++tile) {
+        const u64 tb = (u64)tile * 4096;
+        if (tb >= n) break;
+        u64 k[16]; u32 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) k[i] = kin[tb + w * 1024 + i * 64 + lane];
+        if (MODE == 1 || MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = vin[tb + w * 1024 + i * 64 + lane];
+        }
+        if (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { kout[tb + w * 1024 + i * 64 + lane] = k[i]; vout[tb + w * 1024 + i * 64 + lane] = v[i]; }
+        } else if (MODE == 3) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) atomicAdd(&h[w * 256 + (u32)(k[i] >> 24 & 255)], 1u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc += k[i]; if (MODE == 1) acc += v[i]; }
+        }
+    }
+    if (MODE == 3) { __syncthreads(); if (h[t] == 0x7fffffff) sink[0] = 1; }
+    if (acc == 0x1234567) sink[0] = (u32)acc;
+}
+// scatter-shaped writes: each WG writes runs of `run` keys to 256 streams (bucket b base = b * n/256), like a uniform digit pass
+__global__ __launch_bounds__(256) void k_scatter_runs(const u64* __restrict__ kin, u64* __restrict__ kout, u32 n, u32 chunk_tiles, u32 num_chunks) {
+    const u32 t = threadIdx.x;
+    const u32 per_bucket = n / 256;
+    for (u32 tt = 0; tt < chunk_tiles; ++tt) {
+        const u32 tile = blockIdx.x * chunk_tiles + tt;
+        const u64 tb = (u64)tile * 4096;
+        if (tb >= n) break;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const u32 q = j * 256 + t;               // position in the locally sorted tile
+            const u32 bucket = q >> 4, r = q & 15;   // 16 keys per bucket per tile
+            const u64 key = kin[tb + q];
+            kout[(u64)bucket * per_bucket + (u64)tile * 16 + r] = key;
+        }
+    }
+}
+template <class F> static float timeit(F f, int reps = 5) {
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    f(); CHECK(hipDeviceSynchronize());
+    float best = 1e9;
+    for (int r = 0; r < reps; ++r) { CHECK(hipEventRecord(a)); f(); CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b)); float ms; CHECK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms; }
+    return best;
+}
+int main() {
+    const u32 n = 64u << 20;
+    u64 *ka, *kb; u32 *va, *vb, *sink;
+    CHECK(hipMalloc(&ka, n * 8ull)); CHECK(hipMalloc(&kb, n * 8ull)); CHECK(hipMalloc(&va, n * 4ull)); CHECK(hipMalloc(&vb, n * 4ull)); CHECK(hipMalloc(&sink, 64));
+    CHECK(hipMemset(ka, 0x5a, n * 8ull)); CHECK(hipMemset(va, 1, n * 4ull));
+    const size_t n16 = n * 8ull / 16;
+    for (int grid : {1024, 2048, 8192}) {
+        float ms = timeit([&] { hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, 0, (const uint4*)ka, (uint4*)kb, n16); });
+        printf("copy16 grid-stride grid=%d: %.3f ms -> %.0f GB/s\n", grid, ms, 2.0 * n * 8 / 1e6 / ms);
+        ms = timeit([&] { hipLaunchKernelGGL(k_read16, dim3(grid), dim3(256), 0, 0, (const uint4*)ka, sink, n16); });
+        printf("read16 grid-stride grid=%d: %.3f ms -> %.0f GB/s\n", grid, ms, 1.0 * n * 8 / 1e6 / ms);
+    }
+    const u32 ct = 16, nc = 1024;
+    float ms = timeit([&] { hipLaunchKernelGGL(k_chunked<0>, dim3(nc), dim3(256), 0, 0, ka, va, kb, vb, n, ct, sink); });
+    printf("chunked read keys (8B/lane striped): %.3f ms -> %.0f GB/s\n", ms, 8.0 * n / 1e6 / ms);
+    ms = timeit([&] { hipLaunchKernelGGL(k_chunked<1>, dim3(nc), dim3(256), 0, 0, ka, va, kb, vb, n, ct, sink); });
+    printf("chunked read keys+vals: %.3f ms -> %.0f GB/s\n", ms, 12.0 * n / 1e6 / ms);
+    ms = timeit([&] { hipLaunchKernelGGL(k_chunked<2>, dim3(nc), dim3(256), 0, 0, ka, va, kb, vb, n, ct, sink); });
+    printf("chunked copy keys+vals (same index): %.3f ms -> %.0f GB/s\n", ms, 24.0 * n / 1e6 / ms);
+    ms = timeit([&] { hipLaunchKernelGGL(k_chunked<3>, dim3(nc), dim3(256), 0, 0, ka, va, kb, vb, n, ct, sink); });
+    printf("chunked read keys + LDS atomics (all same digit): %.3f ms -> %.0f GB/s\n", ms, 8.0 * n / 1e6 / ms);
+    ms = timeit([&] { hipLaunchKernelGGL(k_scatter_runs, dim3(nc), dim3(256), 0, 0, ka, kb, n, ct, nc); });
+    printf("keys: read + write 128-B runs into 256 streams: %.3f ms -> %.0f GB/s\n", ms, 16.0 * n / 1e6 / ms);
+    return 0;
+}
