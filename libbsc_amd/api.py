@@ -76,6 +76,20 @@ def bsc_qlfc_encode_block(data, coder=CODER_QLFC_STATIC, out_size=None):
     return out[:r].tobytes() if r >= 0 else r
 
 
+def bsc_qlfc_decode_block(data, n, coder=CODER_QLFC_STATIC):
+    a = _arr(data)
+    out = np.empty(n + 64, np.uint8)
+    r = _L().bsc_qlfc_decode_block(N.np_ptr(a), N.np_ptr(out), coder)
+    return out[:r].tobytes() if r >= 0 else r
+
+
+def bsc_bwt_decode(L, index, aux=(), features=3):
+    T = _arr(L, copy=True)
+    idx = (C.c_int * 256)(*aux)
+    r = _L().bsc_bwt_decode(N.np_ptr(T), T.size, index, len(aux), idx, features)
+    return T, r
+
+
 def bsc_qlfc_ranks(data):
     a = _arr(data)
     ranks = np.empty(a.size + 8, np.uint8)

@@ -170,23 +170,24 @@ int coder_compress(const uint8_t* in, uint8_t* out, int n, int coder, int featur
     return compress_serial(in, out, n, coder);
 }
 
-int coder_decompress(const uint8_t* in, uint8_t* out, int coder, int features)
+int coder_decompress_bounded(const uint8_t* in, uint8_t* out, int coder, int features, int max_out)
 {
     if (coder != CODER_STATIC && coder != CODER_ADAPTIVE && coder != CODER_FAST) return BAD_PARAMETER;
     const int nblocks = in[0];
-    if (nblocks == 1) return qlfc_decode_block(in + 1, out, coder);
+    if (nblocks == 1) return qlfc_decode_block_bounded(in + 1, out, coder, max_out);
     if (nblocks < 1 || nblocks > 8) return DATA_CORRUPT;   // the format never writes more than 8 (coder.cpp:52-59)
 
     int res[8], iptr[8], optr[8], isz[8], osz[8];
-    int ip = 1 + 8 * nblocks, op = 0;
+    long long ip = 1 + 8 * nblocks, op = 0;
     for (int b = 0; b < nblocks; ++b) {
         osz[b] = get_i32(in + 1 + 8 * b);
         isz[b] = get_i32(in + 1 + 8 * b + 4);
-        iptr[b] = ip; optr[b] = op;
+        if (osz[b] < 0 || isz[b] < 0 || op + osz[b] > max_out) return DATA_CORRUPT;
+        iptr[b] = (int)ip; optr[b] = (int)op;
         ip += isz[b]; op += osz[b];
     }
     auto one = [&](int b) {
-        if (isz[b] != osz[b]) res[b] = qlfc_decode_block(in + iptr[b], out + optr[b], coder);
+        if (isz[b] != osz[b]) { res[b] = qlfc_decode_block_bounded(in + iptr[b], out + optr[b], coder, osz[b]); if (res[b] >= 0 && res[b] != osz[b]) res[b] = DATA_CORRUPT; }
         else { res[b] = isz[b]; memcpy(out + optr[b], in + iptr[b], (size_t)isz[b]); }
     };
     if (features & FEATURE_MULTITHREADING) {
@@ -200,6 +201,7 @@ int coder_decompress(const uint8_t* in, uint8_t* out, int coder, int features)
     for (int b = 0; b < nblocks; ++b) { if (res[b] < 0) err = res[b]; total += res[b]; }
     return err == OK ? total : err;
 }
+int coder_decompress(const uint8_t* in, uint8_t* out, int coder, int features) { return coder_decompress_bounded(in, out, coder, features, 0x7fffffff); }
 
 // Adler-32 (adler32.cpp:82-204): s1 = 1 + sum, s2 = sum of s1, mod 65521; deferred modulo every 5552 bytes.
 uint32_t adler32(const uint8_t* p, size_t n)

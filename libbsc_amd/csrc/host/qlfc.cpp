@@ -11,6 +11,7 @@
 #include <memory>
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 #include <thread>
 
 #include "qlfc_data.inc"
@@ -110,11 +111,13 @@ public:
     }
     bool full() const { return (out_ - begin_) >= limit_; }
 
-    template <int P> inline void encode(unsigned bit, int p)
+    template <int P> __attribute__((always_inline)) inline void encode(unsigned bit, int p)
     {
-        if (range_ < 0x10000u) { shift(); range_ <<= 16; }
+        if (__builtin_expect(range_ < 0x10000u, 0)) { shift(); range_ <<= 16; }
         const uint32_t r = (range_ >> P) * (uint32_t)p;
-        if (bit) { low_ += r; range_ -= r; } else range_ = r;
+        const uint32_t m = 0u - bit;                 // branch-free: mantissa bits are close to coin flips
+        low_  += (uint64_t)(r & m);
+        range_ = r + (m & (range_ - r - r));
     }
     inline void encode_half(unsigned bit) { encode<12>(bit, 2048); }     // rangecoder.h:179-182
     void encode_word(uint32_t w) { for (int b = 31; b >= 0; --b) encode_half((w >> b) & 1u); }
@@ -161,11 +164,13 @@ struct Mixer {                       // predictor.h:74-213
     }
 };
 
-static inline void bump(short& p, unsigned bit, int th0, int ar0, int th1, int ar1)
+#define BSC_ALWAYS_INLINE __attribute__((always_inline)) inline
+static BSC_ALWAYS_INLINE void bump(short& p, unsigned bit, int th0, int ar0, int th1, int ar1)
 {
     // predictor.h:53-61 (the four-argument form at :44-50 is algebraically the same map)
-    if (bit) p = (short)(p - (((p - th1) * ar1) >> 12));
-    else     p = (short)(p + (((4096 - th0 - p) * ar0) >> 12));
+    const int up   = ((4096 - th0 - p) * ar0) >> 12;       // bit 0: move towards 4096 - th0
+    const int down = ((p - th1) * ar1) >> 12;               // bit 1: move towards th1
+    p = (short)(p + (bit ? -down : up));                    // select, not branch (constant-folds when bit is a literal)
 }
 
 struct Counters1 {
@@ -191,7 +196,7 @@ static void fill_shorts(void* p, size_t bytes, short v)
 
 // One binary decision of class CLS: three counters (+ mixer), update, code.
 template <int CLS, bool ADAPT>
-static inline void decide(RangeEncoder& rc, const QlfcTables& T, unsigned bit, short& st, short& ch, short& sp, Mixer* mx)
+static BSC_ALWAYS_INLINE void decide(RangeEncoder& rc, const QlfcTables& T, unsigned bit, short& st, short& ch, short& sp, Mixer* mx)
 {
     constexpr const short* P = ADAPT ? kAdaptiveParams[CLS] : kStaticParams[CLS];
     const int p0 = ch, p1 = st, p2 = sp;
@@ -273,17 +278,34 @@ static bool walk_model1(const RunView& R, const QlfcTables& T, const int max_ran
             } else {
                 const int bits = bsr32((unsigned)rank);
                 rank_hist[c] = (uint8_t)bits;
-                for (int b = 1; b < bits; ++b)
-                    pol.template decide<RANK_EXP>(1, K.rE_state[state][b - 1], K.rE_chr[c][b - 1], K.rE_stat[b - 1],
-                                            ADAPT ? &M->rank_exp[hist > b ? hist : b][b] : nullptr);
-                if (bits < max_rank)
-                    pol.template decide<RANK_EXP>(0, K.rE_state[state][bits - 1], K.rE_chr[c][bits - 1], K.rE_stat[bits - 1],
-                                            ADAPT ? &M->rank_exp[hist > bits ? hist : bits][bits] : nullptr);
-                short* ms = K.rM_state[bits][state]; short* mc = K.rM_chr[bits][c]; short* mp = K.rM_stat[bits];
-                for (int ctx = 1, b = bits - 1; b >= 0; --b) {
-                    const unsigned v = (unsigned)(rank >> b) & 1u;
-                    pol.template decide<RANK_MANT>(v, ms[ctx], mc[ctx], mp[ctx], ADAPT ? &M->rank_mant[bits] : nullptr);
-                    ctx += ctx + (int)v;
+                // One indirect jump on the exponent instead of data-dependent loop exits: each case is straight-line
+                // code (bits-1 ones, the optional terminating zero, then `bits` mantissa decisions).
+                auto tail = [&](auto BITS_T) {
+                    constexpr int BITS = decltype(BITS_T)::value;
+#pragma GCC unroll 8
+                    for (int b = 1; b < BITS; ++b)
+                        pol.template decide<RANK_EXP>(1, K.rE_state[state][b - 1], K.rE_chr[c][b - 1], K.rE_stat[b - 1],
+                                                ADAPT ? &M->rank_exp[hist > b ? hist : b][b] : nullptr);
+                    if (BITS < max_rank)
+                        pol.template decide<RANK_EXP>(0, K.rE_state[state][BITS - 1], K.rE_chr[c][BITS - 1], K.rE_stat[BITS - 1],
+                                                ADAPT ? &M->rank_exp[hist > BITS ? hist : BITS][BITS] : nullptr);
+                    short* ms = K.rM_state[BITS][state]; short* mc = K.rM_chr[BITS][c]; short* mp = K.rM_stat[BITS];
+                    int ctx = 1;
+#pragma GCC unroll 8
+                    for (int b = BITS - 1; b >= 0; --b) {
+                        const unsigned v = (unsigned)(rank >> b) & 1u;
+                        pol.template decide<RANK_MANT>(v, ms[ctx], mc[ctx], mp[ctx], ADAPT ? &M->rank_mant[BITS] : nullptr);
+                        ctx += ctx + (int)v;
+                    }
+                };
+                switch (bits) {
+                    case 1: tail(std::integral_constant<int, 1>()); break;
+                    case 2: tail(std::integral_constant<int, 2>()); break;
+                    case 3: tail(std::integral_constant<int, 3>()); break;
+                    case 4: tail(std::integral_constant<int, 4>()); break;
+                    case 5: tail(std::integral_constant<int, 5>()); break;
+                    case 6: tail(std::integral_constant<int, 6>()); break;
+                    default: tail(std::integral_constant<int, 7>()); break;
                 }
             }
         } else {
@@ -332,7 +354,7 @@ template <bool ADAPT>
 struct DirectPolicy {
     RangeEncoder& rc; const QlfcTables& T;
     inline bool begin_run() { return !rc.full(); }
-    template <int CLS> inline void decide(unsigned bit, short& st, short& ch, short& sp, Mixer* mx) { bschost::decide<CLS, ADAPT>(rc, T, bit, st, ch, sp, mx); }
+    template <int CLS> __attribute__((always_inline)) inline void decide(unsigned bit, short& st, short& ch, short& sp, Mixer* mx) { bschost::decide<CLS, ADAPT>(rc, T, bit, st, ch, sp, mx); }
 };
 
 static Counters1* new_counters()
@@ -550,6 +572,268 @@ static int encode_model2(const RunView& R, uint8_t* out, int in_size, int out_si
     return rc.finish();
 }
 
+// ------------------------------------------------------------------------------------------------
+// decoders (qlfc.cpp:1366-2127, rangecoder.h:200-270): the same models driven by decoded bits
+// ------------------------------------------------------------------------------------------------
+class RangeDecoder {
+public:
+    void init(const uint8_t* in)
+    {
+        in_ = in; code_ = 0; range_ = 0xffffffffu;
+        code_ = (code_ << 16) | next16(); code_ = (code_ << 16) | next16(); code_ = (code_ << 16) | next16();
+    }
+    template <int P> inline unsigned decode(int p)
+    {
+        if (range_ < 0x10000u) { range_ <<= 16; code_ = (code_ << 16) | next16(); }
+        const uint32_t r = (range_ >> P) * (uint32_t)p;
+        const unsigned bit = code_ >= r;
+        range_ = bit ? range_ - r : r;
+        code_  = bit ? code_ - r : code_;
+        return bit;
+    }
+    inline unsigned decode_half() { return decode<12>(2048); }
+    uint32_t decode_word() { uint32_t w = 0; for (int b = 0; b < 32; ++b) w += w + decode_half(); return w; }
+private:
+    inline uint32_t next16() { const uint32_t v = (uint32_t)in_[0] | ((uint32_t)in_[1] << 8); in_ += 2; return v; }
+    const uint8_t* in_; uint32_t code_, range_;
+};
+
+// Alphabet header: rebuilds the first-appearance list (with its terminator) and max_rank.
+template <class GetBit>
+static int decode_alphabet(uint8_t* mtf, GetBit&& get)
+{
+    bool used[256] = {false};
+    int prev = -1, max_rank = 7;
+    for (int slot = 0; slot < 256; ++slot) {
+        int cur = 0;
+        for (int bit = 7; bit >= 0; --bit) {
+            bool can0 = false, can1 = false;
+            for (int c = 0; c < 256 && !(can0 && can1); ++c)
+                if ((c == prev || !used[c]) && cur == (c >> (bit + 1))) { if (c & (1 << bit)) can1 = true; else can0 = true; }
+            if (can0 && can1) cur += cur + (int)get();
+            else cur += cur + (can1 ? 1 : 0);
+        }
+        mtf[slot] = (uint8_t)cur;
+        if (cur == prev) { max_rank = bsr32((unsigned)(slot - 1)); break; }
+        prev = cur; used[cur] = true;
+    }
+    return max_rank;
+}
+
+// one decoded decision of class CLS
+template <int CLS, bool ADAPT>
+static BSC_ALWAYS_INLINE unsigned undecide(RangeDecoder& rd, const QlfcTables& T, short& st, short& ch, short& sp, Mixer* mx)
+{
+    constexpr const short* P = ADAPT ? kAdaptiveParams[CLS] : kStaticParams[CLS];
+    const int p0 = ch, p1 = st, p2 = sp;
+    unsigned bit;
+    if (!ADAPT) {
+        bit = rd.decode<12>((p0 * P[16] + p1 * P[17] + p2 * P[18]) >> 5);
+    } else {
+        const int s0 = T.stretch[p0], s1 = T.stretch[p1], s2 = T.stretch[p2];
+        short sp16 = (short)((s0 * mx->w0 + s1 * mx->w1 + s2 * mx->w2) >> 17);
+        if (sp16 < -2047) sp16 = -2047;
+        if (sp16 >  2047) sp16 =  2047;
+        const int frac = sp16 & 255, idx = (sp16 + 2048) >> 8, sq = T.squash[2048 + sp16];
+        const int mapped = mx->map[idx] + (((mx->map[idx + 1] - mx->map[idx]) * frac) >> 8);
+        const int p = (3 * sq + mapped) >> 2;
+        bit = rd.decode<12>(p);
+        bump(mx->map[idx],     bit, P[12], P[13], P[14], P[15]);
+        bump(mx->map[idx + 1], bit, P[12], P[13], P[14], P[15]);
+        const int eps = p - (bit ? 1 : 4095);
+        mx->w0 -= (P[16] * eps * s0) >> 16;
+        mx->w1 -= (P[17] * eps * s1) >> 16;
+        mx->w2 -= (P[18] * eps * s2) >> 16;
+    }
+    bump(st, bit, P[0], P[1], P[2],  P[3]);
+    bump(ch, bit, P[4], P[5], P[6],  P[7]);
+    bump(sp, bit, P[8], P[9], P[10], P[11]);
+    return bit;
+}
+
+static inline void requeue(uint8_t* mtf, int rank, uint8_t c)      // the head symbol will next be met at position `rank`
+{
+    for (int r = 0; r < rank; ++r) mtf[r] = mtf[r + 1];
+    mtf[rank] = c;
+}
+
+template <bool ADAPT>
+static int decode_model1(const uint8_t* in, uint8_t* out, int max_out)
+{
+    const QlfcTables& T = qlfc_tables();
+    std::unique_ptr<Counters1> Cn(new_counters());
+    std::unique_ptr<Mixers1> Mx;
+    if (ADAPT) {
+        Mx.reset(new Mixers1);
+        Mixer* all = reinterpret_cast<Mixer*>(Mx.get());
+        for (size_t i = 0; i < sizeof(Mixers1) / sizeof(Mixer); ++i) all[i].init(T);
+    }
+    Counters1& K = *Cn; Mixers1* M = Mx.get();
+    RangeDecoder rd; rd.init(in);
+    const int n = (int)rd.decode_word();
+    if (n < 0 || n > max_out) return DATA_CORRUPT;
+    alignas(64) uint8_t mtf[256 + 16] = {0};
+    const int max_rank = decode_alphabet(mtf, [&] { return rd.decode_half(); });
+
+    int ctx_rank0 = 0, ctx_rank4 = 0, ctx_run = 0, avg_rank = 0;
+    uint8_t rank_hist[256] = {0}, run_hist[256] = {0};
+    for (int i = 0; i < n;) {
+        const int c = mtf[0];
+        int hist = rank_hist[c];
+        int state = T.rank_state[(ctx_run << 11) | (ctx_rank4 << 3) | hist];
+        int rank = 1;
+        if (avg_rank < 32) {
+            if (undecide<RANK_FIRST, ADAPT>(rd, T, K.rT_state[state], K.rT_chr[c], K.rT_stat, ADAPT ? &M->rank[c] : nullptr)) {
+                int bits = 1;
+                while (bits != max_rank &&
+                       undecide<RANK_EXP, ADAPT>(rd, T, K.rE_state[state][bits - 1], K.rE_chr[c][bits - 1], K.rE_stat[bits - 1],
+                                                 ADAPT ? &M->rank_exp[hist > bits ? hist : bits][bits] : nullptr))
+                    ++bits;
+                rank_hist[c] = (uint8_t)bits;
+                short* ms = K.rM_state[bits][state]; short* mc = K.rM_chr[bits][c]; short* mp = K.rM_stat[bits];
+                for (int b = bits - 1; b >= 0; --b)
+                    rank += rank + (int)undecide<RANK_MANT, ADAPT>(rd, T, ms[rank], mc[rank], mp[rank], ADAPT ? &M->rank_mant[bits] : nullptr);
+            } else {
+                rank_hist[c] = 0;
+            }
+        } else {
+            short* es = K.rP_state[state]; short* ec = K.rP_chr[c]; short* ep = K.rP_stat;
+            rank = 0;
+            for (int ctx = 1, b = max_rank; b >= 0; --b) {
+                const int v = (int)undecide<RANK_ESC, ADAPT>(rd, T, es[ctx], ec[ctx], ep[ctx], ADAPT ? &M->rank_esc[ctx] : nullptr);
+                ctx += ctx + v; rank += rank + v;
+            }
+            rank_hist[c] = (uint8_t)bsr32((unsigned)rank);
+        }
+        if (rank > 255) return DATA_CORRUPT;
+        requeue(mtf, rank, (uint8_t)c);
+
+        avg_rank = (avg_rank * 124 + rank * 4) >> 7;
+        rank -= 1;
+        hist = run_hist[c];
+        state = T.run_state[(ctx_rank0 << 10) | (ctx_run << 6) | ((rank < 7 ? rank : 7) << 3) | (hist < 7 ? hist : 7)];
+        int run = 1;
+        if (undecide<RUN_FIRST, ADAPT>(rd, T, K.nT_state[state], K.nT_chr[c], K.nT_stat, ADAPT ? &M->run[c] : nullptr)) {
+            int bits = 1;
+            while (bits < 31 &&
+                   undecide<RUN_EXP, ADAPT>(rd, T, K.nE_state[state][bits - 1], K.nE_chr[c][bits - 1], K.nE_stat[bits - 1],
+                                            ADAPT ? &M->run_exp[hist > bits ? hist : bits][bits] : nullptr))
+                ++bits;
+            run_hist[c] = (uint8_t)((run_hist[c] + 3 * bits + 3) >> 2);
+            short* ms = K.nM_state[bits][state]; short* mc = K.nM_chr[bits][c]; short* mp = K.nM_stat[bits];
+            for (int ctx = 1, b = bits - 1; b >= 0; --b) {
+                const int v = (int)undecide<RUN_MANT, ADAPT>(rd, T, ms[ctx], mc[ctx], mp[ctx], ADAPT ? &M->run_mant[bits] : nullptr);
+                run += run + v;
+                ctx = (bits <= 5) ? (ctx + ctx + v) : (ctx + 1);
+            }
+        } else {
+            run_hist[c] = (uint8_t)((run_hist[c] + 2) >> 2);
+        }
+        ctx_rank0 = ((ctx_rank0 << 1) | (rank == 0 ? 1 : 0)) & 0x7;
+        ctx_rank4 = ((ctx_rank4 << 2) | (rank < 3 ? rank : 3)) & 0xff;
+        ctx_run   = ((ctx_run   << 1) | (run < 3 ? 1 : 0)) & 0xf;
+        if (run <= 0 || run > n - i) return DATA_CORRUPT;
+        memset(out + i, c, (size_t)run);
+        i += run;
+    }
+    return n;
+}
+
+static int decode_model2(const uint8_t* in, uint8_t* out, int max_out)
+{
+    std::unique_ptr<Counters2> Cn(new Counters2);
+    fill_shorts(Cn->r_exp, sizeof(Cn->r_exp) + sizeof(Cn->r_mant), 4096);
+    fill_shorts(Cn->n_exp, sizeof(Cn->n_exp) + sizeof(Cn->n_mant), 1024);
+    Counters2& K = *Cn;
+    RangeDecoder rd; rd.init(in);
+    const int n = (int)rd.decode_word();
+    if (n < 0 || n > max_out) return DATA_CORRUPT;
+    alignas(64) uint8_t mtf[256 + 16] = {0};
+    decode_alphabet(mtf, [&] { return rd.decode<1>(1); });
+    for (int i = 0; i < n;) {
+        const int c = mtf[0];
+        int rank = 1;
+        {
+            short* e = K.r_exp[c];
+            const int p = e[0];
+            if (rd.decode<13>(p)) {
+                nudge<4>(e[0], 83);
+                int bits = 1;
+                for (;;) {
+                    if (bits == 7) break;
+                    const int q = e[bits];
+                    if (rd.decode<13>(q)) { nudge<4>(e[bits], 122); ++bits; } else { nudge<4>(e[bits], 8114); break; }
+                }
+                short* mt = K.r_mant[c][bits];
+                for (int b = bits - 1; b >= 0; --b) {
+                    const int q = mt[rank];
+                    const unsigned v = rd.decode<13>(q);
+                    nudge<7>(mt[rank], v ? 235 : 7999);
+                    rank += rank + (int)v;
+                }
+            } else nudge<4>(e[0], 8016);
+        }
+        if (rank > 255) return DATA_CORRUPT;
+        requeue(mtf, rank, (uint8_t)c);
+        int run = 1;
+        {
+            short* e = K.n_exp[c];
+            const int p = e[0];
+            if (rd.decode<11>(p)) {
+                nudge<5>(e[0], 42);
+                int bits = 1;
+                for (;;) {
+                    if (bits >= 31) break;
+                    const int q = e[bits];
+                    if (rd.decode<11>(q)) { nudge<4>(e[bits], 142); ++bits; } else { nudge<4>(e[bits], 1962); break; }
+                }
+                short* mt = K.n_mant[c][bits];
+                for (int ctx = 1, b = bits - 1; b >= 0; --b) {
+                    const int q = mt[ctx];
+                    const unsigned v = rd.decode<11>(q);
+                    if (bits <= 5) { nudge<6>(mt[ctx], v ? 147 : 1951); ctx += ctx + (int)v; }
+                    else           { nudge<5>(mt[ctx], v ? 46 : 1987);  ctx += 1; }
+                    run += run + (int)v;
+                }
+            } else nudge<5>(e[0], 2025);
+        }
+        if (run <= 0 || run > n - i) return DATA_CORRUPT;
+        memset(out + i, c, (size_t)run);
+        i += run;
+    }
+    return n;
+}
+
+int qlfc_decode_block_bounded(const uint8_t* in, uint8_t* out, int coder, int max_out)
+{
+    switch (coder) {
+        case CODER_STATIC:   return decode_model1<false>(in, out, max_out);
+        case CODER_ADAPTIVE: return decode_model1<true>(in, out, max_out);
+        case CODER_FAST:     return decode_model2(in, out, max_out);
+    }
+    return BAD_PARAMETER;
+}
+int qlfc_decode_block(const uint8_t* in, uint8_t* out, int coder) { return qlfc_decode_block_bounded(in, out, coder, 0x7fffffff); }
+
+// ---- ablation hooks for tools/host_coder_probe.py (timing experiments only; never on the product path) ----
+struct CountPolicy { uint64_t n = 0; inline bool begin_run() { return true; }
+    template <int CLS> inline void decide(unsigned bit, short&, short&, short&, Mixer*) { n += 1 + bit; } };
+struct CounterOnlyPolicy { uint64_t acc = 0; inline bool begin_run() { return true; }
+    template <int CLS> inline void decide(unsigned bit, short& st, short& ch, short& sp, Mixer*) {
+        constexpr const short* P = kStaticParams[CLS];
+        acc += (uint64_t)((ch * P[16] + st * P[17] + sp * P[18]) >> 5);
+        bump(st, bit, P[0], P[1], P[2], P[3]); bump(ch, bit, P[4], P[5], P[6], P[7]); bump(sp, bit, P[8], P[9], P[10], P[11]); } };
+uint64_t qlfc_ablate(const uint8_t* in, int n, int mode)
+{
+    const QlfcTables& T = qlfc_tables();
+    QlfcRuns R; qlfc_runs(in, n, R);
+    if (mode == 0) return R.view.count;
+    std::unique_ptr<Counters1> Cn(new_counters());
+    const int max_rank = encode_alphabet(R.view, [](unsigned) {});
+    if (mode == 1) { CountPolicy p; walk_model1<false>(R.view, T, max_rank, *Cn, nullptr, p); return p.n; }
+    CounterOnlyPolicy p; walk_model1<false>(R.view, T, max_rank, *Cn, nullptr, p); return p.acc;
+}
+
 static int g_pipeline = -1;      // BSC_QLFC_PIPELINE=0 disables the 4-thread static coder
 int qlfc_encode_runs(const RunView& R, int in_size, uint8_t* out, int out_size, int coder, bool allow_threads)
 {
@@ -579,3 +863,6 @@ int qlfc_encode_block(const uint8_t* in, uint8_t* out, int in_size, int out_size
 }
 
 }  // namespace bschost
+
+extern "C" __attribute__((visibility("default")))
+unsigned long long bsc_qlfc_ablate(const unsigned char* in, int n, int mode) { return bschost::qlfc_ablate(in, n, mode); }

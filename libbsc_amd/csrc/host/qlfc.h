@@ -65,6 +65,9 @@ int qlfc_decode_block(const uint8_t* in, uint8_t* out, int coder);
 // Block-level coder (coder.cpp:244 / :273): split into 1/2/4/8 sub-blocks, encode, frame.
 int coder_compress(const uint8_t* in, uint8_t* out, int n, int coder, int features);
 int coder_decompress(const uint8_t* in, uint8_t* out, int coder, int features);
+// as above, but never writes more than max_out bytes (DATA_CORRUPT otherwise)
+int coder_decompress_bounded(const uint8_t* in, uint8_t* out, int coder, int features, int max_out);
+int qlfc_decode_block_bounded(const uint8_t* in, uint8_t* out, int coder, int max_out);
 int coder_num_blocks(int n);
 // Same framing, but the sub-blocks arrive as run arrays (GPU front end).  fetch_raw(start, size, dst) supplies the
 // original bytes of a sub-block that has to be stored raw.
