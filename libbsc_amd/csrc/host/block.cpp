@@ -5,9 +5,11 @@
 // [0]blockSize [4]dataSize [8]mode [12]index [16]adler(data) [20]adler(payload) [24]adler(header[0..24)),
 // trailer = indexes[num] + num byte.  Stage entry points mirror bwt.cpp:178, st.cpp:990, coder.cpp:244.
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <chrono>
 #include <mutex>
+#include <condition_variable>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -309,6 +311,8 @@ static int gpu_stage(BlockJob& J, int blockSorter)
 static void host_stage(BlockJob& J)
 {
     if (J.stored_small) return;
+    const bool dbg = getenv("BSCGPU_DEBUG") != nullptr;
+    const auto th0 = clk::now();
     const int n = J.n;
     uint8_t* output = J.output;
     RunView views[8];
@@ -332,9 +336,12 @@ static void host_stage(BlockJob& J)
     {
         unsigned char* buffer = (unsigned char*)bsc_malloc((size_t)n + 4096);
         if (!buffer) { J.result = LIBBSC_NOT_ENOUGH_MEMORY; return; }
+        const auto tc0 = clk::now();
         result = coder_compress_views(views, J.nblocks, J.start, J.size, n, buffer, J.coder, J.features, fetch);
+        const double t_coder = ms_since(tc0);
         if (result >= 0) memcpy(output + LIBBSC_HEADER_SIZE, buffer, (size_t)result);
         bsc_free(buffer);
+        if (dbg) fprintf(stderr, "[host_stage] setup+alloc %.1f ms, coder %.1f ms, total so far %.1f ms\n", ms_since(th0) - t_coder, t_coder, ms_since(th0));
     }
     if (result < LIBBSC_NO_ERROR || result + 1 + 4 * J.num_indexes >= n) {       // store (libbsc.cpp:315-318)
         if (hipSetDevice(J.c->device) != hipSuccess ||
@@ -390,6 +397,10 @@ struct bscgpu_pipe {
     bscgpu_ctx* c = nullptr;
     int depth = 1;
     int next_ticket = 0;
+    // at most `host_slots` host stages run at once (8 coder threads each), so the host-thread budget per GPU is fixed
+    // (16 by default) while a further block's GPU stage overlaps; FIFO so blocks finish in ticket order
+    int host_slots = 2;
+    std::mutex mu; std::condition_variable cv; int running = 0; int next_to_run = 0;
     struct Lane { std::unique_ptr<BlockJob> job; std::thread worker; int ticket = -1; bool busy = false; int result = 0; };
     Lane lanes[MAX_SLOTS];
 };
@@ -407,6 +418,7 @@ int bscgpu_pipe_create(bscgpu_ctx* c, int depth, bscgpu_pipe** out)
     if (rc < 0) return rc;
     bscgpu_pipe* p = new bscgpu_pipe;
     p->c = c; p->depth = depth;
+    if (const char* e = getenv("BSCGPU_HOST_CONCURRENCY")) { int v = atoi(e); if (v >= 1 && v <= MAX_SLOTS) p->host_slots = v; }
     for (int i = 0; i < depth; ++i) p->lanes[i].job.reset(new BlockJob);
     *out = p;
     return LIBBSC_NO_ERROR;
@@ -432,7 +444,17 @@ int bscgpu_pipe_submit(bscgpu_pipe* p, const void* dInput, uint8_t* output, int 
     rc = gpu_stage(J, blockSorter);
     if (rc < 0) return rc;
     L.ticket = ticket; L.busy = true;
-    L.worker = std::thread([&J] { host_stage(J); });
+    L.worker = std::thread([p, &J, ticket] {
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv.wait(lk, [&] { return p->next_to_run == ticket && p->running < p->host_slots; });
+            ++p->running; ++p->next_to_run;
+        }
+        p->cv.notify_all();
+        host_stage(J);
+        { std::lock_guard<std::mutex> lk(p->mu); --p->running; }
+        p->cv.notify_all();
+    });
     p->next_ticket = ticket + 1;
     return ticket;
 }

@@ -4,6 +4,10 @@
 #include "qlfc.h"
 
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <chrono>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -121,18 +125,22 @@ int coder_compress_views(const RunView* views, int nblocks, const int* start, co
     }
     out[0] = (uint8_t)nblocks;
     if (features & FEATURE_MULTITHREADING) {               // coder.cpp:159-240
-        std::vector<std::vector<uint8_t>> scratch((size_t)nblocks);
+        std::vector<std::unique_ptr<uint8_t[]>> scratch((size_t)nblocks);
         int res[8];
+        double tms[8];
         {
             std::vector<std::thread> pool;
             for (int b = 0; b < nblocks; ++b)
                 pool.emplace_back([&, b] {
-                    scratch[(size_t)b].resize((size_t)size[b] + 64);
-                    int r = qlfc_encode_runs(views[b], size[b], scratch[(size_t)b].data(), size[b], coder, true);
+                    const auto t0 = std::chrono::steady_clock::now();
+                    scratch[(size_t)b].reset(new uint8_t[(size_t)size[b] + 64]);        // uninitialised on purpose
+                    int r = qlfc_encode_runs(views[b], size[b], scratch[(size_t)b].get(), size[b], coder, true);
                     res[b] = (r < 0) ? size[b] : r;
+                    tms[b] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
                 });
             for (auto& t : pool) t.join();
         }
+        if (getenv("BSCGPU_DEBUG")) { fprintf(stderr, "[coder] sub-block ms:"); for (int b = 0; b < nblocks; ++b) fprintf(stderr, " %.1f", tms[b]); fprintf(stderr, "\n"); }
         int total = 1 + 8 * nblocks;
         for (int b = 0; b < nblocks; ++b) total += res[b];
         if (total >= n) return NOT_COMPRESSIBLE;
@@ -140,7 +148,7 @@ int coder_compress_views(const RunView* views, int nblocks, const int* start, co
         for (int b = 0; b < nblocks; ++b) {
             put_i32(out + 1 + 8 * b, size[b]);
             put_i32(out + 1 + 8 * b + 4, res[b]);
-            if (res[b] != size[b]) memcpy(out + optr, scratch[(size_t)b].data(), (size_t)res[b]);
+            if (res[b] != size[b]) memcpy(out + optr, scratch[(size_t)b].get(), (size_t)res[b]);
             else { int rc = fetch_raw(start[b], size[b], out + optr); if (rc < 0) return rc; }
             optr += res[b];
         }
