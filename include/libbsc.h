@@ -7,8 +7,7 @@
  * (DESIGN.md): the block sorters run on the GPU only (no CPU sorter is shipped: without a usable GPU
  * the sorters return LIBBSC_GPU_NOT_SUPPORTED instead of silently falling back), and LZP
  * preprocessing is not implemented (lzpHashSize / lzpMinLen must be 0, else LIBBSC_NOT_SUPPORTED).
- * Decode side: bsc_decompress handles stored and BWT blocks (host inverse BWT + QLFC decoders); inverse ST is not
- * built yet (bsc_st_decode and ST blocks return LIBBSC_NOT_SUPPORTED).
+ * Decode side: bsc_decompress is self-hosted (QLFC decoders, inverse BWT and inverse ST3..8 on the host).
  */
 #ifndef LIBBSC_MI355X_LIBBSC_H
 #define LIBBSC_MI355X_LIBBSC_H

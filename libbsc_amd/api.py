@@ -90,6 +90,12 @@ def bsc_bwt_decode(L, index, aux=(), features=3):
     return T, r
 
 
+def bsc_st_decode(data, k, index, features=3):
+    T = _arr(data, copy=True)
+    r = _L().bsc_st_decode(N.np_ptr(T), T.size, k, index, features)
+    return T, r
+
+
 def bsc_qlfc_ranks(data):
     a = _arr(data)
     ranks = np.empty(a.size + 8, np.uint8)

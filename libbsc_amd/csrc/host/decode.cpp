@@ -2,8 +2,7 @@
 //
 // Container checks follow libbsc.cpp:522-617 (bsc_decompress) and :420-519 (in-place twin).  The inverse BWT is a
 // plain host LF-mapping walk (the reference uses libsais_unbwt[_aux], bwt.cpp:283-334; same result, no auxiliary
-// index parallelism yet).  Inverse ST (st.cpp:1014-1527) is row f4 and not built: ST blocks return
-// LIBBSC_NOT_SUPPORTED from bsc_st_decode / bsc_decompress.
+// index parallelism yet).  The inverse ST (reference: st.cpp:1014-1527) is our own algorithm from the definition.
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -45,7 +44,66 @@ int bsc_bwt_decode(unsigned char* T, int n, int index, unsigned char num_indexes
     return LIBBSC_NO_ERROR;
 }
 
-int bsc_st_decode(unsigned char*, int, int, int, int) { return LIBBSC_NOT_SUPPORTED; }
+// Inverse Sort Transform of order k (contract: st.cpp:1491-1527; algorithm ours, from the definition).
+// Rows are the positions sorted stably by their k cyclic bytes; L[row] is the byte before the position.
+//  * img(j) = stable counting-sort image of row j by L[j]: it orders the predecessors (p-1) by (L[j], context(p), p),
+//    i.e. by their (k+1)-context — in particular by their k-context, so every k-context group occupies the same index
+//    range in image order as in row order.
+//  * group starts for contexts of length d+1 follow from those of length d: image m = img(j) starts a group iff j is
+//    the first row of its d-group carrying that byte (k-1 linear rounds).
+//  * walking the text backwards visits positions in decreasing order, and rows inside a group are in increasing
+//    position order, so the predecessor of the current row is the LAST unvisited row of the group holding img(row).
+int bsc_st_decode(unsigned char* T, int n, int k, int index, int features)
+{
+    (void)features;
+    if (T == nullptr || n < 0 || index < 0 || index > n) return LIBBSC_BAD_PARAMETER;
+    if (k < 3 || k > 8) return LIBBSC_BAD_PARAMETER;
+    if (n <= 1) return LIBBSC_NO_ERROR;
+    if (index >= n) return LIBBSC_BAD_PARAMETER;
+    const size_t N = (size_t)n;
+    std::vector<unsigned> img(N), gstart(N);
+    std::vector<unsigned char> head(N), next_head(N);
+    unsigned base[256] = {0};
+    {
+        unsigned cnt[256] = {0};
+        for (size_t j = 0; j < N; ++j) cnt[T[j]]++;
+        unsigned sum = 0;
+        for (int c = 0; c < 256; ++c) { base[c] = sum; if (cnt[c]) head[sum] = 1; sum += cnt[c]; }   // 1-context groups
+        unsigned run[256];
+        memcpy(run, base, sizeof run);
+        for (size_t j = 0; j < N; ++j) img[j] = run[T[j]]++;
+    }
+    for (int d = 1; d < k; ++d) {                          // d-context groups -> (d+1)-context groups
+        std::fill(next_head.begin(), next_head.end(), 0);
+        long long last_group[256];
+        for (int c = 0; c < 256; ++c) last_group[c] = -1;
+        long long g = -1;
+        for (size_t j = 0; j < N; ++j) {
+            if (head[j]) g = (long long)j;
+            const unsigned char c = T[j];
+            if (last_group[c] != g) { last_group[c] = g; next_head[img[j]] = 1; }
+        }
+        head.swap(next_head);
+    }
+    {   // group start of every index, and per-group count of unvisited rows (kept at the group start)
+        unsigned gs = 0;
+        for (size_t j = 0; j < N; ++j) { if (head[j]) gs = (unsigned)j; gstart[j] = gs; }
+    }
+    std::vector<unsigned> remaining(N, 0);
+    for (size_t j = 0; j < N; ++j) remaining[gstart[j]]++;
+
+    std::vector<unsigned char> out(N);
+    unsigned row = (unsigned)index;
+    for (size_t t = N; t-- > 0;) {
+        out[t] = T[row];
+        const unsigned gs = gstart[img[row]];
+        if (remaining[gs] == 0) return LIBBSC_DATA_CORRUPT;
+        row = gs + --remaining[gs];
+    }
+    if (row != (unsigned)index) return LIBBSC_DATA_CORRUPT;        // the walk must close on position 0's row
+    memcpy(T, out.data(), N);
+    return LIBBSC_NO_ERROR;
+}
 
 int bsc_decompress(const unsigned char* input, int inputSize, unsigned char* output, int outputSize, int features)
 {
@@ -61,7 +119,6 @@ int bsc_decompress(const unsigned char* input, int inputSize, unsigned char* out
     const unsigned adler_data = (unsigned)get_i32(input + 16);
     const int lzpHashSize = (mode >> 16) & 0xff, lzpMinLen = (mode >> 8) & 0xff, coder = (mode >> 5) & 0x7, sorter = mode & 0x1f;
     if (lzpHashSize != 0 || lzpMinLen != 0) return LIBBSC_NOT_SUPPORTED;                  // LZP: out of scope (f3)
-    if (sorter != LIBBSC_BLOCKSORTER_BWT) return LIBBSC_NOT_SUPPORTED;                    // inverse ST: row f4
 
     // the coder writes dataSize bytes; decode through a scratch buffer when decompressing in place
     const bool inplace = (input == output);
@@ -77,7 +134,8 @@ int bsc_decompress(const unsigned char* input, int inputSize, unsigned char* out
     // guard the decoder's output size before it writes: the stream announces its own length
     int lzSize = coder_decompress_bounded(src + LIBBSC_HEADER_SIZE, output, coder, features, dataSize);
     if (lzSize < LIBBSC_NO_ERROR) return lzSize;
-    int rc = bsc_bwt_decode(output, lzSize, index, (unsigned char)num_indexes, indexes, features);
+    int rc = (sorter == LIBBSC_BLOCKSORTER_BWT) ? bsc_bwt_decode(output, lzSize, index, (unsigned char)num_indexes, indexes, features)
+                                                : bsc_st_decode(output, lzSize, sorter, index, features);
     if (rc < LIBBSC_NO_ERROR) return rc;
     if (lzSize != dataSize) return LIBBSC_DATA_CORRUPT;
     return adler_data == adler32(output, (size_t)dataSize) ? LIBBSC_NO_ERROR : LIBBSC_DATA_CORRUPT;

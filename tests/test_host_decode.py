@@ -55,5 +55,28 @@ def test_bsc_decompress_reads_reference_blocks(ref):
     assert api.bsc_decompress(bytes(blk)) == api.DATA_CORRUPT
     blk = bytearray(ref.compress(T, 1, 1)); blk[13] ^= 1
     assert api.bsc_decompress(bytes(blk)) == api.DATA_CORRUPT
-    # ST blocks: inverse ST is not built yet (row f4)
-    assert api.bsc_decompress(ref.compress(T, 5, 1)) == api.NOT_SUPPORTED
+    for k in (3, 4, 5, 6):
+        assert api.bsc_decompress(ref.compress(T, k, 1)) == T.tobytes(), k
+
+
+def test_st_decode_inverts_reference_encoder(ref):
+    """inverse ST (row f4) against the reference's CPU encoder for k = 3..6, and against its decoder's verdict for
+    k = 7, 8 via the numpy model of our GPU encoder (tests/pipeline_model.py)."""
+    from pipeline_model import st_model
+    rng = np.random.default_rng(4)
+    cases = [t for _, t in _texts() if t.size <= 300_000]
+    for n in (2, 3, 4, 5, 7, 8, 9, 16, 100, 1000):
+        cases += [rng.integers(0, 256, n, dtype=np.uint8), rng.integers(0, 2, n, dtype=np.uint8), np.zeros(n, np.uint8),
+                  (np.arange(n) % 3).astype(np.uint8)]
+    for T in cases:
+        for k in (3, 4, 5, 6):
+            enc, idx = ref.st_encode(T, k)
+            back, rc = api.bsc_st_decode(enc, k, idx)
+            assert rc == 0 and np.array_equal(back, T), (T.size, k)
+        if T.size <= 5000:
+            for k in (7, 8):
+                enc, idx = st_model(T, k)
+                back, rc = api.bsc_st_decode(enc, k, idx)
+                assert rc == 0 and np.array_equal(back, T), (T.size, k)
+    assert api.bsc_st_decode(np.zeros(10, np.uint8), 2, 0)[1] == api.BAD_PARAMETER
+    assert api.bsc_st_decode(np.zeros(10, np.uint8), 5, 10)[1] == api.BAD_PARAMETER
