@@ -8,16 +8,16 @@
 // The reference GPU path (libcubwt.cu:2031-2223: DC3 2/3 sample + 64-bit prefix sort + segmented sort
 // + merge) is NOT followed; this is a different algorithm with the same result:
 //
-//   1. bwt_pack:   key[s] = big-endian T[i..i+8) (zero padded), value = i.  The <= 7 "tail" suffixes
-//                  whose 8-byte window crosses the block end are placed FIRST in input order,
+//   1. bwt_pack:   key[s] = the first w characters of suffix i as dense alphabet codes (w = 8..16), value = i.  The < w "tail" suffixes
+//                  whose window crosses the block end are placed FIRST in input order,
 //                  shortest first; the LSD sort is stable, so inside a group of equal padded keys
 //                  they come out first and already in final order ("proper prefix is smaller"),
 //                  and seg marks each of them as a finished singleton.
-//   2. 8 radix passes over (u64 key, u32 suffix) -> order by 8-byte prefix.
+//   2. <= 8 radix passes over (u64 key, u32 suffix) -> order by w-character prefix.
 //   3. seg (reduce / scan / apply): group heads, rank = position of the group head (so ranks are valid
 //      SA slots and only ever grow under refinement), ISA scatter, and stream compaction of every
 //      suffix still sharing its rank ("unsorted").
-//   4. doubling round h = 8, 16, ...: key = (rank << 32) | (ISA[sa+h]+1, or 0 when sa+h == n),
+//   4. doubling round h = w, 2w, ...: key = (rank << bits(n)) | (ISA[sa+h]+1, or 0 when sa+h == n),
 //      radix-sort the compacted set on the used bits only, seg again (new heads where the 64-bit
 //      key changes), write SA/ISA back through the saved slot list, compact again.  One 4-byte
 //      D2H + stream sync per round for the loop test (libcubwt does the same, libcubwt.cu:1383).
@@ -30,23 +30,69 @@ constexpr int SEG_ITEMS = 8;
 constexpr int SEG_TILE  = WG * SEG_ITEMS;      // 2048 records per tile, 8 consecutive per thread
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void bwt_pack_kernel(const u8* __restrict__ T, u32 n, u32 tc,
-                                                      u64* __restrict__ keys, u32* __restrict__ vals)
+// Byte histogram of the block (replicated LDS bins against skew) -> alphabet size K and dense codes.
+__global__ __launch_bounds__(WG) void bwt_bytehist_kernel(const u8* __restrict__ T, u32 n, u32 chunk_bytes, u32* __restrict__ hist)
 {
+    __shared__ u32 h[8 * 256];
+    for (u32 i = threadIdx.x; i < 8 * 256; i += WG) h[i] = 0;
+    __syncthreads();
+    u32* hw = h + (threadIdx.x & 7) * 256;
+    const u64 start = (u64)blockIdx.x * chunk_bytes;
+    u64 end = start + chunk_bytes; if (end > n) end = n;
+    for (u64 i = start + 16ull * threadIdx.x; i < end; i += 16ull * WG) {
+        if (i + 16 <= end) {
+            const uint4 q = *reinterpret_cast<const uint4*>(T + i);
+            const u32 w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                atomicAdd(&hw[w[x] & 255u], 1u); atomicAdd(&hw[(w[x] >> 8) & 255u], 1u);
+                atomicAdd(&hw[(w[x] >> 16) & 255u], 1u); atomicAdd(&hw[w[x] >> 24], 1u);
+            }
+        } else for (u64 p = i; p < end; ++p) atomicAdd(&hw[T[p]], 1u);
+    }
+    __syncthreads();
+    u32 sum = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sum += h[r * 256 + threadIdx.x];
+    if (sum) atomicAdd(&hist[threadIdx.x], sum);
+}
+
+// Alphabet-compacted prefix keys.  codes[c] = order-preserving dense code of byte c (bits per code = cb), a key
+// holds the first w = min(16, 64 / cb) characters of the suffix, most significant first, zero (= smallest code)
+// padded past the block end.  Text with <= 32 distinct bytes thus sorts on 12-16 characters in the same 8 passes
+// that raw bytes spend on 8, which removes most of the first doubling round's work.
+// Suffixes whose window crosses the end ("tails", i + w > n, at most w-1 of them) go FIRST in input order, shortest
+// first: the stable sort then leaves them first inside any group of equal padded keys, already in final order.
+struct PackParams { u32 cb; u32 w; u32 tc; u32 low_shift; };
+
+__global__ __launch_bounds__(WG) void bwt_pack_kernel(const u8* __restrict__ T, u32 n, PackParams pp,
+                                                      const u8* __restrict__ codes, u64* __restrict__ keys, u32* __restrict__ vals)
+{
+    __shared__ u8 lut[256];
+    lut[threadIdx.x] = codes[threadIdx.x];
+    __syncthreads();
     const u32 i0 = 4u * (blockIdx.x * WG + threadIdx.x);
     if (i0 >= n) return;
-    const u32* T32 = reinterpret_cast<const u32*>(T + i0);      // T is 16-B aligned, zero padded past n
-    const u32 a = __builtin_bswap32(T32[0]);
-    const u32 b = __builtin_bswap32(T32[1]);
-    const u32 c = __builtin_bswap32(T32[2]);
-    const u64 hi = ((u64)a << 32) | b;                            // bytes i0 .. i0+7, big endian
+    // characters i0 .. i0 + w + 2 (<= 19 bytes; T is 16-B aligned at T[0] and zero padded for 32 bytes past n)
+    const u32* T32 = reinterpret_cast<const u32*>(T + i0);
+    u32 wds[5];
+#pragma unroll
+    for (int x = 0; x < 5; ++x) wds[x] = T32[x];
+    u64 cd[19];                                     // codes of characters i0 .. i0+18 (0 past the end)
+#pragma unroll
+    for (u32 t = 0; t < 19; ++t) {
+        const u32 c = (wds[t >> 2] >> (8 * (t & 3))) & 0xffu;
+        cd[t] = (i0 + t < n) ? (u64)lut[c] : 0ull;
+    }
 #pragma unroll
     for (u32 j = 0; j < 4; ++j) {
         const u32 i = i0 + j;
         if (i < n) {
-            const u64 key = (j == 0) ? hi : ((hi << (8 * j)) | (u64)(c >> (32 - 8 * j)));
-            const bool tail = (u64)i + 8 > (u64)n;
-            const u32 slot = tail ? (n - 1 - i) : (i + tc);
+            u64 key = 0;
+#pragma unroll
+            for (u32 t = 0; t < 16; ++t) if (t < pp.w) key |= cd[j + t] << (64 - pp.cb * (t + 1));
+            const bool tail = (u64)i + pp.w > (u64)n;
+            const u32 slot = tail ? (n - 1 - i) : (i + pp.tc);
             keys[slot] = key;
             vals[slot] = i;
         }
@@ -61,14 +107,14 @@ __global__ __launch_bounds__(WG) void bwt_pack_kernel(const u8* __restrict__ T, 
 // ---------------------------------------------------------------------------------------------
 template <bool INITIAL>
 __global__ __launch_bounds__(WG) void seg_reduce_kernel(const u64* __restrict__ keys, const u32* __restrict__ sa,
-                                                        u32 m, u32 n, u32 chunk_tiles, u32 num_tiles,
+                                                        u32 m, u32 tail_lo, u32 chunk_tiles, u32 num_tiles,
                                                         u8* __restrict__ flags, u32* __restrict__ segsum /*[2][MAX_CHUNKS]*/)
 {
     __shared__ u32 scr[8];
     const u32 t = threadIdx.x;
     const u32 tile0 = blockIdx.x * chunk_tiles;
     u32 tile1 = tile0 + chunk_tiles; if (tile1 > num_tiles) tile1 = num_tiles;
-    const u32 tail_lo = (n >= 8) ? (n - 7) : 0;      // suffix i is a tail iff i >= tail_lo
+    // suffix i is a tail (window crosses the block end) iff i >= tail_lo
 
     u32 cnt = 0, last1 = 0;
     for (u32 tile = tile0; tile < tile1; ++tile) {
@@ -230,7 +276,7 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
 // doubling round key build: key = rank << 32 | (ISA[sa + h] + 1, 0 when sa + h == n)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void bwt_gather_kernel(const u32* __restrict__ csa, const u32* __restrict__ cgrp,
-                                                        const u32* __restrict__ ISA, u32 U, u64 h, u64 n,
+                                                        const u32* __restrict__ ISA, u32 U, u64 h, u64 n, int lo_bits,
                                                         u64* __restrict__ keys, u32* __restrict__ vals)
 {
     const u32 stride = gridDim.x * WG;
@@ -238,7 +284,7 @@ __global__ __launch_bounds__(WG) void bwt_gather_kernel(const u32* __restrict__ 
         const u32 s = csa[k];
         const u64 p = (u64)s + h;
         const u32 nxt = (p < n) ? (ISA[p] + 1u) : 0u;
-        keys[k] = ((u64)cgrp[k] << 32) | nxt;
+        keys[k] = ((u64)cgrp[k] << lo_bits) | nxt;
         vals[k] = s;
     }
 }
@@ -287,13 +333,13 @@ void launch_seg_scan(bscgpu_ctx* c, u32 num_chunks)
 static int bit_length(u64 x) { int b = 0; while (x) { ++b; x >>= 1; } return b; }
 
 template <bool INITIAL>
-static int run_seg(bscgpu_ctx* c, const u64* keys, const u32* sa_sorted, const u32* cpos_in, u32 m, u32 n,
+static int run_seg(bscgpu_ctx* c, const u64* keys, const u32* sa_sorted, const u32* cpos_in, u32 m, u32 tail_lo,
                    u32* cpos_out, u32* csa_out, u32* cgrp_out, u32* U_out)
 {
     const Chunking ch = make_chunking(m, SEG_TILE);
     prof_begin(c, BSCGPU_K_SEG, (u64)m * (8 + (INITIAL ? 4 : 0) + 1), m);
     hipLaunchKernelGGL(seg_reduce_kernel<INITIAL>, dim3(ch.num_chunks), dim3(WG), 0, c->stream,
-                       keys, sa_sorted, m, n, ch.chunk_tiles, ch.num_tiles, c->flags, c->segsum);
+                       keys, sa_sorted, m, tail_lo, ch.chunk_tiles, ch.num_tiles, c->flags, c->segsum);
     prof_end(c);
     prof_begin(c, BSCGPU_K_SEG, 0, 0);
     hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(WG), 0, c->stream, c->segsum, ch.num_chunks, c->segoff, c->dscal);
@@ -322,28 +368,48 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
     HIP_TRY(c, hipMemcpyAsync(c->dT, dT_user, n, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->dT + n, 0, 32, c->stream));
 
-    const u32 tc = n < 7 ? n : 7;
+    // alphabet: byte histogram -> dense order-preserving codes
+    HIP_TRY(c, hipMemsetAsync(c->dscal + 300, 0, 256 * 4, c->stream));
+    {
+        const Chunking hc = make_chunking(n, 16 * WG * 16);
+        prof_begin(c, BSCGPU_K_MISC, n, 0);
+        hipLaunchKernelGGL(bwt_bytehist_kernel, dim3(hc.num_chunks), dim3(WG), 0, c->stream, c->dT, n, hc.chunk_tiles * 16u * WG * 16u, c->dscal + 300);
+        prof_end(c);
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->hscal + 300, c->dscal + 300, 256 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    u8 codes[256]; u32 K = 0;
+    for (int b = 0; b < 256; ++b) { codes[b] = (u8)K; if (c->hscal[300 + b]) ++K; }
+    PackParams pp;
+    pp.cb = 1; while ((1u << pp.cb) < K) ++pp.cb;
+    if (pp.cb < 4) pp.cb = 4;                                   // at most 16 characters per key
+    pp.w = 64 / pp.cb;
+    pp.tc = n < pp.w - 1 ? n : pp.w - 1;
+    pp.low_shift = 64 - pp.cb * pp.w;
+    const u32 tail_lo = (n >= pp.w) ? (n - (pp.w - 1)) : 0;
+    u8* dcodes = reinterpret_cast<u8*>(c->dscal + 560);         // 256 bytes of the scalar area
+    HIP_TRY(c, hipMemcpyAsync(dcodes, codes, 256, hipMemcpyHostToDevice, c->stream));
     prof_begin(c, BSCGPU_K_PACK, (u64)n * 13, n);
     hipLaunchKernelGGL(bwt_pack_kernel, dim3((n + 4 * WG - 1) / (4 * WG)), dim3(WG), 0, c->stream,
-                       c->dT, n, tc, c->kA, c->vA);
+                       c->dT, n, pp, dcodes, c->kA, c->vA);
     prof_end(c);
 
-    RadixPass passes[8];
-    for (int p = 0; p < 8; ++p) { passes[p].shift = 8 * p; passes[p].bits = 8; }
+    RadixPass passes[8]; int npass = 0;
+    for (u32 sft = pp.low_shift; sft < 64; sft += 8) { passes[npass].shift = (int)sft; passes[npass].bits = (64 - sft < 8) ? (int)(64 - sft) : 8; ++npass; }
     int in_alt = 0;
-    rc = radix_sort_passes(c, c->kA, c->kB, c->vA, c->vB, n, passes, 8, &in_alt);
+    rc = radix_sort_passes(c, c->kA, c->kB, c->vA, c->vB, n, passes, npass, &in_alt);
     if (rc < 0) return rc;
     const u64* ks = in_alt ? c->kB : c->kA;
     const u32* vs = in_alt ? c->vB : c->vA;
 
     int cur = 0;
     u32 U = 0;
-    rc = run_seg<true>(c, ks, vs, nullptr, n, n, c->cpos[cur], c->csa[cur], c->cgrp[cur], &U);
+    rc = run_seg<true>(c, ks, vs, nullptr, n, tail_lo, c->cpos[cur], c->csa[cur], c->cgrp[cur], &U);
     if (rc < 0) return rc;
 
     const int lo_bits = bit_length(n);          // next-rank field: values 0 .. n
     const int hi_bits = bit_length(n - 1);      // group rank field: values 0 .. n-1
-    u64 h = 8;
+    u64 h = pp.w;
     int rounds = 0;
     const bool dbg = getenv("BSCGPU_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[bwt] n=%u initial unsorted=%u\n", n, U);
@@ -352,19 +418,19 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
         u32 blocks = (U + WG - 1) / WG; if (blocks > 8192) blocks = 8192;
         prof_begin(c, BSCGPU_K_GATHER, (u64)U * (4 + 4 + 4 + 8 + 4), U);
         hipLaunchKernelGGL(bwt_gather_kernel, dim3(blocks), dim3(WG), 0, c->stream,
-                           c->csa[cur], c->cgrp[cur], c->ISA, U, h, (u64)n, c->kA, c->vA);
+                           c->csa[cur], c->cgrp[cur], c->ISA, U, h, (u64)n, lo_bits, c->kA, c->vA);
         prof_end(c);
 
         RadixPass rp[8]; int np = 0;
-        for (int s = 0; s < lo_bits; s += 8) { rp[np].shift = s;      rp[np].bits = (lo_bits - s < 8) ? lo_bits - s : 8; ++np; }
-        for (int s = 0; s < hi_bits; s += 8) { rp[np].shift = 32 + s; rp[np].bits = (hi_bits - s < 8) ? hi_bits - s : 8; ++np; }
+        const int kbits = lo_bits + hi_bits;            // key = (group rank << lo_bits) | next rank : 53 bits at n = 2^26 -> 7 passes
+        for (int s = 0; s < kbits; s += 8) { rp[np].shift = s; rp[np].bits = (kbits - s < 8) ? kbits - s : 8; ++np; }
         rc = radix_sort_passes(c, c->kA, c->kB, c->vA, c->vB, U, rp, np, &in_alt);
         if (rc < 0) return rc;
         ks = in_alt ? c->kB : c->kA;
         vs = in_alt ? c->vB : c->vA;
 
         u32 U2 = 0;
-        rc = run_seg<false>(c, ks, vs, c->cpos[cur], U, n, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2);
+        rc = run_seg<false>(c, ks, vs, c->cpos[cur], U, 0, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2);
         if (rc < 0) return rc;
         cur ^= 1;
         if (dbg) fprintf(stderr, "[bwt] round %d h=%llu U %u -> %u (passes %d)\n", rounds, h, U, U2, np);

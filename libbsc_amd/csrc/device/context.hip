@@ -71,7 +71,7 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
         {(void**)&c->rowtot,  256 * 4, 0},
         {(void**)&c->segsum,  2 * MAX_CHUNKS * 4, 0},
         {(void**)&c->segoff,  2 * MAX_CHUNKS * 4, 0},
-        {(void**)&c->dscal,   512 * 4, 0},
+        {(void**)&c->dscal,   1024 * 4, 0},
         {(void**)&c->dscal64, 16 * 8, 0},
         {(void**)&c->adler_part, (size_t)MAX_CHUNKS * 16, 0},
     };
@@ -84,7 +84,7 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
     for (auto& cv : carve) { *cv.p = c->arena + off + cv.lead; off += align_up(cv.bytes, 256); }
     if (hipMemsetAsync(c->arena, 0, total, c->stream) != hipSuccess) { bscgpu_destroy(c); return BSC_GPU_ERROR; }
 
-    bool ok = hipHostMalloc((void**)&c->hscal, 512 * 4, hipHostMallocDefault) == hipSuccess
+    bool ok = hipHostMalloc((void**)&c->hscal, 1024 * 4, hipHostMallocDefault) == hipSuccess
            && hipHostMalloc((void**)&c->hscal64, 16 * 8, hipHostMallocDefault) == hipSuccess
            && hipHostMalloc((void**)&c->hadler, (size_t)MAX_CHUNKS * 16, hipHostMallocDefault) == hipSuccess
            && hipHostMalloc((void**)&c->hsplit, N / 256 + 64, hipHostMallocDefault) == hipSuccess
