@@ -49,14 +49,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # BSC_BENCH_BACKEND=gloo is a functional-test mode for boxes with fewer GPUs than ranks: ranks share GPUs
+    # (LOCAL_RANK modulo the device count) and the concatenation travels over gloo/CPU instead of RCCL/xGMI.
+    backend = os.environ.get("BSC_BENCH_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
     n = args.block
 
     # one 64 MiB synth-text v1 block per GPU: seed 2 at N=1 (BASELINE config 3), seeds 10..17 at N>1 (config 4)
@@ -65,7 +73,7 @@ def main():
     d_in = torch.from_numpy(host_in).to(dev)
     ctx = GpuContext(local, max_n=n + 4096)
 
-    gather_buf = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    gather_buf = torch.empty(n + 64, dtype=torch.uint8, device=comm_dev)
 
     from libbsc_amd.multigpu import gather_blocks_to_rank0
     pipe = ctx.pipe(args.depth)
@@ -74,7 +82,7 @@ def main():
     def finish(ticket):
         blk = pipe.wait(ticket)
         if world > 1:       # final concatenation on rank 0 over RCCL / xGMI (sizes all_gather + send/recv)
-            gather_blocks_to_rank0(blk, rank, world, dev, staging=gather_buf)
+            gather_blocks_to_rank0(blk, rank, world, comm_dev, staging=gather_buf)
         return blk
 
     def run(steps, record=False):
@@ -105,7 +113,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ctx.profile(False)

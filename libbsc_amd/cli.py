@@ -91,7 +91,7 @@ def compress_file(in_path, out_path, block_size=64 << 20, sorter=1, coder=1, dep
         payload = done.get(b, np.zeros(0, np.uint8))
         got = gather_blocks_to_rank0(np.ascontiguousarray(payload), rank, world, dev)
         if rank == 0:
-            ordered += [g for g in got if len(g)]
+            ordered += [bytes(g) for g in got if len(g)]
     ctx.close()
     if rank == 0:
         img = bsc_file_image(ordered, [b * block_size for b in range(nblocks)])

@@ -16,13 +16,13 @@ def assign_blocks(num_blocks: int, world: int) -> List[List[int]]:
     return [list(range(r, num_blocks, world)) for r in range(world)]
 
 
-def gather_blocks_to_rank0(payload: np.ndarray, rank: int, world: int, device, staging=None) -> Optional[List[bytes]]:
-    """Every rank contributes one compressed block (np.uint8).  Rank 0 returns them in rank order
+def gather_blocks_to_rank0(payload: np.ndarray, rank: int, world: int, device, staging=None) -> Optional[List[np.ndarray]]:
+    """Every rank contributes one compressed block (np.uint8).  Rank 0 returns them (np.uint8 arrays) in rank order
     (= block order for one block per rank), other ranks return None."""
     import torch
     import torch.distributed as dist
     if world == 1:
-        return [payload.tobytes()]
+        return [payload]
     n = int(payload.size)
     size_t = torch.tensor([n], dtype=torch.int64, device=device)
     sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
@@ -36,22 +36,23 @@ def gather_blocks_to_rank0(payload: np.ndarray, rank: int, world: int, device, s
     if rank != 0:
         dist.send(buf, dst=0)
         return None
-    parts = [buf]
+    parts = [payload]
     reqs = []
+    recv = []
     for r in range(1, world):
         t = torch.empty(sizes[r], dtype=torch.uint8, device=device)
         reqs.append(dist.irecv(t, src=r))
-        parts.append(t)
+        recv.append(t)
     for q in reqs:
         q.wait()
-    return [p.cpu().numpy().tobytes() for p in parts]
+    return parts + [t.cpu().numpy() for t in recv]
 
 
-def bsc_file_image(blocks: List[bytes], block_offsets: List[int]) -> bytes:
+def bsc_file_image(blocks, block_offsets: List[int]) -> bytes:
     """The reference CLI's container around independent blocks (bsc.cpp:46-59, 163-178, 397-418):
     'bsc1', int32 nBlocks, then per block {int64 offset, int8 recordSize=1, int8 sortingContexts=1} + block."""
     import struct
     out = bytearray(b"bsc1" + struct.pack("<i", len(blocks)))
     for blk, off in zip(blocks, block_offsets):
-        out += struct.pack("<qbb", off, 1, 1) + blk
+        out += struct.pack("<qbb", off, 1, 1) + bytes(blk)
     return bytes(out)

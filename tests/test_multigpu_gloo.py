@@ -28,7 +28,7 @@ def _worker(rank, world, port, q):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
         import hashlib
-        q.put(([hashlib.md5(b).hexdigest() for b in got], [len(b) for b in got], float(t.item())))
+        q.put(([hashlib.md5(bytes(b)).hexdigest() for b in got], [len(b) for b in got], float(t.item())))
     dist.barrier()
     dist.destroy_process_group()
 
