@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <type_traits>
+#include <emmintrin.h>
 #include <thread>
 
 #include "qlfc_data.inc"
@@ -195,34 +196,56 @@ static void fill_shorts(void* p, size_t bytes, short v)
 }
 
 // One binary decision of class CLS: three counters (+ mixer), update, code.
+//
+// Static coder: the three counters are handled as one SSE vector [char, state, pos]: pmaddwd forms the weighted
+// probability, pmulhw(d, rate << 4) is exactly (d * rate) >> 12 for |d| < 2^15 and rate < 2^11 (all tuned rates are
+// <= 1364), so the update is bit-identical to predictor.h:53-61 at a third of the scalar instruction count.
+template <int CLS>
+static BSC_ALWAYS_INLINE int static_step(unsigned bit, short& st, short& ch, short& sp)
+{
+    constexpr const short* P = kStaticParams[CLS];
+    __m128i v = _mm_cvtsi32_si128((int)((uint32_t)(uint16_t)ch | ((uint32_t)(uint16_t)st << 16)));
+    v = _mm_insert_epi16(v, sp, 2);                                           // [ch, st, sp, 0, ...]
+    const __m128i lr = _mm_setr_epi16(P[16], P[17], P[18], 0, 0, 0, 0, 0);
+    const __m128i m  = _mm_madd_epi16(v, lr);                                 // [ch*LR0 + st*LR1, sp*LR2, 0, 0]
+    const int p = (_mm_cvtsi128_si32(m) + _mm_cvtsi128_si32(_mm_srli_si128(m, 4))) >> 5;
+    const __m128i tgt0 = _mm_setr_epi16((short)(4096 - P[4]), (short)(4096 - P[0]), (short)(4096 - P[8]), 0, 0, 0, 0, 0);
+    const __m128i ar0  = _mm_setr_epi16((short)(P[5] << 4), (short)(P[1] << 4), (short)(P[9] << 4), 0, 0, 0, 0, 0);
+    const __m128i tgt1 = _mm_setr_epi16(P[6], P[2], P[10], 0, 0, 0, 0, 0);
+    const __m128i ar1  = _mm_setr_epi16((short)(P[7] << 4), (short)(P[3] << 4), (short)(P[11] << 4), 0, 0, 0, 0, 0);
+    const __m128i up   = _mm_add_epi16(v, _mm_mulhi_epi16(_mm_sub_epi16(tgt0, v), ar0));   // bit 0
+    const __m128i down = _mm_sub_epi16(v, _mm_mulhi_epi16(_mm_sub_epi16(v, tgt1), ar1));   // bit 1
+    const __m128i sel  = _mm_set1_epi16((short)(0 - (int)bit));
+    const __m128i nv   = _mm_or_si128(_mm_and_si128(sel, down), _mm_andnot_si128(sel, up));
+    const uint32_t lo = (uint32_t)_mm_cvtsi128_si32(nv);
+    ch = (short)(lo & 0xffffu); st = (short)(lo >> 16); sp = (short)_mm_extract_epi16(nv, 2);
+    return p;
+}
+
 template <int CLS, bool ADAPT>
 static BSC_ALWAYS_INLINE void decide(RangeEncoder& rc, const QlfcTables& T, unsigned bit, short& st, short& ch, short& sp, Mixer* mx)
 {
-    constexpr const short* P = ADAPT ? kAdaptiveParams[CLS] : kStaticParams[CLS];
+    if (!ADAPT) { rc.encode<12>(bit, static_step<CLS>(bit, st, ch, sp)); return; }
+    constexpr const short* P = kAdaptiveParams[CLS];
     const int p0 = ch, p1 = st, p2 = sp;
     bump(st, bit, P[0], P[1], P[2],  P[3]);
     bump(ch, bit, P[4], P[5], P[6],  P[7]);
     bump(sp, bit, P[8], P[9], P[10], P[11]);
-    int p;
-    if (!ADAPT) {
-        p = (p0 * P[16] + p1 * P[17] + p2 * P[18]) >> 5;
-    } else {
-        const int s0 = T.stretch[p0], s1 = T.stretch[p1], s2 = T.stretch[p2];
-        short sp16 = (short)((s0 * mx->w0 + s1 * mx->w1 + s2 * mx->w2) >> 17);
-        if (sp16 < -2047) sp16 = -2047;
-        if (sp16 >  2047) sp16 =  2047;
-        const int frac = sp16 & 255;
-        const int idx  = (sp16 + 2048) >> 8;
-        const int sq   = T.squash[2048 + sp16];
-        const int mapped = mx->map[idx] + (((mx->map[idx + 1] - mx->map[idx]) * frac) >> 8);
-        p = (3 * sq + mapped) >> 2;
-        bump(mx->map[idx],     bit, P[12], P[13], P[14], P[15]);
-        bump(mx->map[idx + 1], bit, P[12], P[13], P[14], P[15]);
-        const int eps = p - (bit ? 1 : 4095);
-        mx->w0 -= (P[16] * eps * s0) >> 16;
-        mx->w1 -= (P[17] * eps * s1) >> 16;
-        mx->w2 -= (P[18] * eps * s2) >> 16;
-    }
+    const int s0 = T.stretch[p0], s1 = T.stretch[p1], s2 = T.stretch[p2];
+    short sp16 = (short)((s0 * mx->w0 + s1 * mx->w1 + s2 * mx->w2) >> 17);
+    if (sp16 < -2047) sp16 = -2047;
+    if (sp16 >  2047) sp16 =  2047;
+    const int frac = sp16 & 255;
+    const int idx  = (sp16 + 2048) >> 8;
+    const int sq   = T.squash[2048 + sp16];
+    const int mapped = mx->map[idx] + (((mx->map[idx + 1] - mx->map[idx]) * frac) >> 8);
+    const int p = (3 * sq + mapped) >> 2;
+    bump(mx->map[idx],     bit, P[12], P[13], P[14], P[15]);
+    bump(mx->map[idx + 1], bit, P[12], P[13], P[14], P[15]);
+    const int eps = p - (bit ? 1 : 4095);
+    mx->w0 -= (P[16] * eps * s0) >> 16;
+    mx->w1 -= (P[17] * eps * s1) >> 16;
+    mx->w2 -= (P[18] * eps * s2) >> 16;
     rc.encode<12>(bit, p);
 }
 
