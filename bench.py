@@ -129,10 +129,21 @@ def main():
         tot_ms = sum(ms for ms, _ in big) or 1e-9
         tot_bytes = sum(2 * rec_bytes * rec for _, rec in big)
         achieved = tot_bytes / 1e6 / tot_ms                                  # GB/s
+        # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
+        # runs, tools/profile_round.sh): per full-size launch, corrected as MI355X_MICROARCH.md prescribes
+        # (KiB units; FETCH_SIZE x2 on gfx950 for wide coalesced loads).  Static artefact, not measured in this run.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if args.sorter == 1 and n == pm.get("records"):
+                traffic = pm["rs_scatter_pairs"]["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         roofline = {
             "bound": "hbm", "kernel": "rs_scatter_kernel (one 8-bit LSD digit pass: read + scatter of u64 key + u32 value)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": None,
+            "traffic": traffic, "traffic_note": "bytes per full-size launch = 2 x FETCH_SIZE + WRITE_SIZE from profiles/pmc_traffic.json "
+                                                "(rocprofv3 PMC passes; algorithmic bytes per full-size launch = %d)" % (2 * rec_bytes * n),
             "launches": len(big), "avg_launch_ms": round(tot_ms / max(len(big), 1), 4),
             "bytes_per_launch_avg": int(tot_bytes / max(len(big), 1)),
             "full_block_launches": {"count": len(full),

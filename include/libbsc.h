@@ -7,7 +7,8 @@
  * (DESIGN.md): the block sorters run on the GPU only (no CPU sorter is shipped: without a usable GPU
  * the sorters return LIBBSC_GPU_NOT_SUPPORTED instead of silently falling back), and LZP
  * preprocessing is not implemented (lzpHashSize / lzpMinLen must be 0, else LIBBSC_NOT_SUPPORTED).
- * Decode side: bsc_decompress is self-hosted (QLFC decoders, inverse BWT and inverse ST3..8 on the host).
+ * Decode side: bsc_decompress is self-hosted (QLFC decoders, inverse BWT, inverse ST3..8 and LZP decoding on the
+ * host), so it reads every block the reference can write, including blocks written with LZP on.
  */
 #ifndef LIBBSC_MI355X_LIBBSC_H
 #define LIBBSC_MI355X_LIBBSC_H

@@ -14,6 +14,67 @@ using namespace bschost;
 
 static inline int get_i32(const unsigned char* p) { int v; memcpy(&v, p, 4); return v; }
 
+// ---- LZP decoding (lzp.cpp:564-676 block decoder, :813-885 framing) -------------------------------------------
+// The stream is literal bytes; wherever the 4-byte context has been seen before (hash table of last positions), an
+// 0xF2 byte is an escape: 0xF2 0xFF = a literal 0xF2, otherwise 0xF2 l1 l2 .. = copy (minLen + sum of the length bytes,
+// a length byte of 254 continues) bytes from the predicted position.
+static int lzp_decode_block(const unsigned char* in, const unsigned char* in_end, unsigned char* out, int out_cap, int hashSize, int minLen)
+{
+    if (in_end - in < 4) return LIBBSC_UNEXPECTED_EOB;
+    if (out_cap < 4) return LIBBSC_DATA_CORRUPT;
+    std::vector<int> lookup((size_t)1 << hashSize, 0);
+    const unsigned mask = (1u << hashSize) - 1u;
+    unsigned char* const out0 = out;
+    unsigned char* const out_end = out + out_cap;
+    for (int i = 0; i < 4; ++i) *out++ = *in++;
+    unsigned ctx = out[-1] | (out[-2] << 8) | (out[-3] << 16) | ((unsigned)out[-4] << 24);
+    while (in < in_end) {
+        const unsigned idx = ((ctx >> 15) ^ ctx ^ (ctx >> 3)) & mask;
+        const int value = lookup[idx];
+        lookup[idx] = (int)(out - out0);
+        if (*in == 0xf2 && value > 0) {
+            if (++in >= in_end) return LIBBSC_DATA_CORRUPT;
+            if (*in != 255) {
+                long long len = minLen;
+                for (;;) { const unsigned char l = *in++; len += l; if (l != 254) break; if (in >= in_end) return LIBBSC_DATA_CORRUPT; }
+                if (len > out_end - out) return LIBBSC_DATA_CORRUPT;
+                const unsigned char* ref = out0 + value;
+                for (long long k = 0; k < len; ++k) *out++ = *ref++;          // may overlap forward, byte by byte
+                ctx = out[-1] | (out[-2] << 8) | (out[-3] << 16) | ((unsigned)out[-4] << 24);
+            } else {
+                ++in;
+                if (out >= out_end) return LIBBSC_DATA_CORRUPT;
+                *out++ = 0xf2; ctx = (ctx << 8) | 0xf2;
+            }
+        } else {
+            if (out >= out_end) return LIBBSC_DATA_CORRUPT;
+            const unsigned char c = *in++;
+            *out++ = c; ctx = (ctx << 8) | c;
+        }
+    }
+    return (int)(out - out0);
+}
+
+static int lzp_decompress(const unsigned char* in, unsigned char* out, int n, int out_cap, int hashSize, int minLen)
+{
+    if (n < 1) return LIBBSC_DATA_CORRUPT;
+    const int nblocks = in[0];
+    if (nblocks == 1) return lzp_decode_block(in + 1, in + n, out, out_cap, hashSize, minLen);
+    if (nblocks < 1 || nblocks > 8 || n < 1 + 8 * nblocks) return LIBBSC_DATA_CORRUPT;
+    long long ip = 1 + 8 * nblocks, op = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        const int osz = get_i32(in + 1 + 8 * b), isz = get_i32(in + 1 + 8 * b + 4);
+        if (osz < 0 || isz < 0 || ip + isz > n || op + osz > out_cap) return LIBBSC_DATA_CORRUPT;
+        int r;
+        if (isz != osz) r = lzp_decode_block(in + ip, in + ip + isz, out + op, osz, hashSize, minLen);
+        else { r = isz; memcpy(out + op, in + ip, (size_t)isz); }
+        if (r < 0) return r;
+        if (r != osz) return LIBBSC_DATA_CORRUPT;
+        ip += isz; op += osz;
+    }
+    return (int)op;
+}
+
 extern "C" {
 
 // L = [T[n-1]] ++ [T[SA[j]-1] : SA[j] != 0]; `index` (1-based) is where the end-of-text row was removed.
@@ -118,7 +179,6 @@ int bsc_decompress(const unsigned char* input, int inputSize, unsigned char* out
     const int index = get_i32(input + 12);
     const unsigned adler_data = (unsigned)get_i32(input + 16);
     const int lzpHashSize = (mode >> 16) & 0xff, lzpMinLen = (mode >> 8) & 0xff, coder = (mode >> 5) & 0x7, sorter = mode & 0x1f;
-    if (lzpHashSize != 0 || lzpMinLen != 0) return LIBBSC_NOT_SUPPORTED;                  // LZP: out of scope (f3)
 
     // the coder writes dataSize bytes; decode through a scratch buffer when decompressing in place
     const bool inplace = (input == output);
@@ -137,7 +197,12 @@ int bsc_decompress(const unsigned char* input, int inputSize, unsigned char* out
     int rc = (sorter == LIBBSC_BLOCKSORTER_BWT) ? bsc_bwt_decode(output, lzSize, index, (unsigned char)num_indexes, indexes, features)
                                                 : bsc_st_decode(output, lzSize, sorter, index, features);
     if (rc < LIBBSC_NO_ERROR) return rc;
-    if (lzSize != dataSize) return LIBBSC_DATA_CORRUPT;
+    if (lzpHashSize != 0 || lzpMinLen != 0) {                  // undo LZP (libbsc.cpp:594-609); encoding it is not built (f3)
+        std::vector<unsigned char> tmp(output, output + lzSize);
+        const int r = lzp_decompress(tmp.data(), output, lzSize, dataSize, lzpHashSize, lzpMinLen);
+        if (r < LIBBSC_NO_ERROR) return r;
+        if (r != dataSize) return LIBBSC_DATA_CORRUPT;
+    } else if (lzSize != dataSize) return LIBBSC_DATA_CORRUPT;
     return adler_data == adler32(output, (size_t)dataSize) ? LIBBSC_NO_ERROR : LIBBSC_DATA_CORRUPT;
 }
 

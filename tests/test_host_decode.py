@@ -80,3 +80,19 @@ def test_st_decode_inverts_reference_encoder(ref):
                 assert rc == 0 and np.array_equal(back, T), (T.size, k)
     assert api.bsc_st_decode(np.zeros(10, np.uint8), 2, 0)[1] == api.BAD_PARAMETER
     assert api.bsc_st_decode(np.zeros(10, np.uint8), 5, 10)[1] == api.BAD_PARAMETER
+
+
+def test_bsc_decompress_reads_reference_blocks_with_lzp(ref):
+    """LZP is not encoded here (row f3), but blocks the reference writes with LZP on — the CLI default -H15 -M128 —
+    must still decode: literal runs, matches, escaped 0xF2 bytes, 1..4 LZP sub-blocks."""
+    from libbsc_amd.synth import synth_text_v1
+    rng = np.random.default_rng(8)
+    base = synth_text_v1(12, 40_000)
+    rep = np.concatenate([base, rng.integers(0, 256, 500, dtype=np.uint8), base, base[:20_000], np.full(3000, 0xF2, np.uint8), base])
+    big = np.concatenate([synth_text_v1(13, 200_000)] * 3 + [rng.integers(0, 256, 1000, dtype=np.uint8)])      # >= 256 KiB: 2 LZP sub-blocks
+    for T in (rep, big):
+        for h, m in ((15, 128), (16, 32), (10, 4), (20, 255)):
+            for sorter in (1, 5):
+                blk = ref.compress(T, sorter, 1, lzp_hash=h, lzp_min=m)
+                assert isinstance(blk, bytes)
+                assert api.bsc_decompress(blk) == T.tobytes(), (T.size, h, m, sorter)

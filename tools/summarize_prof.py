@@ -42,3 +42,24 @@ for tag, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         print(f"-- {cname} ({os.path.relpath(f, root)})")
         for k, (cnt, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
             print(f"{k:62s} dispatches {cnt:4d}  sum {v:16.0f}  per-dispatch {v/cnt:14.0f}")
+
+# machine-readable traffic for bench.py's roofline.traffic
+import json
+def per_launch(tag, cname, kname):
+    for f in find("*counter_collection.csv"):
+        if tag not in f: continue
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r.get("Counter_Name") == cname and kname in r["Kernel_Name"]]
+        return vals
+    return []
+fe = per_launch("pmc_fetch", "FETCH_SIZE", "rs_scatter_kernel<true")
+wr = per_launch("pmc_write", "WRITE_SIZE", "rs_scatter_kernel<true")
+if fe and wr:
+    nfull = 8
+    fetch_kib = sum(fe[:nfull]) / nfull; write_kib = sum(wr[:nfull]) / nfull
+    out = {"records": 67108864, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), first 8 rs_scatter launches of one 64 MiB BWT",
+           "rs_scatter_pairs": {"fetch_size_kib_reported": fetch_kib, "write_size_kib_reported": write_kib,
+                                "traffic_bytes_per_launch": int((2 * fetch_kib + write_kib) * 1024),
+                                "algorithmic_bytes_per_launch": 24 * 67108864,
+                                "note": "FETCH_SIZE doubled per the gfx950 rule for wide coalesced loads; this over-corrects the 4-B/lane value loads (true read = 768 MiB)"}}
+    json.dump(out, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
+    print("pmc_traffic.json:", out["rs_scatter_pairs"])
