@@ -66,7 +66,8 @@ def _compile(src, force):
         cmd += DEVFLAGS
     else:
         # host-only translation units: plain C++ through hipcc's clang (HIP runtime API headers only)
-        cmd += ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROCM, "include")]
+        # x86-64-v3 (AVX2/BMI2/LZCNT): same ISA floor as the reference's own makefile (-mavx2, makefile:20)
+        cmd += ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROCM, "include"), "-march=x86-64-v3"]
     cmd += ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
