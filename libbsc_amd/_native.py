@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libbsc_mi355x.so")
+LIB_PATH = os.environ.get("BSC_LIB_OVERRIDE") or os.path.join(HERE, "lib", "libbsc_mi355x.so")
 
 u8p = C.POINTER(C.c_ubyte)
 i32p = C.POINTER(C.c_int)

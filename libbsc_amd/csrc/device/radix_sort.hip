@@ -25,6 +25,10 @@
 #include "dev_common.h"
 #include <cstdlib>
 
+#ifndef RS_NT
+#define RS_NT 5      // bit0: non-temporal loads (+10-20 %: the streamed-once input stops evicting the partially
+                     // written output lines from L2), bit1: non-temporal stores (measured 20-50 % SLOWER), bit2: nt loads in rs_hist
+#endif
 #ifndef RS_WG
 #define RS_WG 256      // measured: 512 threads / 8192-record tiles are 10-25 % slower (barrier stalls, spills)
 #endif
@@ -81,10 +85,18 @@ __global__ __launch_bounds__(RS_WG) void rs_hist_kernel(const u64* __restrict__ 
     // 16-byte loads (2 keys per lane), 4 in flight per lane.
     u64 i = start + 2 * t;
     for (; i + 3 * 2 * WG + 1 < end; i += 4 * 2 * WG) {
-        ulonglong2 a = *reinterpret_cast<const ulonglong2*>(keys + i);
-        ulonglong2 b = *reinterpret_cast<const ulonglong2*>(keys + i + 2 * WG);
-        ulonglong2 c = *reinterpret_cast<const ulonglong2*>(keys + i + 4 * WG);
-        ulonglong2 d = *reinterpret_cast<const ulonglong2*>(keys + i + 6 * WG);
+        ulonglong2 a, b, c, d;
+        if (RS_NT & 4) {
+            a.x = __builtin_nontemporal_load(keys + i);          a.y = __builtin_nontemporal_load(keys + i + 1);
+            b.x = __builtin_nontemporal_load(keys + i + 2 * WG); b.y = __builtin_nontemporal_load(keys + i + 2 * WG + 1);
+            c.x = __builtin_nontemporal_load(keys + i + 4 * WG); c.y = __builtin_nontemporal_load(keys + i + 4 * WG + 1);
+            d.x = __builtin_nontemporal_load(keys + i + 6 * WG); d.y = __builtin_nontemporal_load(keys + i + 6 * WG + 1);
+        } else {
+            a = *reinterpret_cast<const ulonglong2*>(keys + i);
+            b = *reinterpret_cast<const ulonglong2*>(keys + i + 2 * WG);
+            c = *reinterpret_cast<const ulonglong2*>(keys + i + 4 * WG);
+            d = *reinterpret_cast<const ulonglong2*>(keys + i + 6 * WG);
+        }
         atomicAdd(&hw[(u32)(a.x >> shift) & mask], 1u); atomicAdd(&hw[(u32)(a.y >> shift) & mask], 1u);
         atomicAdd(&hw[(u32)(b.x >> shift) & mask], 1u); atomicAdd(&hw[(u32)(b.y >> shift) & mask], 1u);
         atomicAdd(&hw[(u32)(c.x >> shift) & mask], 1u); atomicAdd(&hw[(u32)(c.y >> shift) & mask], 1u);
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
 #pragma unroll
         for (int i = 0; i < RS_ITEMS; ++i) {
             const u32 idx = wbase + i * 64;
-            k[i] = (idx < nvalid) ? kin[tbase + idx] : ~0ull;
+            k[i] = (idx < nvalid) ? (RS_NT ? __builtin_nontemporal_load(&kin[tbase + idx]) : kin[tbase + idx]) : ~0ull;
         }
         for (u32 i = t; i < (u32)WAVES * 256; i += WG) whist[i] = 0;
         __syncthreads();
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
 #pragma unroll
             for (int i = 0; i < RS_ITEMS; ++i) {
                 const u32 idx = wbase + i * 64;
-                v[i] = (idx < nvalid) ? vin[tbase + idx] : 0u;
+                v[i] = (idx < nvalid) ? (RS_NT ? __builtin_nontemporal_load(&vin[tbase + idx]) : vin[tbase + idx]) : 0u;
             }
         }
         __syncthreads();
@@ -248,7 +260,7 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
             const u64 key = skeys[q];
             const u32 d = (u32)(key >> shift) & mask;
             if ((j & 3) == 0) dd[j >> 2] = d; else dd[j >> 2] |= d << (8 * (j & 3));
-            if (q < nvalid) kout[adj[d] + q] = key;
+            if (q < nvalid) { if (RS_NT & 2) __builtin_nontemporal_store(key, &kout[adj[d] + q]); else kout[adj[d] + q] = key; }
         }
 
         if (HAS_VAL) {
@@ -261,7 +273,7 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
             for (int j = 0; j < RS_ITEMS; ++j) {
                 const u32 q = j * WG + t;
                 const u32 d = (dd[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                if (q < nvalid) vout[adj[d] + q] = svals[q];
+                if (q < nvalid) { if (RS_NT & 2) __builtin_nontemporal_store(svals[q], &vout[adj[d] + q]); else vout[adj[d] + q] = svals[q]; }
             }
         }
         __syncthreads();
