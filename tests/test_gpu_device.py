@@ -152,3 +152,38 @@ def test_st_matches_reference(ctx, ref, k):
             if rc != 0 or not np.array_equal(back, T):
                 bad.append((name, n, idx, rc))
     assert not bad, bad
+
+
+def test_error_paths_and_two_contexts(torch_cuda, ref):
+    """C-ABI misuse returns libbsc error codes instead of crashing; two contexts on one GPU work side by side."""
+    import ctypes as C
+    from libbsc_amd import GpuContext, GpuError
+    from libbsc_amd.synth import synth_text_v1
+    torch = torch_cuda
+    a = GpuContext(0, max_n=1 << 20)
+    b = GpuContext(0, max_n=1 << 20)
+    try:
+        T = synth_text_v1(3, 300_000)
+        want = ref.compress(T, 1, 1)
+        d = torch.from_numpy(T).cuda()
+        assert a.compress_device(d, T.size, 1, 1).tobytes() == want
+        assert b.compress_device(d, T.size, 1, 1).tobytes() == want
+        big = torch.zeros((1 << 20) + 4097, dtype=torch.uint8, device="cuda")
+        with pytest.raises(GpuError) as e:
+            a.compress_device(big, big.numel(), 1, 1)
+        assert e.value.code == -1                                   # n > max_n -> LIBBSC_BAD_PARAMETER
+        with pytest.raises(GpuError):
+            a.compress_device(d, T.size, 2, 1)                      # bad sorter
+        with pytest.raises(GpuError):
+            a.compress_device(d, T.size, 1, 7)                      # bad coder
+        with pytest.raises(GpuError):
+            a.bwt(np.zeros((1 << 20) + 8192, np.uint8))            # host-pointer hook: arena too small -> -9
+        pipe = a.pipe(2)
+        assert a.L.bscgpu_pipe_wait(pipe.h, 0) == -1                # nothing submitted yet
+        t = pipe.submit(d, T.size, 1, 1)
+        assert pipe.wait(t).tobytes() == want
+        pipe.close()
+        h = C.c_void_p()
+        assert a.L.bscgpu_create(C.byref(h), 99, 1 << 20) == -1     # no such device
+    finally:
+        a.close(); b.close()
