@@ -394,8 +394,9 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
                        c->dT, n, pp, dcodes, c->kA, c->vA);
     prof_end(c);
 
-    RadixPass passes[8]; int npass = 0;
-    for (u32 sft = pp.low_shift; sft < 64; sft += 8) { passes[npass].shift = (int)sft; passes[npass].bits = (64 - sft < 8) ? (int)(64 - sft) : 8; ++npass; }
+    RadixPass passes[16]; int npass = 0;
+    constexpr int dbits = 8;    // measured: 7- / 6-bit digits raise per-pass bandwidth (3.5 -> 3.8 / 4.0 TB/s) but the extra passes lose overall
+    for (u32 sft = pp.low_shift; sft < 64; sft += dbits) { passes[npass].shift = (int)sft; passes[npass].bits = (64 - sft < (u32)dbits) ? (int)(64 - sft) : dbits; ++npass; }
     int in_alt = 0;
     rc = radix_sort_passes(c, c->kA, c->kB, c->vA, c->vB, n, passes, npass, &in_alt);
     if (rc < 0) return rc;

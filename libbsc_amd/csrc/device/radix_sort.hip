@@ -39,10 +39,12 @@ constexpr int RS_LDS   = RS_TILE * 8 + RS_WAVES * 256 * 4 + 3 * 256 * 4 + 16 * 4
 constexpr int RS_MAX_CHUNKS = 256 * (1024 / RS_WG);       // all workgroups resident at once: 4 per CU
 
 static inline Chunking rs_chunking(u64 n) {
+    // measured: 768 / 512 / 256 chunks (fewer open output lines per XCD, but fewer waves) are 1 / 5 / 40 % slower
+    constexpr u32 RS_MAX_CHUNKS_RT = RS_MAX_CHUNKS;
     Chunking c;
     c.num_tiles   = (u32)((n + RS_TILE - 1) / RS_TILE);
     if (c.num_tiles == 0) c.num_tiles = 1;
-    c.chunk_tiles = (c.num_tiles + RS_MAX_CHUNKS - 1) / RS_MAX_CHUNKS;
+    c.chunk_tiles = (c.num_tiles + RS_MAX_CHUNKS_RT - 1) / RS_MAX_CHUNKS_RT;
     c.num_chunks  = (c.num_tiles + c.chunk_tiles - 1) / c.chunk_tiles;
     return c;
 }
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(WG) void rs_scan_kernel(u32* __restrict__ counts, u
 // ---------------------------------------------------------------------------------------------
 // rs_scatter: the digit pass.  Reads each record once, writes it once.
 // ---------------------------------------------------------------------------------------------
-template <bool HAS_VAL, int ABLATE = 0>
+template <bool HAS_VAL>
 __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restrict__ kin, u64* __restrict__ kout,
                                                         const u32* __restrict__ vin, u32* __restrict__ vout,
                                                         u32 n, int shift, u32 mask,
@@ -195,7 +197,6 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
 #pragma unroll
         for (int i = 0; i < RS_ITEMS; ++i) {
             const u32 d = (u32)(k[i] >> shift) & mask;
-            if (ABLATE == 1) { rk[i] = atomicAdd(&whist[w * 256 + d], 1u); continue; }   // timing experiment only (unstable)
             u32 mlo = ~0u, mhi = ~0u;
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
@@ -311,12 +312,7 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
         prof_end(c);
 
         prof_begin(c, BSCGPU_K_RADIX_SCATTER, 2 * n * rec_bytes, n);
-        static const int ablate = getenv("BSCGPU_ABLATE") ? atoi(getenv("BSCGPU_ABLATE")) : 0;
-        if (has_val && ablate == 1)
-            hipLaunchKernelGGL((rs_scatter_kernel<true, 1>), dim3(ch.num_chunks), dim3(RS_WG), RS_LDS, c->stream,
-                               ksrc, kdst, vsrc, vdst, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks,
-                               ch.num_tiles, c->counts, c->rowtot);
-        else if (has_val)
+        if (has_val)
             hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(ch.num_chunks), dim3(RS_WG), RS_LDS, c->stream,
                                ksrc, kdst, vsrc, vdst, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks,
                                ch.num_tiles, c->counts, c->rowtot);
