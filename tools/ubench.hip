@@ -47,9 +47,10 @@ __global__ __launch_bounds__(256) void k_chunked(const u64* __restrict__ kin, co
     if (acc == 0x1234567) sink[0] = (u32)acc;
 }
 // scatter-shaped writes: each WG writes runs of `run` keys to 256 streams (bucket b base = b * n/256), like a uniform digit pass
-__global__ __launch_bounds__(256) void k_scatter_runs(const u64* __restrict__ kin, u64* __restrict__ kout, u32 n, u32 chunk_tiles, u32 num_chunks) {
+__global__ __launch_bounds__(256) void k_scatter_runs(const u64* __restrict__ kin, u64* __restrict__ kout, u32 n, u32 chunk_tiles, u32 num_chunks, u32 misalign) {
     const u32 t = threadIdx.x;
-    const u32 per_bucket = n / 256;
+    const u32 per_bucket = n / 256 - 16;
+    kout += misalign;
     for (u32 tt = 0; tt < chunk_tiles; ++tt) {
         const u32 tile = blockIdx.x * chunk_tiles + tt;
         const u64 tb = (u64)tile * 4096;
@@ -60,6 +61,32 @@ __global__ __launch_bounds__(256) void k_scatter_runs(const u64* __restrict__ ki
             const u32 bucket = q >> 4, r = q & 15;   // 16 keys per bucket per tile
             const u64 key = kin[tb + q];
             kout[(u64)bucket * per_bucket + (u64)tile * 16 + r] = key;
+        }
+    }
+}
+// pairs: per tile and bucket one aligned 128-B key line + one aligned 64-B value half-line (what a write-combining
+// scatter would emit on uniform digits); LDSPAD bytes of dynamic LDS limit residency (81920 -> 1 WG/CU, 40960 -> 3)
+extern __shared__ unsigned char pad_lds[];
+__global__ __launch_bounds__(256) void k_scatter_pairs_aligned(const u64* __restrict__ kin, const u32* __restrict__ vin, u64* __restrict__ kout, u32* __restrict__ vout,
+                                                               u32 n, u32 chunk_tiles, u32 misalign, u32* sink) {
+    const u32 t = threadIdx.x;
+    if (pad_lds[t] == 77 && n == 1) sink[0] = 1;
+    const u32 per_bucket = n / 256 - 16;
+    kout += misalign; vout += misalign;
+    for (u32 tt = 0; tt < chunk_tiles; ++tt) {
+        const u32 tile = blockIdx.x * chunk_tiles + tt;
+        const u64 tb = (u64)tile * 4096;
+        if (tb >= n) break;
+        u64 k[16]; u32 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { k[j] = __builtin_nontemporal_load(&kin[tb + j * 256 + t]); }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { v[j] = __builtin_nontemporal_load(&vin[tb + j * 256 + t]); }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const u32 q = j * 256 + t; const u32 bucket = q >> 4, r = q & 15;
+            const u64 o = (u64)bucket * per_bucket + (u64)tile * 16 + r;
+            kout[o] = k[j]; vout[o] = v[j];
         }
     }
 }
@@ -91,7 +118,14 @@ int main() {
     printf("chunked copy keys+vals (same index): %.3f ms -> %.0f GB/s\n", ms, 24.0 * n / 1e6 / ms);
     ms = timeit([&] { hipLaunchKernelGGL(k_chunked<3>, dim3(nc), dim3(256), 0, 0, ka, va, kb, vb, n, ct, sink); });
     printf("chunked read keys + LDS atomics (all same digit): %.3f ms -> %.0f GB/s\n", ms, 8.0 * n / 1e6 / ms);
-    ms = timeit([&] { hipLaunchKernelGGL(k_scatter_runs, dim3(nc), dim3(256), 0, 0, ka, kb, n, ct, nc); });
-    printf("keys: read + write 128-B runs into 256 streams: %.3f ms -> %.0f GB/s\n", ms, 16.0 * n / 1e6 / ms);
+    for (u32 mis : {0u, 5u, 8u}) {
+        ms = timeit([&] { hipLaunchKernelGGL(k_scatter_runs, dim3(nc), dim3(256), 0, 0, ka, kb, n, ct, nc, mis); });
+        printf("keys: read + write 128-B runs into 256 streams, misaligned by %u keys: %.3f ms -> %.0f GB/s\n", mis, ms, 16.0 * n / 1e6 / ms);
+    }
+    CHECK(hipFuncSetAttribute((const void*)k_scatter_pairs_aligned, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (u32 lds : {0u, 40000u, 64000u, 81000u}) for (u32 mis : {0u, 5u}) {
+        ms = timeit([&] { hipLaunchKernelGGL(k_scatter_pairs_aligned, dim3(nc), dim3(256), lds, 0, ka, va, kb, vb, n, ct, mis, sink); });
+        printf("pairs: 16 records/bucket/tile, misalign %u records, dyn LDS %u B: %.3f ms -> %.0f GB/s\n", mis, lds, ms, 24.0 * n / 1e6 / ms);
+    }
     return 0;
 }
