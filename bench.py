@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--block", type=int, default=BLOCK)
     ap.add_argument("--sorter", type=int, default=1)
     ap.add_argument("--coder", type=int, default=1)
-    ap.add_argument("--depth", type=int, default=3, help="blocks in flight per GPU: at most 2 host stages (16 coder threads) run at once, a third block's GPU stage overlaps them")
+    ap.add_argument("--depth", type=int, default=3, help="blocks in flight per GPU; their sub-blocks feed a pool of 16 coder threads per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -159,8 +159,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{world} x {n >> 20} MiB synth-text-v1 block(s) per step (seed {'2' if world == 1 else '10..'+str(9+world)}), "
                                    f"bsc_compress(lzp off, sorter={args.sorter}, coder={args.coder}); input resident in HBM; "
-                                   "Adler-32 + BWT + QLFC run/rank front end on GPU, QLFC modelling + range coding on 8 host threads per block, "
-                                   f"{args.depth} block(s) in flight per GPU, <= 2 host stages (16 coder threads) at once; output bit-identical to reference libbsc",
+                                   "Adler-32 + BWT + QLFC run/rank front end on GPU, QLFC modelling + range coding on host threads (one per sub-block, 8 per block), "
+                                   f"{args.depth} block(s) in flight per GPU feeding a pool of 16 coder threads; output bit-identical to reference libbsc",
                        "block_bytes": n, "blocks_per_step": world, "sorter": "BWT" if args.sorter == 1 else f"ST{args.sorter}",
                        "coder": {1: "QLFC static (-e1)", 2: "QLFC adaptive (-e2)", 3: "QLFC fast (-e0)"}[args.coder],
                        "parallelism": f"block-parallel x{world}", "compressed_bytes_rank0": int(blk.size)},

@@ -82,8 +82,9 @@ BSCGPU_API int bscgpu_compress_device(bscgpu_ctx* ctx, const void* dInput, uint8
  * (Adler-32, sort transform, QLFC front end, D2H of the run arrays) on the calling thread and hands the host stage
  * (QLFC modelling + range coding on 8 threads, container) to a worker, so block i+1 sorts while block i is coded.
  * dInput and output must stay valid until wait() returns for that ticket.  wait() returns what
- * bscgpu_compress_device would have returned.  One submitting thread per pipe.  At most 2 host stages (16 coder
- * threads) run concurrently (BSCGPU_HOST_CONCURRENCY overrides), so depth 3 keeps those threads and the GPU busy. */
+ * bscgpu_compress_device would have returned.  One submitting thread per pipe.  The host work is queued as
+ * per-sub-block tasks for a pool of 16 coder threads per pipe (BSCGPU_HOST_THREADS overrides), so depth 3 keeps those
+ * threads and the GPU busy. */
 typedef struct bscgpu_pipe bscgpu_pipe;
 BSCGPU_API int  bscgpu_pipe_create(bscgpu_ctx* ctx, int depth, bscgpu_pipe** out);
 BSCGPU_API void bscgpu_pipe_destroy(bscgpu_pipe* pipe);

@@ -10,6 +10,8 @@
 #include <chrono>
 #include <mutex>
 #include <condition_variable>
+#include <deque>
+#include <atomic>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -255,6 +257,12 @@ struct BlockJob {
     HostSlot slot;
     bool stored_small = false;       // n <= header size: finished in the GPU stage
     int  result = 0;
+    // host stage, split into per-sub-block tasks for the pipe's worker pool
+    RunView views[8];
+    std::unique_ptr<uint8_t[]> scratch[8];
+    int  sub_res[8];
+    std::atomic<int> remaining{0};
+    bool done = false;
 };
 
 using clk = std::chrono::steady_clock;
@@ -308,16 +316,11 @@ static int gpu_stage(BlockJob& J, int blockSorter)
     return LIBBSC_NO_ERROR;
 }
 
-static void host_stage(BlockJob& J)
+static void host_prepare(BlockJob& J)
 {
-    if (J.stored_small) return;
-    const bool dbg = getenv("BSCGPU_DEBUG") != nullptr;
-    const auto th0 = clk::now();
-    const int n = J.n;
-    uint8_t* output = J.output;
-    RunView views[8];
     for (int b = 0; b < J.nblocks; ++b) {
-        RunView& V = views[b];
+        RunView& V = J.views[b];
+        V = RunView();
         V.sym = J.slot.hsym + J.run_first[b]; V.rank = J.slot.hrank + J.run_first[b]; V.start = J.slot.hstart + J.run_first[b];
         V.count = J.run_first[b + 1] - J.run_first[b];
         V.end = (u32)(J.start[b] + J.size[b]);
@@ -328,30 +331,31 @@ static void host_stage(BlockJob& J)
         V.nsym = k;
         for (int i = 0; i < k; ++i) V.first_seen[i] = (uint8_t)order[i].second;
     }
-    struct Fetch : RawFetch {
-        const uint8_t* L;
-        int operator()(int st, int sz, uint8_t* dst) override { memcpy(dst, L + st, (size_t)sz); return 0; }
-    } fetch; fetch.L = J.slot.hL;
-    int result;
-    {
-        unsigned char* buffer = (unsigned char*)bsc_malloc((size_t)n + 4096);
-        if (!buffer) { J.result = LIBBSC_NOT_ENOUGH_MEMORY; return; }
-        const auto tc0 = clk::now();
-        result = coder_compress_views(views, J.nblocks, J.start, J.size, n, buffer, J.coder, J.features, fetch);
-        const double t_coder = ms_since(tc0);
-        if (result >= 0) memcpy(output + LIBBSC_HEADER_SIZE, buffer, (size_t)result);
-        bsc_free(buffer);
-        if (dbg) fprintf(stderr, "[host_stage] setup+alloc %.1f ms, coder %.1f ms, total so far %.1f ms\n", ms_since(th0) - t_coder, t_coder, ms_since(th0));
-    }
-    if (result < LIBBSC_NO_ERROR || result + 1 + 4 * J.num_indexes >= n) {       // store (libbsc.cpp:315-318)
-        if (hipSetDevice(J.c->device) != hipSuccess ||
-            hipMemcpy(output + LIBBSC_HEADER_SIZE, J.dInput, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) { J.result = LIBBSC_GPU_ERROR; return; }
-        put_i32(output + 0, n + LIBBSC_HEADER_SIZE); put_i32(output + 4, n); put_i32(output + 8, 0); put_i32(output + 12, 0);
-        put_i32(output + 16, (int)J.adler_data); put_i32(output + 20, (int)J.adler_data);
-        put_i32(output + 24, (int)adler32(output, 24));
-        J.result = n + LIBBSC_HEADER_SIZE;
-        return;
-    }
+}
+
+// parallel framing semantics (coder.cpp:159-240): every sub-block is coded with outputSize = its own size
+static void host_encode_sub(BlockJob& J, int b)
+{
+    J.scratch[b].reset(new uint8_t[(size_t)J.size[b] + 64]);
+    const int r = qlfc_encode_runs(J.views[b], J.size[b], J.scratch[b].get(), J.size[b], J.coder, true);
+    J.sub_res[b] = (r < 0) ? J.size[b] : r;
+}
+
+static void write_stored(BlockJob& J)
+{
+    uint8_t* output = J.output; const int n = J.n;
+    if (hipSetDevice(J.c->device) != hipSuccess ||
+        hipMemcpy(output + LIBBSC_HEADER_SIZE, J.dInput, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) { J.result = LIBBSC_GPU_ERROR; return; }
+    put_i32(output + 0, n + LIBBSC_HEADER_SIZE); put_i32(output + 4, n); put_i32(output + 8, 0); put_i32(output + 12, 0);
+    put_i32(output + 16, (int)J.adler_data); put_i32(output + 20, (int)J.adler_data);
+    put_i32(output + 24, (int)adler32(output, 24));
+    J.result = n + LIBBSC_HEADER_SIZE;
+}
+
+static void write_header_and_trailer(BlockJob& J, int result)
+{
+    uint8_t* output = J.output; const int n = J.n;
+    if (result < LIBBSC_NO_ERROR || result + 1 + 4 * J.num_indexes >= n) { write_stored(J); return; }      // libbsc.cpp:315-318
     if (J.num_indexes > 0) memcpy(output + LIBBSC_HEADER_SIZE + result, J.indexes, (size_t)4 * J.num_indexes);
     output[LIBBSC_HEADER_SIZE + result + 4 * J.num_indexes] = (unsigned char)J.num_indexes;
     result += 1 + 4 * J.num_indexes;
@@ -363,6 +367,54 @@ static void host_stage(BlockJob& J)
     put_i32(output + 20, (int)adler32(output + LIBBSC_HEADER_SIZE, (size_t)result));
     put_i32(output + 24, (int)adler32(output, 24));
     J.result = result + LIBBSC_HEADER_SIZE;
+}
+
+// frame the independently coded sub-blocks (nblocks > 1, MULTITHREADING semantics)
+static void host_finalize_parallel(BlockJob& J)
+{
+    uint8_t* out = J.output + LIBBSC_HEADER_SIZE; const int n = J.n, nb = J.nblocks;
+    int total = 1 + 8 * nb;
+    for (int b = 0; b < nb; ++b) total += J.sub_res[b];
+    if (total >= n) { write_header_and_trailer(J, LIBBSC_NOT_COMPRESSIBLE); }
+    else {
+        out[0] = (uint8_t)nb;
+        int optr = 1 + 8 * nb;
+        for (int b = 0; b < nb; ++b) {
+            put_i32(out + 1 + 8 * b, J.size[b]);
+            put_i32(out + 1 + 8 * b + 4, J.sub_res[b]);
+            memcpy(out + optr, (J.sub_res[b] != J.size[b]) ? J.scratch[b].get() : J.slot.hL + J.start[b], (size_t)J.sub_res[b]);
+            optr += J.sub_res[b];
+        }
+        write_header_and_trailer(J, total);
+    }
+    for (int b = 0; b < nb; ++b) J.scratch[b].reset();
+}
+
+static bool job_is_parallel(const BlockJob& J) { return !J.stored_small && J.nblocks > 1 && (J.features & LIBBSC_FEATURE_MULTITHREADING); }
+
+// whole host stage on the calling thread (+ its own sub-block threads): used by the synchronous entry point and for
+// blocks that do not take the per-sub-block task path (single sub-block, or serial framing semantics)
+static void host_stage(BlockJob& J)
+{
+    if (J.stored_small) return;
+    host_prepare(J);
+    if (job_is_parallel(J)) {
+        std::vector<std::thread> pool;
+        for (int b = 0; b < J.nblocks; ++b) pool.emplace_back([&J, b] { host_encode_sub(J, b); });
+        for (auto& t : pool) t.join();
+        host_finalize_parallel(J);
+        return;
+    }
+    struct Fetch : RawFetch {
+        const uint8_t* L;
+        int operator()(int st, int sz, uint8_t* dst) override { memcpy(dst, L + st, (size_t)sz); return 0; }
+    } fetch; fetch.L = J.slot.hL;
+    unsigned char* buffer = (unsigned char*)bsc_malloc((size_t)J.n + 4096);
+    if (!buffer) { J.result = LIBBSC_NOT_ENOUGH_MEMORY; return; }
+    const int result = coder_compress_views(J.views, J.nblocks, J.start, J.size, J.n, buffer, J.coder, J.features & ~LIBBSC_FEATURE_MULTITHREADING, fetch);
+    if (result >= 0) memcpy(J.output + LIBBSC_HEADER_SIZE, buffer, (size_t)result);
+    bsc_free(buffer);
+    write_header_and_trailer(J, result);
 }
 
 static int prepare_job(BlockJob& J, bscgpu_ctx* c, const void* dInput, uint8_t* output, int n, int blockSorter, int coder, int features)
@@ -392,22 +444,50 @@ int bscgpu_compress_device(bscgpu_ctx* c, const void* dInput, uint8_t* output, i
     return J->result;
 }
 
-// ---- pipe: several blocks in flight ------------------------------------------------------------------------
+// ---- pipe: several blocks in flight -------------------------------------------------------------------------
+// submit() runs the GPU stage on the calling thread and queues the block's host work as per-sub-block tasks; a fixed
+// pool of worker threads (16 by default = the per-GPU host budget) drains the FIFO queue, so the coder threads stay
+// busy across block boundaries; the worker that finishes a block's last sub-block frames it.
 struct bscgpu_pipe {
     bscgpu_ctx* c = nullptr;
     int depth = 1;
     int next_ticket = 0;
-    // at most `host_slots` host stages run at once (8 coder threads each), so the host-thread budget per GPU is fixed
-    // (16 by default) while a further block's GPU stage overlaps; FIFO so blocks finish in ticket order
-    int host_slots = 2;
-    std::mutex mu; std::condition_variable cv; int running = 0; int next_to_run = 0;
-    struct Lane { std::unique_ptr<BlockJob> job; std::thread worker; int ticket = -1; bool busy = false; int result = 0; };
+    struct Lane { std::unique_ptr<BlockJob> job; int ticket = -1; bool busy = false; };
     Lane lanes[MAX_SLOTS];
+    struct Task { BlockJob* job; int sub; };          // sub = -1: whole host stage of the block as one task
+    std::mutex mu; std::condition_variable cv_work, cv_done;
+    std::deque<Task> queue;
+    std::vector<std::thread> workers;
+    bool stop = false;
+
+    void worker_loop()
+    {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || !queue.empty(); });
+                if (queue.empty()) return;
+                t = queue.front(); queue.pop_front();
+            }
+            BlockJob& J = *t.job;
+            bool finished = false;
+            if (t.sub < 0) { host_stage(J); finished = true; }
+            else {
+                host_encode_sub(J, t.sub);
+                if (J.remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) { host_finalize_parallel(J); finished = true; }
+            }
+            if (finished) { { std::lock_guard<std::mutex> lk(mu); J.done = true; } cv_done.notify_all(); }
+        }
+    }
 };
 
-static void lane_join(bscgpu_pipe::Lane& L)
+static void lane_join(bscgpu_pipe* p, bscgpu_pipe::Lane& L)
 {
-    if (L.busy) { if (L.worker.joinable()) L.worker.join(); L.result = L.job->result; L.busy = false; }
+    if (!L.busy) return;
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cv_done.wait(lk, [&] { return L.job->done; });
+    L.busy = false;
 }
 
 int bscgpu_pipe_create(bscgpu_ctx* c, int depth, bscgpu_pipe** out)
@@ -418,8 +498,10 @@ int bscgpu_pipe_create(bscgpu_ctx* c, int depth, bscgpu_pipe** out)
     if (rc < 0) return rc;
     bscgpu_pipe* p = new bscgpu_pipe;
     p->c = c; p->depth = depth;
-    if (const char* e = getenv("BSCGPU_HOST_CONCURRENCY")) { int v = atoi(e); if (v >= 1 && v <= MAX_SLOTS) p->host_slots = v; }
+    int nworkers = 16;                                  // host-thread budget per GPU (two blocks' worth of sub-blocks)
+    if (const char* e = getenv("BSCGPU_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) nworkers = v; }
     for (int i = 0; i < depth; ++i) p->lanes[i].job.reset(new BlockJob);
+    for (int i = 0; i < nworkers; ++i) p->workers.emplace_back([p] { p->worker_loop(); });
     *out = p;
     return LIBBSC_NO_ERROR;
 }
@@ -427,7 +509,10 @@ int bscgpu_pipe_create(bscgpu_ctx* c, int depth, bscgpu_pipe** out)
 void bscgpu_pipe_destroy(bscgpu_pipe* p)
 {
     if (!p) return;
-    for (int i = 0; i < p->depth; ++i) lane_join(p->lanes[i]);
+    for (int i = 0; i < p->depth; ++i) lane_join(p, p->lanes[i]);
+    { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
+    p->cv_work.notify_all();
+    for (auto& t : p->workers) t.join();
     delete p;
 }
 
@@ -436,25 +521,26 @@ int bscgpu_pipe_submit(bscgpu_pipe* p, const void* dInput, uint8_t* output, int 
     if (!p) return LIBBSC_BAD_PARAMETER;
     const int ticket = p->next_ticket;
     bscgpu_pipe::Lane& L = p->lanes[ticket % p->depth];
-    lane_join(L);                                   // the lane's previous block must have been waited for or is finished now
+    lane_join(p, L);                                // the slot's previous block must be finished before its buffers are reused
     BlockJob& J = *L.job;
     int rc = prepare_job(J, p->c, dInput, output, n, blockSorter, coder, features);
     if (rc < 0) return rc;
     J.slot = p->c->slots[ticket % p->depth];
+    J.done = false;
     rc = gpu_stage(J, blockSorter);
     if (rc < 0) return rc;
     L.ticket = ticket; L.busy = true;
-    L.worker = std::thread([p, &J, ticket] {
-        {
-            std::unique_lock<std::mutex> lk(p->mu);
-            p->cv.wait(lk, [&] { return p->next_to_run == ticket && p->running < p->host_slots; });
-            ++p->running; ++p->next_to_run;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        if (job_is_parallel(J)) {
+            host_prepare(J);
+            J.remaining.store(J.nblocks, std::memory_order_release);
+            for (int b = 0; b < J.nblocks; ++b) p->queue.push_back({&J, b});
+        } else {
+            p->queue.push_back({&J, -1});
         }
-        p->cv.notify_all();
-        host_stage(J);
-        { std::lock_guard<std::mutex> lk(p->mu); --p->running; }
-        p->cv.notify_all();
-    });
+    }
+    p->cv_work.notify_all();
     p->next_ticket = ticket + 1;
     return ticket;
 }
@@ -464,8 +550,8 @@ int bscgpu_pipe_wait(bscgpu_pipe* p, int ticket)
     if (!p || ticket < 0 || ticket >= p->next_ticket) return LIBBSC_BAD_PARAMETER;
     bscgpu_pipe::Lane& L = p->lanes[ticket % p->depth];
     if (L.ticket != ticket) return LIBBSC_BAD_PARAMETER;   // already overwritten by a later submit
-    lane_join(L);
-    return L.result;
+    lane_join(p, L);
+    return L.job->result;
 }
 
 // ---- `synth-text v1` -----------------------------------------------------------------
