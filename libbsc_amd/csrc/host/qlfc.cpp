@@ -200,10 +200,10 @@ static void fill_shorts(void* p, size_t bytes, short v)
 // Static coder: the three counters are handled as one SSE vector [char, state, pos]: pmaddwd forms the weighted
 // probability, pmulhw(d, rate << 4) is exactly (d * rate) >> 12 for |d| < 2^15 and rate < 2^11 (all tuned rates are
 // <= 1364), so the update is bit-identical to predictor.h:53-61 at a third of the scalar instruction count.
-template <int CLS>
+template <int CLS, bool ADAPT = false>
 static BSC_ALWAYS_INLINE int static_step(unsigned bit, short& st, short& ch, short& sp)
 {
-    constexpr const short* P = kStaticParams[CLS];
+    constexpr const short* P = ADAPT ? kAdaptiveParams[CLS] : kStaticParams[CLS];
     __m128i v = _mm_cvtsi32_si128((int)((uint32_t)(uint16_t)ch | ((uint32_t)(uint16_t)st << 16)));
     v = _mm_insert_epi16(v, sp, 2);                                           // [ch, st, sp, 0, ...]
     const __m128i lr = _mm_setr_epi16(P[16], P[17], P[18], 0, 0, 0, 0, 0);
@@ -228,9 +228,7 @@ static BSC_ALWAYS_INLINE void decide(RangeEncoder& rc, const QlfcTables& T, unsi
     if (!ADAPT) { rc.encode<12>(bit, static_step<CLS>(bit, st, ch, sp)); return; }
     constexpr const short* P = kAdaptiveParams[CLS];
     const int p0 = ch, p1 = st, p2 = sp;
-    bump(st, bit, P[0], P[1], P[2],  P[3]);
-    bump(ch, bit, P[4], P[5], P[6],  P[7]);
-    bump(sp, bit, P[8], P[9], P[10], P[11]);
+    (void)static_step<CLS, true>(bit, st, ch, sp);            // the three counter updates as one vector op
     const int s0 = T.stretch[p0], s1 = T.stretch[p1], s2 = T.stretch[p2];
     short sp16 = (short)((s0 * mx->w0 + s1 * mx->w1 + s2 * mx->w2) >> 17);
     if (sp16 < -2047) sp16 = -2047;
