@@ -171,7 +171,7 @@ def main():
                                   "doubling_rounds": stage[5] / args.steps, "pipeline_depth": args.depth},
             "sorter_only_MBps": round(n / 1e6 / max(stage[1] / args.steps / 1e3, 1e-9), 1),
             "kernels": per_kernel,
-            "host": {"cpus": os.cpu_count()},
+            "host": {"cpus": os.cpu_count(), "effective_cpus": effective_cpus(), "coder_threads_per_gpu": int(os.environ.get("BSCGPU_HOST_THREADS", "16"))},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(host_in, args.sorter, args.coder)
@@ -181,13 +181,25 @@ def main():
         dist.destroy_process_group()
 
 
+def effective_cpus():
+    """CPUs this process may actually use: min(affinity, cgroup v2 cpu.max quota) — the 1-GPU box is a 16-CPU slice."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(host_in, sorter, coder):
     """The reference libbsc CPU path (oracle/_ref/libbsc_ref.so, compiled from /root/reference with its own flags)
     on the same block, best of 2 after a warm-up, MB = 1e6 bytes (bsc.cpp:427)."""
     try:
         os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         from oracle.refbind import Ref
-        threads = min(os.cpu_count() or 1, 32)
+        threads = min(effective_cpus(), 32)
         os.environ["BSC_REF_THREADS"] = str(threads)
         ref = Ref()
         ref.compress(host_in[: 1 << 20], sorter, coder)            # warm-up (OpenMP team start)

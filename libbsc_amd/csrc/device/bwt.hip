@@ -351,7 +351,7 @@ static int run_seg(bscgpu_ctx* c, const u64* keys, const u32* sa_sorted, const u
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->hscal, c->dscal, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync(c));
     prof_collect(c);
     *U_out = c->hscal[0];
     return BSC_NO_ERROR;
@@ -377,7 +377,7 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
         prof_end(c);
     }
     HIP_TRY(c, hipMemcpyAsync(c->hscal + 300, c->dscal + 300, 256 * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync(c));
     u8 codes[256]; u32 K = 0;
     for (int b = 0; b < 256; ++b) { codes[b] = (u8)K; if (c->hscal[300 + b]) ++K; }
     PackParams pp;
@@ -453,7 +453,7 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->hscal, c->dscal, (8 + 256) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync(c));
     prof_collect(c);
     *primary_out = c->hscal[1];
     for (u32 t = 0; t < cnt; ++t) I_host[t] = c->hscal[8 + t];

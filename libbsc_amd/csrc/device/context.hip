@@ -16,6 +16,13 @@ int ctx_fail(bscgpu_ctx* c, int code, const char* what, hipError_t e)
     return code;
 }
 
+hipError_t ctx_sync(bscgpu_ctx* c)
+{
+    hipError_t e = hipEventRecord(c->sync_ev, c->stream);
+    if (e != hipSuccess) return e;
+    return hipEventSynchronize(c->sync_ev);
+}
+
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 int ctx_ensure_slots(bscgpu_ctx* c, int count)
@@ -54,6 +61,7 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
     c->max_n  = max_n;
     memset(c->kstat, 0, sizeof c->kstat);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BSC_GPU_ERROR; }
+    if (hipEventCreateWithFlags(&c->sync_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return BSC_GPU_ERROR; }
 
     const size_t N = align_up((size_t)max_n + 4096, 4096);
     struct Carve { void** p; size_t bytes; size_t lead; };
@@ -89,7 +97,7 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
            && hipHostMalloc((void**)&c->hadler, (size_t)MAX_CHUNKS * 16, hipHostMallocDefault) == hipSuccess
            && hipHostMalloc((void**)&c->hsplit, N / 256 + 64, hipHostMallocDefault) == hipSuccess
            && ctx_ensure_slots(c, 1) == BSC_NO_ERROR;
-    if (!ok || hipStreamSynchronize(c->stream) != hipSuccess) { bscgpu_destroy(c); return BSC_GPU_NOT_ENOUGH_MEMORY; }
+    if (!ok || ctx_sync(c) != hipSuccess) { bscgpu_destroy(c); return BSC_GPU_NOT_ENOUGH_MEMORY; }
     *out = c;
     return BSC_NO_ERROR;
 }
@@ -98,7 +106,7 @@ extern "C" void bscgpu_destroy(bscgpu_ctx* c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream) ctx_sync(c);
     for (auto& p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& e : c->event_pool) hipEventDestroy(e);
     if (c->hscal) hipHostFree(c->hscal);
@@ -113,6 +121,7 @@ extern "C" void bscgpu_destroy(bscgpu_ctx* c)
         if (s.hL) hipHostFree(s.hL);
     }
     if (c->arena) hipFree(c->arena);
+    if (c->sync_ev) hipEventDestroy(c->sync_ev);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -222,7 +231,7 @@ extern "C" int bscgpu_radix_sort_u64(bscgpu_ctx* c, void* keys, void* keys_alt, 
     for (int s = begin_bit; s < end_bit; s += 8) { passes[np].shift = s; passes[np].bits = (end_bit - s < 8) ? end_bit - s : 8; ++np; }
     int rc = radix_sort_passes(c, (u64*)keys, (u64*)keys_alt, (u32*)vals, (u32*)vals_alt, (u64)n, passes, np, result_in_alt);
     if (rc < 0) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync(c));
     prof_collect(c);
     return BSC_NO_ERROR;
 }
@@ -239,7 +248,7 @@ static int64_t bwt_host(bscgpu_ctx* c, const uint8_t* T, uint8_t* L, int64_t n, 
     int rc = bwt_device(c, c->dL, c->dL, n, r, I, &primary);
     if (rc < 0) return rc;
     HIP_TRY(c, hipMemcpyAsync(L, c->dL, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync(c));
     return primary;
 }
 extern "C" int64_t bscgpu_bwt(bscgpu_ctx* c, const uint8_t* T, uint8_t* L, int64_t n) { return bwt_host(c, T, L, n, 0, nullptr); }
@@ -262,6 +271,6 @@ extern "C" int bscgpu_st_encode(bscgpu_ctx* c, uint8_t* T, int n, int k)
     int rc = st_device(c, c->dL, c->dL, n, k, &index);
     if (rc < 0) return rc;
     HIP_TRY(c, hipMemcpyAsync(T, c->dL, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync(c));
     return index;
 }

@@ -64,6 +64,7 @@ constexpr int MAX_SLOTS = 4;
 struct bscgpu_ctx {
     int          device      = 0;
     hipStream_t  stream      = nullptr;
+    hipEvent_t   sync_ev     = nullptr;   // blocking-sync event: waiting threads sleep instead of spinning (host CPUs are the scarce resource)
     int64_t      max_n       = 0;
     char*        arena       = nullptr;
     size_t       arena_bytes = 0;
@@ -107,6 +108,7 @@ struct bscgpu_ctx {
 };
 
 int  ctx_fail(bscgpu_ctx* c, int code, const char* what, hipError_t e);
+hipError_t ctx_sync(bscgpu_ctx* c);   // wait for everything queued on c->stream without burning a CPU
 #define HIP_TRY(ctx, expr)                                                         \
     do { hipError_t _e = (expr);                                                   \
          if (_e != hipSuccess) return ctx_fail((ctx), BSC_GPU_ERROR, #expr, _e);   \

@@ -192,7 +192,7 @@ int qlfc_front_split(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, int* start
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->hsplit, dwords, (size_t)nwords * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync(c));
     const u64* w = c->hsplit;
     u64 changes = 0;
     for (u32 k = 0; k < nwords; ++k) changes += (u64)__builtin_popcountll(w[k]);
@@ -249,7 +249,7 @@ int qlfc_front_runs(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, const int* 
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->hscal, c->dscal, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(first_run_host, dfirst, 8 * 256 * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync(c));
     const u32 m = c->hscal[0];
     *m_out = m;
 
@@ -276,7 +276,7 @@ int qlfc_front_runs(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, const int* 
     HIP_TRY(c, hipMemcpyAsync(slot.hrank, drank, m, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(slot.hstart, dstart, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
     if (copy_block) HIP_TRY(c, hipMemcpyAsync(slot.hL, dL, n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync(c));
     prof_collect(c);
     return BSC_NO_ERROR;
 }

@@ -81,7 +81,7 @@ int st_device(bscgpu_ctx* c, const u8* dT_user, u8* dOut_user, int n_, int k, in
     const u32 n = (u32)n_;
     if (n <= 1) {                                   // st.cpp:994
         if (n == 1 && dOut_user != dT_user) HIP_TRY(c, hipMemcpyAsync(dOut_user, dT_user, 1, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, ctx_sync(c));
         *index_out = 0;
         return BSC_NO_ERROR;
     }
@@ -117,7 +117,7 @@ int st_device(bscgpu_ctx* c, const u8* dT_user, u8* dOut_user, int n_, int k, in
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->hscal, c->dscal, 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync(c));
     prof_collect(c);
     *index_out = (int)c->hscal[2];
     return BSC_NO_ERROR;
@@ -186,7 +186,7 @@ int adler32_device(bscgpu_ctx* c, const u8* d, int64_t n, u32* out)
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->hadler, c->adler_part, (size_t)ch.num_chunks * 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, ctx_sync(c));
     prof_collect(c);
     u64 s1 = 1, s2 = 0;
     const u64 chunk_bytes = (u64)ch.chunk_tiles * ADLER_TILE;
