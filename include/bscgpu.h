@@ -90,6 +90,10 @@ BSCGPU_API int  bscgpu_pipe_create(bscgpu_ctx* ctx, int depth, bscgpu_pipe** out
 BSCGPU_API void bscgpu_pipe_destroy(bscgpu_pipe* pipe);
 BSCGPU_API int  bscgpu_pipe_submit(bscgpu_pipe* pipe, const void* dInput, uint8_t* output, int n,
                                    int blockSorter, int coder, int features);       /* ticket >= 0 or error */
+/* Host-resident block with bsc_compress's full parameter list (libbsc.cpp:213), LZP included: LZP runs on the calling
+ * thread (+ up to 8 chunk threads), then one H2D copy feeds the same GPU stage.  input must stay valid until wait(). */
+BSCGPU_API int  bscgpu_pipe_submit_host(bscgpu_pipe* pipe, const uint8_t* input, uint8_t* output, int n,
+                                        int lzpHashSize, int lzpMinLen, int blockSorter, int coder, int features);
 BSCGPU_API int  bscgpu_pipe_wait(bscgpu_pipe* pipe, int ticket);
 
 /* ---- profiling --------------------------------------------------------------------------- */

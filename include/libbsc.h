@@ -5,10 +5,10 @@
  * names, argument meaning, constants and error codes, so existing callers relink unchanged.  The text
  * of this header is ours.  Differences in behaviour are limited to what the hot-path scope states
  * (DESIGN.md): the block sorters run on the GPU only (no CPU sorter is shipped: without a usable GPU
- * the sorters return LIBBSC_GPU_NOT_SUPPORTED instead of silently falling back), and LZP
- * preprocessing is not implemented (lzpHashSize / lzpMinLen must be 0, else LIBBSC_NOT_SUPPORTED).
+ * the sorters return LIBBSC_GPU_NOT_SUPPORTED instead of silently falling back).  LZP preprocessing
+ * (lzpHashSize / lzpMinLen) runs on the host, byte-identical to the reference's encoder.
  * Decode side: bsc_decompress is self-hosted (QLFC decoders, inverse BWT, inverse ST3..8 and LZP decoding on the
- * host), so it reads every block the reference can write, including blocks written with LZP on.
+ * host), so it reads every block the reference can write.
  */
 #ifndef LIBBSC_MI355X_LIBBSC_H
 #define LIBBSC_MI355X_LIBBSC_H
@@ -95,6 +95,9 @@ LIBBSC_API int bsc_coder_init(int features);
 LIBBSC_API int bsc_coder_compress(const unsigned char* input, unsigned char* output, int n, int coder, int features);
 LIBBSC_API int bsc_coder_decompress(const unsigned char* input, unsigned char* output, int coder, int features);
 LIBBSC_API unsigned int bsc_adler32(const unsigned char* T, int n, int features);
+/* LZP preprocessor (lzp/lzp.h:50-62); output must hold n bytes (compress) / the original size (decompress) */
+LIBBSC_API int bsc_lzp_compress(const unsigned char* input, unsigned char* output, int n, int hashSize, int minLen, int features);
+LIBBSC_API int bsc_lzp_decompress(const unsigned char* input, unsigned char* output, int n, int hashSize, int minLen, int features);
 
 /* one QLFC sub-block (coder/qlfc/qlfc.h:44-101), exposed for stage-level parity tests */
 LIBBSC_API int bsc_qlfc_encode_block(const unsigned char* input, unsigned char* output, int inputSize, int outputSize, int coder);

@@ -69,6 +69,7 @@ def lib():
     L.bscgpu_pipe_destroy.restype = None
     L.bscgpu_pipe_submit.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.bscgpu_pipe_wait.argtypes = [vp, C.c_int]
+    L.bscgpu_pipe_submit_host.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     if hasattr(L, "bscgpu_compress_device"):
         L.bscgpu_compress_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
     _lib = L

@@ -124,6 +124,21 @@ def bsc_compress(data, sorter=BLOCKSORTER_BWT, coder=CODER_QLFC_STATIC, lzp_hash
     return out[:r].tobytes() if r >= 0 else r
 
 
+def bsc_lzp_compress(data, hash_size, min_len, features=3):
+    """LZP stage (lzp/lzp.h:50): -> bytes or the negative error code (LIBBSC_NOT_COMPRESSIBLE = -3)."""
+    a = _arr(data)
+    out = np.empty(a.size + 64, np.uint8)
+    r = _L().bsc_lzp_compress(N.np_ptr(a), N.np_ptr(out), a.size, hash_size, min_len, features)
+    return out[:r].tobytes() if r >= 0 else r
+
+
+def bsc_lzp_decompress(data, orig_size, hash_size, min_len, features=3):
+    a = _arr(data)
+    out = np.empty(orig_size + 64, np.uint8)
+    r = _L().bsc_lzp_decompress(N.np_ptr(a), N.np_ptr(out), a.size, hash_size, min_len, features)
+    return out[:r].tobytes() if r >= 0 else r
+
+
 def bsc_block_info(block, features=3):
     a = _arr(block)
     bs, ds = C.c_int(), C.c_int()

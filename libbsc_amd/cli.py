@@ -1,9 +1,10 @@
 """`.bsc` file driver: independent blocks in the reference CLI's container (bsc.cpp:46-59, 163-178,
 397-418): "bsc1", int32 nBlocks, then per block {int64 blockOffset, int8 recordSize = 1, int8 sortingContexts = 1}
-followed by the bsc_compress block.  Files written here unpack with the reference `bsc d`; files written by
-`bsc e -p` (preprocessing off) unpack here.
+followed by the bsc_compress block.  Files written here unpack with the reference `bsc d` and the other way round;
+with the same flags the two files are byte-identical (LZP on by default like the reference, -H15 -M128; -p turns it
+off).  Segmentation / record reordering (`-s`, `-r`, off by default in the reference too) are not offered.
 
-    python -m libbsc_amd.cli e <in> <out> [-b<MiB>] [-m0|-m3..8] [-e0|-e1|-e2]
+    python -m libbsc_amd.cli e <in> <out> [-b<MiB>] [-m0|-m3..8] [-e0|-e1|-e2] [-H<bits>] [-M<len>] [-p]
     python -m libbsc_amd.cli d <in> <out>
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 -m libbsc_amd.cli e <in> <out> ...
 
@@ -52,7 +53,7 @@ def decompress_file(in_path, out_path):
     return total
 
 
-def compress_file(in_path, out_path, block_size=64 << 20, sorter=1, coder=1, depth=3):
+def compress_file(in_path, out_path, block_size=64 << 20, sorter=1, coder=1, depth=3, lzp_hash=0, lzp_min=0):
     import torch
     from . import GpuContext
     from .multigpu import assign_blocks, bsc_file_image, gather_blocks_to_rank0
@@ -75,8 +76,11 @@ def compress_file(in_path, out_path, block_size=64 << 20, sorter=1, coder=1, dep
     inflight = []
     for b in mine:
         lo = b * block_size
-        d = torch.from_numpy(data[lo:lo + block_size]).to(dev)
-        inflight.append((b, pipe.submit(d, d.numel(), sorter, coder, 3)))
+        if lzp_hash or lzp_min:                      # LZP is host work: hand the pipe the host block
+            inflight.append((b, pipe.submit_host(data[lo:lo + block_size], sorter, coder, lzp_hash, lzp_min, 3)))
+        else:
+            d = torch.from_numpy(data[lo:lo + block_size]).to(dev)
+            inflight.append((b, pipe.submit(d, d.numel(), sorter, coder, 3)))
         if len(inflight) >= depth:
             bb, t = inflight.pop(0)
             done[bb] = pipe.wait(t)
@@ -109,11 +113,16 @@ def main(argv):
         print(decompress_file(argv[2], argv[3]), "bytes")
         return 0
     block, sorter, coder = 64 << 20, 1, 1
+    lzp, lzp_hash, lzp_min = True, 15, 128           # the reference CLI's defaults (bsc.cpp:73-78): LZP on, -H15 -M128
     for a in argv[4:]:
         if a.startswith("-b"): block = int(a[2:]) << 20
         elif a.startswith("-m"): sorter = 1 if a[2:] == "0" else int(a[2:])
         elif a.startswith("-e"): coder = {0: 3, 1: 1, 2: 2}[int(a[2:])]
-    size = compress_file(argv[2], argv[3], block, sorter, coder)
+        elif a.startswith("-H"): lzp_hash = int(a[2:])
+        elif a.startswith("-M"): lzp_min = int(a[2:])
+        elif a == "-p": lzp = False
+        elif a == "-l": lzp = True
+    size = compress_file(argv[2], argv[3], block, sorter, coder, lzp_hash=lzp_hash if lzp else 0, lzp_min=lzp_min if lzp else 0)
     if int(os.environ.get("RANK", "0")) == 0:
         print(size, "bytes")
     return 0

@@ -24,6 +24,7 @@
 #include "../../../include/bscgpu.h"
 #include "../device/dev_common.h"
 #include "qlfc.h"
+#include "lzp.h"
 
 using namespace bschost;
 
@@ -162,59 +163,10 @@ static int make_mode(int sorter, int coder, int lzpHashSize, int lzpMinLen, int*
     if (lzpMinLen != 0 || lzpHashSize != 0) {
         if (lzpMinLen < 4 || lzpMinLen > 255) return LIBBSC_BAD_PARAMETER;
         if (lzpHashSize < 10 || lzpHashSize > 28) return LIBBSC_BAD_PARAMETER;
-        return LIBBSC_NOT_SUPPORTED;       // LZP is outside the hot-path scope
+        mode += (lzpMinLen << 8) + (lzpHashSize << 16);
     }
     *mode_out = mode;
     return LIBBSC_NO_ERROR;
-}
-
-// Shared tail of bsc_compress: `sorted` holds the sorter output (lzSize bytes) at output[0..), finish the block.
-static int finish_block(const unsigned char* input, unsigned adler_data, unsigned char* output, int n, int mode, int index,
-                        int num_indexes, const int* indexes, int coder, int features, bool inplace)
-{
-    unsigned char* buffer = (unsigned char*)bsc_malloc((size_t)n + 4096);
-    if (!buffer) return LIBBSC_NOT_ENOUGH_MEMORY;
-    int result = coder_compress(output, buffer, n, coder, features);
-    if (result >= LIBBSC_NO_ERROR) memcpy(output + LIBBSC_HEADER_SIZE, buffer, (size_t)result);
-    bsc_free(buffer);
-    if (result < LIBBSC_NO_ERROR || result + 1 + 4 * num_indexes >= n) {
-        if (inplace) return LIBBSC_NOT_COMPRESSIBLE;          // libbsc.cpp:188-191
-        return bsc_store(input, output, n, features);         // libbsc.cpp:315-318
-    }
-    if (num_indexes > 0) memcpy(output + LIBBSC_HEADER_SIZE + result, indexes, (size_t)4 * num_indexes);
-    output[LIBBSC_HEADER_SIZE + result + 4 * num_indexes] = (unsigned char)num_indexes;
-    result += 1 + 4 * num_indexes;
-    put_i32(output + 0, result + LIBBSC_HEADER_SIZE);
-    put_i32(output + 4, n);
-    put_i32(output + 8, mode);
-    put_i32(output + 12, index);
-    put_i32(output + 16, (int)adler_data);
-    put_i32(output + 20, (int)adler32(output + LIBBSC_HEADER_SIZE, (size_t)result));
-    put_i32(output + 24, (int)adler32(output, 24));
-    return result + LIBBSC_HEADER_SIZE;
-}
-
-int bsc_compress(const unsigned char* input, unsigned char* output, int n, int lzpHashSize, int lzpMinLen,
-                 int blockSorter, int coder, int features)
-{
-    const bool inplace = (input == output);
-    int mode = 0;
-    int rc = make_mode(blockSorter, coder, lzpHashSize, lzpMinLen, &mode);
-    if (rc != LIBBSC_NO_ERROR) return rc;
-    if (n < 0 || n > (inplace ? 2146435072 : 1073741824)) return LIBBSC_BAD_PARAMETER;
-    if (n <= LIBBSC_HEADER_SIZE) return bsc_store(input, output, n, features);
-
-    const unsigned adler_data = adler32(input, (size_t)n);
-    if (!inplace) memcpy(output, input, (size_t)n);
-
-    int indexes[256];
-    unsigned char num_indexes = 0;
-    int index;
-    if (blockSorter == LIBBSC_BLOCKSORTER_BWT) index = bsc_bwt_encode(output, n, &num_indexes, indexes, features);
-    else                                       index = bsc_st_encode(output, n, blockSorter, features);
-    if (n < 64 * 1024) num_indexes = 0;                       // libbsc.cpp:176
-    if (index < LIBBSC_NO_ERROR) return index;
-    return finish_block(input, adler_data, output, n, mode, index, num_indexes, indexes, coder, features, inplace);
 }
 
 int bsc_block_info(const unsigned char* hdr, int headerSize, int* pBlockSize, int* pDataSize, int)
@@ -247,7 +199,11 @@ int bsc_block_info(const unsigned char* hdr, int headerSize, int* pBlockSize, in
 struct BlockJob {
     bscgpu_ctx* c = nullptr;
     const void* dInput = nullptr;
+    const uint8_t* hInput = nullptr; // host copy of the original block (bsc_compress); null for device-resident callers
     uint8_t*    output = nullptr;
+    int n_orig = 0;                  // size of the original block; n below is what the sorter sees (LZP output or the same)
+    bool have_adler = false, inplace = false;
+    std::unique_ptr<unsigned char, void (*)(void*)> lz{nullptr, nullptr};   // LZP output while the block is in flight
     int n = 0, coder = 0, features = 0, mode = 0, index = 0, num_indexes = 0, nblocks = 0;
     int indexes[256];
     uint32_t adler_data = 0;
@@ -281,7 +237,7 @@ static int gpu_stage(BlockJob& J, int blockSorter)
         return LIBBSC_NO_ERROR;
     }
     auto t0 = clk::now();
-    int rc = adler32_device(c, (const u8*)J.dInput, n, &J.adler_data);
+    int rc = J.have_adler ? LIBBSC_NO_ERROR : adler32_device(c, (const u8*)J.dInput, n, &J.adler_data);
     if (rc < 0) return rc;
     c->stage_ms[0] = ms_since(t0);
 
@@ -300,7 +256,7 @@ static int gpu_stage(BlockJob& J, int blockSorter)
         rc = st_device(c, (const u8*)J.dInput, c->dL, n, blockSorter, &J.index);
         if (rc < 0) return rc;
     }
-    if (n < 64 * 1024) J.num_indexes = 0;
+    if (J.n_orig < 64 * 1024) J.num_indexes = 0;              // libbsc.cpp:290 (the original size decides)
     c->stage_ms[1] = ms_since(t0);
 
     // QLFC front half on the GPU (sub-block split, runs, ranks); only the run arrays (+ L for the rare raw
@@ -343,7 +299,8 @@ static void host_encode_sub(BlockJob& J, int b)
 
 static void write_stored(BlockJob& J)
 {
-    uint8_t* output = J.output; const int n = J.n;
+    uint8_t* output = J.output; const int n = J.n_orig;
+    if (J.hInput) { J.result = J.inplace ? LIBBSC_NOT_COMPRESSIBLE : bsc_store(J.hInput, output, n, J.features); return; }   // libbsc.cpp:188, :315
     if (hipSetDevice(J.c->device) != hipSuccess ||
         hipMemcpy(output + LIBBSC_HEADER_SIZE, J.dInput, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) { J.result = LIBBSC_GPU_ERROR; return; }
     put_i32(output + 0, n + LIBBSC_HEADER_SIZE); put_i32(output + 4, n); put_i32(output + 8, 0); put_i32(output + 12, 0);
@@ -354,7 +311,7 @@ static void write_stored(BlockJob& J)
 
 static void write_header_and_trailer(BlockJob& J, int result)
 {
-    uint8_t* output = J.output; const int n = J.n;
+    uint8_t* output = J.output; const int n = J.n_orig;
     if (result < LIBBSC_NO_ERROR || result + 1 + 4 * J.num_indexes >= n) { write_stored(J); return; }      // libbsc.cpp:315-318
     if (J.num_indexes > 0) memcpy(output + LIBBSC_HEADER_SIZE + result, J.indexes, (size_t)4 * J.num_indexes);
     output[LIBBSC_HEADER_SIZE + result + 4 * J.num_indexes] = (unsigned char)J.num_indexes;
@@ -417,13 +374,81 @@ static void host_stage(BlockJob& J)
     write_header_and_trailer(J, result);
 }
 
+// Host-resident block -> job: optional LZP on the host (lzp.cpp:798 semantics), then one H2D copy into the context's
+// text buffer.  `sorter` may be changed (a tiny LZP output is always BWT-sorted, libbsc.cpp:277-281).
+static int stage_host_input(BlockJob& J, bscgpu_ctx* c, const unsigned char* input, unsigned char* output, int n,
+                            int lzpHashSize, int lzpMinLen, int* sorter, int coder, int features, int mode)
+{
+    const unsigned char* data = input;
+    int lzSize = n;
+    J.lz.reset();
+    if (mode != (mode & 0xff)) {
+        J.lz = std::unique_ptr<unsigned char, void (*)(void*)>((unsigned char*)bsc_malloc((size_t)n), bsc_free);
+        if (!J.lz) return LIBBSC_NOT_ENOUGH_MEMORY;
+        const int r = lzp_compress(input, J.lz.get(), n, lzpHashSize, lzpMinLen, features);
+        if (r < LIBBSC_NO_ERROR) { mode &= 0xff; J.lz.reset(); }            // libbsc.cpp:266-269: the block goes on without LZP
+        else { data = J.lz.get(); lzSize = r; }
+    }
+    if (lzSize <= LIBBSC_HEADER_SIZE) { *sorter = LIBBSC_BLOCKSORTER_BWT; mode = (mode & ~0x1f) | LIBBSC_BLOCKSORTER_BWT; }
+    J.c = c; J.dInput = c->dL; J.hInput = input; J.output = output; J.n = lzSize; J.n_orig = n; J.inplace = (input == output);
+    J.coder = coder; J.features = features; J.mode = mode; J.stored_small = false; J.result = 0; J.have_adler = false;
+    if (data != input) { J.adler_data = adler32(input, (size_t)n); J.have_adler = true; }
+    if (hipSetDevice(c->device) != hipSuccess) return LIBBSC_GPU_ERROR;
+    if (hipMemcpyAsync(c->dL, data, (size_t)lzSize, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LIBBSC_GPU_ERROR;
+    return LIBBSC_NO_ERROR;
+}
+
+// bsc_compress (libbsc.cpp:213-338; input == output selects the in-place rules, :83-211): optional LZP on the host, then
+// the same GPU stage + host coder as the device-resident entry point.
+int bsc_compress(const unsigned char* input, unsigned char* output, int n, int lzpHashSize, int lzpMinLen,
+                 int blockSorter, int coder, int features)
+{
+    const bool inplace = (input == output);
+    int mode = 0;
+    int rc = make_mode(blockSorter, coder, lzpHashSize, lzpMinLen, &mode);
+    if (rc != LIBBSC_NO_ERROR) return rc;
+    if (!input || !output) return LIBBSC_BAD_PARAMETER;
+    if (n < 0 || n > (inplace ? 2146435072 : 1073741824)) return LIBBSC_BAD_PARAMETER;
+    if (n <= LIBBSC_HEADER_SIZE) return bsc_store(input, output, n, features);
+
+    std::unique_ptr<BlockJob> J(new BlockJob);
+    std::lock_guard<std::mutex> g(g_gpu_lock);
+    bscgpu_ctx* c = nullptr;
+    rc = default_gpu(n, &c);
+    if (rc != LIBBSC_NO_ERROR) return rc;
+    if (hipSetDevice(c->device) != hipSuccess) return LIBBSC_GPU_ERROR;
+    rc = ctx_ensure_slots(c, 1);
+    if (rc < 0) return rc;
+    J->slot = c->slots[0];
+    rc = stage_host_input(*J, c, input, output, n, lzpHashSize, lzpMinLen, &blockSorter, coder, features, mode);
+    if (rc < 0) return rc;
+    rc = gpu_stage(*J, blockSorter);
+    if (rc < 0) return rc;
+    host_stage(*J);
+    J->lz.reset();
+    return J->result;
+}
+
+int bsc_lzp_compress(const unsigned char* input, unsigned char* output, int n, int hashSize, int minLen, int features)
+{
+    if (!input || !output || n < 0 || minLen < 4 || minLen > 255 || hashSize < 10 || hashSize > 28) return LIBBSC_BAD_PARAMETER;
+    return lzp_compress(input, output, n, hashSize, minLen, features);
+}
+int bsc_lzp_decompress(const unsigned char* input, unsigned char* output, int n, int hashSize, int minLen, int features)
+{
+    (void)features;
+    if (!input || !output || n < 0 || minLen < 4 || minLen > 255 || hashSize < 10 || hashSize > 28) return LIBBSC_BAD_PARAMETER;
+    return lzp_decompress(input, output, n, 0x7fffffff, hashSize, minLen);
+}
+
 static int prepare_job(BlockJob& J, bscgpu_ctx* c, const void* dInput, uint8_t* output, int n, int blockSorter, int coder, int features)
 {
     if (!c || !dInput || !output) return LIBBSC_BAD_PARAMETER;
     int rc = make_mode(blockSorter, coder, 0, 0, &J.mode);
     if (rc != LIBBSC_NO_ERROR) return rc;
     if (n < 0 || n > c->max_n) return LIBBSC_BAD_PARAMETER;
-    J.c = c; J.dInput = dInput; J.output = output; J.n = n; J.coder = coder; J.features = features;
+    J.c = c; J.dInput = dInput; J.output = output; J.n = n; J.n_orig = n; J.coder = coder; J.features = features;
+    J.hInput = nullptr; J.have_adler = false; J.inplace = false; J.lz.reset();
     J.stored_small = false; J.result = 0;
     return LIBBSC_NO_ERROR;
 }
@@ -516,19 +541,10 @@ void bscgpu_pipe_destroy(bscgpu_pipe* p)
     delete p;
 }
 
-int bscgpu_pipe_submit(bscgpu_pipe* p, const void* dInput, uint8_t* output, int n, int blockSorter, int coder, int features)
+// queue the host half of a block whose GPU stage has run
+static int pipe_enqueue(bscgpu_pipe* p, bscgpu_pipe::Lane& L, int ticket)
 {
-    if (!p) return LIBBSC_BAD_PARAMETER;
-    const int ticket = p->next_ticket;
-    bscgpu_pipe::Lane& L = p->lanes[ticket % p->depth];
-    lane_join(p, L);                                // the slot's previous block must be finished before its buffers are reused
     BlockJob& J = *L.job;
-    int rc = prepare_job(J, p->c, dInput, output, n, blockSorter, coder, features);
-    if (rc < 0) return rc;
-    J.slot = p->c->slots[ticket % p->depth];
-    J.done = false;
-    rc = gpu_stage(J, blockSorter);
-    if (rc < 0) return rc;
     L.ticket = ticket; L.busy = true;
     {
         std::lock_guard<std::mutex> lk(p->mu);
@@ -543,6 +559,53 @@ int bscgpu_pipe_submit(bscgpu_pipe* p, const void* dInput, uint8_t* output, int 
     p->cv_work.notify_all();
     p->next_ticket = ticket + 1;
     return ticket;
+}
+
+int bscgpu_pipe_submit(bscgpu_pipe* p, const void* dInput, uint8_t* output, int n, int blockSorter, int coder, int features)
+{
+    if (!p) return LIBBSC_BAD_PARAMETER;
+    const int ticket = p->next_ticket;
+    bscgpu_pipe::Lane& L = p->lanes[ticket % p->depth];
+    lane_join(p, L);                                // the slot's previous block must be finished before its buffers are reused
+    BlockJob& J = *L.job;
+    int rc = prepare_job(J, p->c, dInput, output, n, blockSorter, coder, features);
+    if (rc < 0) return rc;
+    J.slot = p->c->slots[ticket % p->depth];
+    J.done = false;
+    rc = gpu_stage(J, blockSorter);
+    J.lz.reset();                                   // the LZP output lives in HBM from here on
+    if (rc < 0) return rc;
+    return pipe_enqueue(p, L, ticket);
+}
+
+// Host-resident block with the full bsc_compress parameter set (LZP included); `input` must stay valid until the
+// ticket has been waited for (a block that does not compress is stored from it).
+int bscgpu_pipe_submit_host(bscgpu_pipe* p, const uint8_t* input, uint8_t* output, int n, int lzpHashSize, int lzpMinLen,
+                            int blockSorter, int coder, int features)
+{
+    if (!p || !input || !output) return LIBBSC_BAD_PARAMETER;
+    int mode = 0;
+    int rc = make_mode(blockSorter, coder, lzpHashSize, lzpMinLen, &mode);
+    if (rc != LIBBSC_NO_ERROR) return rc;
+    if (n < 0 || n > p->c->max_n) return LIBBSC_BAD_PARAMETER;
+    const int ticket = p->next_ticket;
+    bscgpu_pipe::Lane& L = p->lanes[ticket % p->depth];
+    lane_join(p, L);
+    BlockJob& J = *L.job;
+    J.done = false;
+    J.slot = p->c->slots[ticket % p->depth];
+    if (n <= LIBBSC_HEADER_SIZE) {
+        J.c = p->c; J.n = J.n_orig = n; J.output = output; J.lz.reset();
+        J.result = bsc_store(input, output, n, features);
+        J.stored_small = true;
+        return pipe_enqueue(p, L, ticket);
+    }
+    rc = stage_host_input(J, p->c, input, output, n, lzpHashSize, lzpMinLen, &blockSorter, coder, features, mode);
+    if (rc < 0) return rc;
+    rc = gpu_stage(J, blockSorter);
+    J.lz.reset();                                   // the LZP output lives in HBM from here on
+    if (rc < 0) return rc;
+    return pipe_enqueue(p, L, ticket);
 }
 
 int bscgpu_pipe_wait(bscgpu_pipe* p, int ticket)

@@ -9,6 +9,7 @@
 
 #include "../../../include/libbsc.h"
 #include "qlfc.h"
+#include "lzp.h"
 
 using namespace bschost;
 
@@ -55,7 +56,8 @@ static int lzp_decode_block(const unsigned char* in, const unsigned char* in_end
     return (int)(out - out0);
 }
 
-static int lzp_decompress(const unsigned char* in, unsigned char* out, int n, int out_cap, int hashSize, int minLen)
+namespace bschost {
+int lzp_decompress(const uint8_t* in, uint8_t* out, int n, int out_cap, int hashSize, int minLen)
 {
     if (n < 1) return LIBBSC_DATA_CORRUPT;
     const int nblocks = in[0];
@@ -74,6 +76,7 @@ static int lzp_decompress(const unsigned char* in, unsigned char* out, int n, in
     }
     return (int)op;
 }
+}  // namespace bschost
 
 extern "C" {
 

@@ -156,6 +156,15 @@ class Pipe:
         self._out[t] = (out, dInput)          # keep both alive until wait()
         return t
 
+    def submit_host(self, data, sorter=1, coder=1, lzp_hash=0, lzp_min=0, features=3):
+        """Host-resident block (np.uint8) with bsc_compress's full parameter list, LZP included."""
+        a = np.ascontiguousarray(data, dtype=np.uint8)
+        out = np.empty(a.size + 28, np.uint8)
+        t = self.ctx._check(self.L.bscgpu_pipe_submit_host(self.h, N.np_ptr(a), N.np_ptr(out), a.size, lzp_hash, lzp_min,
+                                                            sorter, coder, features))
+        self._out[t] = (out, a)
+        return t
+
     def wait(self, ticket):
         rc = self.ctx._check(self.L.bscgpu_pipe_wait(self.h, ticket))
         out, _ = self._out.pop(ticket)

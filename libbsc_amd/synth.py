@@ -81,3 +81,28 @@ def synth_text_v1(seed: int, n: int) -> np.ndarray:
         pos += take
         words += k
     return out[:n].copy()
+
+
+def _splitmix64(i: np.ndarray, seed: int) -> np.ndarray:
+    """Counter-based 64-bit mix (splitmix64 finaliser) of the uint64 counters i; wraps mod 2^64."""
+    with np.errstate(over="ignore"):
+        z = i.astype(np.uint64) + np.uint64((seed * 0x9E3779B97F4A7C15) & _M64)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def synth_repeat_v1(seed: int, n: int, period: int, noise_every: int = 512) -> np.ndarray:
+    """`synth-repeat v1`: a `period`-byte slice of synth-text v1 tiled to n bytes, then about n / noise_every bytes
+    overwritten at hashed positions, every other one with 0xF2 (the LZP escape byte).  Long repeats with sparse
+    damage: the kind of input the LZP preprocessor exists for.  Deterministic, integer-only."""
+    base = synth_text_v1(seed, period)
+    out = np.tile(base, n // period + 1)[:n].copy()
+    k = n // noise_every
+    if k:
+        h = _splitmix64(np.arange(k, dtype=np.uint64), seed)
+        pos = (h % np.uint64(n)).astype(np.int64)
+        val = ((h >> np.uint64(40)) & np.uint64(0xff)).astype(np.uint8)
+        val[::2] = 0xF2
+        out[pos] = val          # duplicate positions: numpy assigns in index order, the last write wins
+    return out

@@ -19,6 +19,7 @@
 #include "coder/coder.h"
 #include "coder/qlfc/qlfc.h"
 #include "adler32/adler32.h"
+#include "lzp/lzp.h"
 
 // Internal (non-static) reference function, qlfc.cpp:398 (scalar) / :200 (SSE/AVX).
 unsigned char* bsc_qlfc_transform(const unsigned char* input, unsigned char* buffer, int n, unsigned char* MTFTable);
@@ -49,6 +50,11 @@ REF_API int ref_bsc_coder_compress(const unsigned char* in, unsigned char* out, 
 { return bsc_coder_compress(in, out, n, coder, features); }
 REF_API int ref_bsc_coder_decompress(const unsigned char* in, unsigned char* out, int coder, int features)            // coder.cpp:273
 { return bsc_coder_decompress(in, out, coder, features); }
+
+REF_API int ref_bsc_lzp_compress(const unsigned char* in, unsigned char* out, int n, int hashSize, int minLen, int features)   // lzp.cpp:798
+{ return bsc_lzp_compress(in, out, n, hashSize, minLen, features); }
+REF_API int ref_bsc_lzp_decompress(const unsigned char* in, unsigned char* out, int n, int hashSize, int minLen, int features) // lzp.cpp:813
+{ return bsc_lzp_decompress(in, out, n, hashSize, minLen, features); }
 
 // One QLFC sub-block (what coder.cpp:61 dispatches to); coder = 1 static / 2 adaptive / 3 fast.
 REF_API int ref_bsc_qlfc_encode_block(const unsigned char* in, unsigned char* out, int inSize, int outSize, int coder)

@@ -51,6 +51,8 @@ class Ref:
         L.ref_bsc_qlfc_decode_block.argtypes = [u8p, u8p, C.c_int]
         L.ref_bsc_qlfc_transform.argtypes = [u8p, C.c_int, u8p, u8p]
         L.ref_bsc_adler32.argtypes = [u8p, C.c_int, C.c_int]
+        L.ref_bsc_lzp_compress.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ref_bsc_lzp_decompress.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ref_bsc_adler32.restype = C.c_uint
         L.ref_wtime.restype = C.c_double
         self.features = features
@@ -87,6 +89,23 @@ class Ref:
         return out[:ds.value].tobytes()
 
     # --- stage API -------------------------------------------------------
+    def lzp_compress(self, data, hash_size, min_len, features=None):
+        """bsc_lzp_compress (lzp.cpp:798) -> bytes, or the negative error code"""
+        import numpy as np
+        f = self.features if features is None else features
+        src = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        out = np.empty(src.size + 64, dtype=np.uint8)
+        r = self.L.ref_bsc_lzp_compress(src.ctypes.data_as(u8p), out.ctypes.data_as(u8p), src.size, hash_size, min_len, f)
+        return out[:r].tobytes() if r >= 0 else r
+
+    def lzp_decompress(self, data, orig_size, hash_size, min_len, features=None):
+        import numpy as np
+        f = self.features if features is None else features
+        src = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        out = np.empty(orig_size + 64, dtype=np.uint8)
+        r = self.L.ref_bsc_lzp_decompress(src.ctypes.data_as(u8p), out.ctypes.data_as(u8p), src.size, hash_size, min_len, f)
+        return out[:r].tobytes() if r >= 0 else r
+
     def bwt_encode(self, data, aux=True, features=None):
         """-> (L bytes, primary index, [aux indexes])"""
         import numpy as np
