@@ -82,6 +82,7 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
         {(void**)&c->dscal,   1024 * 4, 0},
         {(void**)&c->dscal64, 16 * 8, 0},
         {(void**)&c->adler_part, (size_t)MAX_CHUNKS * 16, 0},
+        {(void**)&c->wc_sink, (size_t)512 * 1024 * 8, 0},
     };
     size_t total = 0;
     for (auto& cv : carve) total += align_up(cv.bytes, 256);

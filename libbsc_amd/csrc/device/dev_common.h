@@ -87,6 +87,7 @@ struct bscgpu_ctx {
     u32* dscal  = nullptr;   // small device scalars (64 u32)
     u64* dscal64 = nullptr;  // small device u64 scalars (16)
     u64* adler_part = nullptr; // [MAX_CHUNKS][2]
+    u64* wc_sink = nullptr;  // [512 * 1024] write sink for predicated-off lanes of rs_scatter_wc
     // pinned host
     u32* hscal  = nullptr;   // 64 u32
     u64* hscal64 = nullptr;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(WG) void qf_apply_kernel(const u8* __restrict__ L, 
 #pragma unroll
             for (int q = 1; q < 8; ++q) if ((u32)q < sp.nblocks && pos >= sp.start[q]) b = q;
             u32* fr = first_run + b * 256 + c;
-            if (j < *reinterpret_cast<volatile u32*>(fr)) atomicMin(fr, j);
+            if (j < __hip_atomic_load(fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(fr, j);   // cheap filter before the atomic
             ++j;
         }
         off += tot;

@@ -32,6 +32,24 @@
 #ifndef RS_WG
 #define RS_WG 256      // measured: 512 threads / 8192-record tiles are 10-25 % slower (barrier stalls, spills)
 #endif
+// Volatile accesses must keep the LDS address space: through a generic `volatile u32*` the compiler emits system-scope
+// FLAT loads/stores followed by s_waitcnt vmcnt(0) — every in-wave rank step would then drain all outstanding global
+// loads and stores of the wave.
+#ifndef RS_FLAT_VOLATILE
+#define RS_FLAT_VOLATILE 0     // 1 = the old generic-pointer volatile (A/B builds only)
+#endif
+#if RS_FLAT_VOLATILE
+typedef volatile u32 lds_vu32;
+#else
+typedef __attribute__((address_space(3))) volatile u32 lds_vu32;
+#endif
+#ifndef RS_UNCOND
+#define RS_UNCOND 1            // no branch around any global load/store of rs_scatter (clamped loads, sink stores): lets the
+                               // compiler wait with exact vmcnt values instead of vmcnt(0); measured +0..12 % (A/B on one box)
+#endif
+#ifndef RS_WC_DEFAULT
+#define RS_WC_DEFAULT 0        // default of BSC_RS_WC (write-combining scatter for large inputs)
+#endif
 constexpr int RS_WAVES = RS_WG / 64;
 constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE  = RS_WG * RS_ITEMS;       // 4096 records per tile
@@ -145,9 +163,11 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
                                                         u32 n, int shift, u32 mask,
                                                         u32 chunk_tiles, u32 num_chunks, u32 num_tiles,
                                                         const u32* __restrict__ offsets,
-                                                        const u32* __restrict__ rowtot)
+                                                        const u32* __restrict__ rowtot, u64* __restrict__ sink)
 {
     constexpr int WG = RS_WG, WAVES = RS_WAVES;
+    u64* const ksink = sink + (size_t)blockIdx.x * WG + threadIdx.x;
+    u32* const vsink = reinterpret_cast<u32*>(ksink);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* skeys  = reinterpret_cast<u64*>(smem);                       // [RS_TILE] staging (reused as u32 for values)
     u32* whist  = reinterpret_cast<u32*>(smem + RS_TILE * 8);         // [4][256] per-wave digit counts / prefixes
@@ -155,7 +175,7 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
     u32* adj    = goff + 256;                                         // [256] goff - tile-local bucket start
     u32* dstart = adj + 256;                                          // [256] (scratch)
     u32* scr    = dstart + 256;                                       // [8]
-    volatile u32* vwh = whist;
+    lds_vu32* vwh = (lds_vu32*)whist;
 
     const u32 t = threadIdx.x, w = t >> 6, lane = t & 63;
     const u64 lt = lanemask_lt();
@@ -183,7 +203,8 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
 #pragma unroll
         for (int i = 0; i < RS_ITEMS; ++i) {
             const u32 idx = wbase + i * 64;
-            k[i] = (idx < nvalid) ? (RS_NT ? __builtin_nontemporal_load(&kin[tbase + idx]) : kin[tbase + idx]) : ~0ull;
+            if (RS_UNCOND) { const u64 kv = __builtin_nontemporal_load(&kin[tbase + (idx < nvalid ? idx : nvalid - 1)]); k[i] = (idx < nvalid) ? kv : ~0ull; }
+            else k[i] = (idx < nvalid) ? (RS_NT ? __builtin_nontemporal_load(&kin[tbase + idx]) : kin[tbase + idx]) : ~0ull;
         }
         for (u32 i = t; i < (u32)WAVES * 256; i += WG) whist[i] = 0;
         __syncthreads();
@@ -218,7 +239,8 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
 #pragma unroll
             for (int i = 0; i < RS_ITEMS; ++i) {
                 const u32 idx = wbase + i * 64;
-                v[i] = (idx < nvalid) ? (RS_NT ? __builtin_nontemporal_load(&vin[tbase + idx]) : vin[tbase + idx]) : 0u;
+                if (RS_UNCOND) v[i] = __builtin_nontemporal_load(&vin[tbase + (idx < nvalid ? idx : nvalid - 1)]);
+                else v[i] = (idx < nvalid) ? (RS_NT ? __builtin_nontemporal_load(&vin[tbase + idx]) : vin[tbase + idx]) : 0u;
             }
         }
         __syncthreads();
@@ -261,7 +283,8 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
             const u64 key = skeys[q];
             const u32 d = (u32)(key >> shift) & mask;
             if ((j & 3) == 0) dd[j >> 2] = d; else dd[j >> 2] |= d << (8 * (j & 3));
-            if (q < nvalid) { if (RS_NT & 2) __builtin_nontemporal_store(key, &kout[adj[d] + q]); else kout[adj[d] + q] = key; }
+            if (RS_UNCOND) *(q < nvalid ? &kout[adj[d] + q] : ksink) = key;
+            else if (q < nvalid) { if (RS_NT & 2) __builtin_nontemporal_store(key, &kout[adj[d] + q]); else kout[adj[d] + q] = key; }
         }
 
         if (HAS_VAL) {
@@ -274,11 +297,230 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
             for (int j = 0; j < RS_ITEMS; ++j) {
                 const u32 q = j * WG + t;
                 const u32 d = (dd[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                if (q < nvalid) { if (RS_NT & 2) __builtin_nontemporal_store(svals[q], &vout[adj[d] + q]); else vout[adj[d] + q] = svals[q]; }
+                if (RS_UNCOND) *(q < nvalid ? &vout[adj[d] + q] : vsink) = svals[q];
+                else if (q < nvalid) { if (RS_NT & 2) __builtin_nontemporal_store(svals[q], &vout[adj[d] + q]); else vout[adj[d] + q] = svals[q]; }
             }
         }
         __syncthreads();
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// rs_scatter_wc: the digit pass with write combining (large inputs).
+//
+// What limits rs_scatter above on uniform digits is not bytes but write *requests*: a tile leaves 256 runs of ~16
+// records, i.e. ~128 B of keys and ~64 B of values at arbitrary 8-/4-byte alignment, so almost every run touches two
+// partially written 128-B lines (tools/ubench.hip: pairs in aligned full lines 5.1 TB/s, the same bytes as misaligned
+// 16-record runs 2.4 TB/s; HBM byte counters stay at the algorithmic volume in both cases).  Here every workgroup
+// keeps, per digit, up to 31 not-yet-written records in LDS and only ever writes whole 32-record groups that start on
+// a 32-record boundary of the output (2 full key lines + 1 full value line); the unaligned head of a (chunk, digit)
+// segment and its tail are written once each.  Output is identical to rs_scatter (same stable order).
+//
+// Price: 96 KB of LDS for the pending records (150 KB per workgroup with staging), so one workgroup of 1024 threads
+// per CU (16 waves, 4 records per lane and tile) that walks four of rs_hist's chunks; the next tile's records are
+// loaded into registers before the current one is ranked, so the loads fly under the LDS phases.
+// ---------------------------------------------------------------------------------------------
+constexpr int WC_WG = 1024, WC_WAVES = WC_WG / 64, WC_ITEMS = RS_TILE / WC_WG, WC_GRP = 32, WC_SPAN = 4;
+constexpr int WC_LDS_KEYS  = RS_TILE * 8 + 256 * WC_GRP * 8 + WC_WAVES * 256 * 4 + 7 * 256 * 4 + 16 * 4;
+constexpr int WC_LDS_PAIRS = WC_LDS_KEYS + 256 * WC_GRP * 4;
+
+// exclusive sum over the digit values held by threads 0..255 (waves 0..3) of a 1024-thread workgroup
+__device__ __forceinline__ u32 wc_digit_excl_sum(u32 v, u32* scr)
+{
+    const u32 incl = wave_incl_sum(v);
+    const u32 w = threadIdx.x >> 6, l = lane_id();
+    __syncthreads();
+    if (l == 63 && w < 4) scr[w] = incl;
+    __syncthreads();
+    u32 base = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) if ((u32)i < w) base += scr[i];
+    return base + incl - v;
+}
+
+template <bool HAS_VAL>
+__global__ __launch_bounds__(WC_WG) void rs_scatter_wc_kernel(const u64* __restrict__ kin, u64* __restrict__ kout,
+                                                              const u32* __restrict__ vin, u32* __restrict__ vout,
+                                                              u32 n, int shift, u32 mask,
+                                                              u32 chunk_tiles, u32 num_chunks, u32 num_tiles,
+                                                              const u32* __restrict__ offsets,
+                                                              const u32* __restrict__ rowtot, u64* __restrict__ sink)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* skeys = reinterpret_cast<u64*>(smem);                        // [RS_TILE] staging (reused as u32 for values)
+    u64* pendK = skeys + RS_TILE;                                     // [256][32] pending keys per digit
+    u32* whist = reinterpret_cast<u32*>(pendK + 256 * WC_GRP);        // [16][256] per-wave digit counts / prefixes
+    u32* gofs  = whist + WC_WAVES * 256;                              // [256] output position of the first unwritten record
+    u32* pcnt  = gofs + 256;                                          // [256] pending records
+    u32* infoA = pcnt + 256;                                          // [256] staging slot q of digit d goes to kout[q + A]
+    u32* infoB = infoA + 256;                                         // [256] (first pending slot) | (end of valid slots) << 16
+    u32* infoC = infoB + 256;                                         // [256] ... or to pend[d][q + C]
+    u32* fcnt  = infoC + 256;                                         // [256] old pending records written this tile
+    u32* gold  = fcnt + 256;                                          // [256] their output position
+    u32* scr   = gold + 256;                                          // [16]
+    u32* pendV = scr + 16;                                            // [256][32] pending values (pairs only)
+    lds_vu32* vwh = (lds_vu32*)whist;
+
+    const u32 t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const u64 lt = lanemask_lt();
+    const u32 lt_lo = (u32)lt, lt_hi = (u32)(lt >> 32);
+
+    {
+        const u32 base = wc_digit_excl_sum(t < 256 ? rowtot[t] : 0u, scr);
+        if (t < 256) { gofs[t] = base + offsets[(size_t)t * num_chunks + (size_t)blockIdx.x * WC_SPAN]; pcnt[t] = 0; }
+    }
+    __syncthreads();
+
+    const u32 tile0 = blockIdx.x * WC_SPAN * chunk_tiles;
+    u32 tile1 = tile0 + WC_SPAN * chunk_tiles;
+    if (tile1 > num_tiles) tile1 = num_tiles;
+
+    // wave-striped ownership: wave w holds records [w*256, w*256+256) of the tile, item i = 64 consecutive records
+    const u32 wbase = w * (64 * WC_ITEMS) + lane;
+    u64 k[WC_ITEMS], kn[WC_ITEMS];
+    u32 v[WC_ITEMS], vn[WC_ITEMS];
+    auto fetch = [&](u32 tile, u64* kk, u32* vv) {
+        const u64 tbase = (u64)tile * RS_TILE;
+        const u32 rem = (u32)((u64)n - tbase);
+        const u32 nv = rem < (u32)RS_TILE ? rem : (u32)RS_TILE;
+#pragma unroll
+        for (int i = 0; i < WC_ITEMS; ++i) {
+            // every lane always loads (a clamped address when it is past the end) and every lane always stores below (to
+            // a private sink slot when it has nothing to write): with no branch around a memory instruction the compiler
+            // knows how many are outstanding and can wait for the prefetched tile with an exact vmcnt instead of vmcnt(0),
+            // which would stall every tile on the stores it has just issued and on the loads for the tile after it.
+            const u32 idx = wbase + i * 64;
+            const u64 a = tbase + (idx < nv ? idx : nv - 1);
+            const u64 kv = __builtin_nontemporal_load(&kin[a]);
+            kk[i] = (idx < nv) ? kv : ~0ull;
+            if (HAS_VAL) vv[i] = __builtin_nontemporal_load(&vin[a]);
+        }
+    };
+    u64* const ksink = sink + (size_t)blockIdx.x * WC_WG + t;
+    u32* const vsink = reinterpret_cast<u32*>(ksink);
+    // write the first fcnt[b] pending records of every digit b to gold[b]..: half a wave per digit
+    auto flush_pending = [&]() {
+#pragma unroll
+        for (int s = 0; s < 256 / (WC_WG / WC_GRP); ++s) {
+            const u32 b = s * (WC_WG / WC_GRP) + (t >> 5), i = t & 31;
+            const bool on = i < fcnt[b];
+            const u32 o = gold[b] + i;
+            *(on ? &kout[o] : ksink) = pendK[b * WC_GRP + i];
+            if (HAS_VAL) *(on ? &vout[o] : vsink) = pendV[b * WC_GRP + i];
+        }
+    };
+
+    if (tile0 < tile1) fetch(tile0, k, v);
+    for (u32 tile = tile0; tile < tile1; ++tile) {
+        const u32 rem = (u32)((u64)n - (u64)tile * RS_TILE);
+        const u32 nvalid = rem < (u32)RS_TILE ? rem : (u32)RS_TILE;
+        fetch(tile + 1 < tile1 ? tile + 1 : tile, kn, vn);             // in flight during everything below
+
+        for (u32 i = t; i < (u32)WC_WAVES * 256; i += WC_WG) whist[i] = 0;
+        __syncthreads();
+
+        // ---- stable in-wave ranking by ballot match (as in rs_scatter) ---------------------------
+        u32 rk[WC_ITEMS];
+#pragma unroll
+        for (int i = 0; i < WC_ITEMS; ++i) {
+            const u32 d = (u32)(k[i] >> shift) & mask;
+            u32 mlo = ~0u, mhi = ~0u;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int bitm = __builtin_amdgcn_sbfe((int)d, b, 1);
+                const u64 bal = __ballot(bitm != 0);
+                const u32 nb = ~(u32)bitm;
+                mlo &= (u32)bal ^ nb;
+                mhi &= (u32)(bal >> 32) ^ nb;
+            }
+            const u32 before = vwh[w * 256 + d];
+            const u32 r      = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));
+            const u32 cnt    = (u32)(__popc(mlo) + __popc(mhi));
+            rk[i] = before + r;
+            if (r == cnt - 1) vwh[w * 256 + d] = before + cnt;
+        }
+        __syncthreads();
+
+        // ---- per digit: wave prefixes, tile-local start, and what to write / keep this tile ----------
+        {
+            u32 c[WC_WAVES];
+            u32 tot = 0;
+            if (t < 256) {
+#pragma unroll
+                for (int i = 0; i < WC_WAVES; ++i) { c[i] = whist[i * 256 + t]; tot += c[i]; }
+            }
+            const u32 ds = wc_digit_excl_sum(t < 256 ? tot : 0u, scr);
+            if (t < 256) {
+                u32 run = ds;
+#pragma unroll
+                for (int i = 0; i < WC_WAVES; ++i) { whist[i * 256 + t] = run; run += c[i]; }
+                const u32 cv = tot - ((t == mask) ? ((u32)RS_TILE - nvalid) : 0u);      // padding records sort last
+                const u32 pc = pcnt[t], g = gofs[t];
+                const u32 E = g + pc + cv, F = E & ~(u32)(WC_GRP - 1);
+                const bool fl = F > g;                                  // at least one group boundary reached
+                const u32 nn = fl ? (F - g - pc) : 0u;                  // new records written straight from staging
+                infoA[t] = g + pc - ds;
+                infoB[t] = (ds + nn) | ((ds + cv) << 16);
+                infoC[t] = (fl ? (0u - nn) : pc) - ds;
+                fcnt[t]  = fl ? pc : 0u;
+                gold[t]  = g;
+                gofs[t]  = fl ? F : g;
+                pcnt[t]  = fl ? (E - F) : (pc + cv);
+            }
+        }
+        __syncthreads();
+
+        // ---- local reorder of the keys; old pending records of the digits that flush leave now -------
+#pragma unroll
+        for (int i = 0; i < WC_ITEMS; ++i) {
+            const u32 d = (u32)(k[i] >> shift) & mask;
+            const u32 pos = whist[w * 256 + d] + rk[i];
+            rk[i] = pos;
+            skeys[pos] = k[i];
+        }
+        flush_pending();
+        __syncthreads();
+
+        u32 dd = 0;
+#pragma unroll
+        for (int j = 0; j < WC_ITEMS; ++j) {
+            const u32 q = j * WC_WG + t;
+            const u64 key = skeys[q];
+            const u32 d = (u32)(key >> shift) & mask;
+            dd |= d << (8 * j);
+            const u32 B = infoB[d];
+            const bool direct = q < (B & 0xffffu);
+            *(direct ? &kout[infoA[d] + q] : ksink) = key;
+            if (!direct && q < (B >> 16)) pendK[d * WC_GRP + q + infoC[d]] = key;
+        }
+
+        if (HAS_VAL) {
+            __syncthreads();
+            u32* svals = reinterpret_cast<u32*>(skeys);
+#pragma unroll
+            for (int i = 0; i < WC_ITEMS; ++i) svals[rk[i]] = v[i];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < WC_ITEMS; ++j) {
+                const u32 q = j * WC_WG + t;
+                const u32 d = (dd >> (8 * j)) & 0xffu;
+                const u32 B = infoB[d];
+                const bool direct = q < (B & 0xffffu);
+                const u32 val = svals[q];
+                *(direct ? &vout[infoA[d] + q] : vsink) = val;
+                if (!direct && q < (B >> 16)) pendV[d * WC_GRP + q + infoC[d]] = val;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < WC_ITEMS; ++i) { k[i] = kn[i]; if (HAS_VAL) v[i] = vn[i]; }
+    }
+
+    // tails of this workgroup's segments
+    if (t < 256) { fcnt[t] = pcnt[t]; gold[t] = gofs[t]; }
+    __syncthreads();
+    flush_pending();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -293,6 +535,17 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
     if ((((uintptr_t)keys) | ((uintptr_t)keys_alt)) & 15) return ctx_fail(c, BSC_BAD_PARAMETER, "radix keys not 16B aligned", hipSuccess);
 
     const Chunking ch = rs_chunking(n);
+    // write-combining scatter for inputs that fill the chip (>= 2 tiles per rs_hist chunk at the full chunk count);
+    // BSC_RS_WC=0 keeps the plain kernel, BSC_RS_WC=2 forces the combining one whenever there are >= 4 chunks
+    static int wc_mode = -1;
+    if (wc_mode < 0) {
+        const char* e = getenv("BSC_RS_WC");
+        wc_mode = e ? atoi(e) : RS_WC_DEFAULT;
+        if (hipFuncSetAttribute((const void*)rs_scatter_wc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_LDS_PAIRS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)rs_scatter_wc_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_LDS_KEYS) != hipSuccess)
+            wc_mode = 0;
+    }
+    const bool use_wc = (wc_mode == 2 && ch.num_chunks >= 4) || (wc_mode == 1 && ch.num_chunks >= 512 && ch.chunk_tiles >= 2);
     u64 *ksrc = keys, *kdst = keys_alt;
     u32 *vsrc = vals, *vdst = vals_alt;
     const bool has_val = (vals != nullptr);
@@ -312,14 +565,24 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
         prof_end(c);
 
         prof_begin(c, BSCGPU_K_RADIX_SCATTER, 2 * n * rec_bytes, n);
-        if (has_val)
+        if (use_wc) {
+            const u32 grid = (ch.num_chunks + WC_SPAN - 1) / WC_SPAN;
+            if (has_val)
+                hipLaunchKernelGGL(rs_scatter_wc_kernel<true>, dim3(grid), dim3(WC_WG), WC_LDS_PAIRS, c->stream,
+                                   ksrc, kdst, vsrc, vdst, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks,
+                                   ch.num_tiles, c->counts, c->rowtot, c->wc_sink);
+            else
+                hipLaunchKernelGGL(rs_scatter_wc_kernel<false>, dim3(grid), dim3(WC_WG), WC_LDS_KEYS, c->stream,
+                                   ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, shift, mask,
+                                   ch.chunk_tiles, ch.num_chunks, ch.num_tiles, c->counts, c->rowtot, c->wc_sink);
+        } else if (has_val)
             hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(ch.num_chunks), dim3(RS_WG), RS_LDS, c->stream,
                                ksrc, kdst, vsrc, vdst, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks,
-                               ch.num_tiles, c->counts, c->rowtot);
+                               ch.num_tiles, c->counts, c->rowtot, c->wc_sink);
         else
             hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(ch.num_chunks), dim3(RS_WG), RS_LDS, c->stream,
                                ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, shift, mask,
-                               ch.chunk_tiles, ch.num_chunks, ch.num_tiles, c->counts, c->rowtot);
+                               ch.chunk_tiles, ch.num_chunks, ch.num_tiles, c->counts, c->rowtot, c->wc_sink);
         prof_end(c);
         HIP_TRY(c, hipGetLastError());
 

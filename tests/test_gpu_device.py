@@ -187,3 +187,16 @@ def test_error_paths_and_two_contexts(torch_cuda, ref):
         assert a.L.bscgpu_create(C.byref(h), 99, 1 << 20) == -1     # no such device
     finally:
         a.close(); b.close()
+
+
+def test_write_combining_scatter_variant(torch_cuda):
+    """The opt-in write-combining digit pass (BSC_RS_WC, radix_sort.hip) must produce the same stable order: run the
+    radix parity cases in a child process with the variant forced on for every size that has >= 4 chunks."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BSC_RS_WC="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_device.py"), "-q", "-x",
+                        "-k", "radix_sort_matches or bwt_device_resident_16m"], capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -90,6 +90,59 @@ __global__ __launch_bounds__(256) void k_scatter_pairs_aligned(const u64* __rest
         }
     }
 }
+// what a write-combining scatter would emit: every (tile, bucket) flush is 32 records = 2 full key lines + 1 full value line;
+// a bucket is flushed every other tile (256 buckets, 4096-record tiles, 16 records/bucket/tile on average)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_scatter_pairs_comb(const u64* __restrict__ kin, const u32* __restrict__ vin, u64* __restrict__ kout, u32* __restrict__ vout,
+                                                                u32 n, u32 chunk_tiles, u32* sink) {
+    constexpr int ITEMS = 4096 / THREADS;
+    const u32 t = threadIdx.x;
+    if (pad_lds[t] == 77 && n == 1) sink[0] = 1;
+    const u32 per_bucket = (n / 256) & ~31u;
+    for (u32 tt = 0; tt < chunk_tiles; ++tt) {
+        const u32 tile = blockIdx.x * chunk_tiles + tt;
+        const u64 tb = (u64)tile * 4096;
+        if (tb >= n) break;
+        u64 k[ITEMS]; u32 v[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { k[j] = __builtin_nontemporal_load(&kin[tb + j * THREADS + t]); }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { v[j] = __builtin_nontemporal_load(&vin[tb + j * THREADS + t]); }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 q = j * THREADS + t; const u32 bucket = ((q >> 5) << 1) | (tt & 1), r = q & 31;
+            const u64 o = (u64)bucket * per_bucket + (u64)(blockIdx.x * chunk_tiles + (tt & ~1u)) * 16 + r;
+            kout[o] = k[j]; vout[o] = v[j];
+        }
+    }
+}
+// misaligned 16-record runs (what the plain scatter emits on uniform digits) at different residency: does L2 merge the
+// partial lines of consecutive tiles when the open-line frontier (workgroups x 256 digits x 2 lines) fits in the 4 MB L2?
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_scatter_pairs_mis(const u64* __restrict__ kin, const u32* __restrict__ vin, u64* __restrict__ kout, u32* __restrict__ vout,
+                                                               u32 n, u32 chunk_tiles, u32 misalign, u32* sink) {
+    constexpr int ITEMS = 4096 / THREADS;
+    const u32 t = threadIdx.x;
+    if (pad_lds[t] == 77 && n == 1) sink[0] = 1;
+    const u32 per_bucket = n / 256 - 16;
+    kout += misalign; vout += misalign;
+    for (u32 tt = 0; tt < chunk_tiles; ++tt) {
+        const u32 tile = blockIdx.x * chunk_tiles + tt;
+        const u64 tb = (u64)tile * 4096;
+        if (tb >= n) break;
+        u64 k[ITEMS]; u32 v[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { k[j] = __builtin_nontemporal_load(&kin[tb + j * THREADS + t]); }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { v[j] = __builtin_nontemporal_load(&vin[tb + j * THREADS + t]); }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 q = j * THREADS + t; const u32 bucket = q >> 4, r = q & 15;
+            const u64 o = (u64)bucket * per_bucket + (u64)tile * 16 + r;
+            kout[o] = k[j]; vout[o] = v[j];
+        }
+    }
+}
 template <class F> static float timeit(F f, int reps = 5) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     f(); CHECK(hipDeviceSynchronize());
@@ -126,6 +179,26 @@ int main() {
     for (u32 lds : {0u, 40000u, 64000u, 81000u}) for (u32 mis : {0u, 5u}) {
         ms = timeit([&] { hipLaunchKernelGGL(k_scatter_pairs_aligned, dim3(nc), dim3(256), lds, 0, ka, va, kb, vb, n, ct, mis, sink); });
         printf("pairs: 16 records/bucket/tile, misalign %u records, dyn LDS %u B: %.3f ms -> %.0f GB/s\n", mis, lds, ms, 24.0 * n / 1e6 / ms);
+    }
+    CHECK(hipFuncSetAttribute((const void*)k_scatter_pairs_comb<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CHECK(hipFuncSetAttribute((const void*)k_scatter_pairs_comb<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (u32 lds : {0u, 48000u, 78000u, 112000u}) {
+        ms = timeit([&] { hipLaunchKernelGGL(k_scatter_pairs_comb<256>, dim3(nc), dim3(256), lds, 0, ka, va, kb, vb, n, ct, sink); });
+        printf("pairs write-combined (32-record aligned flushes), 256 thr, dyn LDS %u B: %.3f ms -> %.0f GB/s\n", lds, ms, 24.0 * n / 1e6 / ms);
+        ms = timeit([&] { hipLaunchKernelGGL(k_scatter_pairs_comb<512>, dim3(nc), dim3(512), lds, 0, ka, va, kb, vb, n, ct, sink); });
+        printf("pairs write-combined (32-record aligned flushes), 512 thr, dyn LDS %u B: %.3f ms -> %.0f GB/s\n", lds, ms, 24.0 * n / 1e6 / ms);
+    }
+    CHECK(hipFuncSetAttribute((const void*)k_scatter_pairs_mis<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CHECK(hipFuncSetAttribute((const void*)k_scatter_pairs_mis<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (u32 mis : {0u, 5u}) {
+        ms = timeit([&] { hipLaunchKernelGGL(k_scatter_pairs_mis<1024>, dim3(256), dim3(1024), 100000, 0, ka, va, kb, vb, n, 64, mis, sink); });
+        printf("pairs 16-record runs misalign %u: 256 WG x 1024 thr (1 WG/CU, frontier 2 MB/XCD): %.3f ms -> %.0f GB/s\n", mis, ms, 24.0 * n / 1e6 / ms);
+        ms = timeit([&] { hipLaunchKernelGGL(k_scatter_pairs_mis<1024>, dim3(512), dim3(1024), 60000, 0, ka, va, kb, vb, n, 32, mis, sink); });
+        printf("pairs 16-record runs misalign %u: 512 WG x 1024 thr (2 WG/CU, frontier 4 MB/XCD): %.3f ms -> %.0f GB/s\n", mis, ms, 24.0 * n / 1e6 / ms);
+        ms = timeit([&] { hipLaunchKernelGGL(k_scatter_pairs_mis<256>, dim3(256), dim3(256), 100000, 0, ka, va, kb, vb, n, 64, mis, sink); });
+        printf("pairs 16-record runs misalign %u: 256 WG x 256 thr (1 WG/CU): %.3f ms -> %.0f GB/s\n", mis, ms, 24.0 * n / 1e6 / ms);
+        ms = timeit([&] { hipLaunchKernelGGL(k_scatter_pairs_mis<256>, dim3(1024), dim3(256), 0, 0, ka, va, kb, vb, n, 16, mis, sink); });
+        printf("pairs 16-record runs misalign %u: 1024 WG x 256 thr (4 WG/CU, frontier 8 MB/XCD): %.3f ms -> %.0f GB/s\n", mis, ms, 24.0 * n / 1e6 / ms);
     }
     return 0;
 }
