@@ -24,6 +24,7 @@
 //    consecutive lanes store consecutive addresses.  Integer/index work only — no MFMA.
 #include "dev_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 #ifndef RS_NT
 #define RS_NT 5      // bit0: non-temporal loads (+10-20 %: the streamed-once input stops evicting the partially
@@ -51,10 +52,22 @@ typedef __attribute__((address_space(3))) volatile u32 lds_vu32;
 #define RS_WC_DEFAULT 0        // default of BSC_RS_WC (write-combining scatter for large inputs)
 #endif
 constexpr int RS_WAVES = RS_WG / 64;
-constexpr int RS_ITEMS = 16;
+#ifndef RS_ITEMS_N
+#define RS_ITEMS_N 16
+#endif
+constexpr int RS_ITEMS = RS_ITEMS_N;
 constexpr int RS_TILE  = RS_WG * RS_ITEMS;       // 4096 records per tile
 constexpr int RS_LDS   = RS_TILE * 8 + RS_WAVES * 256 * 4 + 3 * 256 * 4 + 16 * 4;   // 40,000 B -> 4 WG (16 waves) / CU
 constexpr int RS_MAX_CHUNKS = 256 * (1024 / RS_WG);       // all workgroups resident at once: 4 per CU
+// second shape of rs_scatter for large (key, value) passes
+#ifndef RS_BIG_PAIRS
+#define RS_BIG_PAIRS 1
+#endif
+#ifndef RSB_ITEMS_N
+#define RSB_ITEMS_N 8
+#endif
+constexpr int RSB_WG = 1024, RSB_ITEMS = RSB_ITEMS_N, RSB_SPAN = 4;
+constexpr int RSB_LDS = RSB_WG * RSB_ITEMS * 8 + (RSB_WG / 64) * 256 * 4 + 3 * 256 * 4 + 16 * 4;      // 85,056 B -> 1 WG (16 waves) / CU
 
 static inline Chunking rs_chunking(u64 n) {
     // measured: 768 / 512 / 256 chunks (fewer open output lines per XCD, but fewer waves) are 1 / 5 / 40 % slower
@@ -69,6 +82,7 @@ static inline Chunking rs_chunking(u64 n) {
 
 // Exclusive sum over the first 256 threads' values (one per digit); every thread of the workgroup calls it
 // (threads >= 256 pass 0).  scr: RS_WAVES u32.
+template <int WAVES = RS_WAVES>
 __device__ __forceinline__ u32 rs_digit_excl_sum(u32 v, u32* scr, u32* total) {
     const u32 incl = wave_incl_sum(v);
     const u32 w = threadIdx.x >> 6, l = lane_id();
@@ -77,7 +91,7 @@ __device__ __forceinline__ u32 rs_digit_excl_sum(u32 v, u32* scr, u32* total) {
     __syncthreads();
     u32 base = 0, tot = 0;
 #pragma unroll
-    for (int i = 0; i < RS_WAVES; ++i) { const u32 t = scr[i]; if ((u32)i < w) base += t; tot += t; }
+    for (int i = 0; i < WAVES; ++i) { const u32 t = scr[i]; if ((u32)i < w) base += t; tot += t; }
     *total = tot;
     return base + incl - v;
 }
@@ -91,7 +105,7 @@ __global__ __launch_bounds__(RS_WG) void rs_hist_kernel(const u64* __restrict__ 
     // BWT keys are text: a handful of digit values dominate, so a single 256-bin histogram per wave serialises its
     // LDS atomics (measured 2.4 TB/s with every lane on one bin).  Each wave keeps HREP replicas selected by the
     // low lane bits, which cuts the worst case from 64-way to 8-way conflicts; replicas are summed at the end.
-    constexpr int WG = RS_WG, WAVES = RS_WAVES, HREP = 8;
+    constexpr int WG = RS_WG, WAVES = RS_WAVES, HREP = 32 / RS_WAVES;
     __shared__ u32 h[WAVES * HREP * 256];
     const u32 t = threadIdx.x, w = t >> 6;
     for (u32 i = t; i < WAVES * HREP * 256; i += WG) h[i] = 0;
@@ -157,20 +171,24 @@ __global__ __launch_bounds__(WG) void rs_scan_kernel(u32* __restrict__ counts, u
 // ---------------------------------------------------------------------------------------------
 // rs_scatter: the digit pass.  Reads each record once, writes it once.
 // ---------------------------------------------------------------------------------------------
-template <bool HAS_VAL>
-__global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restrict__ kin, u64* __restrict__ kout,
+// Two shapes of the same kernel (SHAPE = workgroup size x records per lane):
+//   256 x 16 (4096-record tiles, 4 workgroups per CU, one rs_hist chunk each)   - keys-only passes and small inputs;
+//   1024 x 8 (8192-record tiles, 1 workgroup per CU walking SPAN = 4 rs_hist chunks) - large (key, value) passes: twice the
+//            records per digit and tile, i.e. half as many partially written lines per byte.  Same box, 64 MiB BWT:
+//            first-sort pass 0.447 -> 0.410 ms, whole BWT 11.5 -> 10.8 ms; keys-only (ST) is 6 % slower with it.
+template <bool HAS_VAL, int WGSZ, int ITEMS, int SPAN>
+__global__ __launch_bounds__(WGSZ, 4) void rs_scatter_kernel(const u64* __restrict__ kin, u64* __restrict__ kout,
                                                         const u32* __restrict__ vin, u32* __restrict__ vout,
                                                         u32 n, int shift, u32 mask,
                                                         u32 chunk_tiles, u32 num_chunks, u32 num_tiles,
                                                         const u32* __restrict__ offsets,
                                                         const u32* __restrict__ rowtot, u64* __restrict__ sink)
 {
-    constexpr int WG = RS_WG, WAVES = RS_WAVES;
-    u64* const ksink = sink + (size_t)blockIdx.x * WG + threadIdx.x;
-    u32* const vsink = reinterpret_cast<u32*>(ksink);
+    constexpr int WG = WGSZ, WAVES = WGSZ / 64, TILE = WGSZ * ITEMS;
+    (void)sink;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* skeys  = reinterpret_cast<u64*>(smem);                       // [RS_TILE] staging (reused as u32 for values)
-    u32* whist  = reinterpret_cast<u32*>(smem + RS_TILE * 8);         // [4][256] per-wave digit counts / prefixes
+    u64* skeys  = reinterpret_cast<u64*>(smem);                       // [TILE] staging (reused as u32 for values)
+    u32* whist  = reinterpret_cast<u32*>(smem + TILE * 8);            // [WAVES][256] per-wave digit counts / prefixes
     u32* goff   = whist + WAVES * 256;                                // [256] running global bucket offsets
     u32* adj    = goff + 256;                                         // [256] goff - tile-local bucket start
     u32* dstart = adj + 256;                                          // [256] (scratch)
@@ -182,29 +200,31 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
 
     {   // global offset of this chunk's first record of digit t
         u32 tot;
-        const u32 base = rs_digit_excl_sum(t < 256 ? rowtot[t] : 0u, scr, &tot);
-        if (t < 256) goff[t] = base + offsets[(size_t)t * num_chunks + blockIdx.x];
+        const u32 base = rs_digit_excl_sum<WAVES>(t < 256 ? rowtot[t] : 0u, scr, &tot);
+        if (t < 256) goff[t] = base + offsets[(size_t)t * num_chunks + (size_t)blockIdx.x * SPAN];
     }
     __syncthreads();
 
-    const u32 tile0 = blockIdx.x * chunk_tiles;
-    u32 tile1 = tile0 + chunk_tiles;
-    if (tile1 > num_tiles) tile1 = num_tiles;
+    // this workgroup's records: SPAN consecutive rs_hist chunks (chunk_tiles tiles of RS_TILE records each)
+    const u64 rec0 = (u64)blockIdx.x * SPAN * chunk_tiles * RS_TILE;
+    u64 rec1 = rec0 + (u64)SPAN * chunk_tiles * RS_TILE;
+    if (rec1 > n) rec1 = n;
 
-    for (u32 tile = tile0; tile < tile1; ++tile) {
-        const u64 tbase = (u64)tile * RS_TILE;
-        const u32 rem = (u32)((u64)n - tbase);
-        const u32 nvalid = rem < (u32)RS_TILE ? rem : (u32)RS_TILE;
+    // Full tiles run without any branch around a global load or store, so the compiler can wait with exact vmcnt values
+    // (a guarded memory instruction makes the number of outstanding operations unknown and every later wait vmcnt(0));
+    // the one partial tile of the whole input is handled by a second, guarded instantiation after the loop.
+    auto do_tile = [&](const u64 tbase, const u32 nvalid, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
 
         // ---- wave-striped loads: wave w owns records [w*1024, w*1024+1024) of the tile -------
-        u64 k[RS_ITEMS];
-        u32 v[RS_ITEMS];
-        const u32 wbase = w * (64 * RS_ITEMS) + lane;
+        u64 k[ITEMS];
+        u32 v[ITEMS];
+        const u32 wbase = w * (64 * ITEMS) + lane;
 #pragma unroll
-        for (int i = 0; i < RS_ITEMS; ++i) {
+        for (int i = 0; i < ITEMS; ++i) {
             const u32 idx = wbase + i * 64;
-            if (RS_UNCOND) { const u64 kv = __builtin_nontemporal_load(&kin[tbase + (idx < nvalid ? idx : nvalid - 1)]); k[i] = (idx < nvalid) ? kv : ~0ull; }
-            else k[i] = (idx < nvalid) ? (RS_NT ? __builtin_nontemporal_load(&kin[tbase + idx]) : kin[tbase + idx]) : ~0ull;
+            if (FULL) k[i] = __builtin_nontemporal_load(&kin[tbase + idx]);
+            else k[i] = (idx < nvalid) ? __builtin_nontemporal_load(&kin[tbase + idx]) : ~0ull;
         }
         for (u32 i = t; i < (u32)WAVES * 256; i += WG) whist[i] = 0;
         __syncthreads();
@@ -213,10 +233,10 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
         // peers(lane) = lanes whose digit equals this lane's.  Per digit bit: nb = all-ones if this lane's bit is
         // clear; the lanes agreeing with us on that bit are (ballot ^ nb), so the running mask is one 3-input
         // boolean op per 32-bit half (v_bitop3 on gfx950).
-        u32 rk[RS_ITEMS];
+        u32 rk[ITEMS];
         const u32 lt_lo = (u32)lt, lt_hi = (u32)(lt >> 32);
 #pragma unroll
-        for (int i = 0; i < RS_ITEMS; ++i) {
+        for (int i = 0; i < ITEMS; ++i) {
             const u32 d = (u32)(k[i] >> shift) & mask;
             u32 mlo = ~0u, mhi = ~0u;
 #pragma unroll
@@ -237,10 +257,10 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
         // register footprint at 4 waves/SIMD, and the loads fly under the bucket scan + key reorder.
         if (HAS_VAL) {
 #pragma unroll
-            for (int i = 0; i < RS_ITEMS; ++i) {
+            for (int i = 0; i < ITEMS; ++i) {
                 const u32 idx = wbase + i * 64;
-                if (RS_UNCOND) v[i] = __builtin_nontemporal_load(&vin[tbase + (idx < nvalid ? idx : nvalid - 1)]);
-                else v[i] = (idx < nvalid) ? (RS_NT ? __builtin_nontemporal_load(&vin[tbase + idx]) : vin[tbase + idx]) : 0u;
+                if (FULL) v[i] = __builtin_nontemporal_load(&vin[tbase + idx]);
+                else v[i] = (idx < nvalid) ? __builtin_nontemporal_load(&vin[tbase + idx]) : 0u;
             }
         }
         __syncthreads();
@@ -254,7 +274,7 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
                 for (int i = 0; i < WAVES; ++i) { c[i] = whist[i * 256 + t]; tot += c[i]; }
             }
             u32 all;
-            const u32 ds = rs_digit_excl_sum(tot, scr, &all);
+            const u32 ds = rs_digit_excl_sum<WAVES>(tot, scr, &all);
             if (t < 256) {
                 u32 run = ds;
 #pragma unroll
@@ -268,7 +288,7 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
 
         // ---- local reorder through LDS --------------------------------------------------------
 #pragma unroll
-        for (int i = 0; i < RS_ITEMS; ++i) {
+        for (int i = 0; i < ITEMS; ++i) {
             const u32 d = (u32)(k[i] >> shift) & mask;
             const u32 pos = whist[w * 256 + d] + rk[i];
             rk[i] = pos;
@@ -276,35 +296,35 @@ __global__ __launch_bounds__(RS_WG, 4) void rs_scatter_kernel(const u64* __restr
         }
         __syncthreads();
 
-        u32 dd[RS_ITEMS / 4];
+        u32 dd[ITEMS / 4];
 #pragma unroll
-        for (int j = 0; j < RS_ITEMS; ++j) {
+        for (int j = 0; j < ITEMS; ++j) {
             const u32 q = j * WG + t;
             const u64 key = skeys[q];
             const u32 d = (u32)(key >> shift) & mask;
             if ((j & 3) == 0) dd[j >> 2] = d; else dd[j >> 2] |= d << (8 * (j & 3));
-            if (RS_UNCOND) *(q < nvalid ? &kout[adj[d] + q] : ksink) = key;
-            else if (q < nvalid) { if (RS_NT & 2) __builtin_nontemporal_store(key, &kout[adj[d] + q]); else kout[adj[d] + q] = key; }
+            if (FULL || q < nvalid) kout[adj[d] + q] = key;
         }
 
         if (HAS_VAL) {
             __syncthreads();
             u32* svals = reinterpret_cast<u32*>(skeys);
 #pragma unroll
-            for (int i = 0; i < RS_ITEMS; ++i) svals[rk[i]] = v[i];
+            for (int i = 0; i < ITEMS; ++i) svals[rk[i]] = v[i];
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < RS_ITEMS; ++j) {
+            for (int j = 0; j < ITEMS; ++j) {
                 const u32 q = j * WG + t;
                 const u32 d = (dd[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                if (RS_UNCOND) *(q < nvalid ? &vout[adj[d] + q] : vsink) = svals[q];
-                else if (q < nvalid) { if (RS_NT & 2) __builtin_nontemporal_store(svals[q], &vout[adj[d] + q]); else vout[adj[d] + q] = svals[q]; }
+                if (FULL || q < nvalid) vout[adj[d] + q] = svals[q];
             }
         }
         __syncthreads();
-    }
+        };
+    u64 tbase = rec0;
+    for (; tbase + TILE <= rec1; tbase += TILE) do_tile(tbase, (u32)TILE, std::true_type());
+    if (tbase < rec1) do_tile(tbase, (u32)(rec1 - tbase), std::false_type());
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // rs_scatter_wc: the digit pass with write combining (large inputs).
@@ -541,10 +561,15 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
     if (wc_mode < 0) {
         const char* e = getenv("BSC_RS_WC");
         wc_mode = e ? atoi(e) : RS_WC_DEFAULT;
-        if (hipFuncSetAttribute((const void*)rs_scatter_wc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_LDS_PAIRS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)rs_scatter_wc_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_LDS_KEYS) != hipSuccess)
+        if (WC_LDS_PAIRS > 160 * 1024 ||
+            hipFuncSetAttribute((const void*)rs_scatter_wc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_LDS_PAIRS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)rs_scatter_wc_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_LDS_KEYS) != hipSuccess) {
             wc_mode = 0;
+            (void)hipGetLastError();               // do not leave a sticky error behind
+        }
+        HIP_TRY(c, hipFuncSetAttribute((const void*)rs_scatter_kernel<true, RSB_WG, RSB_ITEMS, RSB_SPAN>, hipFuncAttributeMaxDynamicSharedMemorySize, RSB_LDS));
     }
+    const bool big_pairs = RS_BIG_PAIRS && ch.num_chunks >= 512 && ch.chunk_tiles >= 2;   // enough records for 8192-record tiles on every CU
     const bool use_wc = (wc_mode == 2 && ch.num_chunks >= 4) || (wc_mode == 1 && ch.num_chunks >= 512 && ch.chunk_tiles >= 2);
     u64 *ksrc = keys, *kdst = keys_alt;
     u32 *vsrc = vals, *vdst = vals_alt;
@@ -575,12 +600,16 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
                 hipLaunchKernelGGL(rs_scatter_wc_kernel<false>, dim3(grid), dim3(WC_WG), WC_LDS_KEYS, c->stream,
                                    ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, shift, mask,
                                    ch.chunk_tiles, ch.num_chunks, ch.num_tiles, c->counts, c->rowtot, c->wc_sink);
+        } else if (has_val && big_pairs) {
+            hipLaunchKernelGGL((rs_scatter_kernel<true, RSB_WG, RSB_ITEMS, RSB_SPAN>), dim3((ch.num_chunks + RSB_SPAN - 1) / RSB_SPAN), dim3(RSB_WG), RSB_LDS, c->stream,
+                               ksrc, kdst, vsrc, vdst, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks,
+                               ch.num_tiles, c->counts, c->rowtot, c->wc_sink);
         } else if (has_val)
-            hipLaunchKernelGGL(rs_scatter_kernel<true>, dim3(ch.num_chunks), dim3(RS_WG), RS_LDS, c->stream,
+            hipLaunchKernelGGL((rs_scatter_kernel<true, RS_WG, RS_ITEMS, 1>), dim3(ch.num_chunks), dim3(RS_WG), RS_LDS, c->stream,
                                ksrc, kdst, vsrc, vdst, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks,
                                ch.num_tiles, c->counts, c->rowtot, c->wc_sink);
         else
-            hipLaunchKernelGGL(rs_scatter_kernel<false>, dim3(ch.num_chunks), dim3(RS_WG), RS_LDS, c->stream,
+            hipLaunchKernelGGL((rs_scatter_kernel<false, RS_WG, RS_ITEMS, 1>), dim3(ch.num_chunks), dim3(RS_WG), RS_LDS, c->stream,
                                ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, shift, mask,
                                ch.chunk_tiles, ch.num_chunks, ch.num_tiles, c->counts, c->rowtot, c->wc_sink);
         prof_end(c);
