@@ -108,73 +108,108 @@ __global__ __launch_bounds__(WG) void qf_apply_kernel(const u8* __restrict__ L, 
     }
 }
 
-// 256-bit symbol sets: masks[t][4] for runs [256 t, 256 t + 256)
-__global__ __launch_bounds__(WG) void qf_tile_masks_kernel(const u8* __restrict__ sym, u32 m, u64* __restrict__ masks)
+// Symbol sets per 256 runs ("tile") and per 65 536 runs ("super tile").  Two layouts:
+//   DENSE (<= 64 distinct symbols in the block, e.g. any text): symbols are renumbered 0..K-1 (lut) and a set is ONE u64;
+//   otherwise a set is four u64 indexed by the raw byte.
+template <bool DENSE>
+__global__ __launch_bounds__(WG) void qf_tile_masks_kernel(const u8* __restrict__ sym, u32 m, const u8* __restrict__ lut, u64* __restrict__ masks)
 {
     __shared__ u32 bits[8];
     if (threadIdx.x < 8) bits[threadIdx.x] = 0;
     __syncthreads();
     const u32 j = blockIdx.x * WG + threadIdx.x;
-    if (j < m) { const u32 c = sym[j]; atomicOr(&bits[c >> 5], 1u << (c & 31)); }
+    if (j < m) { const u32 c = DENSE ? lut[sym[j]] : sym[j]; atomicOr(&bits[c >> 5], 1u << (c & 31)); }
     __syncthreads();
-    if (threadIdx.x < 4) masks[(size_t)blockIdx.x * 4 + threadIdx.x] = (u64)bits[2 * threadIdx.x] | ((u64)bits[2 * threadIdx.x + 1] << 32);
+    constexpr u32 W = DENSE ? 1 : 4;
+    if (threadIdx.x < W) masks[(size_t)blockIdx.x * W + threadIdx.x] = (u64)bits[2 * threadIdx.x] | ((u64)bits[2 * threadIdx.x + 1] << 32);
 }
-// super masks: OR of 256 tile masks (65536 runs)
+template <bool DENSE>
 __global__ __launch_bounds__(WG) void qf_super_masks_kernel(const u64* __restrict__ masks, u32 ntiles, u64* __restrict__ super)
 {
-    __shared__ u64 red[4][WAVES];
+    constexpr int W = DENSE ? 1 : 4;
+    __shared__ u64 red[W][WAVES];
     const u32 t = blockIdx.x * WG + threadIdx.x;
-    u64 v[4] = {0, 0, 0, 0};
-    if (t < ntiles) { for (int k = 0; k < 4; ++k) v[k] = masks[(size_t)t * 4 + k]; }
-    for (int k = 0; k < 4; ++k) {
+    u64 v[W];
+    for (int k = 0; k < W; ++k) v[k] = (t < ntiles) ? masks[(size_t)t * W + k] : 0ull;
+    for (int k = 0; k < W; ++k) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) v[k] |= __shfl_xor(v[k], d, 64);
     }
-    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 4; ++k) red[k][threadIdx.x >> 6] = v[k];
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < W; ++k) red[k][threadIdx.x >> 6] = v[k];
     __syncthreads();
-    if (threadIdx.x < 4) { u64 r = 0; for (int w = 0; w < WAVES; ++w) r |= red[threadIdx.x][w]; super[(size_t)blockIdx.x * 4 + threadIdx.x] = r; }
+    if (threadIdx.x < (u32)W) { u64 r = 0; for (int w = 0; w < WAVES; ++w) r |= red[threadIdx.x][w]; super[(size_t)blockIdx.x * W + threadIdx.x] = r; }
 }
 
 struct QfRuns { u32 nblocks; u32 first[9]; };      // run index range of each sub-block; first[nblocks] = m
 
-__global__ __launch_bounds__(WG) void qf_rank_kernel(const u8* __restrict__ sym, u32 m, QfRuns rb,
+// QLFC rank of run j = number of distinct symbols strictly between run j and the next run of the same symbol (or, for
+// the last run of a symbol in its sub-block, all distinct symbols that still follow); the last run of a sub-block is 1
+// (qlfc.cpp:249 / :449).  One lane per run walks forward: inside its own 256-run tile from an LDS copy, then over whole
+// tiles / super tiles whose set does not contain its symbol, then inside the tile that holds the next occurrence.
+template <bool DENSE>
+__global__ __launch_bounds__(WG) void qf_rank_kernel(const u8* __restrict__ sym, u32 m, QfRuns rb, const u8* __restrict__ lut,
                                                      const u64* __restrict__ masks, const u64* __restrict__ super,
                                                      u8* __restrict__ rank)
 {
-    const u32 j = blockIdx.x * WG + threadIdx.x;
+    __shared__ u8 scode[WG];
+    __shared__ u8 slut[256];
+    const u32 base = blockIdx.x * WG, t = threadIdx.x;
+    const u32 j = base + t;
+    if (DENSE) slut[t] = lut[t];
+    const u32 raw = (j < m) ? sym[j] : 0u;
+    __syncthreads();
+    scode[t] = (u8)(DENSE ? slut[raw] : raw);
+    __syncthreads();
     if (j >= m) return;
     u32 re = m;
 #pragma unroll
     for (int b = 8; b >= 1; --b) if ((u32)b <= rb.nblocks && j < rb.first[b]) re = rb.first[b];
-    const u32 c = sym[j];
-    if (j + 1 == re) { rank[j] = 1; return; }                       // qlfc.cpp:249 / :449
-    u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    auto add = [&](u32 s) {
-        const u64 bit = 1ull << (s & 63);
-        const u32 w = s >> 6;
-        s0 |= (w == 0) ? bit : 0; s1 |= (w == 1) ? bit : 0; s2 |= (w == 2) ? bit : 0; s3 |= (w == 3) ? bit : 0;
-    };
-    const u32 cw = c >> 6; const u64 cbit = 1ull << (c & 63);
+    if (j + 1 == re) { rank[j] = 1; return; }
+    const u32 c = scode[t];
     u32 i = j + 1;
     bool found = false;
-    // phase 1: run by run to the next tile boundary
-    while (i < re && (i & 255u) != 0) { const u32 s = sym[i]; if (s == c) { found = true; break; } add(s); ++i; }
-    if (!found) {
-        // phase 2: whole tiles / super tiles that do not contain c
-        while (i + 256 <= re) {
-            if ((i & 65535u) == 0 && i + 65536 <= re) {
-                const u64* sm = super + (size_t)(i >> 16) * 4;
-                if (!(sm[cw] & cbit)) { s0 |= sm[0]; s1 |= sm[1]; s2 |= sm[2]; s3 |= sm[3]; i += 65536; continue; }
+    if (DENSE) {
+        u64 set = 0;
+        const u64 cbit = 1ull << c;
+        while (i < re && (i & 255u) != 0) { const u32 s = scode[i - base]; if (s == c) { found = true; break; } set |= 1ull << s; ++i; }
+        if (!found) {
+            while (i + 256 <= re) {
+                if ((i & 65535u) == 0 && i + 65536 <= re) {
+                    const u64 sm = super[i >> 16];
+                    if (!(sm & cbit)) { set |= sm; i += 65536; continue; }
+                }
+                const u64 tm = masks[i >> 8];
+                if (tm & cbit) break;
+                set |= tm;
+                i += 256;
             }
-            const u64* tm = masks + (size_t)(i >> 8) * 4;
-            if (tm[cw] & cbit) break;
-            s0 |= tm[0]; s1 |= tm[1]; s2 |= tm[2]; s3 |= tm[3];
-            i += 256;
+            while (i < re) { const u32 s = slut[sym[i]]; if (s == c) break; set |= 1ull << s; ++i; }
         }
-        // phase 3: inside the tile that holds the next occurrence (or the ragged end of the sub-block)
-        while (i < re) { const u32 s = sym[i]; if (s == c) break; add(s); ++i; }
+        rank[j] = (u8)__popcll(set);
+    } else {
+        u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        auto add = [&](u32 s) {
+            const u64 bit = 1ull << (s & 63);
+            const u32 w = s >> 6;
+            s0 |= (w == 0) ? bit : 0; s1 |= (w == 1) ? bit : 0; s2 |= (w == 2) ? bit : 0; s3 |= (w == 3) ? bit : 0;
+        };
+        const u32 cw = c >> 6; const u64 cbit = 1ull << (c & 63);
+        while (i < re && (i & 255u) != 0) { const u32 s = scode[i - base]; if (s == c) { found = true; break; } add(s); ++i; }
+        if (!found) {
+            while (i + 256 <= re) {
+                if ((i & 65535u) == 0 && i + 65536 <= re) {
+                    const u64* sm = super + (size_t)(i >> 16) * 4;
+                    if (!(sm[cw] & cbit)) { s0 |= sm[0]; s1 |= sm[1]; s2 |= sm[2]; s3 |= sm[3]; i += 65536; continue; }
+                }
+                const u64* tm = masks + (size_t)(i >> 8) * 4;
+                if (tm[cw] & cbit) break;
+                s0 |= tm[0]; s1 |= tm[1]; s2 |= tm[2]; s3 |= tm[3];
+                i += 256;
+            }
+            while (i < re) { const u32 s = sym[i]; if (s == c) break; add(s); ++i; }
+        }
+        rank[j] = (u8)(__popcll(s0) + __popcll(s1) + __popcll(s2) + __popcll(s3));
     }
-    rank[j] = (u8)(__popcll(s0) + __popcll(s1) + __popcll(s2) + __popcll(s3));
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -263,13 +298,32 @@ int qlfc_front_runs(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, const int* 
     for (int b = nblocks; b < 9; ++b) rb.first[b] = m;
     for (int b = 0; b <= nblocks; ++b) run_first[b] = rb.first[b];
 
+    // alphabet of the block = symbols that start a run somewhere; <= 64 of them -> one-word symbol sets
+    u8* hlut = reinterpret_cast<u8*>(c->hscal + 640);      // pinned; the copy below is consumed before the next block
+    u8* dlut = reinterpret_cast<u8*>(c->dscal + 640);
+    u32 K = 0;
+    for (int s = 0; s < 256; ++s) {
+        bool present = false;
+        for (int b = 0; b < nblocks; ++b) present |= (first_run_host[b * 256 + s] != 0xffffffffu);
+        hlut[s] = (u8)(present ? (K < 255 ? K : 255) : 0);
+        K += present;
+    }
+    const bool dense = K <= 64;
+    if (dense) HIP_TRY(c, hipMemcpyAsync(dlut, hlut, 256, hipMemcpyHostToDevice, c->stream));
+
     const u32 ntiles = (m + 255) / 256, nsuper = (ntiles + 255) / 256;
     prof_begin(c, BSCGPU_K_MISC, m, 0);
-    hipLaunchKernelGGL(qf_tile_masks_kernel, dim3(ntiles), dim3(WG), 0, c->stream, dsym, m, dmask);
-    hipLaunchKernelGGL(qf_super_masks_kernel, dim3(nsuper), dim3(WG), 0, c->stream, dmask, ntiles, dsuper);
+    if (dense) {
+        hipLaunchKernelGGL(qf_tile_masks_kernel<true>, dim3(ntiles), dim3(WG), 0, c->stream, dsym, m, dlut, dmask);
+        hipLaunchKernelGGL(qf_super_masks_kernel<true>, dim3(nsuper), dim3(WG), 0, c->stream, dmask, ntiles, dsuper);
+    } else {
+        hipLaunchKernelGGL(qf_tile_masks_kernel<false>, dim3(ntiles), dim3(WG), 0, c->stream, dsym, m, dlut, dmask);
+        hipLaunchKernelGGL(qf_super_masks_kernel<false>, dim3(nsuper), dim3(WG), 0, c->stream, dmask, ntiles, dsuper);
+    }
     prof_end(c);
     prof_begin(c, BSCGPU_K_GATHER, (u64)m * 2, m);
-    hipLaunchKernelGGL(qf_rank_kernel, dim3((m + WG - 1) / WG), dim3(WG), 0, c->stream, dsym, m, rb, dmask, dsuper, drank);
+    if (dense) hipLaunchKernelGGL(qf_rank_kernel<true>, dim3((m + WG - 1) / WG), dim3(WG), 0, c->stream, dsym, m, rb, dlut, dmask, dsuper, drank);
+    else       hipLaunchKernelGGL(qf_rank_kernel<false>, dim3((m + WG - 1) / WG), dim3(WG), 0, c->stream, dsym, m, rb, dlut, dmask, dsuper, drank);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(slot.hsym, dsym, m, hipMemcpyDeviceToHost, c->stream));
