@@ -33,8 +33,7 @@ int ctx_ensure_slots(bscgpu_ctx* c, int count)
         HostSlot& s = c->slots[c->nslots];
         bool ok = hipHostMalloc((void**)&s.hsym, N, hipHostMallocDefault) == hipSuccess
                && hipHostMalloc((void**)&s.hrank, N, hipHostMallocDefault) == hipSuccess
-               && hipHostMalloc((void**)&s.hstart, 4 * N, hipHostMallocDefault) == hipSuccess
-               && hipHostMalloc((void**)&s.hL, N + 64, hipHostMallocDefault) == hipSuccess;
+               && hipHostMalloc((void**)&s.hstart, 4 * N, hipHostMallocDefault) == hipSuccess;
         if (!ok) return BSC_NOT_ENOUGH_MEMORY;
     }
     return BSC_NO_ERROR;
@@ -119,7 +118,6 @@ extern "C" void bscgpu_destroy(bscgpu_ctx* c)
         if (s.hsym) hipHostFree(s.hsym);
         if (s.hrank) hipHostFree(s.hrank);
         if (s.hstart) hipHostFree(s.hstart);
-        if (s.hL) hipHostFree(s.hL);
     }
     if (c->arena) hipFree(c->arena);
     if (c->sync_ev) hipEventDestroy(c->sync_ev);

@@ -57,7 +57,6 @@ struct HostSlot {
     u8*  hsym   = nullptr;   // run symbols
     u8*  hrank  = nullptr;   // QLFC ranks
     u32* hstart = nullptr;   // run start positions
-    u8*  hL     = nullptr;   // the sorted block itself (only read if a sub-block must be stored raw)
 };
 constexpr int MAX_SLOTS = 4;
 
@@ -134,7 +133,7 @@ int adler32_device(bscgpu_ctx* c, const u8* d, int64_t n, u32* out);
 void launch_seg_scan(bscgpu_ctx* c, u32 num_chunks);
 int qlfc_front_split(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, int* start, int* size);
 int qlfc_front_runs(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, const int* start, u32* m_out, u32* run_first, u32* first_run_host,
-                    HostSlot& slot, bool copy_block);
+                    HostSlot& slot);
 int ctx_ensure_slots(bscgpu_ctx* c, int count);
 
 // ---------------------------------------------------------------------------------------------

@@ -260,7 +260,7 @@ int qlfc_front_split(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, int* start
 // Runs + ranks of all sub-blocks of dL.  Results in pinned host memory: c->hsym / c->hrank / c->hstart (m entries),
 // run_first[0..nblocks] (run index range per sub-block) and first_run[8][256].
 int qlfc_front_runs(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, const int* start, u32* m_out, u32* run_first /*[9]*/,
-                    u32* first_run_host /*[8*256]*/, HostSlot& slot, bool copy_block)
+                    u32* first_run_host /*[8*256]*/, HostSlot& slot)
 {
     QfSplit sp; sp.nblocks = (u32)nblocks;
     for (int b = 0; b < 9; ++b) sp.start[b] = (b < nblocks) ? (u32)start[b] : n;
@@ -329,7 +329,6 @@ int qlfc_front_runs(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, const int* 
     HIP_TRY(c, hipMemcpyAsync(slot.hsym, dsym, m, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(slot.hrank, drank, m, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(slot.hstart, dstart, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
-    if (copy_block) HIP_TRY(c, hipMemcpyAsync(slot.hL, dL, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, ctx_sync(c));
     prof_collect(c);
     return BSC_NO_ERROR;

@@ -266,7 +266,7 @@ static int gpu_stage(BlockJob& J, int blockSorter)
     rc = qlfc_front_split(c, c->dL, (u32)n, J.nblocks, J.start, J.size);
     if (rc < 0) return rc;
     u32 m = 0;
-    rc = qlfc_front_runs(c, c->dL, (u32)n, J.nblocks, J.start, &m, J.run_first, J.first_run, J.slot, true);
+    rc = qlfc_front_runs(c, c->dL, (u32)n, J.nblocks, J.start, &m, J.run_first, J.first_run, J.slot);
     if (rc < 0) return rc;
     c->stage_ms[2] = ms_since(t0);
     return LIBBSC_NO_ERROR;
@@ -287,6 +287,13 @@ static void host_prepare(BlockJob& J)
         V.nsym = k;
         for (int i = 0; i < k; ++i) V.first_seen[i] = (uint8_t)order[i].second;
     }
+}
+
+// The sorted bytes of a sub-block, rebuilt from its run arrays (needed only when a sub-block has to be stored raw; this is
+// why the sorted block itself never crosses PCIe).
+static void expand_runs(const RunView& V, int sub_start, uint8_t* dst)
+{
+    for (uint32_t j = 0; j < V.count; ++j) memset(dst + (V.start[j] - (uint32_t)sub_start), V.sym[j], V.len(j));
 }
 
 // parallel framing semantics (coder.cpp:159-240): every sub-block is coded with outputSize = its own size
@@ -339,7 +346,8 @@ static void host_finalize_parallel(BlockJob& J)
         for (int b = 0; b < nb; ++b) {
             put_i32(out + 1 + 8 * b, J.size[b]);
             put_i32(out + 1 + 8 * b + 4, J.sub_res[b]);
-            memcpy(out + optr, (J.sub_res[b] != J.size[b]) ? J.scratch[b].get() : J.slot.hL + J.start[b], (size_t)J.sub_res[b]);
+            if (J.sub_res[b] != J.size[b]) memcpy(out + optr, J.scratch[b].get(), (size_t)J.sub_res[b]);
+            else expand_runs(J.views[b], J.start[b], out + optr);
             optr += J.sub_res[b];
         }
         write_header_and_trailer(J, total);
@@ -363,9 +371,13 @@ static void host_stage(BlockJob& J)
         return;
     }
     struct Fetch : RawFetch {
-        const uint8_t* L;
-        int operator()(int st, int sz, uint8_t* dst) override { memcpy(dst, L + st, (size_t)sz); return 0; }
-    } fetch; fetch.L = J.slot.hL;
+        const BlockJob* J;
+        int operator()(int st, int sz, uint8_t* dst) override
+        {
+            for (int b = 0; b < J->nblocks; ++b) if (J->start[b] == st && J->size[b] == sz) { expand_runs(J->views[b], st, dst); return 0; }
+            return LIBBSC_BAD_PARAMETER;
+        }
+    } fetch; fetch.J = &J;
     unsigned char* buffer = (unsigned char*)bsc_malloc((size_t)J.n + 4096);
     if (!buffer) { J.result = LIBBSC_NOT_ENOUGH_MEMORY; return; }
     const int result = coder_compress_views(J.views, J.nblocks, J.start, J.size, J.n, buffer, J.coder, J.features & ~LIBBSC_FEATURE_MULTITHREADING, fetch);
