@@ -35,26 +35,58 @@ static void  (*g_free)(void*) = nullptr;
 static void* bsc_malloc(size_t n) { return g_malloc ? g_malloc(n) : malloc(n); }
 static void  bsc_free(void* p) { if (g_free) g_free(p); else free(p); }
 
-// ---- process-wide default GPU context for the host-pointer stage API -------------------------------
-// (the reference keeps one cached arena behind one lock, bwt.cpp:50-52; multi-GPU drivers create their
-// own bscgpu_ctx per device instead of going through this)
-static std::mutex   g_gpu_lock;
+// ---- process-wide default GPU context for the host-pointer API ------------------------------------------
+// (the reference keeps one cached arena behind one lock, bwt.cpp:50-52; multi-GPU drivers create their own bscgpu_ctx per
+// device instead of going through this).  Callers may be concurrent (the reference CLI compresses blocks from an OpenMP
+// team, bsc.cpp:197): the GPU stage of a call is serialised by g_gpu_lock, but bsc_compress releases it before its host
+// stage, so up to DEFAULT_SLOTS calls overlap — one on the GPU, the others coding on host threads.  Each holds one of the
+// context's pinned slots; the context is only re-created (for a larger block) when nobody is using it.
+static std::mutex   g_gpu_lock;                 // the GPU stage
+static std::mutex   g_user_mu;                  // g_gpu / g_gpu_cap / g_users / g_slot_busy
+static std::condition_variable g_user_cv;
 static bscgpu_ctx*  g_gpu = nullptr;
 static int64_t      g_gpu_cap = 0;
+static int          g_users = 0;
+constexpr int       DEFAULT_SLOTS = 3;
+static bool         g_slot_busy[DEFAULT_SLOTS] = {false, false, false};
 
-static int default_gpu(int64_t n, bscgpu_ctx** out)
+// Register as a user of a default context that can take n bytes; with want_slot also reserve a pinned slot.
+static int default_gpu_acquire(int64_t n, bool want_slot, bscgpu_ctx** out, int* slot_out)
 {
-    if (g_gpu && g_gpu_cap >= n) { *out = g_gpu; return LIBBSC_NO_ERROR; }
-    if (g_gpu) { bscgpu_destroy(g_gpu); g_gpu = nullptr; g_gpu_cap = 0; }
-    int dev = 0;
-    if (const char* e = getenv("BSC_GPU_DEVICE")) dev = atoi(e);
-    const int64_t cap = n + n / 32 + 4096;                    // headroom like bwt.cpp:106
-    int rc = bscgpu_create(&g_gpu, dev, cap);
-    if (rc != LIBBSC_NO_ERROR) { g_gpu = nullptr; return rc; }
-    g_gpu_cap = cap;
-    *out = g_gpu;
-    return LIBBSC_NO_ERROR;
+    std::unique_lock<std::mutex> lk(g_user_mu);
+    for (;;) {
+        if (g_gpu && g_gpu_cap >= n) {
+            int s = -1;
+            if (want_slot) { for (int i = 0; i < DEFAULT_SLOTS; ++i) if (!g_slot_busy[i]) { s = i; break; } }
+            if (!want_slot || s >= 0) {
+                if (s >= 0) g_slot_busy[s] = true;
+                ++g_users;
+                *out = g_gpu; if (slot_out) *slot_out = s;
+                return LIBBSC_NO_ERROR;
+            }
+        } else if (g_users == 0) {
+            if (g_gpu) { bscgpu_destroy(g_gpu); g_gpu = nullptr; g_gpu_cap = 0; }
+            int dev = 0;
+            if (const char* e = getenv("BSC_GPU_DEVICE")) dev = atoi(e);
+            const int64_t cap = n + n / 32 + 4096;                    // headroom like bwt.cpp:106
+            const int rc = bscgpu_create(&g_gpu, dev, cap);
+            if (rc != LIBBSC_NO_ERROR) { g_gpu = nullptr; return rc; }
+            g_gpu_cap = cap;
+            continue;
+        }
+        g_user_cv.wait(lk);
+    }
 }
+static void default_gpu_release(int slot)
+{
+    { std::lock_guard<std::mutex> lk(g_user_mu); if (slot >= 0) g_slot_busy[slot] = false; --g_users; }
+    g_user_cv.notify_all();
+}
+struct DefaultGpuUser {                         // RAII around acquire / release
+    bscgpu_ctx* c = nullptr; int slot = -1; int rc;
+    DefaultGpuUser(int64_t n, bool want_slot) { rc = default_gpu_acquire(n, want_slot, &c, &slot); }
+    ~DefaultGpuUser() { if (rc == LIBBSC_NO_ERROR) default_gpu_release(slot); }
+};
 
 static inline void put_i32(unsigned char* p, int v) { memcpy(p, &v, 4); }
 static inline int  get_i32(const unsigned char* p) { int v; memcpy(&v, p, 4); return v; }
@@ -106,10 +138,10 @@ int bsc_bwt_encode(unsigned char* T, int n, unsigned char* num_indexes, int* ind
     (void)features;
     if (T == nullptr || n < 0) return LIBBSC_BAD_PARAMETER;
     if (n == 0) { if (num_indexes) *num_indexes = 0; return 0; }
+    DefaultGpuUser user(n, false);
+    if (user.rc != LIBBSC_NO_ERROR) return user.rc;
+    bscgpu_ctx* c = user.c;
     std::lock_guard<std::mutex> g(g_gpu_lock);
-    bscgpu_ctx* c = nullptr;
-    int rc = default_gpu(n, &c);
-    if (rc != LIBBSC_NO_ERROR) return rc;
     if (num_indexes != nullptr && indexes != nullptr) {
         const int r = aux_rate(n);
         if (r < 2) return LIBBSC_BAD_PARAMETER;               // libsais_bwt_aux rejects r < 2 (libsais.c:6711)
@@ -131,11 +163,10 @@ int bsc_st_encode(unsigned char* T, int n, int k, int features)
     if (T == nullptr || n < 0) return LIBBSC_BAD_PARAMETER;
     if (k < 3 || k > 8) return LIBBSC_BAD_PARAMETER;
     if (n <= 1) return 0;
+    DefaultGpuUser user(n, false);
+    if (user.rc != LIBBSC_NO_ERROR) return user.rc;
     std::lock_guard<std::mutex> g(g_gpu_lock);
-    bscgpu_ctx* c = nullptr;
-    int rc = default_gpu(n, &c);
-    if (rc != LIBBSC_NO_ERROR) return rc;
-    return bscgpu_st_encode(c, T, n, k);
+    return bscgpu_st_encode(user.c, T, n, k);
 }
 
 // ---- container ---------------------------------------------------------------------------------------------
@@ -386,12 +417,11 @@ static void host_stage(BlockJob& J)
     write_header_and_trailer(J, result);
 }
 
-// Host-resident block -> job: optional LZP on the host (lzp.cpp:798 semantics), then one H2D copy into the context's
-// text buffer.  `sorter` may be changed (a tiny LZP output is always BWT-sorted, libbsc.cpp:277-281).
-static int stage_host_input(BlockJob& J, bscgpu_ctx* c, const unsigned char* input, unsigned char* output, int n,
-                            int lzpHashSize, int lzpMinLen, int* sorter, int coder, int features, int mode)
+// Host-resident block -> job, part 1 (no GPU involved): optional LZP on the host (lzp.cpp:798 semantics).  `sorter` may be
+// changed (a tiny LZP output is always BWT-sorted, libbsc.cpp:277-281).
+static int stage_host_lzp(BlockJob& J, const unsigned char* input, unsigned char* output, int n,
+                          int lzpHashSize, int lzpMinLen, int* sorter, int coder, int features, int mode)
 {
-    const unsigned char* data = input;
     int lzSize = n;
     J.lz.reset();
     if (mode != (mode & 0xff)) {
@@ -399,14 +429,21 @@ static int stage_host_input(BlockJob& J, bscgpu_ctx* c, const unsigned char* inp
         if (!J.lz) return LIBBSC_NOT_ENOUGH_MEMORY;
         const int r = lzp_compress(input, J.lz.get(), n, lzpHashSize, lzpMinLen, features);
         if (r < LIBBSC_NO_ERROR) { mode &= 0xff; J.lz.reset(); }            // libbsc.cpp:266-269: the block goes on without LZP
-        else { data = J.lz.get(); lzSize = r; }
+        else lzSize = r;
     }
     if (lzSize <= LIBBSC_HEADER_SIZE) { *sorter = LIBBSC_BLOCKSORTER_BWT; mode = (mode & ~0x1f) | LIBBSC_BLOCKSORTER_BWT; }
-    J.c = c; J.dInput = c->dL; J.hInput = input; J.output = output; J.n = lzSize; J.n_orig = n; J.inplace = (input == output);
+    J.hInput = input; J.output = output; J.n = lzSize; J.n_orig = n; J.inplace = (input == output);
     J.coder = coder; J.features = features; J.mode = mode; J.stored_small = false; J.result = 0; J.have_adler = false;
-    if (data != input) { J.adler_data = adler32(input, (size_t)n); J.have_adler = true; }
+    if (J.lz) { J.adler_data = adler32(input, (size_t)n); J.have_adler = true; }
+    return LIBBSC_NO_ERROR;
+}
+// part 2: one H2D copy of what the sorter will see into the context's text buffer
+static int stage_host_h2d(BlockJob& J, bscgpu_ctx* c)
+{
+    J.c = c; J.dInput = c->dL;
     if (hipSetDevice(c->device) != hipSuccess) return LIBBSC_GPU_ERROR;
-    if (hipMemcpyAsync(c->dL, data, (size_t)lzSize, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LIBBSC_GPU_ERROR;
+    const unsigned char* data = J.lz ? J.lz.get() : J.hInput;
+    if (hipMemcpyAsync(c->dL, data, (size_t)J.n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LIBBSC_GPU_ERROR;
     return LIBBSC_NO_ERROR;
 }
 
@@ -424,20 +461,24 @@ int bsc_compress(const unsigned char* input, unsigned char* output, int n, int l
     if (n <= LIBBSC_HEADER_SIZE) return bsc_store(input, output, n, features);
 
     std::unique_ptr<BlockJob> J(new BlockJob);
-    std::lock_guard<std::mutex> g(g_gpu_lock);
-    bscgpu_ctx* c = nullptr;
-    rc = default_gpu(n, &c);
-    if (rc != LIBBSC_NO_ERROR) return rc;
-    if (hipSetDevice(c->device) != hipSuccess) return LIBBSC_GPU_ERROR;
-    rc = ctx_ensure_slots(c, 1);
+    rc = stage_host_lzp(*J, input, output, n, lzpHashSize, lzpMinLen, &blockSorter, coder, features, mode);
     if (rc < 0) return rc;
-    J->slot = c->slots[0];
-    rc = stage_host_input(*J, c, input, output, n, lzpHashSize, lzpMinLen, &blockSorter, coder, features, mode);
-    if (rc < 0) return rc;
-    rc = gpu_stage(*J, blockSorter);
-    if (rc < 0) return rc;
-    host_stage(*J);
-    J->lz.reset();
+    DefaultGpuUser user(J->n, true);
+    if (user.rc != LIBBSC_NO_ERROR) return user.rc;
+    bscgpu_ctx* c = user.c;
+    {
+        std::lock_guard<std::mutex> g(g_gpu_lock);              // GPU stage; concurrent callers queue here
+        if (hipSetDevice(c->device) != hipSuccess) return LIBBSC_GPU_ERROR;
+        rc = ctx_ensure_slots(c, user.slot + 1);
+        if (rc < 0) return rc;
+        J->slot = c->slots[user.slot];
+        rc = stage_host_h2d(*J, c);
+        if (rc < 0) return rc;
+        rc = gpu_stage(*J, blockSorter);
+        J->lz.reset();
+        if (rc < 0) return rc;
+    }
+    host_stage(*J);                                             // host coder: overlaps the next caller's GPU stage
     return J->result;
 }
 
@@ -612,7 +653,9 @@ int bscgpu_pipe_submit_host(bscgpu_pipe* p, const uint8_t* input, uint8_t* outpu
         J.stored_small = true;
         return pipe_enqueue(p, L, ticket);
     }
-    rc = stage_host_input(J, p->c, input, output, n, lzpHashSize, lzpMinLen, &blockSorter, coder, features, mode);
+    rc = stage_host_lzp(J, input, output, n, lzpHashSize, lzpMinLen, &blockSorter, coder, features, mode);
+    if (rc < 0) return rc;
+    rc = stage_host_h2d(J, p->c);
     if (rc < 0) return rc;
     rc = gpu_stage(J, blockSorter);
     J.lz.reset();                                   // the LZP output lives in HBM from here on
