@@ -386,21 +386,14 @@ static void host_finalize_parallel(BlockJob& J)
     for (int b = 0; b < nb; ++b) J.scratch[b].reset();
 }
 
-static bool job_is_parallel(const BlockJob& J) { return !J.stored_small && J.nblocks > 1 && (J.features & LIBBSC_FEATURE_MULTITHREADING); }
+// every block with more than one sub-block is coded as independent per-sub-block tasks, whatever the caller's
+// MULTITHREADING flag says: the flag selects the reference's *framing rules* (coder.cpp:111 serial / :159 parallel), which
+// differ only in corner cases, not whether this library may use its coder threads.
+static bool job_uses_tasks(const BlockJob& J) { return !J.stored_small && J.nblocks > 1; }
 
-// whole host stage on the calling thread (+ its own sub-block threads): used by the synchronous entry point and for
-// blocks that do not take the per-sub-block task path (single sub-block, or serial framing semantics)
-static void host_stage(BlockJob& J)
+// the block's sub-blocks through the strictly serial coder (coder.cpp:111-155) on this thread
+static void host_code_serially(BlockJob& J)
 {
-    if (J.stored_small) return;
-    host_prepare(J);
-    if (job_is_parallel(J)) {
-        std::vector<std::thread> pool;
-        for (int b = 0; b < J.nblocks; ++b) pool.emplace_back([&J, b] { host_encode_sub(J, b); });
-        for (auto& t : pool) t.join();
-        host_finalize_parallel(J);
-        return;
-    }
     struct Fetch : RawFetch {
         const BlockJob* J;
         int operator()(int st, int sz, uint8_t* dst) override
@@ -415,6 +408,57 @@ static void host_stage(BlockJob& J)
     if (result >= 0) memcpy(J.output + LIBBSC_HEADER_SIZE, buffer, (size_t)result);
     bsc_free(buffer);
     write_header_and_trailer(J, result);
+}
+
+// Serial framing rules (coder.cpp:111-155) applied to sub-blocks that were coded independently, each with an output
+// budget of its own size.  The serial coder gives sub-block b the budget min(size_b, n - bytes written so far); when that
+// is size_b for every b — always, unless the block is close to incompressible — its result is exactly what the
+// independent run produced.  Otherwise the block is simply coded again serially.
+static void host_finalize_serial(BlockJob& J)
+{
+    uint8_t* out = J.output + LIBBSC_HEADER_SIZE; const int n = J.n, nb = J.nblocks;
+    int optr = 1 + 8 * nb;
+    bool exact = true, incompressible = false;
+    for (int b = 0; b < nb && exact && !incompressible; ++b) {
+        if (n - optr < J.size[b]) { exact = false; break; }
+        if (J.sub_res[b] == J.size[b] && optr + J.size[b] >= n) { incompressible = true; break; }       // coder.cpp:131-134
+        optr += J.sub_res[b];
+    }
+    if (!exact) { for (int b = 0; b < nb; ++b) J.scratch[b].reset(); host_code_serially(J); return; }
+    if (incompressible) write_header_and_trailer(J, LIBBSC_NOT_COMPRESSIBLE);
+    else {
+        out[0] = (uint8_t)nb;
+        optr = 1 + 8 * nb;
+        for (int b = 0; b < nb; ++b) {
+            put_i32(out + 1 + 8 * b, J.size[b]);
+            put_i32(out + 1 + 8 * b + 4, J.sub_res[b]);
+            if (J.sub_res[b] != J.size[b]) memcpy(out + optr, J.scratch[b].get(), (size_t)J.sub_res[b]);
+            else expand_runs(J.views[b], J.start[b], out + optr);
+            optr += J.sub_res[b];
+        }
+        write_header_and_trailer(J, optr);
+    }
+    for (int b = 0; b < nb; ++b) J.scratch[b].reset();
+}
+
+static void host_finalize(BlockJob& J)
+{
+    if (J.features & LIBBSC_FEATURE_MULTITHREADING) host_finalize_parallel(J); else host_finalize_serial(J);
+}
+
+// whole host stage on the calling thread (+ its own sub-block threads): the synchronous entry points
+static void host_stage(BlockJob& J)
+{
+    if (J.stored_small) return;
+    host_prepare(J);
+    if (job_uses_tasks(J)) {
+        std::vector<std::thread> pool;
+        for (int b = 0; b < J.nblocks; ++b) pool.emplace_back([&J, b] { host_encode_sub(J, b); });
+        for (auto& t : pool) t.join();
+        host_finalize(J);
+        return;
+    }
+    host_code_serially(J);
 }
 
 // Host-resident block -> job, part 1 (no GPU involved): optional LZP on the host (lzp.cpp:798 semantics).  `sorter` may be
@@ -553,7 +597,7 @@ struct bscgpu_pipe {
             if (t.sub < 0) { host_stage(J); finished = true; }
             else {
                 host_encode_sub(J, t.sub);
-                if (J.remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) { host_finalize_parallel(J); finished = true; }
+                if (J.remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) { host_finalize(J); finished = true; }
             }
             if (finished) { { std::lock_guard<std::mutex> lk(mu); J.done = true; } cv_done.notify_all(); }
         }
@@ -601,7 +645,7 @@ static int pipe_enqueue(bscgpu_pipe* p, bscgpu_pipe::Lane& L, int ticket)
     L.ticket = ticket; L.busy = true;
     {
         std::lock_guard<std::mutex> lk(p->mu);
-        if (job_is_parallel(J)) {
+        if (job_uses_tasks(J)) {
             host_prepare(J);
             J.remaining.store(J.nblocks, std::memory_order_release);
             for (int b = 0; b < J.nblocks; ++b) p->queue.push_back({&J, b});
