@@ -6,6 +6,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <thread>
+#include <algorithm>
+#include <cstdint>
+#include <memory>
 
 #include "../../../include/libbsc.h"
 #include "qlfc.h"
@@ -81,30 +85,80 @@ int lzp_decompress(const uint8_t* in, uint8_t* out, int n, int out_cap, int hash
 extern "C" {
 
 // L = [T[n-1]] ++ [T[SA[j]-1] : SA[j] != 0]; `index` (1-based) is where the end-of-text row was removed.
-// Re-insert a virtual sentinel row at position `index`, build LF in one counting pass, walk it backwards from row 0.
+// Rows 0..n: row 0 is the empty suffix, row j >= 1 is suffix SA[j-1]; the row of suffix 0 (`index`) carries the sentinel.
+// One counting pass builds P[row] = LF(row) | symbol << 32, so a backward step is a single random access.  The aux
+// indexes written by the encoder (bwt.cpp:192-209: the row of every suffix t * r) cut the text into num_indexes + 1
+// independent backward walks; they run interleaved (several cache misses in flight per core) and, with
+// LIBBSC_FEATURE_MULTITHREADING, on several threads.  The reference reaches the same result through
+// libsais_unbwt_aux (bwt.cpp:283-334).
+static int aux_rate_of(int n)          // largest power of two <= n / 8 (>= 1), bwt.cpp:192-197
+{
+    int mod = n / 8;
+    mod |= mod >> 1; mod |= mod >> 2; mod |= mod >> 4; mod |= mod >> 8; mod |= mod >> 16; mod >>= 1;
+    return mod + 1;
+}
+
 int bsc_bwt_decode(unsigned char* T, int n, int index, unsigned char num_indexes, int* indexes, int features)
 {
-    (void)num_indexes; (void)indexes; (void)features;
     if (T == nullptr || n < 0 || index <= 0 || index > n) return LIBBSC_BAD_PARAMETER;     // bwt.cpp:285
     if (n <= 1) return LIBBSC_NO_ERROR;
-    std::vector<unsigned> lf((size_t)n + 1);
-    unsigned cnt[256] = {0};
-    for (int i = 0; i < n; ++i) cnt[T[i]]++;
-    unsigned base[256], sum = 1;                              // row 0 is the sentinel-first suffix
-    for (int c = 0; c < 256; ++c) { base[c] = sum; sum += cnt[c]; }
-    for (int i = 0; i <= n; ++i) {
-        if (i == index) { lf[(size_t)i] = 0; continue; }
-        const unsigned char c = T[i < index ? i : i - 1];
-        lf[(size_t)i] = base[c]++;
+    const size_t N = (size_t)n;
+    // 8 bytes per row, written once below: no zero fill
+    struct FreeRaw { void operator()(void* q) const { free(q); } };
+    std::unique_ptr<void, FreeRaw> pown(malloc((N + 1) * sizeof(uint64_t)));
+    if (!pown) return LIBBSC_NOT_ENOUGH_MEMORY;
+    uint64_t* const P = static_cast<uint64_t*>(pown.get());
+    {
+        unsigned cnt[256] = {0};
+        for (size_t i = 0; i < N; ++i) cnt[T[i]]++;
+        unsigned base[256], sum = 1;                          // row 0 is the sentinel-first suffix
+        for (int c = 0; c < 256; ++c) { base[c] = sum; sum += cnt[c]; }
+        const size_t idx = (size_t)index;
+        for (size_t i = 0; i < idx; ++i) { const unsigned char c = T[i]; P[i] = (uint64_t)base[c]++ | ((uint64_t)c << 32); }
+        P[idx] = 0;
+        for (size_t i = idx + 1; i <= N; ++i) { const unsigned char c = T[i - 1]; P[i] = (uint64_t)base[c]++ | ((uint64_t)c << 32); }
     }
-    std::vector<unsigned char> out((size_t)n);
-    unsigned r = 0;
-    for (int k = n - 1; k >= 0; --k) {
-        if ((int)r == index) return LIBBSC_DATA_CORRUPT;     // walked into the sentinel early: inconsistent index
-        out[(size_t)k] = T[(int)r < index ? r : r - 1];
-        r = lf[r];
+
+    // walks: chain s rebuilds text positions [s * r, min((s + 1) * r, n)) backwards from the row of its end position
+    int chains = 1;
+    const int r = aux_rate_of(n);
+    if (num_indexes > 0 && indexes != nullptr && (int)num_indexes == (n - 1) / r) {
+        chains = (int)num_indexes + 1;
+        for (int t = 0; t < (int)num_indexes; ++t) if (indexes[t] < 0 || indexes[t] >= n) return LIBBSC_DATA_CORRUPT;
     }
-    memcpy(T, out.data(), (size_t)n);
+    struct Chain { uint32_t row; long long k, stop; uint32_t expect; };
+    std::vector<Chain> ch((size_t)chains);
+    for (int s2 = 0; s2 < chains; ++s2) {
+        Chain& c = ch[(size_t)s2];
+        const long long lo = (long long)s2 * r, hi = (s2 == chains - 1) ? (long long)n : (long long)(s2 + 1) * r;
+        c.k = hi - 1; c.stop = lo;
+        c.row = (s2 == chains - 1) ? 0u : (uint32_t)indexes[s2] + 1u;
+        c.expect = (s2 == 0) ? (uint32_t)index : (uint32_t)indexes[s2 - 1] + 1u;
+    }
+    std::vector<unsigned char> out(N);
+    const uint64_t* Pp = P;
+    unsigned char* op = out.data();
+    auto walk = [&](int first, int step) {                   // chains first, first + step, ... interleaved on one thread
+        Chain* mine[256]; int m = 0;
+        for (int s2 = first; s2 < chains; s2 += step) mine[m++] = &ch[(size_t)s2];
+        long long longest = 0;
+        for (int i = 0; i < m; ++i) longest = std::max(longest, mine[i]->k - mine[i]->stop + 1);
+        for (long long it = 0; it < longest; ++it)
+            for (int i = 0; i < m; ++i) {
+                Chain& c = *mine[i];
+                if (c.k >= c.stop) { const uint64_t p = Pp[c.row]; op[c.k--] = (unsigned char)(p >> 32); c.row = (uint32_t)p; }
+            }
+    };
+    int threads = 1;
+    if ((features & LIBBSC_FEATURE_MULTITHREADING) && chains > 1 && n >= (1 << 20)) threads = chains < 8 ? chains : 8;
+    if (threads == 1) walk(0, 1);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t) pool.emplace_back(walk, t, threads);
+        for (auto& t : pool) t.join();
+    }
+    for (int s2 = 0; s2 < chains; ++s2) if (ch[(size_t)s2].row != ch[(size_t)s2].expect) return LIBBSC_DATA_CORRUPT;   // inconsistent indexes
+    memcpy(T, out.data(), N);
     return LIBBSC_NO_ERROR;
 }
 

@@ -96,3 +96,23 @@ def test_bsc_decompress_reads_reference_blocks_with_lzp(ref):
                 blk = ref.compress(T, sorter, 1, lzp_hash=h, lzp_min=m)
                 assert isinstance(blk, bytes)
                 assert api.bsc_decompress(blk) == T.tobytes(), (T.size, h, m, sorter)
+
+
+def test_bwt_decode_with_aux_indexes(ref):
+    """The aux indexes (bwt.cpp:192-209) cut the inverse BWT into independent walks: same text with and without them, on
+    one or several threads; inconsistent indexes are detected; a count that does not match n falls back to one walk."""
+    from libbsc_amd.synth import synth_text_v1
+    for n in (16, 17, 1000, 65536, 300_000, (1 << 20) + 17, 3 << 20):
+        T = synth_text_v1(12, n)
+        L, idx, aux = ref.bwt_encode(T)
+        assert len(aux) == (n - 1) // (1 << ((n // 8).bit_length() - 1)) if n >= 16 else True
+        for features in (1, 3):
+            back, rc = api.bsc_bwt_decode(L, idx, aux, features=features)
+            assert rc == 0 and np.array_equal(back, T), (n, features)
+        back, rc = api.bsc_bwt_decode(L, idx)                       # no indexes: single walk
+        assert rc == 0 and np.array_equal(back, T)
+        if len(aux) >= 2:
+            bad = list(aux); bad[1] = (bad[1] + 1) % n
+            assert api.bsc_bwt_decode(L, idx, bad)[1] == api.DATA_CORRUPT
+            back, rc = api.bsc_bwt_decode(L, idx, aux[:-1])          # wrong count: ignored
+            assert rc == 0 and np.array_equal(back, T)
