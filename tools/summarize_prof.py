@@ -19,7 +19,7 @@ for f in find("*kernel_trace.csv"):
     if "pmc" in f:
         continue
     rows = list(csv.DictReader(open(f)))
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "rs_scatter_kernelILb1" in r["Kernel_Name"]]
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "rs_scatter_kernelILb1" in r["Kernel_Name"] or "rs_scatter_kernel<true" in r["Kernel_Name"]]
     if d:
         d.sort(reverse=True)
         big = [x for x in d if x > 300]
