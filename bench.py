@@ -204,14 +204,27 @@ def cpu_baseline(host_in, sorter, coder):
         ref = Ref()
         ref.compress(host_in[: 1 << 20], sorter, coder)            # warm-up (OpenMP team start)
         best = None
-        for _ in range(2):
+        for _ in range(2):                                          # (a) one call with the OpenMP team inside (features = 3)
             t0 = time.perf_counter()
             out = ref.compress(host_in, sorter, coder)
             dt = time.perf_counter() - t0
             best = dt if best is None or dt < best else best
-        return {"value": round(host_in.size / 1e6 / best, 1), "unit": "MB/s", "cores": threads, "kind": "reference",
-                "sample": f"one {host_in.size >> 20} MiB block (the bench block), bsc_compress features=3, best of 2 after warm-up; "
-                          f"{best:.2f} s; compressed {len(out)} B"}
+        single = host_in.size / 1e6 / best
+        # (b) what the reference CLI does with many blocks (bsc.cpp:184-197): one block per thread, no threads inside a call
+        import threading
+        def one():
+            ref.compress(host_in, sorter, coder, features=1)
+        ths = [threading.Thread(target=one) for _ in range(threads)]
+        t0 = time.perf_counter()
+        for t in ths: t.start()
+        for t in ths: t.join()
+        dtp = time.perf_counter() - t0
+        par = threads * host_in.size / 1e6 / dtp
+        return {"value": round(max(single, par), 1), "unit": "MB/s", "cores": threads, "kind": "reference",
+                "single_call_MBps": round(single, 1), "block_parallel_MBps": round(par, 1),
+                "sample": f"the bench block ({host_in.size >> 20} MiB) through the reference's bsc_compress: (a) one call, features=3, "
+                          f"{threads} OpenMP threads, best of 2 after warm-up: {best:.2f} s; (b) {threads} concurrent single-threaded calls "
+                          f"(the CLI's block-parallel mode): {dtp:.2f} s; value = the better of the two; compressed {len(out)} B"}
     except Exception as e_ref:
         try:    # no compiled reference on this box: time the plain-C restatement (1 core) on a bounded sample
             import subprocess

@@ -1,5 +1,6 @@
 // Microbenchmarks for the memory shapes used by the radix engine (not part of the product).
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 typedef unsigned long long u64; typedef unsigned int u32;
@@ -143,6 +144,20 @@ __global__ __launch_bounds__(THREADS) void k_scatter_pairs_mis(const u64* __rest
         }
     }
 }
+// inverse-permutation scatter dst[idx[i]] = i (what ISA[SA[j]] = rank does): fully random over 256 MB, and the same number
+// of stores when the records have first been bucketed by destination so that each XCD (blockIdx % 8) works inside one
+// window of `win` elements at a time (32 workgroups of the XCD share a window's records)
+__global__ __launch_bounds__(256) void k_scatter_random(const u32* __restrict__ idx, u32* __restrict__ dst, u32 n) {
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[idx[i]] = i;
+}
+__global__ __launch_bounds__(256) void k_scatter_windowed(const u32* __restrict__ idx, u32* __restrict__ dst, u32 n, u32 win, u32 wgs_per_xcd) {
+    const u32 xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const u32 nwin = n / win;
+    for (u32 w = xcd; w < nwin; w += 8) {                         // records of window w are idx[w*win .. (w+1)*win)
+        const u32 base = w * win;
+        for (u32 i = slot * 256 + threadIdx.x; i < win; i += wgs_per_xcd * 256) dst[idx[base + i]] = base + i;
+    }
+}
 template <class F> static float timeit(F f, int reps = 5) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     f(); CHECK(hipDeviceSynchronize());
@@ -199,6 +214,25 @@ int main() {
         printf("pairs 16-record runs misalign %u: 256 WG x 256 thr (1 WG/CU): %.3f ms -> %.0f GB/s\n", mis, ms, 24.0 * n / 1e6 / ms);
         ms = timeit([&] { hipLaunchKernelGGL(k_scatter_pairs_mis<256>, dim3(1024), dim3(256), 0, 0, ka, va, kb, vb, n, 16, mis, sink); });
         printf("pairs 16-record runs misalign %u: 1024 WG x 256 thr (4 WG/CU, frontier 8 MB/XCD): %.3f ms -> %.0f GB/s\n", mis, ms, 24.0 * n / 1e6 / ms);
+    }
+    {   // idx: a random permutation (host-built), and one that only permutes inside windows
+        std::vector<u32> h(n);
+        for (u32 i = 0; i < n; ++i) h[i] = i;
+        u64 st = 88172645463325252ull;
+        auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+        for (u32 i = n - 1; i > 0; --i) { u32 j = (u32)(rnd() % (i + 1)); u32 t2 = h[i]; h[i] = h[j]; h[j] = t2; }
+        u32* didx; CHECK(hipMalloc(&didx, n * 4ull)); CHECK(hipMemcpy(didx, h.data(), n * 4ull, hipMemcpyHostToDevice));
+        ms = timeit([&] { hipLaunchKernelGGL(k_scatter_random, dim3(2048), dim3(256), 0, 0, didx, va, n); });
+        printf("random 4-B scatter of %u elements over %u MB: %.3f ms\n", n, n / 262144, ms);
+        for (u32 win : {1u << 18, 1u << 20}) {                    // 1 MB and 4 MB windows
+            for (u32 i = 0; i < n; ++i) h[i] = i;
+            for (u32 b = 0; b < n; b += win) for (u32 i = win - 1; i > 0; --i) { u32 j = (u32)(rnd() % (i + 1)); u32 t2 = h[b + i]; h[b + i] = h[b + j]; h[b + j] = t2; }
+            CHECK(hipMemcpy(didx, h.data(), n * 4ull, hipMemcpyHostToDevice));
+            for (u32 wpx : {32u, 64u}) {
+                ms = timeit([&] { hipLaunchKernelGGL(k_scatter_windowed, dim3(8 * wpx), dim3(256), 0, 0, didx, va, n, win, wpx); });
+                printf("windowed 4-B scatter, window %u KB, %u WG per XCD: %.3f ms\n", win / 256, wpx, ms);
+            }
+        }
     }
     return 0;
 }
