@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--block", type=int, default=BLOCK)
     ap.add_argument("--sorter", type=int, default=1)
     ap.add_argument("--coder", type=int, default=1)
-    ap.add_argument("--depth", type=int, default=3, help="blocks in flight per GPU; their sub-blocks feed a pool of 16 coder threads per GPU")
+    ap.add_argument("--depth", type=int, default=4, help="blocks in flight per GPU; their sub-blocks feed a pool of 16 coder threads per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

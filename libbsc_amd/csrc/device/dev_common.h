@@ -58,7 +58,7 @@ struct HostSlot {
     u8*  hrank  = nullptr;   // QLFC ranks
     u32* hstart = nullptr;   // run start positions
 };
-constexpr int MAX_SLOTS = 4;
+constexpr int MAX_SLOTS = 8;
 
 struct bscgpu_ctx {
     int          device      = 0;

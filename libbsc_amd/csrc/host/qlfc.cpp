@@ -276,15 +276,21 @@ static int encode_alphabet(const RunView& R, EmitBit&& emit)
 // three counter slots (state-, char- and position-indexed) and the mixer slot it uses.  All context indices are
 // pure functions of the run data, never of the coder state — which is what lets the policies below either code
 // directly or hand the three counter families to separate threads.  Returns false when the policy aborts.
-template <bool ADAPT, class Policy>
-static bool walk_model1(const RunView& R, const QlfcTables& T, const int max_rank, Counters1& K, Mixers1* M, Policy& pol)
-{
+// Per-stream context state of the walker (everything the context indices depend on besides the run data).
+struct WalkState {
     int ctx_rank0 = 0, ctx_rank4 = 0, ctx_run = 0, avg_rank = 0;
-    uint8_t rank_hist[256] = {0}, run_hist[256] = {0};
+    uint8_t rank_hist[256], run_hist[256];
+    WalkState() { memset(rank_hist, 0, sizeof rank_hist); memset(run_hist, 0, sizeof run_hist); }
+};
 
-    const uint32_t m = R.count;
-    for (uint32_t j = 0; j < m; ++j) {
-        if (!pol.begin_run()) return false;
+// One run: all its binary decisions, in stream order.
+template <bool ADAPT, class Policy>
+static BSC_ALWAYS_INLINE void walk_step(WalkState& W, const RunView& R, const QlfcTables& T, const int max_rank, Counters1& K, Mixers1* M,
+                                        Policy& pol, const uint32_t j)
+{
+    int ctx_rank0 = W.ctx_rank0, ctx_rank4 = W.ctx_rank4, ctx_run = W.ctx_run, avg_rank = W.avg_rank;
+    uint8_t* const rank_hist = W.rank_hist; uint8_t* const run_hist = W.run_hist;
+    {
         const int c = R.sym[j];
         int rank = R.rank[j];
         const int run = (int)R.len(j);
@@ -367,9 +373,20 @@ static bool walk_model1(const RunView& R, const QlfcTables& T, const int max_ran
         ctx_rank4 = ((ctx_rank4 << 2) | (rank < 3 ? rank : 3)) & 0xff;
         ctx_run   = ((ctx_run   << 1) | (run < 3 ? 1 : 0)) & 0xf;
     }
-    return true;
+    W.ctx_rank0 = ctx_rank0; W.ctx_rank4 = ctx_rank4; W.ctx_run = ctx_run; W.avg_rank = avg_rank;
 }
 
+template <bool ADAPT, class Policy>
+static bool walk_model1(const RunView& R, const QlfcTables& T, const int max_rank, Counters1& K, Mixers1* M, Policy& pol)
+{
+    WalkState W;
+    const uint32_t m = R.count;
+    for (uint32_t j = 0; j < m; ++j) {
+        if (!pol.begin_run()) return false;
+        walk_step<ADAPT>(W, R, T, max_rank, K, M, pol, j);
+    }
+    return true;
+}
 
 template <bool ADAPT>
 struct DirectPolicy {
