@@ -76,7 +76,7 @@ def main():
     gather_buf = torch.empty(n + 64, dtype=torch.uint8, device=comm_dev)
 
     from libbsc_amd.multigpu import gather_blocks_to_rank0
-    pipe = ctx.pipe(args.depth)
+    pipe = ctx.pipe(args.depth, reuse_outputs=True)        # compressed blocks land in recycled host buffers
     stage = np.zeros(6)
 
     def finish(ticket):

@@ -246,7 +246,8 @@ struct BlockJob {
     int  result = 0;
     // host stage, split into per-sub-block tasks for the pipe's worker pool
     RunView views[8];
-    std::unique_ptr<uint8_t[]> scratch[8];
+    std::unique_ptr<uint8_t[]> scratch[8];          // coded sub-blocks; kept across the blocks of a pipe lane (no re-faulting)
+    size_t scratch_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int  sub_res[8];
     std::atomic<int> remaining{0};
     bool done = false;
@@ -330,7 +331,8 @@ static void expand_runs(const RunView& V, int sub_start, uint8_t* dst)
 // parallel framing semantics (coder.cpp:159-240): every sub-block is coded with outputSize = its own size
 static void host_encode_sub(BlockJob& J, int b)
 {
-    J.scratch[b].reset(new uint8_t[(size_t)J.size[b] + 64]);
+    const size_t need = (size_t)J.size[b] + 64;
+    if (J.scratch_cap[b] < need) { J.scratch[b].reset(new uint8_t[need + need / 8]); J.scratch_cap[b] = need + need / 8; }
     const int r = qlfc_encode_runs(J.views[b], J.size[b], J.scratch[b].get(), J.size[b], J.coder, true);
     J.sub_res[b] = (r < 0) ? J.size[b] : r;
 }
@@ -383,7 +385,6 @@ static void host_finalize_parallel(BlockJob& J)
         }
         write_header_and_trailer(J, total);
     }
-    for (int b = 0; b < nb; ++b) J.scratch[b].reset();
 }
 
 // every block with more than one sub-block is coded as independent per-sub-block tasks, whatever the caller's
@@ -424,7 +425,7 @@ static void host_finalize_serial(BlockJob& J)
         if (J.sub_res[b] == J.size[b] && optr + J.size[b] >= n) { incompressible = true; break; }       // coder.cpp:131-134
         optr += J.sub_res[b];
     }
-    if (!exact) { for (int b = 0; b < nb; ++b) J.scratch[b].reset(); host_code_serially(J); return; }
+    if (!exact) { host_code_serially(J); return; }
     if (incompressible) write_header_and_trailer(J, LIBBSC_NOT_COMPRESSIBLE);
     else {
         out[0] = (uint8_t)nb;
@@ -438,7 +439,6 @@ static void host_finalize_serial(BlockJob& J)
         }
         write_header_and_trailer(J, optr);
     }
-    for (int b = 0; b < nb; ++b) J.scratch[b].reset();
 }
 
 static void host_finalize(BlockJob& J)

@@ -395,6 +395,23 @@ struct DirectPolicy {
     template <int CLS> __attribute__((always_inline)) inline void decide(unsigned bit, short& st, short& ch, short& sp, Mixer* mx) { bschost::decide<CLS, ADAPT>(rc, T, bit, st, ch, sp, mx); }
 };
 
+// Encoder model storage is kept per thread and re-initialised per sub-block: a fresh 3.5 MB allocation per sub-block costs
+// page faults and kernel zeroing on top of the fill (the coder threads run under a CPU-time quota; every core-ms counts).
+static Counters1* tl_counters()
+{
+    static thread_local std::unique_ptr<Counters1> k;
+    if (!k) k.reset(new Counters1);
+    fill_shorts(k.get(), sizeof(Counters1), 2048);
+    return k.get();
+}
+static Mixers1* tl_mixers(const QlfcTables& T)
+{
+    static thread_local std::unique_ptr<Mixers1> m;
+    if (!m) m.reset(new Mixers1);
+    Mixer* all = reinterpret_cast<Mixer*>(m.get());
+    for (size_t i = 0; i < sizeof(Mixers1) / sizeof(Mixer); ++i) all[i].init(T);
+    return m.get();
+}
 static Counters1* new_counters()
 {
     Counters1* k = new Counters1;
@@ -406,19 +423,14 @@ template <bool ADAPT>
 static int encode_model1(const RunView& R, uint8_t* out, int in_size, int out_size)
 {
     const QlfcTables& T = qlfc_tables();
-    std::unique_ptr<Counters1> Cn(new_counters());
-    std::unique_ptr<Mixers1> Mx;
-    if (ADAPT) {
-        Mx.reset(new Mixers1);
-        Mixer* all = reinterpret_cast<Mixer*>(Mx.get());
-        for (size_t i = 0; i < sizeof(Mixers1) / sizeof(Mixer); ++i) all[i].init(T);
-    }
+    Counters1* Cn = tl_counters();
+    Mixers1* Mx = ADAPT ? tl_mixers(T) : nullptr;
     RangeEncoder rc;
     rc.init(out, out_size);
     rc.encode_word((uint32_t)in_size);
     const int max_rank = encode_alphabet(R, [&](unsigned b) { rc.encode_half(b); });
     DirectPolicy<ADAPT> pol{rc, T};
-    if (!walk_model1<ADAPT>(R, T, max_rank, *Cn, Mx.get(), pol)) return NOT_COMPRESSIBLE;
+    if (!walk_model1<ADAPT>(R, T, max_rank, *Cn, Mx, pol)) return NOT_COMPRESSIBLE;
     return rc.finish();
 }
 

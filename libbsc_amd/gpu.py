@@ -109,8 +109,8 @@ class GpuContext:
         rc = self._check(self.L.bscgpu_compress_device(self.h, _dptr(dInput), N.np_ptr(out), n, sorter, coder, features))
         return out[:rc]
 
-    def pipe(self, depth=2):
-        return Pipe(self, depth)
+    def pipe(self, depth=2, reuse_outputs=False):
+        return Pipe(self, depth, reuse_outputs)
 
     # ---- profiling ---------------------------------------------------------------------------
     def profile(self, on=True):
@@ -141,7 +141,12 @@ class Pipe:
     """Several blocks in flight on one GPU (bscgpu_pipe_*): submit() runs the GPU stage, the host coder of that
     block runs on worker threads while the next block is sorted."""
 
-    def __init__(self, ctx, depth=2):
+    def __init__(self, ctx, depth=2, reuse_outputs=False):
+        # reuse_outputs: wait() returns a view into one of `depth` recycled output buffers, valid until `depth` further
+        # submits (no 64 MiB allocation and no page faults per block); default: a fresh array per block
+        self.reuse = reuse_outputs
+        self._pool = {}
+        self._seq = 0
         self.ctx = ctx
         self.L = ctx.L
         h = C.c_void_p()
@@ -150,8 +155,18 @@ class Pipe:
         self.depth = depth
         self._out = {}
 
+    def _new_out(self, n):
+        if not self.reuse:
+            return np.empty(n + 28, np.uint8)
+        k = self._seq % self.depth
+        self._seq += 1
+        buf = self._pool.get(k)
+        if buf is None or buf.size < n + 28:
+            buf = self._pool[k] = np.empty(n + 28, np.uint8)
+        return buf[:n + 28]
+
     def submit(self, dInput, n, sorter=1, coder=1, features=3):
-        out = np.empty(n + 28, np.uint8)
+        out = self._new_out(n)
         t = self.ctx._check(self.L.bscgpu_pipe_submit(self.h, _dptr(dInput), N.np_ptr(out), n, sorter, coder, features))
         self._out[t] = (out, dInput)          # keep both alive until wait()
         return t
@@ -159,7 +174,7 @@ class Pipe:
     def submit_host(self, data, sorter=1, coder=1, lzp_hash=0, lzp_min=0, features=3):
         """Host-resident block (np.uint8) with bsc_compress's full parameter list, LZP included."""
         a = np.ascontiguousarray(data, dtype=np.uint8)
-        out = np.empty(a.size + 28, np.uint8)
+        out = self._new_out(a.size)
         t = self.ctx._check(self.L.bscgpu_pipe_submit_host(self.h, N.np_ptr(a), N.np_ptr(out), a.size, lzp_hash, lzp_min,
                                                             sorter, coder, features))
         self._out[t] = (out, a)
