@@ -13,6 +13,7 @@
 #include <atomic>
 #include <type_traits>
 #include <emmintrin.h>
+#include <tmmintrin.h>
 #include <thread>
 
 #include "qlfc_data.inc"
@@ -195,6 +196,21 @@ static void fill_shorts(void* p, size_t bytes, short v)
     std::fill(s, s + bytes / 2, v);
 }
 
+// Per class and per coded bit: {target, rate << 4, sign} for the three counters [char, state, pos].  With s = +1 for a
+// 0 bit (move up towards 4096 - th0) and s = -1 for a 1 bit (move down towards th1) both updates are
+//     p += s * (((tgt - p) * s * rate) >> 12),
+// i.e. psignw / pmulhw / psignw: one multiply instead of computing both directions and selecting.
+struct alignas(16) StepTable { short lr[8]; short tgt[2][8]; short ar[2][8]; short sgn[2][8]; };
+template <bool ADAPT, int CLS> struct StepConst {
+    static constexpr const short* P = ADAPT ? kAdaptiveParams[CLS] : kStaticParams[CLS];
+    static constexpr StepTable value = {
+        {P[16], P[17], P[18], 0, 0, 0, 0, 0},
+        {{(short)(4096 - P[4]), (short)(4096 - P[0]), (short)(4096 - P[8]), 0, 0, 0, 0, 0}, {P[6], P[2], P[10], 0, 0, 0, 0, 0}},
+        {{(short)(P[5] << 4), (short)(P[1] << 4), (short)(P[9] << 4), 0, 0, 0, 0, 0}, {(short)(P[7] << 4), (short)(P[3] << 4), (short)(P[11] << 4), 0, 0, 0, 0, 0}},
+        {{1, 1, 1, 1, 1, 1, 1, 1}, {-1, -1, -1, -1, -1, -1, -1, -1}}};
+};
+template <bool ADAPT, int CLS> constexpr StepTable StepConst<ADAPT, CLS>::value;
+
 // One binary decision of class CLS: three counters (+ mixer), update, code.
 //
 // Static coder: the three counters are handled as one SSE vector [char, state, pos]: pmaddwd forms the weighted
@@ -203,20 +219,22 @@ static void fill_shorts(void* p, size_t bytes, short v)
 template <int CLS, bool ADAPT = false>
 static BSC_ALWAYS_INLINE int static_step(unsigned bit, short& st, short& ch, short& sp)
 {
-    constexpr const short* P = ADAPT ? kAdaptiveParams[CLS] : kStaticParams[CLS];
+    constexpr const StepTable& P = StepConst<ADAPT, CLS>::value;
     __m128i v = _mm_cvtsi32_si128((int)((uint32_t)(uint16_t)ch | ((uint32_t)(uint16_t)st << 16)));
     v = _mm_insert_epi16(v, sp, 2);                                           // [ch, st, sp, 0, ...]
-    const __m128i lr = _mm_setr_epi16(P[16], P[17], P[18], 0, 0, 0, 0, 0);
-    const __m128i m  = _mm_madd_epi16(v, lr);                                 // [ch*LR0 + st*LR1, sp*LR2, 0, 0]
+    const __m128i m  = _mm_madd_epi16(v, *reinterpret_cast<const __m128i*>(P.lr));     // [ch*LR0 + st*LR1, sp*LR2, 0, 0]
     const int p = (_mm_cvtsi128_si32(m) + _mm_cvtsi128_si32(_mm_srli_si128(m, 4))) >> 5;
-    const __m128i tgt0 = _mm_setr_epi16((short)(4096 - P[4]), (short)(4096 - P[0]), (short)(4096 - P[8]), 0, 0, 0, 0, 0);
-    const __m128i ar0  = _mm_setr_epi16((short)(P[5] << 4), (short)(P[1] << 4), (short)(P[9] << 4), 0, 0, 0, 0, 0);
-    const __m128i tgt1 = _mm_setr_epi16(P[6], P[2], P[10], 0, 0, 0, 0, 0);
-    const __m128i ar1  = _mm_setr_epi16((short)(P[7] << 4), (short)(P[3] << 4), (short)(P[11] << 4), 0, 0, 0, 0, 0);
-    const __m128i up   = _mm_add_epi16(v, _mm_mulhi_epi16(_mm_sub_epi16(tgt0, v), ar0));   // bit 0
-    const __m128i down = _mm_sub_epi16(v, _mm_mulhi_epi16(_mm_sub_epi16(v, tgt1), ar1));   // bit 1
-    const __m128i sel  = _mm_set1_epi16((short)(0 - (int)bit));
-    const __m128i nv   = _mm_or_si128(_mm_and_si128(sel, down), _mm_andnot_si128(sel, up));
+    __m128i nv;
+    if (!ADAPT) {       // one multiply, parameters picked by the bit (measured on the EPYC 9575F: static coder -2.5 %)
+        const __m128i sg = *reinterpret_cast<const __m128i*>(P.sgn[bit]);
+        const __m128i d  = _mm_sign_epi16(_mm_sub_epi16(*reinterpret_cast<const __m128i*>(P.tgt[bit]), v), sg);      // bit 0: tgt0 - v;  bit 1: v - tgt1
+        nv = _mm_add_epi16(v, _mm_sign_epi16(_mm_mulhi_epi16(d, *reinterpret_cast<const __m128i*>(P.ar[bit])), sg));
+    } else {            // both directions, then select (faster next to the mixer's scalar work: adaptive coder +5 % otherwise)
+        const __m128i up   = _mm_add_epi16(v, _mm_mulhi_epi16(_mm_sub_epi16(*reinterpret_cast<const __m128i*>(P.tgt[0]), v), *reinterpret_cast<const __m128i*>(P.ar[0])));
+        const __m128i down = _mm_sub_epi16(v, _mm_mulhi_epi16(_mm_sub_epi16(v, *reinterpret_cast<const __m128i*>(P.tgt[1])), *reinterpret_cast<const __m128i*>(P.ar[1])));
+        const __m128i sel  = _mm_set1_epi16((short)(0 - (int)bit));
+        nv = _mm_or_si128(_mm_and_si128(sel, down), _mm_andnot_si128(sel, up));
+    }
     const uint32_t lo = (uint32_t)_mm_cvtsi128_si32(nv);
     ch = (short)(lo & 0xffffu); st = (short)(lo >> 16); sp = (short)_mm_extract_epi16(nv, 2);
     return p;
