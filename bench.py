@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--block", type=int, default=BLOCK)
     ap.add_argument("--sorter", type=int, default=1)
     ap.add_argument("--coder", type=int, default=1)
-    ap.add_argument("--depth", type=int, default=4, help="blocks in flight per GPU; their sub-blocks feed a pool of 16 coder threads per GPU")
+    ap.add_argument("--depth", type=int, default=0, help="blocks in flight per GPU (0 = from the coder pool size); their sub-blocks feed the pool of coder threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -62,6 +62,14 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # host-thread budget of this rank: its share of the CPUs the job may use (affinity and cgroup quota); the native default is
+    # "all of them", which is right for one rank per box
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if "BSCGPU_HOST_THREADS" not in os.environ:
+        os.environ["BSCGPU_HOST_THREADS"] = str(max(4, min(64, effective_cpus() // max(local_world, 1))))
+    coder_threads = int(os.environ["BSCGPU_HOST_THREADS"])
+    if args.depth <= 0:                                 # enough sub-block tasks in flight for the pool: 8 per block
+        args.depth = max(4, min(8, -(-3 * coder_threads // 16)))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
@@ -160,7 +168,7 @@ def main():
             "config": {"workload": f"{world} x {n >> 20} MiB synth-text-v1 block(s) per step (seed {'2' if world == 1 else '10..'+str(9+world)}), "
                                    f"bsc_compress(lzp off, sorter={args.sorter}, coder={args.coder}); input resident in HBM; "
                                    "Adler-32 + BWT + QLFC run/rank front end on GPU, QLFC modelling + range coding on host threads (one per sub-block, 8 per block), "
-                                   f"{args.depth} block(s) in flight per GPU feeding a pool of 16 coder threads; output bit-identical to reference libbsc",
+                                   f"{args.depth} block(s) in flight per GPU feeding a pool of {coder_threads} coder threads; output bit-identical to reference libbsc",
                        "block_bytes": n, "blocks_per_step": world, "sorter": "BWT" if args.sorter == 1 else f"ST{args.sorter}",
                        "coder": {1: "QLFC static (-e1)", 2: "QLFC adaptive (-e2)", 3: "QLFC fast (-e0)"}[args.coder],
                        "parallelism": f"block-parallel x{world}", "compressed_bytes_rank0": int(blk.size)},
@@ -171,7 +179,7 @@ def main():
                                   "doubling_rounds": stage[5] / args.steps, "pipeline_depth": args.depth},
             "sorter_only_MBps": round(n / 1e6 / max(stage[1] / args.steps / 1e3, 1e-9), 1),
             "kernels": per_kernel,
-            "host": {"cpus": os.cpu_count(), "effective_cpus": effective_cpus(), "coder_threads_per_gpu": int(os.environ.get("BSCGPU_HOST_THREADS", "16"))},
+            "host": {"cpus": os.cpu_count(), "effective_cpus": effective_cpus(), "coder_threads_per_gpu": coder_threads},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(host_in, args.sorter, args.coder)

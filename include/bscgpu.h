@@ -83,7 +83,8 @@ BSCGPU_API int bscgpu_compress_device(bscgpu_ctx* ctx, const void* dInput, uint8
  * (QLFC modelling + range coding on 8 threads, container) to a worker, so block i+1 sorts while block i is coded.
  * dInput and output must stay valid until wait() returns for that ticket.  wait() returns what
  * bscgpu_compress_device would have returned.  One submitting thread per pipe.  The host work is queued as
- * per-sub-block tasks for a pool of 16 coder threads per pipe (BSCGPU_HOST_THREADS overrides), so depth 3 keeps those
+ * per-sub-block tasks for a pool of coder threads per pipe (default: the CPUs the process may use — affinity and cgroup
+ * quota — clamped to 4..64; BSCGPU_HOST_THREADS overrides), so a depth of 3-4 keeps those
  * threads and the GPU busy. */
 typedef struct bscgpu_pipe bscgpu_pipe;
 BSCGPU_API int  bscgpu_pipe_create(bscgpu_ctx* ctx, int depth, bscgpu_pipe** out);

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <utility>
 
+#include <sched.h>
 #include <hip/hip_runtime.h>
 
 #include "../../../include/libbsc.h"
@@ -566,6 +567,26 @@ int bscgpu_compress_device(bscgpu_ctx* c, const void* dInput, uint8_t* output, i
     return J->result;
 }
 
+// CPUs this process can actually use: min(affinity mask, cgroup v2 cpu.max quota), clamped to [4, 64].  The coder pool of a
+// pipe defaults to this (a multi-rank driver divides it between its ranks through BSCGPU_HOST_THREADS).
+static int default_coder_threads()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = c; }
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; long long period = 0;
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long long quota = atoll(q);
+            if (quota > 0) { const int c = (int)(quota / period); if (c >= 1 && c < n) n = c; }
+        }
+        fclose(f);
+    }
+    if (n < 4) n = 4;
+    if (n > 64) n = 64;
+    return n;
+}
+
 // ---- pipe: several blocks in flight -------------------------------------------------------------------------
 // submit() runs the GPU stage on the calling thread and queues the block's host work as per-sub-block tasks; a fixed
 // pool of worker threads (16 by default = the per-GPU host budget) drains the FIFO queue, so the coder threads stay
@@ -620,7 +641,7 @@ int bscgpu_pipe_create(bscgpu_ctx* c, int depth, bscgpu_pipe** out)
     if (rc < 0) return rc;
     bscgpu_pipe* p = new bscgpu_pipe;
     p->c = c; p->depth = depth;
-    int nworkers = 16;                                  // host-thread budget per GPU (two blocks' worth of sub-blocks)
+    int nworkers = default_coder_threads();             // the CPUs this process may use (affinity and cgroup quota)
     if (const char* e = getenv("BSCGPU_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) nworkers = v; }
     for (int i = 0; i < depth; ++i) p->lanes[i].job.reset(new BlockJob);
     for (int i = 0; i < nworkers; ++i) p->workers.emplace_back([p] { p->worker_loop(); });
