@@ -81,16 +81,19 @@ def main():
     d_in = torch.from_numpy(host_in).to(dev)
     ctx = GpuContext(local, max_n=n + 4096)
 
-    gather_buf = torch.empty(n + 64, dtype=torch.uint8, device=comm_dev)
+    # rank 0 receives world - 1 compressed blocks per round into one staging tensor; the others stage one block
+    gather_buf = torch.empty((n + 64) * (max(world - 1, 1) if rank == 0 else 1), dtype=torch.uint8, device=comm_dev)
 
-    from libbsc_amd.multigpu import gather_blocks_to_rank0
+    from libbsc_amd.multigpu import Concatenator
     pipe = ctx.pipe(args.depth, reuse_outputs=True)        # compressed blocks land in recycled host buffers
     stage = np.zeros(6)
 
+    concat = None
+
     def finish(ticket):
         blk = pipe.wait(ticket)
-        if world > 1:       # final concatenation on rank 0 over RCCL / xGMI (sizes all_gather + send/recv)
-            gather_blocks_to_rank0(blk, rank, world, comm_dev, staging=gather_buf)
+        if concat is not None:      # final concatenation on rank 0 over RCCL / xGMI, on a background thread per rank
+            concat.put(blk)
         return blk
 
     def run(steps, record=False):
@@ -112,12 +115,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        concat = Concatenator(rank, world, comm_dev, staging=gather_buf)
     blk = run(args.warmup)
+    if concat is not None:
+        concat.close()
+        concat = Concatenator(rank, world, comm_dev, staging=gather_buf)
     ctx.profile(True)
     ctx.profile_reset()
     sync()
     t0 = time.perf_counter()
     blk = run(args.steps, record=True)
+    if concat is not None:
+        concat.close()                                  # every block of the timed region has reached rank 0's host memory
     sync()
     dt = time.perf_counter() - t0
     if world > 1:

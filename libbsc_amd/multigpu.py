@@ -18,34 +18,88 @@ def assign_blocks(num_blocks: int, world: int) -> List[List[int]]:
 
 def gather_blocks_to_rank0(payload: np.ndarray, rank: int, world: int, device, staging=None) -> Optional[List[np.ndarray]]:
     """Every rank contributes one compressed block (np.uint8).  Rank 0 returns them (np.uint8 arrays) in rank order
-    (= block order for one block per rank), other ranks return None."""
+    (= block order for one block per rank), other ranks return None.
+    One all_gather of the sizes, then the peers' payloads arrive concurrently (all receives are posted before the first
+    wait; xGMI is point to point, so the seven links of rank 0 work in parallel) into one staging tensor that is copied to
+    the host once."""
     import torch
     import torch.distributed as dist
     if world == 1:
         return [payload]
     n = int(payload.size)
-    size_t = torch.tensor([n], dtype=torch.int64, device=device)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(sizes, size_t)
-    sizes = [int(s.item()) for s in sizes]
-    if staging is not None and staging.numel() >= n:
-        buf = staging[:n]
-        buf.copy_(torch.from_numpy(payload))
-    else:
-        buf = torch.from_numpy(payload).to(device)
+    mine = torch.tensor([n], dtype=torch.int64, device=device)
+    allsz = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(allsz, mine)
+    sizes = [int(x) for x in allsz.tolist()]
     if rank != 0:
+        if staging is not None and staging.numel() >= n:
+            buf = staging[:n]
+            buf.copy_(torch.from_numpy(payload))
+        else:
+            buf = torch.from_numpy(payload).to(device)
         dist.send(buf, dst=0)
         return None
-    parts = [payload]
-    reqs = []
-    recv = []
+    total = sum(sizes[1:])
+    if staging is not None and staging.numel() >= total:
+        big = staging[:total]
+    else:
+        big = torch.empty(total, dtype=torch.uint8, device=device)
+    reqs, off = [], 0
     for r in range(1, world):
-        t = torch.empty(sizes[r], dtype=torch.uint8, device=device)
-        reqs.append(dist.irecv(t, src=r))
-        recv.append(t)
+        reqs.append(dist.irecv(big[off:off + sizes[r]], src=r))
+        off += sizes[r]
     for q in reqs:
         q.wait()
-    return parts + [t.cpu().numpy() for t in recv]
+    host = big.cpu().numpy()
+    parts, off = [payload], 0
+    for r in range(1, world):
+        parts.append(host[off:off + sizes[r]])
+        off += sizes[r]
+    return parts
+
+
+class Concatenator:
+    """The final concatenation as a background stage: every rank hands over its finished blocks in order, a thread per rank
+    runs gather_blocks_to_rank0 for them, so the collective and the D2H on rank 0 overlap the next blocks' GPU and host work
+    instead of stalling the submitting thread.  All ranks must put() the same number of blocks."""
+
+    def __init__(self, rank: int, world: int, device, staging=None, keep: bool = False):
+        import queue
+        import threading
+        self.rank, self.world, self.device, self.staging, self.keep = rank, world, device, staging, keep
+        self.q = queue.Queue()
+        self.blocks: List[List[np.ndarray]] = []        # rank 0 with keep=True: the gathered blocks of every round
+        self.bytes = 0
+        self.err = None
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _run(self):
+        if getattr(self.device, "type", "cpu") == "cuda":       # the current device is per thread
+            import torch
+            torch.cuda.set_device(self.device)
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            try:
+                got = gather_blocks_to_rank0(item, self.rank, self.world, self.device, staging=self.staging)
+                if got is not None:
+                    self.bytes += sum(int(g.size) for g in got)
+                    if self.keep:
+                        self.blocks.append([np.array(g, copy=True) for g in got])
+            except Exception as e:  # surfaced by close()
+                self.err = e
+                return
+
+    def put(self, payload: np.ndarray):
+        self.q.put(np.array(payload, copy=True))        # the caller may recycle its buffer
+
+    def close(self):
+        self.q.put(None)
+        self.t.join()
+        if self.err is not None:
+            raise self.err
 
 
 def bsc_file_image(blocks, block_offsets: List[int]) -> bytes:

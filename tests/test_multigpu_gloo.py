@@ -23,6 +23,17 @@ def _worker(rank, world, port, q):
     rng = np.random.default_rng(100 + rank)
     payload = rng.integers(0, 256, 1000 + 777 * rank, dtype=np.uint8)      # ragged sizes
     got = gather_blocks_to_rank0(payload, rank, world, torch.device("cpu"))
+    # the background concatenation stage used by bench.py: three rounds of ragged blocks
+    from libbsc_amd.multigpu import Concatenator
+    cat = Concatenator(rank, world, torch.device("cpu"), keep=True)
+    for rnd in range(3):
+        cat.put(np.random.default_rng(1000 * rnd + rank).integers(0, 256, 500 + 300 * rank + rnd, dtype=np.uint8))
+    cat.close()
+    if rank == 0:
+        for rnd in range(3):
+            for r in range(world):
+                want = np.random.default_rng(1000 * rnd + r).integers(0, 256, 500 + 300 * r + rnd, dtype=np.uint8)
+                assert np.array_equal(cat.blocks[rnd][r], want), (rnd, r)
     # timing reduction used by bench.py: max over ranks
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
