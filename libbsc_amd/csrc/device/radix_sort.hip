@@ -26,12 +26,13 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Streamed-once inputs are read with non-temporal loads in rs_hist and rs_scatter (+10-20 %: they stop evicting the
+// partially written output lines from L2); non-temporal *stores* were measured 20-50 % slower and are not used.
 #ifndef RS_NT
-#define RS_NT 5      // bit0: non-temporal loads (+10-20 %: the streamed-once input stops evicting the partially
-                     // written output lines from L2), bit1: non-temporal stores (measured 20-50 % SLOWER), bit2: nt loads in rs_hist
+#define RS_NT 5      // bit2: nt loads in rs_hist (A/B builds)
 #endif
 #ifndef RS_WG
-#define RS_WG 256      // measured: 512 threads / 8192-record tiles are 10-25 % slower (barrier stalls, spills)
+#define RS_WG 256      // shape for keys-only passes and small inputs (the second shape below serves large pair passes)
 #endif
 // Volatile accesses must keep the LDS address space: through a generic `volatile u32*` the compiler emits system-scope
 // FLAT loads/stores followed by s_waitcnt vmcnt(0) — every in-wave rank step would then drain all outstanding global
@@ -43,10 +44,6 @@
 typedef volatile u32 lds_vu32;
 #else
 typedef __attribute__((address_space(3))) volatile u32 lds_vu32;
-#endif
-#ifndef RS_UNCOND
-#define RS_UNCOND 1            // no branch around any global load/store of rs_scatter (clamped loads, sink stores): lets the
-                               // compiler wait with exact vmcnt values instead of vmcnt(0); measured +0..12 % (A/B on one box)
 #endif
 #ifndef RS_WC_DEFAULT
 #define RS_WC_DEFAULT 0        // default of BSC_RS_WC (write-combining scatter for large inputs)
