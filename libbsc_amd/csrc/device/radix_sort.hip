@@ -13,14 +13,18 @@
 //    a decoupled-look-back chain ("onesweep") would serialise on that latency.  The price is one
 //    extra streaming read of the keys per pass (8 B/record, rs_hist); the scatter pass itself moves
 //    exactly the algorithmic 2*(8+4) B/record.
-//  * <= 1024 chunks (one workgroup each, 4 per CU, all resident; block b runs on XCD b % 8 so every
-//    XCD streams an equal contiguous share).  A workgroup walks its chunk tile by tile (4096 records)
-//    keeping its 256 running global bucket offsets in LDS, so the per-chunk offsets table is only
-//    256 x 1024 u32.
+//  * <= 1024 chunks for rs_hist (one 256-thread workgroup each, 4 per CU, all resident; block b runs on XCD b % 8 so
+//    every XCD streams an equal contiguous share).  rs_scatter comes in two shapes: 256 threads x 16 records (4096-
+//    record tiles, one chunk per workgroup) for keys-only passes and small inputs, and 1024 threads x 8 records
+//    (8192-record tiles, one workgroup per CU walking four chunks) for large (key, value) passes, where the longer
+//    per-digit runs halve the number of partially written lines.  A workgroup walks its records tile by tile keeping
+//    its 256 running global bucket offsets in LDS, so the per-chunk offsets table is only 256 x 1024 u32.
+//  * rs_scatter_wc (opt-in, BSC_RS_WC=1) additionally keeps up to 31 pending records per digit in LDS and writes only
+//    whole aligned 32-record groups; see its header for why it is not the default.
 //  * Inside a tile: wave-striped coalesced loads (each wave64 load instruction covers 512 contiguous
 //    bytes of keys), 8-bit digit, stable in-wave ranking by wave64 ballot match (8 ballots -> peer
 //    mask, popcount of lower peers), per-wave 256-bin histograms in LDS, then the tile is locally
-//    reordered through LDS (32 KB staging) so that every bucket leaves as one contiguous run:
+//    reordered through LDS (32 / 64 KB staging) so that every bucket leaves as one contiguous run:
 //    consecutive lanes store consecutive addresses.  Integer/index work only — no MFMA.
 #include "dev_common.h"
 #include <cstdlib>
