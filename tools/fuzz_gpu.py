@@ -1,6 +1,6 @@
 """Randomised parity sweep on the GPU box: block sorters (index, aux indexes, bytes) and whole blocks against the compiled
 reference, sizes and contents drawn at random with emphasis on the engine's shape thresholds.
-    python tools/fuzz_gpu.py [seconds] [seed]"""
+    python tools/fuzz_gpu.py [seconds] [seed] [max block bytes]"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np
@@ -12,7 +12,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 ref = Ref()
-MAXN = 12 << 20
+MAXN = int(sys.argv[3]) if len(sys.argv) > 3 else (12 << 20)
 EDGES = [1 << 12, 1 << 16, 1 << 18, 1 << 20, 1 << 21, 1 << 22, (1 << 22) + (1 << 21), 1 << 23, 4096 * 1024, 8192 * 512, 8192 * 1024, 16384 * 256]
 
 def draw_n():
