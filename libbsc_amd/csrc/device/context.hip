@@ -54,6 +54,8 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BSC_GPU_NOT_SUPPORTED;
     if (device < 0 || device >= ndev) return BSC_BAD_PARAMETER;
     if (hipSetDevice(device) != hipSuccess) return BSC_GPU_ERROR;
+    // waits should sleep, not spin: the host CPUs belong to the entropy coder (BSCGPU_SPIN=1 keeps the runtime's default)
+    if (!getenv("BSCGPU_SPIN")) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
 
     bscgpu_ctx* c = new bscgpu_ctx();
     c->device = device;
