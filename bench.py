@@ -124,12 +124,14 @@ def main():
     ctx.profile(True)
     ctx.profile_reset()
     sync()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     blk = run(args.steps, record=True)
     if concat is not None:
         concat.close()                                  # every block of the timed region has reached rank 0's host memory
     sync()
     dt = time.perf_counter() - t0
+    cpu_used = time.process_time() - cpu0               # all threads of this rank
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -189,7 +191,9 @@ def main():
                                   "doubling_rounds": stage[5] / args.steps, "pipeline_depth": args.depth},
             "sorter_only_MBps": round(n / 1e6 / max(stage[1] / args.steps / 1e3, 1e-9), 1),
             "kernels": per_kernel,
-            "host": {"cpus": os.cpu_count(), "effective_cpus": effective_cpus(), "coder_threads_per_gpu": coder_threads},
+            "host": {"cpus": os.cpu_count(), "effective_cpus": effective_cpus(), "coder_threads_per_gpu": coder_threads,
+                     "cpu_seconds_per_block_rank0": round(cpu_used / args.steps, 3),
+                     "cpu_busy_fraction_of_effective": round(cpu_used / (dt * max(effective_cpus() / max(local_world, 1), 1)), 3)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(host_in, args.sorter, args.coder)
