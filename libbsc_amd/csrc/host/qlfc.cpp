@@ -280,7 +280,7 @@ static BSC_ALWAYS_INLINE void decide(RangeEncoder& rc, LiveT& L, const QlfcTable
     mx->w0 -= (P[16] * eps * s0) >> 16;
     mx->w1 -= (P[17] * eps * s1) >> 16;
     mx->w2 -= (P[18] * eps * s2) >> 16;
-    rc.encode<12>(bit, p);
+    rc.encode_live<12>(L, bit, p);
     }
 }
 
@@ -323,11 +323,10 @@ struct WalkState {
 // One run: all its binary decisions, in stream order.
 template <bool ADAPT, class Policy>
 static BSC_ALWAYS_INLINE void walk_step(WalkState& W, const RunView& R, const QlfcTables& T, const int max_rank, Counters1& K, Mixers1* M,
-                                        Policy& pol, const uint32_t j)
+                                        Policy& pol, typename Policy::Live& live, const uint32_t j)
 {
     int ctx_rank0 = W.ctx_rank0, ctx_rank4 = W.ctx_rank4, ctx_run = W.ctx_run, avg_rank = W.avg_rank;
     uint8_t* const rank_hist = W.rank_hist; uint8_t* const run_hist = W.run_hist;
-    typename Policy::Live live = pol.enter();
     {
         const int c = R.sym[j];
         int rank = R.rank[j];
@@ -411,7 +410,6 @@ static BSC_ALWAYS_INLINE void walk_step(WalkState& W, const RunView& R, const Ql
         ctx_rank4 = ((ctx_rank4 << 2) | (rank < 3 ? rank : 3)) & 0xff;
         ctx_run   = ((ctx_run   << 1) | (run < 3 ? 1 : 0)) & 0xf;
     }
-    pol.leave(live);
     W.ctx_rank0 = ctx_rank0; W.ctx_rank4 = ctx_rank4; W.ctx_run = ctx_run; W.avg_rank = avg_rank;
 }
 
@@ -420,24 +418,24 @@ static bool walk_model1(const RunView& R, const QlfcTables& T, const int max_ran
 {
     WalkState W;
     const uint32_t m = R.count;
+    typename Policy::Live live = pol.enter();           // coder state that lives in registers for the whole stream
     for (uint32_t j = 0; j < m; ++j) {
-        if (!pol.begin_run()) return false;
-        walk_step<ADAPT>(W, R, T, max_rank, K, M, pol, j);
+        if (!pol.begin_run()) { pol.leave(live); return false; }
+        walk_step<ADAPT>(W, R, T, max_rank, K, M, pol, live, j);
     }
+    pol.leave(live);
     return true;
 }
 
 template <bool ADAPT>
 struct DirectPolicy {
     RangeEncoder& rc; const QlfcTables& T;
-    // static coder: the range coder's two hot words live in registers for the duration of a run (measured -3.5 % per stream
-    // on the EPYC 9575F); adaptive coder: the mixer's scalar work wants those registers, the words stay in the object (+1.5 %
-    // otherwise)
-    struct NoLive {};
-    using Live = typename std::conditional<ADAPT, NoLive, RangeEncoder::Live>::type;
+    // the range coder's two hot words live in registers for the whole stream (static coder -3.5 % per stream on the EPYC 9575F,
+    // adaptive coder unchanged)
+    using Live = RangeEncoder::Live;
     inline bool begin_run() { return !rc.full(); }
-    __attribute__((always_inline)) inline Live enter() { if constexpr (ADAPT) return NoLive(); else return rc.enter(); }
-    __attribute__((always_inline)) inline void leave(const Live& L) { if constexpr (!ADAPT) rc.leave(L); }
+    __attribute__((always_inline)) inline Live enter() { return rc.enter(); }
+    __attribute__((always_inline)) inline void leave(const Live& L) { rc.leave(L); }
     template <int CLS> __attribute__((always_inline)) inline void decide(Live& L, unsigned bit, short& st, short& ch, short& sp, Mixer* mx) { bschost::decide<CLS, ADAPT>(rc, L, T, bit, st, ch, sp, mx); }
 };
 
