@@ -70,23 +70,40 @@ def compress_file(in_path, out_path, block_size=64 << 20, sorter=1, coder=1, dep
     n = data.size
     nblocks = (n + block_size - 1) // block_size if n else 0
     mine = assign_blocks(nblocks, world)[rank]
-    ctx = GpuContext(local, max_n=min(block_size, max(n, 1)) + 4096)
-    pipe = ctx.pipe(depth)
     done = {}
-    inflight = []
-    for b in mine:
-        lo = b * block_size
-        if lzp_hash or lzp_min:                      # LZP is host work: hand the pipe the host block
-            inflight.append((b, pipe.submit_host(data[lo:lo + block_size], sorter, coder, lzp_hash, lzp_min, 3)))
-        else:
+    if lzp_hash or lzp_min:
+        # LZP is host work in front of the GPU stage: compress the blocks from a few concurrent callers of the drop-in
+        # bsc_compress (what the reference CLI's OpenMP team does, bsc.cpp:197) — one caller's LZP and entropy coding overlap
+        # another's GPU stage
+        from concurrent.futures import ThreadPoolExecutor
+        from . import api
+        os.environ.setdefault("BSC_GPU_DEVICE", str(local))
+
+        def one(b):
+            lo = b * block_size
+            blk = api.bsc_compress(data[lo:lo + block_size], sorter, coder, lzp_hash=lzp_hash, lzp_min=lzp_min, features=3)
+            if isinstance(blk, int):
+                raise RuntimeError(f"bsc_compress failed on block {b}: {blk}")
+            return b, np.frombuffer(blk, np.uint8)
+
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            for b, blk in pool.map(one, mine):
+                done[b] = blk
+        ctx = None
+    else:
+        ctx = GpuContext(local, max_n=min(block_size, max(n, 1)) + 4096)
+        pipe = ctx.pipe(depth)
+        inflight = []
+        for b in mine:
+            lo = b * block_size
             d = torch.from_numpy(data[lo:lo + block_size]).to(dev)
             inflight.append((b, pipe.submit(d, d.numel(), sorter, coder, 3)))
-        if len(inflight) >= depth:
-            bb, t = inflight.pop(0)
+            if len(inflight) >= depth:
+                bb, t = inflight.pop(0)
+                done[bb] = pipe.wait(t)
+        for bb, t in inflight:
             done[bb] = pipe.wait(t)
-    for bb, t in inflight:
-        done[bb] = pipe.wait(t)
-    pipe.close()
+        pipe.close()
     # rounds of one block per rank: gather to rank 0 in block order
     ordered = []
     rounds = (nblocks + world - 1) // world
@@ -96,7 +113,8 @@ def compress_file(in_path, out_path, block_size=64 << 20, sorter=1, coder=1, dep
         got = gather_blocks_to_rank0(np.ascontiguousarray(payload), rank, world, dev)
         if rank == 0:
             ordered += [bytes(g) for g in got if len(g)]
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if rank == 0:
         img = bsc_file_image(ordered, [b * block_size for b in range(nblocks)])
         with open(out_path, "wb") as f:
