@@ -78,9 +78,10 @@ BSCGPU_API int bscgpu_radix_sort_u64(bscgpu_ctx* ctx, void* keys, void* keys_alt
 BSCGPU_API int bscgpu_compress_device(bscgpu_ctx* ctx, const void* dInput, uint8_t* output, int n,
                            int blockSorter, int coder, int features);
 
-/* Pipelined variant: up to `depth` (<= 4) blocks in flight on one GPU.  submit() runs the GPU stage of a block
+/* Pipelined variant: up to `depth` (<= 8) blocks in flight on one GPU.  submit() runs the GPU stage of a block
  * (Adler-32, sort transform, QLFC front end, D2H of the run arrays) on the calling thread and hands the host stage
- * (QLFC modelling + range coding on 8 threads, container) to a worker, so block i+1 sorts while block i is coded.
+ * (QLFC modelling + range coding, one task per sub-block; container) to the pipe's coder threads, so block i+1 sorts
+ * while blocks i, i-1, ... are coded.
  * dInput and output must stay valid until wait() returns for that ticket.  wait() returns what
  * bscgpu_compress_device would have returned.  One submitting thread per pipe.  The host work is queued as
  * per-sub-block tasks for a pool of coder threads per pipe (default: the CPUs the process may use — affinity and cgroup
