@@ -158,6 +158,28 @@ __global__ __launch_bounds__(256) void k_scatter_windowed(const u32* __restrict_
         for (u32 i = slot * 256 + threadIdx.x; i < win; i += wgs_per_xcd * 256) dst[idx[base + i]] = base + i;
     }
 }
+// agent-scope hand-off chain: hop h (owned by workgroup h % gridDim.x) waits for flag[h-1], then sets flag[h].  With
+// `load` > 0 the other waves of every workgroup stream-copy meanwhile.  Bounded spins: a stuck chain gives up, it cannot hang.
+__global__ __launch_bounds__(256) void k_handoff(u32* flag, u32 hops, const uint4* __restrict__ a, uint4* __restrict__ b, size_t n16, u32 load, u32* fail) {
+    if (threadIdx.x >= 64) {                          // waves 1..3: background streaming traffic
+        if (!load) return;
+        const u32 t = threadIdx.x - 64;
+        for (u32 rep = 0; rep < load; ++rep)
+            for (size_t i = (size_t)blockIdx.x * 192 + t; i < n16; i += (size_t)gridDim.x * 192) b[i] = a[i];
+        return;
+    }
+    if (threadIdx.x != 0) return;
+    for (u32 h = blockIdx.x; h < hops; h += gridDim.x) {
+        if (h > 0) {
+            u32 spins = 0;
+            while (__hip_atomic_load(&flag[h - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                if (++spins > (1u << 24)) { *fail = h; return; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __hip_atomic_store(&flag[h], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 template <class F> static float timeit(F f, int reps = 5) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     f(); CHECK(hipDeviceSynchronize());
@@ -214,6 +236,25 @@ int main() {
         printf("pairs 16-record runs misalign %u: 256 WG x 256 thr (1 WG/CU): %.3f ms -> %.0f GB/s\n", mis, ms, 24.0 * n / 1e6 / ms);
         ms = timeit([&] { hipLaunchKernelGGL(k_scatter_pairs_mis<256>, dim3(1024), dim3(256), 0, 0, ka, va, kb, vb, n, 16, mis, sink); });
         printf("pairs 16-record runs misalign %u: 1024 WG x 256 thr (4 WG/CU, frontier 8 MB/XCD): %.3f ms -> %.0f GB/s\n", mis, ms, 24.0 * n / 1e6 / ms);
+    }
+    {   // what a decoupled look-back chain would pay per hop between workgroups on different XCDs
+        const u32 hops = 8192; u32 *flag, *dfail; CHECK(hipMalloc(&flag, hops * 4)); CHECK(hipMalloc(&dfail, 4));
+        for (u32 load : {0u, 4u}) {
+            float best = 1e9; u32 hf = 0;
+            for (int r = 0; r < 3; ++r) {
+                CHECK(hipMemset(flag, 0, hops * 4)); CHECK(hipMemset(dfail, 0, 4)); CHECK(hipDeviceSynchronize());
+                hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+                CHECK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k_handoff, dim3(256), dim3(256), 0, 0, flag, hops, (const uint4*)ka, (uint4*)kb, n16, load, dfail);
+                CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+                float t; CHECK(hipEventElapsedTime(&t, e0, e1)); if (t < best) best = t;
+                CHECK(hipMemcpy(&hf, dfail, 4, hipMemcpyDeviceToHost));
+            }
+            float copy_ms = 0;
+            if (load) copy_ms = timeit([&] { hipLaunchKernelGGL(k_handoff, dim3(256), dim3(256), 0, 0, flag, 0u, (const uint4*)ka, (uint4*)kb, n16, load, dfail); });
+            printf("hand-off chain, %u hops over 256 workgroups (8 XCDs), %s: %.3f ms total -> %.2f us per hop%s (copy alone %.3f ms)\n",
+                   hops, load ? "under streaming load" : "idle machine", best, (best - copy_ms > 0 && load ? best : best) * 1e3 / hops, hf ? " [chain gave up]" : "", copy_ms);
+        }
     }
     {   // idx: a random permutation (host-built), and one that only permutes inside windows
         std::vector<u32> h(n);
