@@ -116,3 +116,31 @@ def test_bwt_decode_with_aux_indexes(ref):
             assert api.bsc_bwt_decode(L, idx, bad)[1] == api.DATA_CORRUPT
             back, rc = api.bsc_bwt_decode(L, idx, aux[:-1])          # wrong count: ignored
             assert rc == 0 and np.array_equal(back, T)
+
+
+def test_decompress_survives_corrupt_streams(ref):
+    """Blocks whose payload was damaged and whose checksums were then repaired reach the QLFC decoders, the inverse
+    transforms and the LZP decoder with garbage: every one must come back as an error code (or, by luck, the right data),
+    never as a crash or an overrun — all decoders here are bounded by the sizes the block header announces."""
+    import struct
+    from libbsc_amd.synth import synth_repeat_v1, synth_text_v1
+    rng = np.random.default_rng(77)
+    blocks = [(T, ref.compress(T, so, co, lzp_hash=lz[0], lzp_min=lz[1])) for T, so, co, lz in
+              [(synth_text_v1(3, 200_000), 1, 1, (0, 0)), (synth_text_v1(4, 70_000), 1, 2, (0, 0)),
+               (synth_text_v1(5, 300_000), 5, 3, (0, 0)), (synth_repeat_v1(6, 400_000, 7000), 1, 1, (15, 32)),
+               (synth_text_v1(7, 2000), 1, 1, (0, 0))]]
+    for it in range(150):
+        T, blk = blocks[it % len(blocks)]
+        b = bytearray(blk)
+        for _ in range(int(rng.integers(1, 4))):
+            mode = int(rng.integers(0, 4)); pos = int(rng.integers(0, len(b)))
+            if mode == 0: b[pos] ^= 1 << int(rng.integers(0, 8))
+            elif mode == 1: b[pos] = int(rng.integers(0, 256))
+            elif mode == 2 and len(b) > 40: del b[pos]
+            else: b.insert(pos, int(rng.integers(0, 256)))
+        if rng.integers(0, 4):
+            b[0:4] = struct.pack("<i", len(b))
+        b[20:24] = struct.pack("<I", api.bsc_adler32(np.frombuffer(bytes(b[28:]), np.uint8)))
+        b[24:28] = struct.pack("<I", api.bsc_adler32(np.frombuffer(bytes(b[:24]), np.uint8)))
+        r = api.bsc_decompress(bytes(b))
+        assert isinstance(r, int) and r < 0 or r == T.tobytes(), it
