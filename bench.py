@@ -33,8 +33,8 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 T
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--block", type=int, default=BLOCK)
     ap.add_argument("--sorter", type=int, default=1)
     ap.add_argument("--coder", type=int, default=1)
