@@ -50,8 +50,20 @@ def _deps_hash(src):
     for f in sorted(set(files)):
         with open(f, "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
-    h.update(" ".join(COMMON + DEVFLAGS).encode())
+    h.update(" ".join(_command(src, "OBJ")).encode())       # the full per-source command line: host-only flags included
     return h.hexdigest()
+
+
+def _command(src, obj):
+    cmd = [HIPCC] + COMMON
+    if src.endswith(".hip"):
+        cmd += DEVFLAGS
+    else:
+        # host-only translation units: plain C++ through hipcc's clang (HIP runtime API headers only)
+        # x86-64-v3 (AVX2/BMI2/LZCNT): same ISA floor as the reference's own makefile (-mavx2, makefile:20)
+        # tuned (scheduling only, the ISA stays x86-64-v3) for the EPYC hosts MI355X boxes ship with: static coder -2.5 % per stream
+        cmd += ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROCM, "include"), "-march=x86-64-v3", "-mtune=znver4"]
+    return cmd + ["-c", src, "-o", obj]
 
 
 def _compile(src, force):
@@ -61,15 +73,7 @@ def _compile(src, force):
     want = _deps_hash(src)
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
         return obj, False
-    cmd = [HIPCC] + COMMON
-    if src.endswith(".hip"):
-        cmd += DEVFLAGS
-    else:
-        # host-only translation units: plain C++ through hipcc's clang (HIP runtime API headers only)
-        # x86-64-v3 (AVX2/BMI2/LZCNT): same ISA floor as the reference's own makefile (-mavx2, makefile:20)
-        # tuned (scheduling only, the ISA stays x86-64-v3) for the EPYC hosts MI355X boxes ship with: static coder -2.5 % per stream
-        cmd += ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROCM, "include"), "-march=x86-64-v3", "-mtune=znver4"]
-    cmd += ["-c", src, "-o", obj]
+    cmd = _command(src, obj)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("compile failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)

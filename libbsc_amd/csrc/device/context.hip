@@ -100,6 +100,7 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
            && hipHostMalloc((void**)&c->hsplit, N / 256 + 64, hipHostMallocDefault) == hipSuccess
            && ctx_ensure_slots(c, 1) == BSC_NO_ERROR;
     if (!ok || ctx_sync(c) != hipSuccess) { bscgpu_destroy(c); return BSC_GPU_NOT_ENOUGH_MEMORY; }
+    if (radix_engine_setup(c) != BSC_NO_ERROR) { bscgpu_destroy(c); return BSC_GPU_ERROR; }
     *out = c;
     return BSC_NO_ERROR;
 }

@@ -94,6 +94,7 @@ struct bscgpu_ctx {
     u64* hsplit = nullptr;   // pinned: split-flag words (max_n / 256 + 64 bytes)
     HostSlot slots[MAX_SLOTS];   // pinned landing zones for the QLFC front end; >1 when blocks are pipelined
     int      nslots = 0;
+    int      rs_wc_mode = 0;     // BSC_RS_WC as read at context creation (radix_engine_setup)
 
     // profiling
     bool         prof        = false;
@@ -125,6 +126,8 @@ struct RadixPass { int shift; int bits; };
 // passes is even, else in (keys_alt, vals_alt); *in_alt tells which.
 int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* vals_alt, u64 n,
                       const RadixPass* passes, int npasses, int* in_alt);
+
+int radix_engine_setup(bscgpu_ctx* c);     // per-device kernel attributes; bscgpu_create calls it with c->device current
 
 int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n, int64_t r, u32* I_host,
                int64_t* primary_out);

@@ -547,6 +547,26 @@ __global__ __launch_bounds__(WC_WG) void rs_scatter_wc_kernel(const u64* __restr
 // ---------------------------------------------------------------------------------------------
 // host launcher
 // ---------------------------------------------------------------------------------------------
+// Per-context (= per-device) setup, called from bscgpu_create with the context's device current: the dynamic-LDS limits
+// of the large-tile kernels are a per-device attribute of the function, so every device that gets a context must be told
+// (a process-wide `static` here would configure only the first device and race between threads).
+// BSC_RS_WC: 0 = plain scatter (default), 1 = write-combining scatter for inputs that fill the chip (>= 2 tiles per rs_hist
+// chunk at the full chunk count), 2 = force it whenever there are >= 4 chunks (tests).
+int radix_engine_setup(bscgpu_ctx* c)
+{
+    const char* e = getenv("BSC_RS_WC");
+    int mode = e ? atoi(e) : RS_WC_DEFAULT;
+    if (WC_LDS_PAIRS > 160 * 1024 ||
+        hipFuncSetAttribute((const void*)rs_scatter_wc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_LDS_PAIRS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)rs_scatter_wc_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_LDS_KEYS) != hipSuccess) {
+        mode = 0;
+        (void)hipGetLastError();               // do not leave a sticky error behind
+    }
+    HIP_TRY(c, hipFuncSetAttribute((const void*)rs_scatter_kernel<true, RSB_WG, RSB_ITEMS, RSB_SPAN>, hipFuncAttributeMaxDynamicSharedMemorySize, RSB_LDS));
+    c->rs_wc_mode = mode;
+    return BSC_NO_ERROR;
+}
+
 int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* vals_alt, u64 n,
                       const RadixPass* passes, int npasses, int* in_alt)
 {
@@ -556,20 +576,7 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
     if ((((uintptr_t)keys) | ((uintptr_t)keys_alt)) & 15) return ctx_fail(c, BSC_BAD_PARAMETER, "radix keys not 16B aligned", hipSuccess);
 
     const Chunking ch = rs_chunking(n);
-    // write-combining scatter for inputs that fill the chip (>= 2 tiles per rs_hist chunk at the full chunk count);
-    // BSC_RS_WC=0 keeps the plain kernel, BSC_RS_WC=2 forces the combining one whenever there are >= 4 chunks
-    static int wc_mode = -1;
-    if (wc_mode < 0) {
-        const char* e = getenv("BSC_RS_WC");
-        wc_mode = e ? atoi(e) : RS_WC_DEFAULT;
-        if (WC_LDS_PAIRS > 160 * 1024 ||
-            hipFuncSetAttribute((const void*)rs_scatter_wc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_LDS_PAIRS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)rs_scatter_wc_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_LDS_KEYS) != hipSuccess) {
-            wc_mode = 0;
-            (void)hipGetLastError();               // do not leave a sticky error behind
-        }
-        HIP_TRY(c, hipFuncSetAttribute((const void*)rs_scatter_kernel<true, RSB_WG, RSB_ITEMS, RSB_SPAN>, hipFuncAttributeMaxDynamicSharedMemorySize, RSB_LDS));
-    }
+    const int wc_mode = c->rs_wc_mode;          // BSC_RS_WC, read once per context (radix_engine_setup)
     const bool big_pairs = RS_BIG_PAIRS && ch.num_chunks >= 512 && ch.chunk_tiles >= 2;   // enough records for 8192-record tiles on every CU
     const bool use_wc = (wc_mode == 2 && ch.num_chunks >= 4) || (wc_mode == 1 && ch.num_chunks >= 512 && ch.chunk_tiles >= 2);
     u64 *ksrc = keys, *kdst = keys_alt;

@@ -26,6 +26,7 @@
 #include "../device/dev_common.h"
 #include "qlfc.h"
 #include "lzp.h"
+#include "par.h"
 
 using namespace bschost;
 
@@ -36,57 +37,89 @@ static void  (*g_free)(void*) = nullptr;
 static void* bsc_malloc(size_t n) { return g_malloc ? g_malloc(n) : malloc(n); }
 static void  bsc_free(void* p) { if (g_free) g_free(p); else free(p); }
 
-// ---- process-wide default GPU context for the host-pointer API ------------------------------------------
-// (the reference keeps one cached arena behind one lock, bwt.cpp:50-52; multi-GPU drivers create their own bscgpu_ctx per
-// device instead of going through this).  Callers may be concurrent (the reference CLI compresses blocks from an OpenMP
-// team, bsc.cpp:197): the GPU stage of a call is serialised by g_gpu_lock, but bsc_compress releases it before its host
-// stage, so up to DEFAULT_SLOTS calls overlap — one on the GPU, the others coding on host threads.  Each holds one of the
-// context's pinned slots; the context is only re-created (for a larger block) when nobody is using it.
-static std::mutex   g_gpu_lock;                 // the GPU stage
-static std::mutex   g_user_mu;                  // g_gpu / g_gpu_cap / g_users / g_slot_busy
-static std::condition_variable g_user_cv;
-static bscgpu_ctx*  g_gpu = nullptr;
-static int64_t      g_gpu_cap = 0;
-static int          g_users = 0;
+// ---- process-wide default GPU contexts for the host-pointer API: one per visible device ----------------------------
+// The reference keeps one cached arena behind one lock (bwt.cpp:50-52) and gets its parallelism from the CLI's OpenMP team
+// calling bsc_compress concurrently, one block per thread (bsc.cpp:184-199).  Relinked against this library those calls
+// are spread over ALL visible GPUs with no API change: every device has its own default context, GPU-stage lock and pinned
+// slots; a call goes to the device with the fewest calls in flight (ties: round robin), so N concurrent callers on an
+// N-GPU node run one block per GPU.  BSC_GPU_DEVICE=<k> pins everything to device k; BSC_GPU_DEVICES=<n> uses the first n.
+// The GPU stage of a call is serialised per device, but bsc_compress releases the lock before its host stage, so up to
+// DEFAULT_SLOTS calls overlap per device — one on the GPU, the others coding on host threads.  A device's context is only
+// re-created (for a larger block) when nobody is using it.
 constexpr int       DEFAULT_SLOTS = 3;
-static bool         g_slot_busy[DEFAULT_SLOTS] = {false, false, false};
+constexpr int       MAX_DEVICES = 16;
+struct DefaultDevice {
+    std::mutex   gpu_lock;                       // the GPU stage on this device
+    bscgpu_ctx*  ctx = nullptr;
+    int64_t      cap = 0;
+    int          users = 0;
+    bool         slot_busy[DEFAULT_SLOTS] = {false, false, false};
+};
+static std::mutex   g_user_mu;                  // every DefaultDevice's ctx / cap / users / slot_busy, g_ndev, g_rr
+static std::condition_variable g_user_cv;
+static DefaultDevice g_dev[MAX_DEVICES];
+static int          g_ndev = -1;                // devices the default path uses (-1: not probed yet)
+static int          g_dev_first = 0;
+static unsigned     g_rr = 0;
+
+static int probe_devices_locked()
+{
+    if (g_ndev >= 0) return g_ndev;
+    int n = bscgpu_device_count();
+    if (n > MAX_DEVICES) n = MAX_DEVICES;
+    g_dev_first = 0;
+    if (const char* e = getenv("BSC_GPU_DEVICE")) { const int d = atoi(e); if (d >= 0 && d < n) { g_dev_first = d; n = 1; } else n = 0; }
+    else if (const char* e2 = getenv("BSC_GPU_DEVICES")) { const int k = atoi(e2); if (k >= 1 && k < n) n = k; }
+    g_ndev = n;
+    return n;
+}
 
 // Register as a user of a default context that can take n bytes; with want_slot also reserve a pinned slot.
-static int default_gpu_acquire(int64_t n, bool want_slot, bscgpu_ctx** out, int* slot_out)
+static int default_gpu_acquire(int64_t n, bool want_slot, DefaultDevice** out, int* slot_out)
 {
     std::unique_lock<std::mutex> lk(g_user_mu);
+    const int ndev = probe_devices_locked();
+    if (ndev <= 0) return LIBBSC_GPU_NOT_SUPPORTED;
     for (;;) {
-        if (g_gpu && g_gpu_cap >= n) {
-            int s = -1;
-            if (want_slot) { for (int i = 0; i < DEFAULT_SLOTS; ++i) if (!g_slot_busy[i]) { s = i; break; } }
-            if (!want_slot || s >= 0) {
-                if (s >= 0) g_slot_busy[s] = true;
-                ++g_users;
-                *out = g_gpu; if (slot_out) *slot_out = s;
-                return LIBBSC_NO_ERROR;
+        // least-loaded device that can take the call right now; round-robin start so equal loads alternate
+        int best = -1;
+        const unsigned start = g_rr;
+        for (int k = 0; k < ndev; ++k) {
+            const int d = (int)((start + (unsigned)k) % (unsigned)ndev);
+            DefaultDevice& D = g_dev[d];
+            bool slot_free = !want_slot;
+            for (int i = 0; i < DEFAULT_SLOTS && !slot_free; ++i) slot_free = !D.slot_busy[i];
+            const bool usable = (D.ctx && D.cap >= n) ? slot_free : (D.users == 0);     // an idle device can be (re)sized
+            if (usable && (best < 0 || D.users < g_dev[best].users)) best = d;
+        }
+        if (best >= 0) {
+            DefaultDevice& D = g_dev[best];
+            if (!(D.ctx && D.cap >= n)) {
+                if (D.ctx) { bscgpu_destroy(D.ctx); D.ctx = nullptr; D.cap = 0; }
+                const int64_t cap = n + n / 32 + 4096;                    // headroom like bwt.cpp:106
+                const int rc = bscgpu_create(&D.ctx, g_dev_first + best, cap);
+                if (rc != LIBBSC_NO_ERROR) { D.ctx = nullptr; return rc; }
+                D.cap = cap;
             }
-        } else if (g_users == 0) {
-            if (g_gpu) { bscgpu_destroy(g_gpu); g_gpu = nullptr; g_gpu_cap = 0; }
-            int dev = 0;
-            if (const char* e = getenv("BSC_GPU_DEVICE")) dev = atoi(e);
-            const int64_t cap = n + n / 32 + 4096;                    // headroom like bwt.cpp:106
-            const int rc = bscgpu_create(&g_gpu, dev, cap);
-            if (rc != LIBBSC_NO_ERROR) { g_gpu = nullptr; return rc; }
-            g_gpu_cap = cap;
-            continue;
+            int s = -1;
+            if (want_slot) { for (int i = 0; i < DEFAULT_SLOTS; ++i) if (!D.slot_busy[i]) { s = i; break; } D.slot_busy[s] = true; }
+            ++D.users;
+            g_rr = (unsigned)best + 1u;
+            *out = &D; if (slot_out) *slot_out = s;
+            return LIBBSC_NO_ERROR;
         }
         g_user_cv.wait(lk);
     }
 }
-static void default_gpu_release(int slot)
+static void default_gpu_release(DefaultDevice* D, int slot)
 {
-    { std::lock_guard<std::mutex> lk(g_user_mu); if (slot >= 0) g_slot_busy[slot] = false; --g_users; }
+    { std::lock_guard<std::mutex> lk(g_user_mu); if (slot >= 0) D->slot_busy[slot] = false; --D->users; }
     g_user_cv.notify_all();
 }
 struct DefaultGpuUser {                         // RAII around acquire / release
-    bscgpu_ctx* c = nullptr; int slot = -1; int rc;
-    DefaultGpuUser(int64_t n, bool want_slot) { rc = default_gpu_acquire(n, want_slot, &c, &slot); }
-    ~DefaultGpuUser() { if (rc == LIBBSC_NO_ERROR) default_gpu_release(slot); }
+    DefaultDevice* dev = nullptr; bscgpu_ctx* c = nullptr; int slot = -1; int rc;
+    DefaultGpuUser(int64_t n, bool want_slot) { rc = default_gpu_acquire(n, want_slot, &dev, &slot); if (rc == LIBBSC_NO_ERROR) c = dev->ctx; }
+    ~DefaultGpuUser() { if (rc == LIBBSC_NO_ERROR) default_gpu_release(dev, slot); }
 };
 
 static inline void put_i32(unsigned char* p, int v) { memcpy(p, &v, 4); }
@@ -142,7 +175,7 @@ int bsc_bwt_encode(unsigned char* T, int n, unsigned char* num_indexes, int* ind
     DefaultGpuUser user(n, false);
     if (user.rc != LIBBSC_NO_ERROR) return user.rc;
     bscgpu_ctx* c = user.c;
-    std::lock_guard<std::mutex> g(g_gpu_lock);
+    std::lock_guard<std::mutex> g(user.dev->gpu_lock);
     if (num_indexes != nullptr && indexes != nullptr) {
         const int r = aux_rate(n);
         if (r < 2) return LIBBSC_BAD_PARAMETER;               // libsais_bwt_aux rejects r < 2 (libsais.c:6711)
@@ -166,7 +199,7 @@ int bsc_st_encode(unsigned char* T, int n, int k, int features)
     if (n <= 1) return 0;
     DefaultGpuUser user(n, false);
     if (user.rc != LIBBSC_NO_ERROR) return user.rc;
-    std::lock_guard<std::mutex> g(g_gpu_lock);
+    std::lock_guard<std::mutex> g(user.dev->gpu_lock);
     return bscgpu_st_encode(user.c, T, n, k);
 }
 
@@ -334,7 +367,7 @@ static void host_encode_sub(BlockJob& J, int b)
 {
     const size_t need = (size_t)J.size[b] + 64;
     if (J.scratch_cap[b] < need) { J.scratch[b].reset(new uint8_t[need + need / 8]); J.scratch_cap[b] = need + need / 8; }
-    const int r = qlfc_encode_runs(J.views[b], J.size[b], J.scratch[b].get(), J.size[b], J.coder, true);
+    const int r = qlfc_encode_runs(J.views[b], J.size[b], J.scratch[b].get(), J.size[b], J.coder);
     J.sub_res[b] = (r < 0) ? J.size[b] : r;
 }
 
@@ -453,9 +486,7 @@ static void host_stage(BlockJob& J)
     if (J.stored_small) return;
     host_prepare(J);
     if (job_uses_tasks(J)) {
-        std::vector<std::thread> pool;
-        for (int b = 0; b < J.nblocks; ++b) pool.emplace_back([&J, b] { host_encode_sub(J, b); });
-        for (auto& t : pool) t.join();
+        run_tasks(J.nblocks, [&J](int b) { host_encode_sub(J, b); });
         host_finalize(J);
         return;
     }
@@ -512,7 +543,7 @@ int bsc_compress(const unsigned char* input, unsigned char* output, int n, int l
     if (user.rc != LIBBSC_NO_ERROR) return user.rc;
     bscgpu_ctx* c = user.c;
     {
-        std::lock_guard<std::mutex> g(g_gpu_lock);              // GPU stage; concurrent callers queue here
+        std::lock_guard<std::mutex> g(user.dev->gpu_lock);      // GPU stage; concurrent callers on this device queue here
         if (hipSetDevice(c->device) != hipSuccess) return LIBBSC_GPU_ERROR;
         rc = ctx_ensure_slots(c, user.slot + 1);
         if (rc < 0) return rc;

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <memory>
 #include <thread>
+#include "par.h"
 #include <vector>
 
 namespace bschost {
@@ -90,15 +91,10 @@ static int compress_parallel(const uint8_t* in, uint8_t* out, int n, int coder)
     int start[8], size[8], res[8];
     coder_split_blocks(in, n, nblocks, start, size);
     std::vector<uint8_t> scratch((size_t)n + 64);
-    {
-        std::vector<std::thread> pool;
-        for (int b = 0; b < nblocks; ++b)
-            pool.emplace_back([&, b] {
-                int r = qlfc_encode_block(in + start[b], scratch.data() + start[b], size[b], size[b], coder, true);
-                res[b] = (r < 0) ? size[b] : r;             // failed sub-block is stored raw (coder.cpp:194)
-            });
-        for (auto& t : pool) t.join();
-    }
+    run_tasks(nblocks, [&](int b) {
+        int r = qlfc_encode_block(in + start[b], scratch.data() + start[b], size[b], size[b], coder);
+        res[b] = (r < 0) ? size[b] : r;                     // failed sub-block is stored raw (coder.cpp:194)
+    });
     int total = 1 + 8 * nblocks;
     for (int b = 0; b < nblocks; ++b) total += res[b];
     if (total >= n) return NOT_COMPRESSIBLE;
@@ -129,18 +125,13 @@ int coder_compress_views(const RunView* views, int nblocks, const int* start, co
         std::vector<std::unique_ptr<uint8_t[]>> scratch((size_t)nblocks);
         int res[8];
         double tms[8];
-        {
-            std::vector<std::thread> pool;
-            for (int b = 0; b < nblocks; ++b)
-                pool.emplace_back([&, b] {
-                    const auto t0 = std::chrono::steady_clock::now();
-                    scratch[(size_t)b].reset(new uint8_t[(size_t)size[b] + 64]);        // uninitialised on purpose
-                    int r = qlfc_encode_runs(views[b], size[b], scratch[(size_t)b].get(), size[b], coder, true);
-                    res[b] = (r < 0) ? size[b] : r;
-                    tms[b] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                });
-            for (auto& t : pool) t.join();
-        }
+        run_tasks(nblocks, [&](int b) {
+            const auto t0 = std::chrono::steady_clock::now();
+            scratch[(size_t)b].reset(new uint8_t[(size_t)size[b] + 64]);        // uninitialised on purpose
+            int r = qlfc_encode_runs(views[b], size[b], scratch[(size_t)b].get(), size[b], coder);
+            res[b] = (r < 0) ? size[b] : r;
+            tms[b] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        });
         if (getenv("BSCGPU_DEBUG")) { fprintf(stderr, "[coder] sub-block ms:"); for (int b = 0; b < nblocks; ++b) fprintf(stderr, " %.1f", tms[b]); fprintf(stderr, "\n"); }
         int total = 1 + 8 * nblocks;
         for (int b = 0; b < nblocks; ++b) total += res[b];
@@ -179,12 +170,14 @@ int coder_compress(const uint8_t* in, uint8_t* out, int n, int coder, int featur
     return compress_serial(in, out, n, coder);
 }
 
-int coder_decompress_bounded(const uint8_t* in, uint8_t* out, int coder, int features, int max_out)
+int coder_decompress_bounded(const uint8_t* in, long long in_size, uint8_t* out, int coder, int features, int max_out)
 {
     if (coder != CODER_STATIC && coder != CODER_ADAPTIVE && coder != CODER_FAST) return BAD_PARAMETER;
+    if (in_size < 1) return DATA_CORRUPT;
     const int nblocks = in[0];
-    if (nblocks == 1) return qlfc_decode_block_bounded(in + 1, out, coder, max_out);
+    if (nblocks == 1) return qlfc_decode_block_bounded(in + 1, in_size - 1, out, coder, max_out);
     if (nblocks < 1 || nblocks > 8) return DATA_CORRUPT;   // the format never writes more than 8 (coder.cpp:52-59)
+    if (in_size < 1 + 8 * nblocks) return DATA_CORRUPT;    // the frame table itself must lie inside the payload
 
     int res[8], iptr[8], optr[8], isz[8], osz[8];
     long long ip = 1 + 8 * nblocks, op = 0;
@@ -192,17 +185,16 @@ int coder_decompress_bounded(const uint8_t* in, uint8_t* out, int coder, int fea
         osz[b] = get_i32(in + 1 + 8 * b);
         isz[b] = get_i32(in + 1 + 8 * b + 4);
         if (osz[b] < 0 || isz[b] < 0 || op + osz[b] > max_out) return DATA_CORRUPT;
+        if (ip + isz[b] > in_size) return DATA_CORRUPT;    // a sub-block may not extend past the payload (checksum-valid corrupt tables)
         iptr[b] = (int)ip; optr[b] = (int)op;
         ip += isz[b]; op += osz[b];
     }
     auto one = [&](int b) {
-        if (isz[b] != osz[b]) { res[b] = qlfc_decode_block_bounded(in + iptr[b], out + optr[b], coder, osz[b]); if (res[b] >= 0 && res[b] != osz[b]) res[b] = DATA_CORRUPT; }
+        if (isz[b] != osz[b]) { res[b] = qlfc_decode_block_bounded(in + iptr[b], isz[b], out + optr[b], coder, osz[b]); if (res[b] >= 0 && res[b] != osz[b]) res[b] = DATA_CORRUPT; }
         else { res[b] = isz[b]; memcpy(out + optr[b], in + iptr[b], (size_t)isz[b]); }
     };
     if (features & FEATURE_MULTITHREADING) {
-        std::vector<std::thread> pool;
-        for (int b = 0; b < nblocks; ++b) pool.emplace_back(one, b);
-        for (auto& t : pool) t.join();
+        run_tasks(nblocks, one);
     } else {
         for (int b = 0; b < nblocks; ++b) one(b);
     }
@@ -210,7 +202,7 @@ int coder_decompress_bounded(const uint8_t* in, uint8_t* out, int coder, int fea
     for (int b = 0; b < nblocks; ++b) { if (res[b] < 0) err = res[b]; total += res[b]; }
     return err == OK ? total : err;
 }
-int coder_decompress(const uint8_t* in, uint8_t* out, int coder, int features) { return coder_decompress_bounded(in, out, coder, features, 0x7fffffff); }
+int coder_decompress(const uint8_t* in, uint8_t* out, int coder, int features) { return coder_decompress_bounded(in, UNBOUNDED_INPUT, out, coder, features, 0x7fffffff); }
 
 // Adler-32 (adler32.cpp:82-204): s1 = 1 + sum, s2 = sum of s1, mod 65521; deferred modulo every 5552 bytes.
 // 32 bytes per step with AVX2: s2 += 32 * s1 + sum (32 - i) * d[i]  (pmaddubsw against the weights 32..1), s1 += sum d[i].

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 #include <thread>
+#include "par.h"
 #include <algorithm>
 #include <cstdint>
 #include <memory>
@@ -152,11 +153,7 @@ int bsc_bwt_decode(unsigned char* T, int n, int index, unsigned char num_indexes
     int threads = 1;
     if ((features & LIBBSC_FEATURE_MULTITHREADING) && chains > 1 && n >= (1 << 20)) threads = chains < 8 ? chains : 8;
     if (threads == 1) walk(0, 1);
-    else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < threads; ++t) pool.emplace_back(walk, t, threads);
-        for (auto& t : pool) t.join();
-    }
+    else bschost::run_tasks(threads, [&](int t) { walk(t, threads); });
     for (int s2 = 0; s2 < chains; ++s2) if (ch[(size_t)s2].row != ch[(size_t)s2].expect) return LIBBSC_DATA_CORRUPT;   // inconsistent indexes
     memcpy(T, out.data(), N);
     return LIBBSC_NO_ERROR;
@@ -251,14 +248,14 @@ int bsc_decompress(const unsigned char* input, int inputSize, unsigned char* out
     std::vector<unsigned char> copy;
     const unsigned char* src = input;
     if (inplace) { copy.assign(input, input + blockSize); src = copy.data(); }
+    if (blockSize < LIBBSC_HEADER_SIZE + 2) return LIBBSC_DATA_CORRUPT;      // a coded block holds at least one payload byte and the index count
     int num_indexes = src[blockSize - 1];
     int indexes[256];
-    if (num_indexes > 0) {
-        if (blockSize - 1 - 4 * num_indexes < LIBBSC_HEADER_SIZE) return LIBBSC_DATA_CORRUPT;
-        memcpy(indexes, src + blockSize - 1 - 4 * num_indexes, (size_t)4 * num_indexes);
-    }
-    // guard the decoder's output size before it writes: the stream announces its own length
-    int lzSize = coder_decompress_bounded(src + LIBBSC_HEADER_SIZE, output, coder, features, dataSize);
+    const long long payload = (long long)blockSize - LIBBSC_HEADER_SIZE - 1 - 4LL * num_indexes;     // what the coder may read
+    if (payload < 1) return LIBBSC_DATA_CORRUPT;
+    if (num_indexes > 0) memcpy(indexes, src + blockSize - 1 - 4 * num_indexes, (size_t)4 * num_indexes);
+    // guard the decoder's input and output before it reads / writes: the stream announces its own lengths
+    int lzSize = coder_decompress_bounded(src + LIBBSC_HEADER_SIZE, payload, output, coder, features, dataSize);
     if (lzSize < LIBBSC_NO_ERROR) return lzSize;
     int rc = (sorter == LIBBSC_BLOCKSORTER_BWT) ? bsc_bwt_decode(output, lzSize, index, (unsigned char)num_indexes, indexes, features)
                                                 : bsc_st_decode(output, lzSize, sorter, index, features);

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include "par.h"
 #include <vector>
 
 #include "qlfc.h"
@@ -226,13 +227,11 @@ int lzp_compress(const uint8_t* in, uint8_t* out, int n, int hashSize, int minLe
         // concurrent chunks, each with a budget of its own size (lzp.cpp:736-790)
         std::vector<uint8_t> tmp((size_t)n);
         int res[8];
-        std::vector<std::thread> pool;
-        for (int b = 0; b < nc; ++b) pool.emplace_back([&, b] {
+        run_tasks(nc, [&](int b) {
             const int st = b * chunk, sz = (b != nc - 1) ? chunk : n - st;
             const int r = lzp_encode_chunk(in + st, sz, tmp.data() + st, sz, hashSize, minLen);
             res[b] = (r < 0) ? sz : r;
         });
-        for (auto& t : pool) t.join();
         int64_t total = 1 + 8 * nc;
         for (int b = 0; b < nc; ++b) total += res[b];
         if (total >= n) return NOT_COMPRESSIBLE;

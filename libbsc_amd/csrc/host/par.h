@@ -1,0 +1,29 @@
+// par.h — run n independent tasks, one per thread where threads can be had (internal).
+//
+// Thread creation can fail (pid / thread limits of a container: std::system_error out of std::thread's constructor).
+// Behind an extern "C" API and inside pipe workers that must never escape: whatever could not get its own thread runs
+// on the calling thread instead, so the result is the same and only the parallelism degrades.  The last task always
+// runs on the caller (one thread fewer to create).
+#pragma once
+#include <system_error>
+#include <thread>
+#include <vector>
+
+namespace bschost {
+
+template <class F>
+inline void run_tasks(int n, F&& fn)
+{
+    if (n <= 0) return;
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)n);
+    int next = 0;
+    for (; next < n - 1; ++next) {
+        try { pool.emplace_back([&fn, next] { fn(next); }); }
+        catch (const std::system_error&) { break; }         // no more threads: the rest runs here
+    }
+    for (int b = next; b < n; ++b) fn(b);
+    for (auto& t : pool) t.join();
+}
+
+}  // namespace bschost

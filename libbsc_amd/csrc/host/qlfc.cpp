@@ -10,11 +10,9 @@
 #include <cstdlib>
 #include <memory>
 #include <algorithm>
-#include <atomic>
 #include <type_traits>
 #include <emmintrin.h>
 #include <tmmintrin.h>
-#include <thread>
 
 #include "qlfc_data.inc"
 
@@ -479,125 +477,6 @@ static int encode_model1(const RunView& R, uint8_t* out, int in_size, int out_si
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pipelined static coder: the three counter families of the -e1 model are independent chains (each counter
-// only ever sees its own events, and which counter a decision touches is decided by the data alone), and the
-// range coder consumes nothing but (bit, probability) pairs.  So one sub-block is coded by four threads:
-//   family threads S / C / P : walk the decisions, update only their own counters, emit the counter value seen
-//                              by each decision into a single-producer single-consumer ring;
-//   coder thread             : pops the three values, forms p = (c*LR0 + s*LR1 + p*LR2) >> 5, range-codes.
-// Output is bit-identical to the single-threaded coder by construction (same values, same order).
-// ------------------------------------------------------------------------------------------------
-template <class Tv>
-class SpscRing {
-public:
-    explicit SpscRing(size_t cap_log2, std::atomic<bool>* abort) : buf_(new Tv[(size_t)1 << cap_log2]), mask_(((size_t)1 << cap_log2) - 1), abort_(abort) {}
-    inline void push(Tv v)
-    {
-        if (w_ - head_cache_ > mask_) {
-            flush();
-            for (unsigned spin = 0;; ++spin) {
-                head_cache_ = head_.load(std::memory_order_acquire);
-                if (w_ - head_cache_ <= mask_) break;
-                if (abort_->load(std::memory_order_relaxed)) return;
-                if (spin > 64) std::this_thread::yield(); else cpu_relax();
-            }
-        }
-        buf_[w_ & mask_] = v;
-        if ((++w_ & 2047) == 0) tail_.store(w_, std::memory_order_release);
-    }
-    inline void flush() { tail_.store(w_, std::memory_order_release); }
-    void close() { flush(); done_.store(true, std::memory_order_release); }
-    inline bool pop(Tv& v)
-    {
-        if (r_ == tail_cache_) {
-            head_.store(r_, std::memory_order_release);
-            for (unsigned spin = 0;; ++spin) {
-                tail_cache_ = tail_.load(std::memory_order_acquire);
-                if (tail_cache_ != r_) break;
-                if (done_.load(std::memory_order_acquire)) {
-                    tail_cache_ = tail_.load(std::memory_order_acquire);
-                    if (tail_cache_ != r_) break;
-                    return false;
-                }
-                if (abort_->load(std::memory_order_relaxed)) return false;
-                if (spin > 64) std::this_thread::yield(); else cpu_relax();
-            }
-        }
-        v = buf_[r_ & mask_];
-        if ((++r_ & 2047) == 0) head_.store(r_, std::memory_order_release);
-        return true;
-    }
-private:
-    static inline void cpu_relax() { __builtin_ia32_pause(); }
-    std::unique_ptr<Tv[]> buf_;
-    const size_t mask_;
-    std::atomic<bool>* abort_;
-    alignas(64) std::atomic<size_t> tail_{0};
-    alignas(64) std::atomic<size_t> head_{0};
-    alignas(64) std::atomic<bool> done_{false};
-    alignas(64) size_t w_ = 0; size_t head_cache_ = 0;
-    alignas(64) size_t r_ = 0; size_t tail_cache_ = 0;
-};
-
-enum { FAM_STATE = 0, FAM_CHAR = 1, FAM_POS = 2 };
-// the state family's ring also carries the decision's bit, class and a start-of-run mark
-static inline uint32_t pack_meta(short v, unsigned bit, int cls, unsigned first) { return (uint32_t)(uint16_t)v | (bit << 16) | ((uint32_t)cls << 17) | (first << 20); }
-
-template <int FAM, class Tv>
-struct FamilyPolicy {
-    SpscRing<Tv>& ring; std::atomic<bool>& abort; unsigned first = 0;
-    struct Live {}; inline Live enter() { return Live(); } inline void leave(const Live&) {}
-    inline bool begin_run() { first = 1; return !abort.load(std::memory_order_relaxed); }
-    template <int CLS> inline void decide(Live&, unsigned bit, short& st, short& ch, short& sp, Mixer*)
-    {
-        constexpr const short* P = kStaticParams[CLS];
-        short& x = (FAM == FAM_STATE) ? st : (FAM == FAM_CHAR) ? ch : sp;
-        const short v = x;
-        bump(x, bit, P[4 * FAM + 0], P[4 * FAM + 1], P[4 * FAM + 2], P[4 * FAM + 3]);
-        if (FAM == FAM_STATE) { ring.push((Tv)pack_meta(v, bit, CLS, first)); first = 0; }
-        else ring.push((Tv)(uint16_t)v);
-    }
-};
-
-static int encode_static_pipelined(const RunView& R, uint8_t* out, int in_size, int out_size)
-{
-    const QlfcTables& T = qlfc_tables();
-    std::atomic<bool> abort{false};
-    SpscRing<uint32_t> ring_s(18, &abort);
-    SpscRing<uint16_t> ring_c(18, &abort), ring_p(18, &abort);
-    const int max_rank = encode_alphabet(R, [](unsigned) {});
-
-    auto producer_s = [&] { std::unique_ptr<Counters1> k(new_counters()); FamilyPolicy<FAM_STATE, uint32_t> pol{ring_s, abort};
-                            walk_model1<false>(R, T, max_rank, *k, nullptr, pol); ring_s.close(); };
-    auto producer_c = [&] { std::unique_ptr<Counters1> k(new_counters()); FamilyPolicy<FAM_CHAR, uint16_t> pol{ring_c, abort};
-                            walk_model1<false>(R, T, max_rank, *k, nullptr, pol); ring_c.close(); };
-    auto producer_p = [&] { std::unique_ptr<Counters1> k(new_counters()); FamilyPolicy<FAM_POS, uint16_t> pol{ring_p, abort};
-                            walk_model1<false>(R, T, max_rank, *k, nullptr, pol); ring_p.close(); };
-    std::thread ts(producer_s), tc(producer_c), tp(producer_p);
-
-    RangeEncoder rc;
-    rc.init(out, out_size);
-    rc.encode_word((uint32_t)in_size);
-    encode_alphabet(R, [&](unsigned b) { rc.encode_half(b); });
-    int lr0[7], lr1[7], lr2[7];
-    for (int k = 0; k < 7; ++k) { lr0[k] = kStaticParams[k][16]; lr1[k] = kStaticParams[k][17]; lr2[k] = kStaticParams[k][18]; }
-    int result = 0;
-    for (;;) {
-        uint32_t a; uint16_t b, c;
-        if (!ring_s.pop(a)) break;
-        if ((a >> 20) & 1u) { if (rc.full()) { result = NOT_COMPRESSIBLE; break; } }
-        if (!ring_c.pop(b) || !ring_p.pop(c)) { result = DATA_CORRUPT; break; }       // cannot happen: same decision count
-        const int cls = (int)((a >> 17) & 7u);
-        const int p = ((int)(short)b * lr0[cls] + (int)(short)(a & 0xffffu) * lr1[cls] + (int)(short)c * lr2[cls]) >> 5;
-        rc.encode<12>((a >> 16) & 1u, p);
-    }
-    if (result != 0) abort.store(true, std::memory_order_relaxed);
-    ts.join(); tc.join(); tp.join();
-    if (result != 0) return result;
-    return rc.finish();
-}
-
-// ------------------------------------------------------------------------------------------------
 // fast coder (-e0): one counter per context, shift updates, 13-bit (rank) / 11-bit (run) precision
 // ------------------------------------------------------------------------------------------------
 struct Counters2 {
@@ -672,9 +551,11 @@ static int encode_model2(const RunView& R, uint8_t* out, int in_size, int out_si
 // ------------------------------------------------------------------------------------------------
 class RangeDecoder {
 public:
-    void init(const uint8_t* in)
+    // in_end: one past the last byte this decoder may read (a corrupt stream must not walk off its payload; past the end
+    // the input reads as zeros, which ends in a size / run-length check failing)
+    void init(const uint8_t* in, const uint8_t* in_end)
     {
-        in_ = in; code_ = 0; range_ = 0xffffffffu;
+        in_ = in; end_ = in_end; code_ = 0; range_ = 0xffffffffu;
         code_ = (code_ << 16) | next16(); code_ = (code_ << 16) | next16(); code_ = (code_ << 16) | next16();
     }
     template <int P> inline unsigned decode(int p)
@@ -689,8 +570,12 @@ public:
     inline unsigned decode_half() { return decode<12>(2048); }
     uint32_t decode_word() { uint32_t w = 0; for (int b = 0; b < 32; ++b) w += w + decode_half(); return w; }
 private:
-    inline uint32_t next16() { const uint32_t v = (uint32_t)in_[0] | ((uint32_t)in_[1] << 8); in_ += 2; return v; }
-    const uint8_t* in_; uint32_t code_, range_;
+    inline uint32_t next16()
+    {
+        if (__builtin_expect((uintptr_t)end_ - (uintptr_t)in_ < 2, 0)) { const uint32_t v = (in_ < end_) ? (uint32_t)in_[0] : 0u; in_ = end_; return v; }
+        const uint32_t v = (uint32_t)in_[0] | ((uint32_t)in_[1] << 8); in_ += 2; return v;
+    }
+    const uint8_t* in_; const uint8_t* end_; uint32_t code_, range_;
 };
 
 // Alphabet header: rebuilds the first-appearance list (with its terminator) and max_rank.
@@ -753,7 +638,7 @@ static inline void requeue(uint8_t* mtf, int rank, uint8_t c)      // the head s
 }
 
 template <bool ADAPT>
-static int decode_model1(const uint8_t* in, uint8_t* out, int max_out)
+static int decode_model1(const uint8_t* in, const uint8_t* in_end, uint8_t* out, int max_out)
 {
     const QlfcTables& T = qlfc_tables();
     std::unique_ptr<Counters1> Cn(new_counters());
@@ -764,7 +649,7 @@ static int decode_model1(const uint8_t* in, uint8_t* out, int max_out)
         for (size_t i = 0; i < sizeof(Mixers1) / sizeof(Mixer); ++i) all[i].init(T);
     }
     Counters1& K = *Cn; Mixers1* M = Mx.get();
-    RangeDecoder rd; rd.init(in);
+    RangeDecoder rd; rd.init(in, in_end);
     const int n = (int)rd.decode_word();
     if (n < 0 || n > max_out) return DATA_CORRUPT;
     alignas(64) uint8_t mtf[256 + 16] = {0};
@@ -834,13 +719,13 @@ static int decode_model1(const uint8_t* in, uint8_t* out, int max_out)
     return n;
 }
 
-static int decode_model2(const uint8_t* in, uint8_t* out, int max_out)
+static int decode_model2(const uint8_t* in, const uint8_t* in_end, uint8_t* out, int max_out)
 {
     std::unique_ptr<Counters2> Cn(new Counters2);
     fill_shorts(Cn->r_exp, sizeof(Cn->r_exp) + sizeof(Cn->r_mant), 4096);
     fill_shorts(Cn->n_exp, sizeof(Cn->n_exp) + sizeof(Cn->n_mant), 1024);
     Counters2& K = *Cn;
-    RangeDecoder rd; rd.init(in);
+    RangeDecoder rd; rd.init(in, in_end);
     const int n = (int)rd.decode_word();
     if (n < 0 || n > max_out) return DATA_CORRUPT;
     alignas(64) uint8_t mtf[256 + 16] = {0};
@@ -899,67 +784,38 @@ static int decode_model2(const uint8_t* in, uint8_t* out, int max_out)
     return n;
 }
 
-int qlfc_decode_block_bounded(const uint8_t* in, uint8_t* out, int coder, int max_out)
+int qlfc_decode_block_bounded(const uint8_t* in, long long in_size, uint8_t* out, int coder, int max_out)
 {
+    if (in_size < 0) return DATA_CORRUPT;
+    const uint8_t* in_end = (in_size >= (long long)1 << 40) ? (const uint8_t*)UINTPTR_MAX : in + in_size;
     switch (coder) {
-        case CODER_STATIC:   return decode_model1<false>(in, out, max_out);
-        case CODER_ADAPTIVE: return decode_model1<true>(in, out, max_out);
-        case CODER_FAST:     return decode_model2(in, out, max_out);
+        case CODER_STATIC:   return decode_model1<false>(in, in_end, out, max_out);
+        case CODER_ADAPTIVE: return decode_model1<true>(in, in_end, out, max_out);
+        case CODER_FAST:     return decode_model2(in, in_end, out, max_out);
     }
     return BAD_PARAMETER;
 }
-int qlfc_decode_block(const uint8_t* in, uint8_t* out, int coder) { return qlfc_decode_block_bounded(in, out, coder, 0x7fffffff); }
+// the reference's entry point carries no input size (qlfc.h:58): the caller vouches for the stream
+int qlfc_decode_block(const uint8_t* in, uint8_t* out, int coder) { return qlfc_decode_block_bounded(in, UNBOUNDED_INPUT, out, coder, 0x7fffffff); }
 
-// ---- ablation hooks for tools/host_coder_probe.py (timing experiments only; never on the product path) ----
-struct CountPolicy { uint64_t n = 0; inline bool begin_run() { return true; }
-    struct Live {}; inline Live enter() { return Live(); } inline void leave(const Live&) {}
-    template <int CLS> inline void decide(Live&, unsigned bit, short&, short&, short&, Mixer*) { n += 1 + bit; } };
-struct CounterOnlyPolicy { uint64_t acc = 0; inline bool begin_run() { return true; }
-    struct Live {}; inline Live enter() { return Live(); } inline void leave(const Live&) {}
-    template <int CLS> inline void decide(Live&, unsigned bit, short& st, short& ch, short& sp, Mixer*) {
-        constexpr const short* P = kStaticParams[CLS];
-        acc += (uint64_t)((ch * P[16] + st * P[17] + sp * P[18]) >> 5);
-        bump(st, bit, P[0], P[1], P[2], P[3]); bump(ch, bit, P[4], P[5], P[6], P[7]); bump(sp, bit, P[8], P[9], P[10], P[11]); } };
-uint64_t qlfc_ablate(const uint8_t* in, int n, int mode)
-{
-    const QlfcTables& T = qlfc_tables();
-    QlfcRuns R; qlfc_runs(in, n, R);
-    if (mode == 0) return R.view.count;
-    std::unique_ptr<Counters1> Cn(new_counters());
-    const int max_rank = encode_alphabet(R.view, [](unsigned) {});
-    if (mode == 1) { CountPolicy p; walk_model1<false>(R.view, T, max_rank, *Cn, nullptr, p); return p.n; }
-    CounterOnlyPolicy p; walk_model1<false>(R.view, T, max_rank, *Cn, nullptr, p); return p.acc;
-}
-
-static int g_pipeline = -1;      // BSC_QLFC_PIPELINE=0 disables the 4-thread static coder
-int qlfc_encode_runs(const RunView& R, int in_size, uint8_t* out, int out_size, int coder, bool allow_threads)
+int qlfc_encode_runs(const RunView& R, int in_size, uint8_t* out, int out_size, int coder)
 {
     if (in_size <= 0 || R.count == 0) return BAD_PARAMETER;
-    // Measured on 2x EPYC 9575F (round 1): the 4-thread split does NOT pay — every family thread still walks the
-    // whole (branch-bound) decision structure: 132 ms vs 147 ms per 8 MiB stream when pinned to one CCD, 240 ms
-    // unpinned.  Kept as an opt-in experiment (BSC_QLFC_PIPELINE=1; =2 forces it), default off; throughput comes
-    // from keeping several blocks in flight instead (bscgpu_pipe_*).
-    if (g_pipeline < 0) { const char* e = getenv("BSC_QLFC_PIPELINE"); g_pipeline = e ? atoi(e) : 0; }
-    if (g_pipeline == 2) allow_threads = true;          // test hook: force the pipelined coder
     switch (coder) {
-        case CODER_STATIC:
-            if (allow_threads && g_pipeline && R.count >= 65536) return encode_static_pipelined(R, out, in_size, out_size);
-            return encode_model1<false>(R, out, in_size, out_size);
+        case CODER_STATIC:   return encode_model1<false>(R, out, in_size, out_size);
         case CODER_ADAPTIVE: return encode_model1<true>(R, out, in_size, out_size);
         case CODER_FAST:     return encode_model2(R, out, in_size, out_size);
     }
     return BAD_PARAMETER;
 }
 
-int qlfc_encode_block(const uint8_t* in, uint8_t* out, int in_size, int out_size, int coder, bool allow_threads)
+int qlfc_encode_block(const uint8_t* in, uint8_t* out, int in_size, int out_size, int coder)
 {
     if (in_size <= 0) return BAD_PARAMETER;
     QlfcRuns R;
     qlfc_runs(in, in_size, R);
-    return qlfc_encode_runs(R.view, in_size, out, out_size, coder, allow_threads);
+    return qlfc_encode_runs(R.view, in_size, out, out_size, coder);
 }
 
 }  // namespace bschost
 
-extern "C" __attribute__((visibility("default")))
-unsigned long long bsc_qlfc_ablate(const unsigned char* in, int n, int mode) { return bschost::qlfc_ablate(in, n, mode); }

@@ -56,18 +56,20 @@ struct QlfcRuns {                       // owning storage for the host-side fron
 void qlfc_runs(const uint8_t* in, int n, QlfcRuns& out);
 
 // Encode one sub-block from its run arrays.  Returns bytes written or NOT_COMPRESSIBLE.
-int qlfc_encode_runs(const RunView& R, int in_size, uint8_t* out, int out_size, int coder, bool allow_threads = false);
+int qlfc_encode_runs(const RunView& R, int in_size, uint8_t* out, int out_size, int coder);
 // Encode one sub-block (what coder.cpp:61 dispatches to).  Returns bytes written or NOT_COMPRESSIBLE.
-int qlfc_encode_block(const uint8_t* in, uint8_t* out, int in_size, int out_size, int coder, bool allow_threads = false);
+int qlfc_encode_block(const uint8_t* in, uint8_t* out, int in_size, int out_size, int coder);
 // Decode one sub-block; returns the decoded size or an error.
 int qlfc_decode_block(const uint8_t* in, uint8_t* out, int coder);
 
 // Block-level coder (coder.cpp:244 / :273): split into 1/2/4/8 sub-blocks, encode, frame.
 int coder_compress(const uint8_t* in, uint8_t* out, int n, int coder, int features);
 int coder_decompress(const uint8_t* in, uint8_t* out, int coder, int features);
-// as above, but never writes more than max_out bytes (DATA_CORRUPT otherwise)
-int coder_decompress_bounded(const uint8_t* in, uint8_t* out, int coder, int features, int max_out);
-int qlfc_decode_block_bounded(const uint8_t* in, uint8_t* out, int coder, int max_out);
+// as above, but never reads more than in_size bytes of `in` nor writes more than max_out bytes (DATA_CORRUPT otherwise);
+// UNBOUNDED_INPUT for callers whose API carries no input size (the reference's stage entry points)
+constexpr long long UNBOUNDED_INPUT = (long long)1 << 62;
+int coder_decompress_bounded(const uint8_t* in, long long in_size, uint8_t* out, int coder, int features, int max_out);
+int qlfc_decode_block_bounded(const uint8_t* in, long long in_size, uint8_t* out, int coder, int max_out);
 int coder_num_blocks(int n);
 // Same framing, but the sub-blocks arrive as run arrays (GPU front end).  fetch_raw(start, size, dst) supplies the
 // original bytes of a sub-block that has to be stored raw.

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/golden_big.json: reference outputs for the full-size BASELINE configurations the `-m gpu` suite
+checks without /root/reference (the GPU box does not have it):
+  config 3 — the 64 MiB seed-2 block of `bench.py` at N=1;
+  config 4 — eight independent 64 MiB synth-text v1 blocks, seeds 10..17, BWT + QLFC static (the N>1 bench blocks);
+  config 5 — one 128 MiB synth-text v1 block, seed 3, ST5 and ST6 + QLFC static (SURVEY.md §8c pins the same md5s);
+  deep-LCP — one 64 MiB block of long repeated passages (synth_repeat_v1), BWT + QLFC static: many doubling rounds.
+Run in the build container: python tests/golden/make_golden_big.py   (needs oracle/_ref, i.e. /root/reference)."""
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from libbsc_amd import api  # noqa: E402
+from libbsc_amd.synth import synth_repeat_v1  # noqa: E402
+from oracle.refbind import Ref  # noqa: E402
+
+os.environ.setdefault("BSC_REF_THREADS", "8")
+ref = Ref()
+out = []
+
+
+def add(tag, gen, T, sorter, coder, features):
+    blk = ref.compress(T, sorter, coder, features=features)
+    e = dict(tag=tag, gen=gen, n=int(T.size), sorter=sorter, coder=coder, features=features, size=len(blk),
+             md5=hashlib.md5(blk).hexdigest(), input_md5=hashlib.md5(T.tobytes()).hexdigest())
+    if sorter == 1:
+        L, idx, aux = ref.bwt_encode(T)
+        e.update(bwt_index=idx, bwt_md5=hashlib.md5(L.tobytes()).hexdigest())
+    out.append(e)
+    print(tag, gen, e["size"], e["md5"], flush=True)
+
+
+add("config3", {"kind": "synth", "seed": 2}, api.synth_text_v1(2, 64 << 20), 1, 1, 3)      # the N=1 bench block
+for seed in range(10, 18):
+    add("config4", {"kind": "synth", "seed": seed}, api.synth_text_v1(seed, 64 << 20), 1, 1, 3)
+T = api.synth_text_v1(3, 128 << 20)
+add("config5", {"kind": "synth", "seed": 3}, T, 5, 1, 3)
+add("config5", {"kind": "synth", "seed": 3}, T, 6, 1, 3)
+add("deep-lcp", {"kind": "repeat", "seed": 7, "period": 3_000_000}, synth_repeat_v1(7, 64 << 20, 3_000_000), 1, 1, 3)
+json.dump({"reference": "libbsc 3.3.5 (oracle/_ref)", "blocks": out},
+          open(os.path.join(ROOT, "tests/golden/golden_big.json"), "w"), indent=1)

@@ -144,3 +144,36 @@ def test_decompress_survives_corrupt_streams(ref):
         b[24:28] = struct.pack("<I", api.bsc_adler32(np.frombuffer(bytes(b[:24]), np.uint8)))
         r = api.bsc_decompress(bytes(b))
         assert isinstance(r, int) and r < 0 or r == T.tobytes(), it
+
+
+def test_decompress_rejects_frame_tables_that_leave_the_payload(ref):
+    """A checksum-valid block whose sub-block table points past the payload (the reference has the same hole,
+    coder.cpp:244-330): compressed sizes are checked against the payload length before anything is read, a truncated
+    frame table and a 28-byte block with a non-zero mode are rejected too."""
+    import struct
+    from libbsc_amd.synth import synth_text_v1
+
+    def seal(b):
+        b[0:4] = struct.pack("<i", len(b))
+        b[20:24] = struct.pack("<I", api.bsc_adler32(np.frombuffer(bytes(b[28:]), np.uint8)))
+        b[24:28] = struct.pack("<I", api.bsc_adler32(np.frombuffer(bytes(b[:24]), np.uint8)))
+        return bytes(b)
+
+    T = synth_text_v1(5, 600_000)                       # >= 256 KiB: 2 sub-blocks
+    blk = bytearray(ref.compress(T, 1, 1))
+    assert blk[28] == 2 and api.bsc_decompress(bytes(blk)) == T.tobytes()
+    for field, value in ((28 + 1 + 4, 16187462), (28 + 1 + 4, 0x7fffffff), (28 + 1 + 8 + 4, len(blk)), (28 + 1 + 4, len(blk) - 28 - 1)):
+        b = bytearray(blk)
+        b[field:field + 4] = struct.pack("<i", value)
+        assert api.bsc_decompress(seal(b)) == api.DATA_CORRUPT, (field, value)
+    # a 212-byte block announcing two sub-blocks, the first 16 MB long (the advisor's reproducer)
+    small = bytearray(blk[:212])
+    small[28 + 1 + 4:28 + 1 + 8] = struct.pack("<i", 16187462)
+    small[211] = 0                                       # no aux indexes
+    assert api.bsc_decompress(seal(small)) == api.DATA_CORRUPT
+    # frame table cut short: nblocks = 8 but only a few bytes of payload
+    tiny = bytearray(blk[:28 + 6]); tiny[28] = 8; tiny[-1] = 0
+    assert api.bsc_decompress(seal(tiny)) == api.DATA_CORRUPT
+    # header only, mode != 0
+    hdr = bytearray(blk[:28])
+    assert api.bsc_decompress(seal(hdr)) < 0
