@@ -72,6 +72,16 @@ BSCGPU_API int bscgpu_adler32_device(bscgpu_ctx* ctx, const void* dT, int64_t n,
 BSCGPU_API int bscgpu_radix_sort_u64(bscgpu_ctx* ctx, void* keys, void* keys_alt, void* vals, void* vals_alt,
                           int64_t n, int begin_bit, int end_bit, int* result_in_alt);
 
+/* ---- QLFC static coder (-e1): the adaptive model on the GPU --------------------------------- */
+/* Stage function: sorted host block L[0..n) -> sub-block split (coder.cpp:70-109) + run/rank front end (qlfc.cpp:398-455)
+ * + every probability of the static model (qlfc.cpp:896-1126, predictor.h:53-61,121) as a stream of 16-bit entries
+ * {[11:0] probability, [12] coded bit, [13] first decision of a run}, stream order, all sub-blocks back to back
+ * (poff[b]..poff[b+1] = sub-block b).  Returns the number of decisions, LIBBSC_NOT_SUPPORTED (-4) when the block has to take
+ * the host model (more than 256 distinct decision types, ...; bscgpu_last_error says which), or a negative libbsc code.
+ * dbg (optional, [3][cap]): the state- / char- / static-counter value behind every decision. */
+BSCGPU_API int64_t bscgpu_qlfc_static_pstream(bscgpu_ctx* ctx, const uint8_t* L, int n, uint16_t* out, int64_t cap, int* nblocks,
+                                   int* sub_start /*[8]*/, int* sub_size /*[8]*/, int64_t* poff /*[9]*/, uint16_t* dbg);
+
 /* ---- full block compression with the BWT/ST + coder split across GPU and host ------------- */
 /* bsc_compress semantics (libbsc.cpp:213) for input already in HBM: Adler-32 + sort transform on
  * the GPU, QLFC coder on host threads.  output is a HOST buffer of n + 28 bytes. */
@@ -110,7 +120,11 @@ enum {
     BSCGPU_K_GATHER        = 5, /* ISA[SA+h] gathers */
     BSCGPU_K_EMIT          = 6, /* BWT / ST output byte emit */
     BSCGPU_K_MISC          = 7,
-    BSCGPU_K_COUNT         = 8
+    BSCGPU_K_DC_CTX        = 8,  /* device coder: contexts, items, setup */
+    BSCGPU_K_DC_PART       = 9,  /* device coder: decisions into chain-major order */
+    BSCGPU_K_DC_EVAL       = 10, /* device coder: counter chains */
+    BSCGPU_K_DC_PSTREAM    = 11, /* device coder: probability stream */
+    BSCGPU_K_COUNT         = 12
 };
 typedef struct bscgpu_kstat {
     double   ms;        /* accumulated HIP-event time */

@@ -122,6 +122,7 @@ extern "C" void bscgpu_destroy(bscgpu_ctx* c)
         if (s.hrank) hipHostFree(s.hrank);
         if (s.hstart) hipHostFree(s.hstart);
     }
+    devcoder_destroy(c);
     if (c->arena) hipFree(c->arena);
     if (c->sync_ev) hipEventDestroy(c->sync_ev);
     if (c->stream) hipStreamDestroy(c->stream);

@@ -60,6 +60,8 @@ struct HostSlot {
 };
 constexpr int MAX_SLOTS = 8;
 
+struct DevCoder;                  // device-side static coder state (devcoder.hip), created on first use
+
 struct bscgpu_ctx {
     int          device      = 0;
     hipStream_t  stream      = nullptr;
@@ -94,6 +96,9 @@ struct bscgpu_ctx {
     u64* hsplit = nullptr;   // pinned: split-flag words (max_n / 256 + 64 bytes)
     HostSlot slots[MAX_SLOTS];   // pinned landing zones for the QLFC front end; >1 when blocks are pipelined
     int      nslots = 0;
+    DevCoder* dc = nullptr;
+    int      dc_last_fail = 0;   // why the last block left the device coder (bit mask, devcoder.hip FAIL_*), 0 = it did not
+    int      dc_replays = 0;     // evaluation chunks replayed serially in the last block
     int      rs_wc_mode = 0;     // BSC_RS_WC as read at context creation (radix_engine_setup)
 
     // profiling
@@ -124,8 +129,9 @@ void prof_collect(bscgpu_ctx* c);   // after a stream sync: fold pending events 
 struct RadixPass { int shift; int bits; };
 // Sort n records; passes applied in order (LSD).  Result lands in (keys, vals) if the number of
 // passes is even, else in (keys_alt, vals_alt); *in_alt tells which.
+// emit_pos (optional; one keys-only pass): emit_pos[i] = index in the output of input record i.
 int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* vals_alt, u64 n,
-                      const RadixPass* passes, int npasses, int* in_alt);
+                      const RadixPass* passes, int npasses, int* in_alt, u32* emit_pos = nullptr);
 
 int radix_engine_setup(bscgpu_ctx* c);     // per-device kernel attributes; bscgpu_create calls it with c->device current
 
@@ -138,6 +144,12 @@ int qlfc_front_split(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, int* start
 int qlfc_front_runs(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, const int* start, u32* m_out, u32* run_first, u32* first_run_host,
                     HostSlot& slot);
 int ctx_ensure_slots(bscgpu_ctx* c, int count);
+// device-side model of the static QLFC coder (devcoder.hip): probability stream of a whole block from the front end's run arrays
+int  devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* dstart, u32 m, u32 n, int nb, const u32* run_first,
+                      const int* max_rank, u32* D_out, u32* poff_out, u16* dbg);
+const u16* devcoder_pstream_ptr(const bscgpu_ctx* c);
+void devcoder_destroy(bscgpu_ctx* c);
+int64_t devcoder_arena_bytes(const bscgpu_ctx* c);
 
 // ---------------------------------------------------------------------------------------------
 // Device helpers (wave64)

@@ -1,0 +1,817 @@
+// devcoder.hip — the adaptive model of the static QLFC coder (-e1) on MI355X: every probability the range coder will
+// need, computed on the GPU, so that the host is left with the range coder's own carry chain and nothing else.
+//
+// The reference codes a sub-block as ONE serial loop (libbsc/coder/qlfc/qlfc.cpp:829-1129): per run ~7 binary decisions,
+// each predicted from three adaptive counters and coded at once.  The counters, though, are independent chains (see
+// devcoder_model.h): chain = (sub-block, decision type, family, X), v <- step(v, bit) over the chain's decisions in stream
+// order.  This file lays the decisions of a whole block (8 sub-blocks, ~2e8 decisions for 64 MiB of text) out chain by
+// chain and walks all chains in parallel:
+//
+//   1. contexts      avg_rank >= 32 flags (two-sided bracket walk with warm-up), per-run packed items; a stable 8-bit
+//                    radix pass by symbol gives the symbol-major order in which "previous run of the same symbol"
+//                    (rank_hist / run_hist, qlfc.cpp:900, :981-987) is the neighbouring element; context states from the
+//                    reference's two state tables; two more radix passes order the runs by rank-state and by run-state.
+//   2. partition     for each family (static: stream order; char: symbol-major; state: state-major) the decisions of the
+//                    runs, generated on the fly round by round (64 runs per wavefront, ballot-match ranking, no atomics on
+//                    the order-defining path), are scattered into chain-major order: row = decision type, inside a row
+//                    X-major, inside that stream order.  Each decision also records where it went (pos).
+//   3. evaluation    8192-event chunks, one lane each.  A chunk that starts inside a chain does not know the chain's value
+//                    there, but the counter maps are monotone, so running them from the two ends of the attainable range
+//                    brackets the truth, and once the two trajectories meet everything after is exact (chunks are long
+//                    enough that they nearly always meet; a chunk whose predecessor did not coalesce replays it serially —
+//                    exactness never depends on luck).  Second walk with the exact start values writes the counter value
+//                    every decision sees.
+//   4. p stream      back in stream order: gather the three values of every decision through pos, blend (predictor.h:121),
+//                    emit 16 bits per decision: probability, coded bit, start-of-run mark.
+//
+// The host (qlfc.cpp: encode_from_pstream) then runs only the range coder.  Whenever something is outside what this path
+// handles exactly (more than 256 distinct decision types in a block, an avg_rank bracket that does not decide, capacity),
+// a flag is raised and the caller falls back to the host model; nothing approximate is ever emitted.
+#include "dev_common.h"
+#include "devcoder_model.h"
+#include "../host/qlfc.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace dcm;
+
+constexpr int DC_WCH_MAX  = 4096;      // wave-chunks of a partition job (one wavefront walks one chunk of runs)
+constexpr int DC_EV       = 8192;      // events per evaluation chunk
+constexpr int DC_AVG_CH   = 1024;      // runs per avg_rank lane
+constexpr int DC_AVG_WARM = 768;       // warm-up runs in front of an avg_rank chunk
+constexpr u32 DC_SIGMASK  = 0x7ffu;    // event = X | sub-block << 8 | bit << 11
+
+// meta scalars (device u32 array)
+enum { DM_FAIL = 0, DM_NHOT, DM_NROUNDS, DM_AVG_UND, DM_REPLAYS, DM_D0, DM_D1, DM_D2, DM_D3, DM_HIST_FAIL, DM_COUNT = 16 };
+enum { FAIL_TYPES = 1, FAIL_AVG = 2, FAIL_HIST = 4, FAIL_CAP = 8, FAIL_REPLAY = 16 };
+
+struct DcSub { u32 nb; u32 first[9]; u32 maxr[8]; };            // run index range and max_rank of each sub-block
+
+struct DevCoder {
+    size_t Mcap = 0, Dcap = 0;
+    char*  arena = nullptr; size_t arena_bytes = 0;
+    u64 *key_ch = nullptr, *key_ch_s = nullptr, *key_sr = nullptr, *key_sr_s = nullptr, *key_sn = nullptr, *key_sn_s = nullptr;
+    u32 *inv_ch = nullptr, *inv_sr = nullptr, *inv_sn = nullptr;
+    u8  *ge32 = nullptr;
+    u32 *doff[4] = {nullptr, nullptr, nullptr, nullptr};       // per job: sp, ch, sr, sn
+    u16 *events = nullptr;
+    u32 *pos[3] = {nullptr, nullptr, nullptr};
+    u16 *V[3] = {nullptr, nullptr, nullptr};
+    u16 *ps = nullptr;
+    u32 *cnt = nullptr, *rowtot = nullptr, *rowstart = nullptr /*[4][257]*/, *wdec = nullptr, *wdecoff = nullptr;
+    u16 *elo = nullptr, *ehi = nullptr, *S = nullptr;
+    u32 *present = nullptr; u8 *hot = nullptr; u16 *hot2tau = nullptr; u8 *rounds = nullptr; u32 *meta = nullptr; u32 *poff = nullptr;
+    u8  *tab_rank = nullptr, *tab_run = nullptr;
+    ModelParams* mp = nullptr;                                 // device copy
+    u32 *hmeta = nullptr;                                      // pinned: meta + poff
+};
+
+__device__ __forceinline__ u32 dc_sb_of(u32 j, const DcSub& S)
+{
+    u32 sb = 0;
+#pragma unroll
+    for (int b = 1; b < 8; ++b) if ((u32)b < S.nb && j >= S.first[b]) sb = b;
+    return sb;
+}
+__device__ __forceinline__ u32 dc_run_len(const u32* __restrict__ start, u32 j, u32 m, u32 n) { return ((j + 1 < m) ? start[j + 1] : n) - start[j]; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 1a. avg_rank >= 32 (qlfc.cpp:903 / :978): avg' = (avg * 124 + rank * 4) >> 7, reset per sub-block.  One lane per chunk,
+// two-sided bracket [0, 255] started DC_AVG_WARM runs early; the flag of a run is decided when both ends agree.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void dc_avg_kernel(const u8* __restrict__ rank, u32 m, DcSub S, u8* __restrict__ ge32, u32* __restrict__ meta)
+{
+    const u32 c = blockIdx.x * WG + threadIdx.x;
+    const u64 j0 = (u64)c * DC_AVG_CH;
+    if (j0 >= m) return;
+    const u32 j1 = (u32)((j0 + DC_AVG_CH < m) ? j0 + DC_AVG_CH : m);
+    u32 sb = dc_sb_of((u32)j0, S);
+    const u32 sb_first = S.first[sb];
+    u32 w0 = ((u32)j0 > sb_first + DC_AVG_WARM) ? (u32)j0 - DC_AVG_WARM : sb_first;
+    u32 lo = 0, hi = (w0 == sb_first) ? 0u : 255u;
+    for (u32 j = w0; j < (u32)j0; ++j) { const u32 r = rank[j]; lo = avg_rank_next(lo, r); hi = avg_rank_next(hi, r); }
+    u32 next_first = (sb + 1 < S.nb) ? S.first[sb + 1] : 0xffffffffu;
+    u32 und = 0;
+    for (u32 j = (u32)j0; j < j1; ++j) {
+        if (j == next_first) { lo = hi = 0; ++sb; next_first = (sb + 1 < S.nb) ? S.first[sb + 1] : 0xffffffffu; }
+        const u32 f = lo >= 32u;
+        und += (f != (u32)(hi >= 32u));
+        ge32[j] = (u8)f;
+        const u32 r = rank[j];
+        lo = avg_rank_next(lo, r); hi = avg_rank_next(hi, r);
+    }
+    if (und) atomicAdd(&meta[DM_AVG_UND], und);
+}
+
+// 1b. packed items in stream order: X = symbol (the char family's sort digit; the static family ignores it)
+__global__ __launch_bounds__(WG) void dc_items_kernel(const u8* __restrict__ sym, const u8* __restrict__ rank, const u32* __restrict__ start,
+                                                      const u8* __restrict__ ge32, u32 m, u32 n, DcSub S, u64* __restrict__ key_ch)
+{
+    const u32 j = blockIdx.x * WG + threadIdx.x;
+    if (j >= m) return;
+    key_ch[j] = item_pack(sym[j], dc_sb_of(j, S), ge32[j], rank[j], dc_run_len(start, j, m, n));
+}
+
+// 1c. context states + the state family's items + which decision types occur.  Thread per run (stream order).
+__global__ __launch_bounds__(WG) void dc_ctx_kernel(const u64* __restrict__ key_ch, const u64* __restrict__ key_ch_s, const u32* __restrict__ inv_ch,
+                                                    u32 m, DcSub S, const u8* __restrict__ tab_rank, const u8* __restrict__ tab_run,
+                                                    u64* __restrict__ key_sr, u64* __restrict__ key_sn, u32* __restrict__ present, u32* __restrict__ meta)
+{
+    __shared__ u32 bits[(NUM_TAU + 31) / 32];
+    for (u32 i = threadIdx.x; i < (NUM_TAU + 31) / 32; i += WG) bits[i] = 0;
+    __syncthreads();
+    const u32 j = blockIdx.x * WG + threadIdx.x;
+    if (j < m) {
+        const u64 key = key_ch[j];
+        const Item it = item_unpack(key);
+        const u32 c = item_X(key);
+        const u32 j0 = S.first[it.sb];
+        // window contexts: previous runs of the same sub-block (qlfc.cpp:1063-1068)
+        u32 ctx_rank0 = 0, ctx_rank4 = 0, ctx_run = 0;
+#pragma unroll
+        for (u32 k = 1; k <= 4; ++k) {
+            if (j >= j0 + k) {
+                const Item p = item_unpack(key_ch[j - k]);
+                if (k <= 3) ctx_rank0 |= (p.rank == 1u ? 1u : 0u) << (k - 1);
+                ctx_rank4 |= (p.rank - 1u < 3u ? p.rank - 1u : 3u) << (2 * (k - 1));
+                ctx_run |= (p.run < 3u ? 1u : 0u) << (k - 1);
+            }
+        }
+        // symbol-major neighbours: the previous runs of this symbol in this sub-block
+        const u32 q = inv_ch[j];
+        const u64 chain_id = key >> 53;                               // X and sub-block
+        u32 rank_hist = 0;
+        if (q > 0) { const u64 pk = key_ch_s[q - 1]; if ((pk >> 53) == chain_id) rank_hist = (u32)bsr(item_unpack(pk).rank); }
+        // run_hist (qlfc.cpp:981-987): h' = (h + x) >> 2 over the symbol's earlier runs; only min(h, 7) is used, so walk a
+        // two-sided bracket forward from K runs back until both ends give the same clamped value
+        u32 run_hist = 0;
+        {
+            u32 K = 6;
+            for (;;) {
+                u32 lo = 0, hi = 63, first = q;                       // first = oldest predecessor used
+                bool exact = false;
+                for (u32 t = 1; t <= K; ++t) {
+                    if (q < t || (key_ch_s[q - t] >> 53) != chain_id) { exact = true; break; }
+                    first = q - t;
+                }
+                if (exact) hi = 0;
+                for (u32 p = first; p < q; ++p) { const u32 r = item_unpack(key_ch_s[p]).run; lo = run_hist_next(lo, r); hi = run_hist_next(hi, r); }
+                const u32 cl = lo < 7u ? lo : 7u, ch = hi < 7u ? hi : 7u;
+                if (cl == ch) { run_hist = cl; break; }
+                if (K >= 4096) { atomicOr(&meta[DM_FAIL], (u32)FAIL_HIST); run_hist = cl; break; }
+                K *= 4;
+            }
+        }
+        const u32 state_rank = tab_rank[rank_state_index(ctx_run, ctx_rank4, rank_hist)];
+        const u32 state_run = tab_run[run_state_index(ctx_rank0, ctx_run, it.rank, run_hist)];
+        const u64 info = key & 0x00ffffffffffffffull;
+        key_sr[j] = ((u64)state_rank << 56) | info;
+        key_sn[j] = ((u64)state_run << 56) | info;
+
+        // decision types of this run
+        const int maxr = (int)S.maxr[it.sb];
+        auto mark = [&](int tau) { const u32 w = (u32)tau >> 5, b = 1u << (tau & 31); if (!(bits[w] & b)) atomicOr(&bits[w], b); };
+        if (it.ge32) { for (int d = 0; d <= maxr; ++d) { u32 bit; mark(decision(it, maxr, ROUND_RP + d, &bit)); } }
+        else {
+            mark(TAU_RF);
+            if (it.rank != 1u) {
+                const int B = bsr(it.rank);
+                for (int s = 0; s <= B - 2; ++s) mark(TAU_RE + s);
+                if (B < maxr) mark(TAU_RE + B - 1);
+                for (int d = 0; d < B; ++d) { u32 bit; mark(decision(it, maxr, ROUND_RM + d, &bit)); }
+            }
+        }
+        mark(TAU_NF);
+        if (it.run != 1u) {
+            const int nb = bsr(it.run);
+            for (int s = 0; s < nb; ++s) mark(TAU_NE + s);
+            for (int d = 0; d < nb; ++d) { u32 bit; mark(decision(it, maxr, ROUND_NM + d, &bit)); }
+        }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < (NUM_TAU + 31) / 32; i += WG) if (bits[i]) atomicOr(&present[i], bits[i]);
+}
+
+// 1d. dense row ids of the types that occur, and the canonical rounds that occur.  One workgroup.
+__global__ __launch_bounds__(WG) void dc_setup_kernel(const u32* __restrict__ present, u8* __restrict__ hot, u16* __restrict__ hot2tau,
+                                                      u8* __restrict__ rounds, u32* __restrict__ meta)
+{
+    __shared__ u32 wpre[(NUM_TAU + 31) / 32 + 1];
+    __shared__ u32 rbits[3];
+    constexpr int NW = (NUM_TAU + 31) / 32;
+    if (threadIdx.x == 0) { u32 acc = 0; for (int w = 0; w < NW; ++w) { wpre[w] = acc; acc += __popc(present[w]); } wpre[NW] = acc; }
+    if (threadIdx.x < 3) rbits[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 nhot = wpre[NW];
+    for (int tau = threadIdx.x; tau < NUM_TAU; tau += WG) {
+        const u32 w = (u32)tau >> 5, b = (u32)tau & 31u, word = present[w];
+        u32 h = 0;
+        if (word & (1u << b)) {
+            h = wpre[w] + __popc(word & ((1u << b) - 1u));
+            if (h < 256u) hot2tau[h] = (u16)tau;
+            const int r = tau_round(tau);
+            atomicOr(&rbits[r >> 5], 1u << (r & 31));
+        }
+        hot[tau] = (u8)(h < 256u ? h : 255u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 nr = 0;
+        for (int r = 0; r < NUM_ROUNDS; ++r) if (rbits[r >> 5] & (1u << (r & 31))) rounds[nr++] = (u8)r;
+        meta[DM_NHOT] = nhot; meta[DM_NROUNDS] = nr;
+        if (nhot > 256u) atomicOr(&meta[DM_FAIL], (u32)FAIL_TYPES);
+        if (meta[DM_AVG_UND] != 0u) atomicOr(&meta[DM_FAIL], (u32)FAIL_AVG);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 2. partition: decisions of a job's items into chain-major order
+// ---------------------------------------------------------------------------------------------------------------------
+struct DcGeom { u32 m; u32 W; u32 per_wave; };                       // items, wave-chunks, items per wave-chunk (multiple of 64)
+static DcGeom dc_geom(u32 m)
+{
+    DcGeom g; g.m = m;
+    u32 W = (m + 63) / 64; if (W > DC_WCH_MAX) W = DC_WCH_MAX; if (W == 0) W = 1;
+    u32 per = (m + W - 1) / W; per = (per + 63) / 64 * 64; if (per == 0) per = 64;
+    g.per_wave = per; g.W = (m + per - 1) / per; if (g.W == 0) g.W = 1;
+    return g;
+}
+
+typedef __attribute__((address_space(3))) volatile u32 dc_lds_vu32;
+
+// lanes of `active` whose h equals this lane's: (lo, hi) halves of the peer mask
+__device__ __forceinline__ void dc_match8(u32 h, u64 active, u32& mlo, u32& mhi)
+{
+    mlo = (u32)active; mhi = (u32)(active >> 32);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int bitm = __builtin_amdgcn_sbfe((int)h, b, 1);
+        const u64 bal = __ballot(bitm != 0);
+        const u32 nb = ~(u32)bitm;
+        mlo &= (u32)bal ^ nb;
+        mhi &= (u32)(bal >> 32) ^ nb;
+    }
+}
+
+template <int SIDES>
+__device__ __forceinline__ bool dc_round_on_side(int r) { return (r < ROUND_NF) ? (SIDES & 1) != 0 : (SIDES & 2) != 0; }
+
+// 2a. per wave-chunk: decisions per row and in total
+template <int SIDES>
+__global__ __launch_bounds__(WG) void dc_part_count_kernel(const u64* __restrict__ items, DcGeom g, DcSub S, const u8* __restrict__ hot,
+                                                           const u8* __restrict__ rounds, const u32* __restrict__ meta,
+                                                           u32* __restrict__ cnt /*[256][W]*/, u32* __restrict__ wdec)
+{
+    __shared__ u8 shot[NUM_TAU];
+    __shared__ u32 hist[WAVES][256];
+    __shared__ u8 srounds[NUM_ROUNDS];
+    for (u32 i = threadIdx.x; i < NUM_TAU; i += WG) shot[i] = hot[i];
+    for (u32 i = threadIdx.x; i < WAVES * 256; i += WG) (&hist[0][0])[i] = 0;
+    const u32 nr = meta[DM_NROUNDS];
+    if (threadIdx.x < NUM_ROUNDS) srounds[threadIdx.x] = threadIdx.x < nr ? rounds[threadIdx.x] : 0;
+    __syncthreads();
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 wc = blockIdx.x * WAVES + w;
+    dc_lds_vu32* vh = (dc_lds_vu32*)&hist[w][0];
+    const u64 lt = lanemask_lt();
+    const u32 lt_lo = (u32)lt, lt_hi = (u32)(lt >> 32);
+    u32 total = 0;
+    if (wc < g.W) {
+        const u64 i0 = (u64)wc * g.per_wave;
+        u64 i1 = i0 + g.per_wave; if (i1 > g.m) i1 = g.m;
+        for (u64 base = i0; base < i1; base += 64) {
+            const u64 i = base + lane;
+            const bool valid = i < i1;
+            const u64 key = valid ? items[i] : 0ull;
+            const Item it = item_unpack(key);
+            const int maxr = (int)S.maxr[it.sb];
+            for (u32 k = 0; k < nr; ++k) {
+                const int r = srounds[k];
+                if (!dc_round_on_side<SIDES>(r)) continue;
+                u32 bit = 0;
+                const int tau = valid ? decision(it, maxr, r, &bit) : -1;
+                const bool on = tau >= 0;
+                const u64 active = __ballot(on);
+                if (active == 0) continue;
+                const u32 h = on ? (u32)shot[tau] : 0u;
+                u32 mlo, mhi;
+                dc_match8(h, active, mlo, mhi);
+                const u32 rr = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));
+                const u32 cn = (u32)(__popc(mlo) + __popc(mhi));
+                if (on && rr == cn - 1) vh[h] = vh[h] + cn;               // one lane per row adds the row's count
+                total += (u32)__popcll(active);
+            }
+        }
+    }
+    __syncthreads();
+    if (wc < g.W) {
+        for (u32 h = lane; h < 256; h += 64) cnt[(size_t)h * g.W + wc] = hist[w][h];
+        if (lane == 0) wdec[wc] = total;
+    }
+}
+
+// 2b. scans: rows over wave-chunks (one workgroup per row), then row bases and the wave-chunks' decision offsets
+__global__ __launch_bounds__(WG) void dc_scan_rows_kernel(u32* __restrict__ cnt, u32 W, u32* __restrict__ rowtot)
+{
+    __shared__ u32 scr[8];
+    u32* row = cnt + (size_t)blockIdx.x * W;
+    u32 carry = 0;
+    for (u32 base = 0; base < W; base += WG) {
+        const u32 i = base + threadIdx.x;
+        const u32 v = (i < W) ? row[i] : 0u;
+        u32 tot;
+        const u32 ex = block_excl_sum(v, scr, &tot);
+        if (i < W) row[i] = carry + ex;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rowtot[blockIdx.x] = carry;
+}
+__global__ __launch_bounds__(WG) void dc_scan_misc_kernel(const u32* __restrict__ rowtot, u32* __restrict__ rowstart /*[257]*/,
+                                                          const u32* __restrict__ wdec, u32 W, u32* __restrict__ wdecoff /*[W+1]*/,
+                                                          u32* __restrict__ meta, int job, u32 Dcap)
+{
+    __shared__ u32 scr[8];
+    u32 tot;
+    const u32 ex = block_excl_sum(rowtot[threadIdx.x], scr, &tot);
+    rowstart[threadIdx.x] = ex;
+    if (threadIdx.x == 0) { rowstart[256] = tot; meta[DM_D0 + job] = tot; if (tot > Dcap) atomicOr(&meta[DM_FAIL], (u32)FAIL_CAP); }
+    u32 carry = 0;
+    for (u32 base = 0; base < W; base += WG) {
+        const u32 i = base + threadIdx.x;
+        const u32 v = (i < W) ? wdec[i] : 0u;
+        u32 t2;
+        const u32 e2 = block_excl_sum(v, scr, &t2);
+        if (i < W) wdecoff[i] = carry + e2;
+        carry += t2;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wdecoff[W] = carry;
+}
+
+// 2c. scatter.  One wavefront per wave-chunk walks its items 64 at a time; per canonical round the lanes that have a decision
+// are ranked stably inside their row (same type -> same round, so rows never interleave across rounds) and write
+//   events[row offset]            = X | sub-block << 8 | bit << 11
+//   pos[decision index of item]   = v_base + that offset (index into the family's value array)
+template <int SIDES>
+__global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restrict__ items, DcGeom g, DcSub S, const u8* __restrict__ hot,
+                                                             const u8* __restrict__ rounds, const u32* __restrict__ meta,
+                                                             const u32* __restrict__ cnt, const u32* __restrict__ rowstart,
+                                                             const u32* __restrict__ wdecoff, u32 v_base, u32 dec_base, u32 ignoreX,
+                                                             u16* __restrict__ events, u32* __restrict__ pos, u32* __restrict__ doff)
+{
+    __shared__ u8 shot[NUM_TAU];
+    __shared__ u32 goff[WAVES][256];
+    __shared__ u8 srounds[NUM_ROUNDS];
+    if (meta[DM_FAIL] != 0u) return;
+    for (u32 i = threadIdx.x; i < NUM_TAU; i += WG) shot[i] = hot[i];
+    const u32 nr = meta[DM_NROUNDS];
+    if (threadIdx.x < NUM_ROUNDS) srounds[threadIdx.x] = threadIdx.x < nr ? rounds[threadIdx.x] : 0;
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 wc = blockIdx.x * WAVES + w;
+    if (wc < g.W) for (u32 h = lane; h < 256; h += 64) goff[w][h] = rowstart[h] + cnt[(size_t)h * g.W + wc];
+    __syncthreads();
+    if (wc >= g.W) return;
+    dc_lds_vu32* vg = (dc_lds_vu32*)&goff[w][0];
+    const u64 lt = lanemask_lt();
+    const u32 lt_lo = (u32)lt, lt_hi = (u32)(lt >> 32);
+    const u64 i0 = (u64)wc * g.per_wave;
+    u64 i1 = i0 + g.per_wave; if (i1 > g.m) i1 = g.m;
+    u32 running = wdecoff[wc];                                        // decision index of the tile's first item
+    for (u64 base = i0; base < i1; base += 64) {
+        const u64 i = base + lane;
+        const bool valid = i < i1;
+        const u64 key = valid ? items[i] : 0ull;
+        const Item it = item_unpack(key);
+        const int maxr = (int)S.maxr[it.sb];
+        u32 nd = 0;
+        if (valid) { if (SIDES & 1) nd += (u32)count_rank_side(it, maxr); if (SIDES & 2) nd += (u32)count_run_side(it); }
+        const u32 incl = wave_incl_sum(nd);
+        const u32 my = running + incl - nd;
+        if (valid) doff[i] = my;
+        running += __shfl(incl, 63, 64);
+        const u32 sig = (ignoreX ? 0u : item_X(key)) | (it.sb << 8);
+        u32 ord = 0;
+        for (u32 k = 0; k < nr; ++k) {
+            const int r = srounds[k];
+            if (!dc_round_on_side<SIDES>(r)) continue;
+            u32 bit = 0;
+            const int tau = valid ? decision(it, maxr, r, &bit) : -1;
+            const bool on = tau >= 0;
+            const u64 active = __ballot(on);
+            if (active == 0) continue;
+            const u32 h = on ? (u32)shot[tau] : 0u;
+            u32 mlo, mhi;
+            dc_match8(h, active, mlo, mhi);
+            const u32 before = vg[h];
+            const u32 rr  = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));
+            const u32 cn  = (u32)(__popc(mlo) + __popc(mhi));
+            if (on) {
+                const u32 p = before + rr;
+                if (rr == cn - 1) vg[h] = before + cn;                // highest peer publishes
+                events[p] = (u16)(sig | (bit << 11));
+                pos[(size_t)dec_base + my + ord] = v_base + p;
+                ++ord;
+            }
+        }
+    }
+    if (wc == g.W - 1 && lane == 0) doff[g.m] = running;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3. chain evaluation over chain-major events
+// ---------------------------------------------------------------------------------------------------------------------
+struct DcEvalJob { const u16* events; u32 E; const u32* rowstart; const u16* hot2tau; int fam; };
+
+__device__ __forceinline__ u32 dc_find_row(const u32* __restrict__ rowstart, u32 k)
+{
+    u32 lo = 0, hi = 256;                                              // largest row with rowstart[row] <= k
+    while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (rowstart[mid] <= k) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// Walk events [k0, k1) of one chunk.  MODE 0: two-sided bracket, returns (lo, hi).  MODE 1: exact from `start`, optionally
+// writing the value each event sees.
+template <bool WRITE>
+__device__ __forceinline__ void dc_walk(const DcEvalJob& J, const ModelParams* __restrict__ mp, u32 k0, u32 k1, int& lo, int& hi, bool bracket,
+                                        u16* __restrict__ Vout)
+{
+    u32 row = dc_find_row(J.rowstart, k0);
+    u32 rowend = J.rowstart[row + 1];
+    while (rowend <= k0 && row < 255) { ++row; rowend = J.rowstart[row + 1]; }     // k0 inside an empty-row run: move to its row
+    int cls = tau_class(J.hot2tau[row]);
+    Rates R = mp->rates[cls][J.fam];
+    u32 prev = (k0 > J.rowstart[row]) ? ((u32)J.events[k0 - 1] & DC_SIGMASK) : 0xffffu;
+    if (bracket) { lo = mp->vmin[cls][J.fam]; hi = mp->vmax[cls][J.fam]; }
+    u32 k = k0;
+    while (k < k1) {
+        if (k == rowend) {
+            do { ++row; rowend = J.rowstart[row + 1]; } while (rowend == k && row < 255);
+            cls = tau_class(J.hot2tau[row]); R = mp->rates[cls][J.fam];
+            prev = 0xffffu;
+        }
+        u32 lim = k1 < rowend ? k1 : rowend;
+        // 8 events per 16-byte load while aligned and inside the row
+        while ((k & 7u) == 0 && k + 8 <= lim) {
+            const uint4 q = *reinterpret_cast<const uint4*>(J.events + k);
+            const u32 wds[4] = {q.x, q.y, q.z, q.w};
+            u32 outw[4];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const u32 e = (wds[x >> 1] >> (16 * (x & 1))) & 0xffffu;
+                const u32 sig = e & DC_SIGMASK;
+                if (sig != prev) { lo = 2048; hi = 2048; prev = sig; }
+                const u32 b = (e >> 11) & 1u;
+                if (WRITE) { if (x & 1) outw[x >> 1] |= (u32)lo << 16; else outw[x >> 1] = (u32)lo; }
+                lo = step(lo, b, R);
+                if (!WRITE) hi = step(hi, b, R);
+            }
+            if (WRITE) *reinterpret_cast<uint4*>(Vout + k) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+            k += 8;
+        }
+        if (k < lim && ((k & 7u) != 0 || k + 8 > lim)) {
+            const u32 stop = ((k & 7u) != 0) ? (((k | 7u) + 1u) < lim ? ((k | 7u) + 1u) : lim) : lim;
+            for (; k < stop; ++k) {
+                const u32 e = J.events[k];
+                const u32 sig = e & DC_SIGMASK;
+                if (sig != prev) { lo = 2048; hi = 2048; prev = sig; }
+                const u32 b = (e >> 11) & 1u;
+                if (WRITE) Vout[k] = (u16)lo;
+                lo = step(lo, b, R);
+                if (!WRITE) hi = step(hi, b, R);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(WG) void dc_eval_a_kernel(DcEvalJob J, const ModelParams* __restrict__ mp, const u32* __restrict__ meta,
+                                                       u16* __restrict__ elo, u16* __restrict__ ehi)
+{
+    if (meta[DM_FAIL] != 0u) return;
+    const u32 c = blockIdx.x * WG + threadIdx.x;
+    const u64 k0 = (u64)c * DC_EV;
+    if (k0 >= J.E) return;
+    const u32 k1 = (u32)((k0 + DC_EV < J.E) ? k0 + DC_EV : J.E);
+    int lo, hi;
+    dc_walk<false>(J, mp, (u32)k0, k1, lo, hi, true, nullptr);
+    elo[c] = (u16)lo; ehi[c] = (u16)hi;
+}
+
+__device__ __forceinline__ bool dc_chunk_continues(const DcEvalJob& J, u32 c)
+{
+    if (c == 0) return false;
+    const u32 k0 = c * DC_EV;
+    u32 row = dc_find_row(J.rowstart, k0);
+    if (J.rowstart[row] == k0) return false;                          // a row (hence a chain) starts exactly here
+    // (an empty row cannot own k0: dc_find_row returns the last row starting at or before k0, which then is non-empty or k0 >= E)
+    return (((u32)J.events[k0 - 1] ^ (u32)J.events[k0]) & DC_SIGMASK) == 0;
+}
+
+// exact value at the start of every chunk that begins inside a chain
+__global__ __launch_bounds__(WG) void dc_eval_b_kernel(DcEvalJob J, const ModelParams* __restrict__ mp, u32* __restrict__ meta,
+                                                       const u16* __restrict__ elo, const u16* __restrict__ ehi, u16* __restrict__ Sv)
+{
+    if (meta[DM_FAIL] != 0u) return;
+    const u32 c = blockIdx.x * WG + threadIdx.x;
+    const u64 k0 = (u64)c * DC_EV;
+    if (k0 >= J.E) return;
+    if (!dc_chunk_continues(J, c)) { Sv[c] = 2048; return; }
+    if (elo[c - 1] == ehi[c - 1]) { Sv[c] = elo[c - 1]; return; }
+    // the predecessor did not coalesce: replay from the nearest chunk whose start value is known
+    u32 j = c - 1;
+    int start = 2048;
+    u32 depth = 1;
+    for (;;) {
+        if (!dc_chunk_continues(J, j)) { start = 2048; break; }
+        if (elo[j - 1] == ehi[j - 1]) { start = elo[j - 1]; break; }
+        --j; ++depth;
+        if (depth > 64) { atomicOr(&meta[DM_FAIL], (u32)FAIL_REPLAY); Sv[c] = 2048; return; }
+    }
+    atomicAdd(&meta[DM_REPLAYS], depth);
+    int lo = start, hi = start;
+    dc_walk<false>(J, mp, j * DC_EV, c * DC_EV, lo, hi, false, nullptr);          // exact walk (lo == hi throughout), no output
+    Sv[c] = (u16)lo;
+}
+
+__global__ __launch_bounds__(WG) void dc_eval_c_kernel(DcEvalJob J, const ModelParams* __restrict__ mp, const u32* __restrict__ meta,
+                                                       const u16* __restrict__ Sv, u16* __restrict__ Vout)
+{
+    if (meta[DM_FAIL] != 0u) return;
+    const u32 c = blockIdx.x * WG + threadIdx.x;
+    const u64 k0 = (u64)c * DC_EV;
+    if (k0 >= J.E) return;
+    const u32 k1 = (u32)((k0 + DC_EV < J.E) ? k0 + DC_EV : J.E);
+    int lo = Sv[c], hi = lo;
+    dc_walk<true>(J, mp, (u32)k0, k1, lo, hi, false, Vout);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 4. probability stream, stream order.  Thread per run.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DcGather {
+    const u64* key_ch; u32 m;
+    const u32 *inv_ch, *inv_sr, *inv_sn;
+    const u32 *doff_sp, *doff_ch, *doff_sr, *doff_sn;
+    const u32 *pos_sp, *pos_ch, *pos_st;
+    const u16 *V_sp, *V_ch, *V_st;
+    u32 dec_base_sn;                                                   // decision-index base of the run-side state job inside pos_st
+};
+__global__ __launch_bounds__(WG) void dc_pstream_kernel(DcGather G, DcSub S, const ModelParams* __restrict__ mp, const u8* __restrict__ rounds,
+                                                        const u32* __restrict__ meta, u16* __restrict__ out, u16* __restrict__ dbg /*[3][D] or null*/, u32 dbgD)
+{
+    __shared__ u8 srounds[NUM_ROUNDS];
+    if (meta[DM_FAIL] != 0u) return;
+    const u32 nr = meta[DM_NROUNDS];
+    if (threadIdx.x < NUM_ROUNDS) srounds[threadIdx.x] = threadIdx.x < nr ? rounds[threadIdx.x] : 0;
+    __syncthreads();
+    const u32 j = blockIdx.x * WG + threadIdx.x;
+    if (j >= G.m) return;
+    const Item it = item_unpack(G.key_ch[j]);
+    const int maxr = (int)S.maxr[it.sb];
+    const u32 n_rank = (u32)count_rank_side(it, maxr);
+    const u32 b_sp = G.doff_sp[j];
+    const u32 b_ch = G.doff_ch[G.inv_ch[j]];
+    const u32 b_sr = G.doff_sr[G.inv_sr[j]];
+    const u32 b_sn = G.doff_sn[G.inv_sn[j]] + G.dec_base_sn;
+    u32 ord = 0;
+    for (u32 k = 0; k < nr; ++k) {
+        const int r = srounds[k];
+        u32 bit = 0;
+        const int tau = decision(it, maxr, r, &bit);
+        if (tau < 0) continue;
+        const int cls = tau_class(tau);
+        const u32 pst = (r < ROUND_NF) ? G.pos_st[b_sr + ord] : G.pos_st[b_sn + (ord - n_rank)];
+        const int v_sp = G.V_sp[G.pos_sp[b_sp + ord]];
+        const int v_ch = G.V_ch[G.pos_ch[b_ch + ord]];
+        const int v_st = G.V_st[pst];
+        const int p = blend(v_ch, v_st, v_sp, mp->lr[cls]);
+        out[b_sp + ord] = (u16)((u32)p | (bit << 12) | (ord == 0 ? (u32)PS_RUN : 0u));
+        if (dbg) { dbg[b_sp + ord] = (u16)v_st; dbg[(size_t)dbgD + b_sp + ord] = (u16)v_ch; dbg[2 * (size_t)dbgD + b_sp + ord] = (u16)v_sp; }
+        ++ord;
+    }
+}
+
+__global__ void dc_poff_kernel(const u32* __restrict__ doff_sp, DcSub S, u32 m, u32* __restrict__ poff)
+{
+    const u32 b = threadIdx.x;
+    if (b <= S.nb) poff[b] = doff_sp[b < S.nb ? S.first[b] : m];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+static size_t dc_align(size_t x) { return (x + 255) / 256 * 256; }
+
+void devcoder_destroy(bscgpu_ctx* c)
+{
+    DevCoder* d = c->dc;
+    if (!d) return;
+    if (d->arena) hipFree(d->arena);
+    if (d->hmeta) hipHostFree(d->hmeta);
+    delete d;
+    c->dc = nullptr;
+}
+
+
+int devcoder_ensure(bscgpu_ctx* c)
+{
+    if (c->dc) return BSC_NO_ERROR;
+    DevCoder* d = new DevCoder();
+    const size_t N = ((size_t)c->max_n + 4096 + 4095) / 4096 * 4096;
+    d->Mcap = N; d->Dcap = 4 * N + 65536;
+    const size_t M = d->Mcap + 64, D = d->Dcap + 64, NCH = d->Dcap / DC_EV + 16;
+    struct Carve { void** p; size_t bytes; };
+    Carve carve[] = {
+        {(void**)&d->key_ch, 8 * M}, {(void**)&d->key_ch_s, 8 * M}, {(void**)&d->key_sr, 8 * M}, {(void**)&d->key_sr_s, 8 * M},
+        {(void**)&d->key_sn, 8 * M}, {(void**)&d->key_sn_s, 8 * M},
+        {(void**)&d->inv_ch, 4 * M}, {(void**)&d->inv_sr, 4 * M}, {(void**)&d->inv_sn, 4 * M}, {(void**)&d->ge32, M},
+        {(void**)&d->doff[0], 4 * M}, {(void**)&d->doff[1], 4 * M}, {(void**)&d->doff[2], 4 * M}, {(void**)&d->doff[3], 4 * M},
+        {(void**)&d->events, 2 * D},
+        {(void**)&d->pos[0], 4 * D}, {(void**)&d->pos[1], 4 * D}, {(void**)&d->pos[2], 4 * D},
+        {(void**)&d->V[0], 2 * D}, {(void**)&d->V[1], 2 * D}, {(void**)&d->V[2], 2 * D},
+        {(void**)&d->ps, 2 * D},
+        {(void**)&d->cnt, (size_t)256 * DC_WCH_MAX * 4}, {(void**)&d->rowtot, 256 * 4}, {(void**)&d->rowstart, 4 * 260 * 4},
+        {(void**)&d->wdec, (DC_WCH_MAX + 8) * 4}, {(void**)&d->wdecoff, (DC_WCH_MAX + 8) * 4},
+        {(void**)&d->elo, 2 * NCH}, {(void**)&d->ehi, 2 * NCH}, {(void**)&d->S, 2 * NCH},
+        {(void**)&d->present, 64 * 4}, {(void**)&d->hot, 2048}, {(void**)&d->hot2tau, 512}, {(void**)&d->rounds, 256},
+        {(void**)&d->meta, DM_COUNT * 4}, {(void**)&d->poff, 16 * 4},
+        {(void**)&d->tab_rank, 32768}, {(void**)&d->tab_run, 8192}, {(void**)&d->mp, sizeof(ModelParams)},
+    };
+    size_t total = 0;
+    for (auto& cv : carve) total += dc_align(cv.bytes);
+    if (hipMalloc((void**)&d->arena, total) != hipSuccess) { (void)hipGetLastError(); delete d; return BSC_GPU_NOT_ENOUGH_MEMORY; }
+    d->arena_bytes = total;
+    size_t off = 0;
+    for (auto& cv : carve) { *cv.p = d->arena + off; off += dc_align(cv.bytes); }
+    if (hipHostMalloc((void**)&d->hmeta, 64 * 4, hipHostMallocDefault) != hipSuccess) { hipFree(d->arena); delete d; return BSC_NOT_ENOUGH_MEMORY; }
+    ModelParams mp; model_params_from_table(bschost::qlfc_static_params(), mp);
+    const bschost::QlfcTables& QT = bschost::qlfc_tables();
+    const uint8_t *rs = QT.rank_state, *ns = QT.run_state;
+    const bool ok = hipMemcpyAsync(d->mp, &mp, sizeof mp, hipMemcpyHostToDevice, c->stream) == hipSuccess
+                 && hipMemcpyAsync(d->tab_rank, rs, 32768, hipMemcpyHostToDevice, c->stream) == hipSuccess
+                 && hipMemcpyAsync(d->tab_run, ns, 8192, hipMemcpyHostToDevice, c->stream) == hipSuccess
+                 && ctx_sync(c) == hipSuccess;                      // mp is a stack object: the copies must have finished
+    if (!ok) { hipFree(d->arena); hipHostFree(d->hmeta); delete d; return ctx_fail(c, BSC_GPU_ERROR, "device coder tables", hipSuccess); }
+    c->dc = d;
+    return BSC_NO_ERROR;
+}
+
+int64_t devcoder_arena_bytes(const bscgpu_ctx* c) { return c->dc ? (int64_t)c->dc->arena_bytes : 0; }
+
+template <int SIDES>
+static void dc_launch_partition(bscgpu_ctx* c, DevCoder* d, const u64* items, u32 m, const DcSub& S, int job, u32 v_base, u32 dec_base,
+                                u32 ignoreX, u32* posarr, u32* doff)
+{
+    const DcGeom g = dc_geom(m);
+    const u32 grid = (g.W + WAVES - 1) / WAVES;
+    u32* rowstart = d->rowstart + 260 * job;
+    prof_begin(c, BSCGPU_K_DC_PART, (u64)m * 8, m);
+    hipLaunchKernelGGL(dc_part_count_kernel<SIDES>, dim3(grid), dim3(WG), 0, c->stream, items, g, S, d->hot, d->rounds, d->meta, d->cnt, d->wdec);
+    hipLaunchKernelGGL(dc_scan_rows_kernel, dim3(256), dim3(WG), 0, c->stream, d->cnt, g.W, d->rowtot);
+    hipLaunchKernelGGL(dc_scan_misc_kernel, dim3(1), dim3(WG), 0, c->stream, d->rowtot, rowstart, d->wdec, g.W, d->wdecoff, d->meta, job, (u32)d->Dcap);
+    hipLaunchKernelGGL(dc_part_scatter_kernel<SIDES>, dim3(grid), dim3(WG), 0, c->stream, items, g, S, d->hot, d->rounds, d->meta, d->cnt, rowstart,
+                       d->wdecoff, v_base, dec_base, ignoreX, d->events, posarr, doff);
+    prof_end(c);
+}
+
+// Probability stream of a whole block.  Inputs: the QLFC front end's run arrays on the device (sym / rank / start, m runs of
+// the n-byte sorted block), the sub-blocks' run ranges and max_rank values.  On success *D_out decisions were written to the
+// device p stream (d->ps) and poff[0..nb] (decision offsets of the sub-blocks) to hmeta[32..]; returns BSC_NOT_SUPPORTED when
+// the block has to go through the host model instead.
+int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* dstart, u32 m, u32 n, int nb, const u32* run_first,
+                     const int* max_rank, u32* D_out, u32* poff_out, u16* dbg)
+{
+    int rc = devcoder_ensure(c);
+    if (rc < 0) return rc;
+    DevCoder* d = c->dc;
+    if (m == 0 || m > d->Mcap || nb < 1 || nb > 8) return BSC_NOT_SUPPORTED;
+    DcSub S; S.nb = (u32)nb;
+    for (int b = 0; b < 9; ++b) S.first[b] = (b <= nb) ? run_first[b] : m;
+    for (int b = 0; b < 8; ++b) S.maxr[b] = (b < nb) ? (u32)max_rank[b] : 0u;
+
+    HIP_TRY(c, hipMemsetAsync(d->meta, 0, DM_COUNT * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(d->present, 0, 64 * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(d->hot2tau, 0, 512, c->stream));
+    const u32 gm = (m + WG - 1) / WG;
+
+    prof_begin(c, BSCGPU_K_DC_CTX, (u64)m * 40, m);
+    hipLaunchKernelGGL(dc_avg_kernel, dim3(((m + DC_AVG_CH - 1) / DC_AVG_CH + WG - 1) / WG), dim3(WG), 0, c->stream, drank, m, S, d->ge32, d->meta);
+    hipLaunchKernelGGL(dc_items_kernel, dim3(gm), dim3(WG), 0, c->stream, dsym, drank, dstart, d->ge32, m, n, S, d->key_ch);
+    prof_end(c);
+    RadixPass top; top.shift = 56; top.bits = 8;
+    int in_alt = 0;
+    // one pass: the engine reads `keys` (left intact) and writes the sorted copy to the alt array
+    rc = radix_sort_passes(c, d->key_ch, d->key_ch_s, nullptr, nullptr, m, &top, 1, &in_alt, d->inv_ch);
+    if (rc < 0) return rc;
+    prof_begin(c, BSCGPU_K_DC_CTX, (u64)m * 40, m);
+    hipLaunchKernelGGL(dc_ctx_kernel, dim3(gm), dim3(WG), 0, c->stream, d->key_ch, d->key_ch_s, d->inv_ch, m, S, d->tab_rank, d->tab_run,
+                       d->key_sr, d->key_sn, d->present, d->meta);
+    hipLaunchKernelGGL(dc_setup_kernel, dim3(1), dim3(WG), 0, c->stream, d->present, d->hot, d->hot2tau, d->rounds, d->meta);
+    prof_end(c);
+    rc = radix_sort_passes(c, d->key_sr, d->key_sr_s, nullptr, nullptr, m, &top, 1, &in_alt, d->inv_sr);
+    if (rc < 0) return rc;
+    rc = radix_sort_passes(c, d->key_sn, d->key_sn_s, nullptr, nullptr, m, &top, 1, &in_alt, d->inv_sn);
+    if (rc < 0) return rc;
+
+    // families: static (stream order, X ignored), char (symbol-major), state (rank side by rank-state, run side by run-state)
+    // (each job's event count is read back once: the evaluation launches are sized by it)
+    u32 E[4] = {0, 0, 0, 0};
+    u32 vbase_sn = 0;                                                           // the run-side state job's values follow the rank-side job's
+    for (int job = 0; job < 4; ++job) {
+        const u64* items = job == 0 ? d->key_ch : job == 1 ? d->key_ch_s : job == 2 ? d->key_sr_s : d->key_sn_s;
+        const int fam = job == 0 ? FAM_STATIC : job == 1 ? FAM_CHAR : FAM_STATE;
+        const int slot = job == 0 ? 0 : job == 1 ? 1 : 2;                       // pos / V array
+        if (job == 3) vbase_sn = (E[2] + 7u) & ~7u;                             // 16-byte aligned rows for the vector stores
+        const u32 v_base = (job == 3) ? vbase_sn : 0u;
+        const u32 dec_base = (job == 3) ? E[2] : 0u;
+        if (job < 2)       dc_launch_partition<3>(c, d, items, m, S, job, v_base, dec_base, job == 0 ? 1u : 0u, d->pos[slot], d->doff[job]);
+        else if (job == 2) dc_launch_partition<1>(c, d, items, m, S, job, v_base, dec_base, 0u, d->pos[slot], d->doff[job]);
+        else               dc_launch_partition<2>(c, d, items, m, S, job, v_base, dec_base, 0u, d->pos[slot], d->doff[job]);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(d->hmeta, d->meta, DM_COUNT * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, ctx_sync(c));
+        prof_collect(c);
+        if (d->hmeta[DM_FAIL] != 0) { c->dc_last_fail = (int)d->hmeta[DM_FAIL]; return BSC_NOT_SUPPORTED; }
+        E[job] = d->hmeta[DM_D0 + job];
+        if (E[job] == 0) continue;
+        DcEvalJob J; J.events = d->events; J.E = E[job]; J.rowstart = d->rowstart + 260 * job; J.hot2tau = d->hot2tau; J.fam = fam;
+        const u32 nch = (E[job] + DC_EV - 1) / DC_EV, ge = (nch + WG - 1) / WG;
+        u16* Vout = d->V[slot] + v_base;
+        prof_begin(c, BSCGPU_K_DC_EVAL, (u64)E[job] * 6, E[job]);
+        hipLaunchKernelGGL(dc_eval_a_kernel, dim3(ge), dim3(WG), 0, c->stream, J, d->mp, d->meta, d->elo, d->ehi);
+        hipLaunchKernelGGL(dc_eval_b_kernel, dim3(ge), dim3(WG), 0, c->stream, J, d->mp, d->meta, d->elo, d->ehi, d->S);
+        hipLaunchKernelGGL(dc_eval_c_kernel, dim3(ge), dim3(WG), 0, c->stream, J, d->mp, d->meta, d->S, Vout);
+        prof_end(c);
+    }
+    if (E[0] != E[1] || E[0] != E[2] + E[3]) return ctx_fail(c, BSC_GPU_ERROR, "device coder: decision counts of the families differ", hipSuccess);
+
+    DcGather G;
+    G.key_ch = d->key_ch; G.m = m; G.inv_ch = d->inv_ch; G.inv_sr = d->inv_sr; G.inv_sn = d->inv_sn;
+    G.doff_sp = d->doff[0]; G.doff_ch = d->doff[1]; G.doff_sr = d->doff[2]; G.doff_sn = d->doff[3];
+    G.pos_sp = d->pos[0]; G.pos_ch = d->pos[1]; G.pos_st = d->pos[2];
+    G.V_sp = d->V[0]; G.V_ch = d->V[1]; G.V_st = d->V[2];
+    G.dec_base_sn = E[2];                                                       // index base inside pos[2]
+    prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)E[0] * 26, E[0]);
+    hipLaunchKernelGGL(dc_pstream_kernel, dim3(gm), dim3(WG), 0, c->stream, G, S, d->mp, d->rounds, d->meta, d->ps, dbg, E[0]);
+    hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, d->doff[0], S, m, d->poff);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(d->hmeta, d->meta, DM_COUNT * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d->hmeta + 32, d->poff, 16 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, ctx_sync(c));
+    if (d->hmeta[DM_FAIL] != 0) { c->dc_last_fail = (int)d->hmeta[DM_FAIL]; return BSC_NOT_SUPPORTED; }
+    c->dc_last_fail = 0;
+    c->dc_replays = (int)d->hmeta[DM_REPLAYS];
+    *D_out = E[0];
+    for (int b = 0; b <= nb; ++b) poff_out[b] = d->hmeta[32 + b];
+    return BSC_NO_ERROR;
+}
+
+const u16* devcoder_pstream_ptr(const bscgpu_ctx* c) { return c->dc ? c->dc->ps : nullptr; }
+
+// ---- C ABI: the stage on its own (host block in, probability stream out) ---------------------------------------------
+// What a maintainer would call next to bsc_qlfc_transform-style stage functions, and what the parity tests compare with the
+// oracle's trace of the reference model: sub-block split (coder.cpp:70-109), run / rank front end and the model on the GPU.
+// Returns the number of decisions (their 16-bit entries are in out[0..)), BSC_NOT_SUPPORTED when the block needs the host
+// model (bscgpu_last_error tells why), or another negative libbsc code.
+extern "C" int64_t bscgpu_qlfc_static_pstream(bscgpu_ctx* c, const uint8_t* L, int n, uint16_t* out, int64_t cap, int* nblocks_out,
+                                              int* sub_start /*[8]*/, int* sub_size /*[8]*/, int64_t* poff_out /*[9]*/, uint16_t* dbg_out /*[3][cap] or NULL*/)
+{
+    if (!c || !L || !out || n <= 0 || !nblocks_out || !sub_start || !sub_size || !poff_out) return BSC_BAD_PARAMETER;
+    if (n > c->max_n) return BSC_GPU_NOT_ENOUGH_MEMORY;
+    if (hipSetDevice(c->device) != hipSuccess) return BSC_GPU_ERROR;
+    HIP_TRY(c, hipMemcpyAsync(c->dL, L, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    const int nb = bschost::coder_num_blocks(n);
+    int rc = qlfc_front_split(c, c->dL, (u32)n, nb, sub_start, sub_size);
+    if (rc < 0) return rc;
+    u32 m = 0, run_first[9];
+    static thread_local u32 first_run[8 * 256];
+    rc = qlfc_front_runs(c, c->dL, (u32)n, nb, sub_start, &m, run_first, first_run, c->slots[0]);
+    if (rc < 0) return rc;
+    int max_rank[8];
+    for (int b = 0; b < nb; ++b) {
+        int nsym = 0;
+        for (int s = 0; s < 256; ++s) nsym += first_run[b * 256 + s] != 0xffffffffu;
+        max_rank[b] = bsr((uint32_t)(nsym - 1));
+    }
+    u16* ddbg = nullptr;
+    if (dbg_out) { rc = devcoder_ensure(c); if (rc < 0) return rc; if (hipMalloc((void**)&ddbg, (size_t)c->dc->Dcap * 6) != hipSuccess) return BSC_GPU_NOT_ENOUGH_MEMORY; }
+    u32 D = 0, poff[9];
+    rc = devcoder_pstream(c, reinterpret_cast<const u8*>(c->vA), reinterpret_cast<const u8*>(c->vB), c->SA, m, (u32)n, nb, run_first, max_rank, &D, poff, ddbg);
+    if (rc == BSC_NOT_SUPPORTED) {
+        char buf[96]; snprintf(buf, sizeof buf, "device coder declined the block (reason mask %d)", c->dc_last_fail);
+        c->err = buf;
+    }
+    if (rc < 0) { if (ddbg) hipFree(ddbg); return rc; }
+    *nblocks_out = nb;
+    for (int b = 0; b <= nb; ++b) poff_out[b] = poff[b];
+    if ((int64_t)D <= cap) {
+        HIP_TRY(c, hipMemcpyAsync(out, devcoder_pstream_ptr(c), (size_t)D * 2, hipMemcpyDeviceToHost, c->stream));
+        if (dbg_out) for (int f = 0; f < 3; ++f) HIP_TRY(c, hipMemcpyAsync(dbg_out + (size_t)f * cap, ddbg + (size_t)f * D, (size_t)D * 2, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, ctx_sync(c));
+    }
+    if (ddbg) hipFree(ddbg);
+    prof_collect(c);
+    return (int64_t)D;
+}

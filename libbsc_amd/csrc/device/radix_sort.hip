@@ -177,13 +177,16 @@ __global__ __launch_bounds__(WG) void rs_scan_kernel(u32* __restrict__ counts, u
 //   1024 x 8 (8192-record tiles, 1 workgroup per CU walking SPAN = 4 rs_hist chunks) - large (key, value) passes: twice the
 //            records per digit and tile, i.e. half as many partially written lines per byte.  Same box, 64 MiB BWT:
 //            first-sort pass 0.447 -> 0.410 ms, whole BWT 11.5 -> 10.8 ms; keys-only (ST) is 6 % slower with it.
-template <bool HAS_VAL, int WGSZ, int ITEMS, int SPAN>
+// EMIT_POS: also write, for every input record (in input order, coalesced), the index it lands on — the inverse of the
+// pass's permutation, which the device coder needs to find a run inside its sorted copies (devcoder.hip).
+template <bool HAS_VAL, int WGSZ, int ITEMS, int SPAN, bool EMIT_POS = false>
 __global__ __launch_bounds__(WGSZ, 4) void rs_scatter_kernel(const u64* __restrict__ kin, u64* __restrict__ kout,
                                                         const u32* __restrict__ vin, u32* __restrict__ vout,
                                                         u32 n, int shift, u32 mask,
                                                         u32 chunk_tiles, u32 num_chunks, u32 num_tiles,
                                                         const u32* __restrict__ offsets,
-                                                        const u32* __restrict__ rowtot, u64* __restrict__ sink)
+                                                        const u32* __restrict__ rowtot, u64* __restrict__ sink,
+                                                        u32* __restrict__ dstpos = nullptr)
 {
     constexpr int WG = WGSZ, WAVES = WGSZ / 64, TILE = WGSZ * ITEMS;
     (void)sink;
@@ -294,6 +297,7 @@ __global__ __launch_bounds__(WGSZ, 4) void rs_scatter_kernel(const u64* __restri
             const u32 pos = whist[w * 256 + d] + rk[i];
             rk[i] = pos;
             skeys[pos] = k[i];
+            if (EMIT_POS) { const u32 idx = wbase + i * 64; if (FULL || idx < nvalid) dstpos[tbase + idx] = adj[d] + pos; }
         }
         __syncthreads();
 
@@ -568,8 +572,9 @@ int radix_engine_setup(bscgpu_ctx* c)
 }
 
 int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* vals_alt, u64 n,
-                      const RadixPass* passes, int npasses, int* in_alt)
+                      const RadixPass* passes, int npasses, int* in_alt, u32* emit_pos)
 {
+    if (emit_pos != nullptr && (npasses != 1 || vals != nullptr)) return BSC_BAD_PARAMETER;     // inverse of ONE keys-only pass
     *in_alt = 0;
     if (n == 0 || npasses == 0) return BSC_NO_ERROR;
     if (n >= 0xffffffffull) return BSC_BAD_PARAMETER;
@@ -578,7 +583,7 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
     const Chunking ch = rs_chunking(n);
     const int wc_mode = c->rs_wc_mode;          // BSC_RS_WC, read once per context (radix_engine_setup)
     const bool big_pairs = RS_BIG_PAIRS && ch.num_chunks >= 512 && ch.chunk_tiles >= 2;   // enough records for 8192-record tiles on every CU
-    const bool use_wc = (wc_mode == 2 && ch.num_chunks >= 4) || (wc_mode == 1 && ch.num_chunks >= 512 && ch.chunk_tiles >= 2);
+    const bool use_wc = emit_pos == nullptr && ((wc_mode == 2 && ch.num_chunks >= 4) || (wc_mode == 1 && ch.num_chunks >= 512 && ch.chunk_tiles >= 2));
     u64 *ksrc = keys, *kdst = keys_alt;
     u32 *vsrc = vals, *vdst = vals_alt;
     const bool has_val = (vals != nullptr);
@@ -616,10 +621,14 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
             hipLaunchKernelGGL((rs_scatter_kernel<true, RS_WG, RS_ITEMS, 1>), dim3(ch.num_chunks), dim3(RS_WG), RS_LDS, c->stream,
                                ksrc, kdst, vsrc, vdst, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks,
                                ch.num_tiles, c->counts, c->rowtot, c->wc_sink);
+        else if (emit_pos != nullptr)
+            hipLaunchKernelGGL((rs_scatter_kernel<false, RS_WG, RS_ITEMS, 1, true>), dim3(ch.num_chunks), dim3(RS_WG), RS_LDS, c->stream,
+                               ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, shift, mask,
+                               ch.chunk_tiles, ch.num_chunks, ch.num_tiles, c->counts, c->rowtot, c->wc_sink, emit_pos);
         else
             hipLaunchKernelGGL((rs_scatter_kernel<false, RS_WG, RS_ITEMS, 1>), dim3(ch.num_chunks), dim3(RS_WG), RS_LDS, c->stream,
                                ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, shift, mask,
-                               ch.chunk_tiles, ch.num_chunks, ch.num_tiles, c->counts, c->rowtot, c->wc_sink);
+                               ch.chunk_tiles, ch.num_chunks, ch.num_tiles, c->counts, c->rowtot, c->wc_sink, (u32*)nullptr);
         prof_end(c);
         HIP_TRY(c, hipGetLastError());
 

@@ -38,6 +38,8 @@ const QlfcTables& qlfc_tables()
     return *t;
 }
 
+const short (*qlfc_static_params())[19] { return kStaticParams; }
+
 static inline int bsr32(unsigned x) { return x ? 31 - __builtin_clz(x) : 0; }
 
 // ------------------------------------------------------------------------------------------------
@@ -797,6 +799,26 @@ int qlfc_decode_block_bounded(const uint8_t* in, long long in_size, uint8_t* out
 }
 // the reference's entry point carries no input size (qlfc.h:58): the caller vouches for the stream
 int qlfc_decode_block(const uint8_t* in, uint8_t* out, int coder) { return qlfc_decode_block_bounded(in, UNBOUNDED_INPUT, out, coder, 0x7fffffff); }
+
+// The static coder's back half alone: the probabilities come from the GPU (devcoder.hip), in stream order, with the first
+// decision of every run marked so that the output-budget test sits where the reference has it (qlfc.cpp:894).
+int qlfc_encode_static_pstream(const uint8_t* first_seen, int nsym, int in_size, const uint16_t* ps, size_t count, uint8_t* out, int out_size)
+{
+    if (in_size <= 0 || nsym <= 0) return BAD_PARAMETER;
+    RunView H; H.nsym = nsym; memcpy(H.first_seen, first_seen, (size_t)nsym);
+    RangeEncoder rc;
+    rc.init(out, out_size);
+    rc.encode_word((uint32_t)in_size);
+    (void)encode_alphabet(H, [&](unsigned b) { rc.encode_half(b); });
+    RangeEncoder::Live L = rc.enter();
+    for (size_t i = 0; i < count; ++i) {
+        const unsigned x = ps[i];
+        if ((x & 0x2000u) && rc.full()) return NOT_COMPRESSIBLE;        // full() looks at the output cursor only
+        rc.encode_live<12>(L, (x >> 12) & 1u, (int)(x & 0xfffu));
+    }
+    rc.leave(L);
+    return rc.finish();
+}
 
 int qlfc_encode_runs(const RunView& R, int in_size, uint8_t* out, int out_size, int coder)
 {

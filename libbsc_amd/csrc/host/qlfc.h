@@ -30,6 +30,8 @@ struct QlfcTables {
     uint8_t run_state[8192];
 };
 const QlfcTables& qlfc_tables();
+// tuned constants of the static model, one row per decision class (layout: tools/gen_qlfc_data.py)
+const short (*qlfc_static_params())[19];
 
 // Run decomposition of a sub-block + QLFC ranks, as flat arrays (the layout the GPU front end produces):
 //   sym[j], start[j] : symbol and start position of the j-th maximal run (length = start[j+1] - start[j], the
@@ -57,6 +59,9 @@ void qlfc_runs(const uint8_t* in, int n, QlfcRuns& out);
 
 // Encode one sub-block from its run arrays.  Returns bytes written or NOT_COMPRESSIBLE.
 int qlfc_encode_runs(const RunView& R, int in_size, uint8_t* out, int out_size, int coder);
+// Static coder (-e1) from a precomputed probability stream (devcoder_model.h: [11:0] p, [12] bit, [13] run start): header,
+// alphabet and range coding only — the model ran on the GPU.  Returns bytes written or NOT_COMPRESSIBLE.
+int qlfc_encode_static_pstream(const uint8_t* first_seen, int nsym, int in_size, const uint16_t* ps, size_t count, uint8_t* out, int out_size);
 // Encode one sub-block (what coder.cpp:61 dispatches to).  Returns bytes written or NOT_COMPRESSIBLE.
 int qlfc_encode_block(const uint8_t* in, uint8_t* out, int in_size, int out_size, int coder);
 // Decode one sub-block; returns the decoded size or an error.

@@ -104,6 +104,22 @@ class GpuContext:
                                                  n, begin_bit, end_bit, C.byref(alt)))
         return (keys_alt, vals_alt) if alt.value else (keys, vals)
 
+    def qlfc_static_pstream(self, L, debug=False):
+        """bscgpu_qlfc_static_pstream: (entries u16[D], sub_start, sub_size, poff[nb+1], dbg [3,D] or None); raises GpuError
+        with code -4 when the block has to take the host model."""
+        a = np.ascontiguousarray(L, dtype=np.uint8)
+        cap = 8 * a.size + 65536
+        out = np.empty(cap, np.uint16)
+        dbg = np.empty((3, cap), np.uint16) if debug else None
+        nb = C.c_int(0); st = (C.c_int * 8)(); sz = (C.c_int * 8)(); poff = (C.c_int64 * 9)()
+        f = self.L.bscgpu_qlfc_static_pstream
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        D = f(self.h, N.np_ptr(a), a.size, out.ctypes.data, cap, C.byref(nb), st, sz, poff, dbg.ctypes.data if debug else None)
+        self._check(D)
+        k = nb.value
+        return out[:D], list(st[:k]), list(sz[:k]), list(poff[:k + 1]), (dbg[:, :D] if debug else None)
+
     def compress_device(self, dInput, n, sorter=1, coder=1, features=3):
         out = np.empty(n + 28, np.uint8)
         rc = self._check(self.L.bscgpu_compress_device(self.h, _dptr(dInput), N.np_ptr(out), n, sorter, coder, features))

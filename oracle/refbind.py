@@ -203,6 +203,8 @@ class Oracle:
         L.orc_coder_compress.argtypes = [u8p, u8p, C.c_int, C.c_int]
         L.orc_store.argtypes = [u8p, u8p, C.c_int]
         L.orc_compress.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int]
+        L.orc_qlfc_static_pstream.argtypes = [u8p, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+        L.orc_qlfc_static_pstream.restype = C.c_long
 
     @staticmethod
     def _np(data, copy=False):
@@ -210,6 +212,17 @@ class Oracle:
         a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
         a = np.ascontiguousarray(a)
         return a.copy() if copy else a
+
+    def static_pstream(self, data, counters=False):
+        """trace of the static model over one sub-block -> (u16 entries, [n,3] counter values or None)"""
+        import numpy as np
+        a = self._np(data)
+        cap = 16 * a.size + 64
+        tr = np.empty(cap, np.uint16)
+        ct = np.empty((cap, 3), np.uint16) if counters else None
+        cnt = self.L.orc_qlfc_static_pstream(a.ctypes.data_as(u8p), a.size, tr.ctypes.data, ct.ctypes.data if counters else None, cap)
+        assert 0 <= cnt <= cap
+        return tr[:cnt], (ct[:cnt] if counters else None)
 
     def adler32(self, data):
         a = self._np(data)
