@@ -39,6 +39,16 @@ int ctx_ensure_slots(bscgpu_ctx* c, int count)
     return BSC_NO_ERROR;
 }
 
+int ctx_ensure_pstream_slot(bscgpu_ctx* c, HostSlot& slot, size_t entries)
+{
+    (void)c;
+    if (slot.hps_cap >= entries) return BSC_NO_ERROR;
+    if (slot.hps) { hipHostFree(slot.hps); slot.hps = nullptr; slot.hps_cap = 0; }
+    if (hipHostMalloc((void**)&slot.hps, entries * 2, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return BSC_NOT_ENOUGH_MEMORY; }
+    slot.hps_cap = entries;
+    return BSC_NO_ERROR;
+}
+
 extern "C" int bscgpu_device_count(void)
 {
     int n = 0;
@@ -121,6 +131,7 @@ extern "C" void bscgpu_destroy(bscgpu_ctx* c)
         if (s.hsym) hipHostFree(s.hsym);
         if (s.hrank) hipHostFree(s.hrank);
         if (s.hstart) hipHostFree(s.hstart);
+        if (s.hps) hipHostFree(s.hps);
     }
     devcoder_destroy(c);
     if (c->arena) hipFree(c->arena);

@@ -57,6 +57,8 @@ struct HostSlot {
     u8*  hsym   = nullptr;   // run symbols
     u8*  hrank  = nullptr;   // QLFC ranks
     u32* hstart = nullptr;   // run start positions
+    u16* hps    = nullptr;   // probability stream of the device coder (allocated when that path is first used)
+    size_t hps_cap = 0;      // entries
 };
 constexpr int MAX_SLOTS = 8;
 
@@ -142,8 +144,10 @@ int adler32_device(bscgpu_ctx* c, const u8* d, int64_t n, u32* out);
 void launch_seg_scan(bscgpu_ctx* c, u32 num_chunks);
 int qlfc_front_split(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, int* start, int* size);
 int qlfc_front_runs(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, const int* start, u32* m_out, u32* run_first, u32* first_run_host,
-                    HostSlot& slot);
+                    HostSlot& slot, bool copy_runs = true);
+int qlfc_front_copy_runs(bscgpu_ctx* c, u32 m, HostSlot& slot);
 int ctx_ensure_slots(bscgpu_ctx* c, int count);
+int ctx_ensure_pstream_slot(bscgpu_ctx* c, HostSlot& slot, size_t entries);     // pinned landing zone for a block's p stream
 // device-side model of the static QLFC coder (devcoder.hip): probability stream of a whole block from the front end's run arrays
 int  devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* dstart, u32 m, u32 n, int nb, const u32* run_first,
                       const int* max_rank, u32* D_out, u32* poff_out, u16* dbg);

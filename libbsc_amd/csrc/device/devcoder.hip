@@ -254,6 +254,15 @@ __device__ __forceinline__ void dc_match8(u32 h, u64 active, u32& mlo, u32& mhi)
     }
 }
 
+// the same, with the common case first: every active lane is in the same row (one decision type per canonical round except
+// in the mantissa rounds) -> the peer mask is the active mask
+__device__ __forceinline__ void dc_match(u32 h, bool on, u64 active, u32& mlo, u32& mhi)
+{
+    const u32 h0 = (u32)__builtin_amdgcn_readlane((int)h, (int)__builtin_ctzll(active));
+    if (__ballot(on && h != h0) == 0) { mlo = (u32)active; mhi = (u32)(active >> 32); return; }
+    dc_match8(h, active, mlo, mhi);
+}
+
 template <int SIDES>
 __device__ __forceinline__ bool dc_round_on_side(int r) { return (r < ROUND_NF) ? (SIDES & 1) != 0 : (SIDES & 2) != 0; }
 
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(WG) void dc_part_count_kernel(const u64* __restrict
                 if (active == 0) continue;
                 const u32 h = on ? (u32)shot[tau] : 0u;
                 u32 mlo, mhi;
-                dc_match8(h, active, mlo, mhi);
+                dc_match(h, on, active, mlo, mhi);
                 const u32 rr = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));
                 const u32 cn = (u32)(__popc(mlo) + __popc(mhi));
                 if (on && rr == cn - 1) vh[h] = vh[h] + cn;               // one lane per row adds the row's count
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
             if (active == 0) continue;
             const u32 h = on ? (u32)shot[tau] : 0u;
             u32 mlo, mhi;
-            dc_match8(h, active, mlo, mhi);
+            dc_match(h, on, active, mlo, mhi);
             const u32 before = vg[h];
             const u32 rr  = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));
             const u32 cn  = (u32)(__popc(mlo) + __popc(mhi));
@@ -485,6 +494,110 @@ __device__ __forceinline__ void dc_walk(const DcEvalJob& J, const ModelParams* _
     }
 }
 
+// Phases a and c as one wavefront per 64 chunks: the lanes own one chunk each (a serial chain), but memory is touched as
+// full lines — for every batch of 64 events per lane the wavefront loads the 64 lanes' 128-byte pieces cooperatively
+// (8 x 16 B per lane, eight rows per instruction), transposes them through LDS, and (phase c) writes the values back the same
+// way.  The next batch is in flight while the current one is walked.
+constexpr int DC_EB = 64;                       // events per lane per batch
+constexpr int DC_EROW = DC_EB * 2 + 16;         // LDS row pitch in bytes (padded)
+template <bool WRITE>
+__global__ __launch_bounds__(64) void dc_eval_wave_kernel(DcEvalJob J, const ModelParams* __restrict__ mp, const u32* __restrict__ meta,
+                                                          u16* __restrict__ elo, u16* __restrict__ ehi, const u16* __restrict__ Sv, u16* __restrict__ Vout)
+{
+    __shared__ __attribute__((aligned(16))) u8 sin[64 * DC_EROW];
+    __shared__ __attribute__((aligned(16))) u8 sout[WRITE ? 64 * DC_EROW : 16];
+    if (meta[DM_FAIL] != 0u) return;
+    const u32 lane = threadIdx.x;
+    const u32 c = blockIdx.x * 64 + lane;
+    const u64 k0 = (u64)c * DC_EV;
+    const bool mine = k0 < J.E;
+    const u32 k1 = mine ? (u32)((k0 + DC_EV < J.E) ? k0 + DC_EV : J.E) : 0u;
+    // cooperative mapping: instruction i moves 16 bytes of row 8 i + lane / 8, column lane % 8
+    const u32 crow = lane >> 3, ccol = lane & 7u;
+    const u64 wave_k0 = (u64)blockIdx.x * 64 * DC_EV;
+
+    u32 row = 0, rowend = 0, prev = 0xffffu;
+    int lo = 2048, hi = 2048;
+    Rates R = mp->rates[0][J.fam];
+    if (mine) {
+        row = dc_find_row(J.rowstart, (u32)k0);
+        rowend = J.rowstart[row + 1];
+        const int cls = tau_class(J.hot2tau[row]);
+        R = mp->rates[cls][J.fam];
+        prev = (k0 > J.rowstart[row]) ? ((u32)J.events[k0 - 1] & DC_SIGMASK) : 0xffffu;
+        if (WRITE) { lo = Sv[c]; hi = lo; } else { lo = mp->vmin[cls][J.fam]; hi = mp->vmax[cls][J.fam]; }
+    }
+    auto fetch = [&](u32 b, uint4* q) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const u64 kk = wave_k0 + (u64)(8 * i + crow) * DC_EV + (u64)b * DC_EB + ccol * 8;
+            q[i] = (kk < J.E) ? *reinterpret_cast<const uint4*>(J.events + kk) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    uint4 nxt[8];
+    fetch(0, nxt);
+    constexpr u32 NB = DC_EV / DC_EB;
+    for (u32 b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(sin + (8 * i + crow) * DC_EROW + ccol * 16) = nxt[i];
+        __syncthreads();
+        if (b + 1 < NB) fetch(b + 1, nxt);
+        const u32 kb = (u32)k0 + b * DC_EB;
+        if (mine && kb < k1) {
+            const u8* myrow = sin + lane * DC_EROW;
+            u8* orow = sout + (WRITE ? lane * DC_EROW : 0);
+            const u32 lim = k1 < rowend ? k1 : rowend;
+            if (kb + DC_EB <= lim) {
+                // whole batch inside the current row: straight-line walk from registers
+#pragma unroll
+                for (int g8 = 0; g8 < 8; ++g8) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(myrow + g8 * 16);
+                    const u32 wds[4] = {q.x, q.y, q.z, q.w};
+                    u32 outw[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) {
+                        const u32 e = (wds[x >> 1] >> (16 * (x & 1))) & 0xffffu;
+                        const u32 sig = e & DC_SIGMASK;
+                        if (sig != prev) { lo = 2048; hi = 2048; prev = sig; }
+                        const u32 bt = (e >> 11) & 1u;
+                        if (WRITE) outw[x >> 1] |= (u32)lo << (16 * (x & 1));
+                        lo = step(lo, bt, R);
+                        if (!WRITE) hi = step(hi, bt, R);
+                    }
+                    if (WRITE) *reinterpret_cast<uint4*>(orow + g8 * 16) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+                }
+            } else {
+                const u32 cnt = (k1 - kb < (u32)DC_EB) ? k1 - kb : (u32)DC_EB;
+                for (u32 x = 0; x < cnt; ++x) {
+                    const u32 k = kb + x;
+                    if (k == rowend) {
+                        do { ++row; rowend = J.rowstart[row + 1]; } while (rowend == k && row < 255);
+                        R = mp->rates[tau_class(J.hot2tau[row])][J.fam];
+                        prev = 0xffffu;
+                    }
+                    const u32 e = *reinterpret_cast<const u16*>(myrow + 2 * x);
+                    const u32 sig = e & DC_SIGMASK;
+                    if (sig != prev) { lo = 2048; hi = 2048; prev = sig; }
+                    const u32 bt = (e >> 11) & 1u;
+                    if (WRITE) *reinterpret_cast<u16*>(orow + 2 * x) = (u16)lo;
+                    lo = step(lo, bt, R);
+                    if (!WRITE) hi = step(hi, bt, R);
+                }
+            }
+        }
+        __syncthreads();
+        if (WRITE) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const u64 kk = wave_k0 + (u64)(8 * i + crow) * DC_EV + (u64)b * DC_EB + ccol * 8;
+                if (kk < J.E) *reinterpret_cast<uint4*>(Vout + kk) = *reinterpret_cast<const uint4*>(sout + (8 * i + crow) * DC_EROW + ccol * 16);
+            }
+            __syncthreads();
+        }
+    }
+    if (!WRITE && mine) { elo[c] = (u16)lo; ehi[c] = (u16)hi; }
+}
+
 __global__ __launch_bounds__(WG) void dc_eval_a_kernel(DcEvalJob J, const ModelParams* __restrict__ mp, const u32* __restrict__ meta,
                                                        u16* __restrict__ elo, u16* __restrict__ ehi)
 {
@@ -557,39 +670,32 @@ struct DcGather {
     const u16 *V_sp, *V_ch, *V_st;
     u32 dec_base_sn;                                                   // decision-index base of the run-side state job inside pos_st
 };
-__global__ __launch_bounds__(WG) void dc_pstream_kernel(DcGather G, DcSub S, const ModelParams* __restrict__ mp, const u8* __restrict__ rounds,
+__global__ __launch_bounds__(WG) void dc_pstream_kernel(DcGather G, DcSub S, const ModelParams* __restrict__ mp,
                                                         const u32* __restrict__ meta, u16* __restrict__ out, u16* __restrict__ dbg /*[3][D] or null*/, u32 dbgD)
 {
-    __shared__ u8 srounds[NUM_ROUNDS];
     if (meta[DM_FAIL] != 0u) return;
-    const u32 nr = meta[DM_NROUNDS];
-    if (threadIdx.x < NUM_ROUNDS) srounds[threadIdx.x] = threadIdx.x < nr ? rounds[threadIdx.x] : 0;
-    __syncthreads();
     const u32 j = blockIdx.x * WG + threadIdx.x;
     if (j >= G.m) return;
     const Item it = item_unpack(G.key_ch[j]);
     const int maxr = (int)S.maxr[it.sb];
-    const u32 n_rank = (u32)count_rank_side(it, maxr);
     const u32 b_sp = G.doff_sp[j];
-    const u32 b_ch = G.doff_ch[G.inv_ch[j]];
-    const u32 b_sr = G.doff_sr[G.inv_sr[j]];
-    const u32 b_sn = G.doff_sn[G.inv_sn[j]] + G.dec_base_sn;
-    u32 ord = 0;
-    for (u32 k = 0; k < nr; ++k) {
-        const int r = srounds[k];
-        u32 bit = 0;
-        const int tau = decision(it, maxr, r, &bit);
-        if (tau < 0) continue;
+    const u32* p_sp = G.pos_sp + b_sp;
+    const u32* p_ch = G.pos_ch + G.doff_ch[G.inv_ch[j]];
+    const u32* p_sr = G.pos_st + G.doff_sr[G.inv_sr[j]];
+    const u32* p_sn = G.pos_st + (G.doff_sn[G.inv_sn[j]] + G.dec_base_sn);
+    u16* o = out + b_sp;
+    u32 ord = 0, ord_run = 0;
+    enumerate(it, maxr, [&](int tau, u32 bit, bool run_side) {
         const int cls = tau_class(tau);
-        const u32 pst = (r < ROUND_NF) ? G.pos_st[b_sr + ord] : G.pos_st[b_sn + (ord - n_rank)];
-        const int v_sp = G.V_sp[G.pos_sp[b_sp + ord]];
-        const int v_ch = G.V_ch[G.pos_ch[b_ch + ord]];
+        const u32 pst = run_side ? p_sn[ord_run++] : p_sr[ord];
+        const int v_sp = G.V_sp[p_sp[ord]];
+        const int v_ch = G.V_ch[p_ch[ord]];
         const int v_st = G.V_st[pst];
         const int p = blend(v_ch, v_st, v_sp, mp->lr[cls]);
-        out[b_sp + ord] = (u16)((u32)p | (bit << 12) | (ord == 0 ? (u32)PS_RUN : 0u));
+        o[ord] = (u16)((u32)p | (bit << 12) | (ord == 0 ? (u32)PS_RUN : 0u));
         if (dbg) { dbg[b_sp + ord] = (u16)v_st; dbg[(size_t)dbgD + b_sp + ord] = (u16)v_ch; dbg[2 * (size_t)dbgD + b_sp + ord] = (u16)v_sp; }
         ++ord;
-    }
+    });
 }
 
 __global__ void dc_poff_kernel(const u32* __restrict__ doff_sp, DcSub S, u32 m, u32* __restrict__ poff)
@@ -739,9 +845,16 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
         const u32 nch = (E[job] + DC_EV - 1) / DC_EV, ge = (nch + WG - 1) / WG;
         u16* Vout = d->V[slot] + v_base;
         prof_begin(c, BSCGPU_K_DC_EVAL, (u64)E[job] * 6, E[job]);
-        hipLaunchKernelGGL(dc_eval_a_kernel, dim3(ge), dim3(WG), 0, c->stream, J, d->mp, d->meta, d->elo, d->ehi);
-        hipLaunchKernelGGL(dc_eval_b_kernel, dim3(ge), dim3(WG), 0, c->stream, J, d->mp, d->meta, d->elo, d->ehi, d->S);
-        hipLaunchKernelGGL(dc_eval_c_kernel, dim3(ge), dim3(WG), 0, c->stream, J, d->mp, d->meta, d->S, Vout);
+        const u32 gw = (nch + 63) / 64;
+        if (getenv("BSC_DC_SCALAR_EVAL")) {
+            hipLaunchKernelGGL(dc_eval_a_kernel, dim3(ge), dim3(WG), 0, c->stream, J, d->mp, d->meta, d->elo, d->ehi);
+            hipLaunchKernelGGL(dc_eval_b_kernel, dim3(ge), dim3(WG), 0, c->stream, J, d->mp, d->meta, d->elo, d->ehi, d->S);
+            hipLaunchKernelGGL(dc_eval_c_kernel, dim3(ge), dim3(WG), 0, c->stream, J, d->mp, d->meta, d->S, Vout);
+        } else {
+            hipLaunchKernelGGL(dc_eval_wave_kernel<false>, dim3(gw), dim3(64), 0, c->stream, J, d->mp, d->meta, d->elo, d->ehi, (const u16*)nullptr, (u16*)nullptr);
+            hipLaunchKernelGGL(dc_eval_b_kernel, dim3(ge), dim3(WG), 0, c->stream, J, d->mp, d->meta, d->elo, d->ehi, d->S);
+            hipLaunchKernelGGL(dc_eval_wave_kernel<true>, dim3(gw), dim3(64), 0, c->stream, J, d->mp, d->meta, (u16*)nullptr, (u16*)nullptr, d->S, Vout);
+        }
         prof_end(c);
     }
     if (E[0] != E[1] || E[0] != E[2] + E[3]) return ctx_fail(c, BSC_GPU_ERROR, "device coder: decision counts of the families differ", hipSuccess);
@@ -753,7 +866,7 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     G.V_sp = d->V[0]; G.V_ch = d->V[1]; G.V_st = d->V[2];
     G.dec_base_sn = E[2];                                                       // index base inside pos[2]
     prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)E[0] * 26, E[0]);
-    hipLaunchKernelGGL(dc_pstream_kernel, dim3(gm), dim3(WG), 0, c->stream, G, S, d->mp, d->rounds, d->meta, d->ps, dbg, E[0]);
+    hipLaunchKernelGGL(dc_pstream_kernel, dim3(gm), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps, dbg, E[0]);
     hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, d->doff[0], S, m, d->poff);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());

@@ -142,6 +142,37 @@ DC_HD int decision(const Item& it, int max_rank, int r, uint32_t* bit)
     return TAU_NM + nm_off(bits) + (int)ctx - 1;
 }
 
+// All decisions of a run in canonical (= stream) order: f(tau, bit, run_side).
+template <class F>
+DC_HD void enumerate(const Item& it, int max_rank, F&& f)
+{
+    const uint32_t rank = it.rank, run = it.run;
+    if (it.ge32) {
+        for (int d = 0; d <= max_rank; ++d) {
+            const uint32_t ctx = (1u << d) | ((rank >> (max_rank + 1 - d)) & ((1u << d) - 1u));
+            f(TAU_RP + (int)ctx - 1, (rank >> (max_rank - d)) & 1u, false);
+        }
+    } else {
+        f(TAU_RF, rank != 1u ? 1u : 0u, false);
+        if (rank != 1u) {
+            const int B = bsr(rank);
+            for (int s = 0; s <= B - 2; ++s) f(TAU_RE + s, 1u, false);
+            if (B < max_rank) f(TAU_RE + B - 1, 0u, false);
+            for (int d = 0; d < B; ++d) f(TAU_RM + rm_off(B) + (int)(rank >> (B - d)) - 1, (rank >> (B - 1 - d)) & 1u, false);
+        }
+    }
+    f(TAU_NF, run != 1u ? 1u : 0u, true);
+    if (run != 1u) {
+        const int bits = bsr(run);
+        for (int s = 0; s <= bits - 2; ++s) f(TAU_NE + s, 1u, true);
+        f(TAU_NE + bits - 1, 0u, true);
+        for (int d = 0; d < bits; ++d) {
+            const uint32_t ctx = bits <= 5 ? (run >> (bits - d)) : (uint32_t)(1 + d);
+            f(TAU_NM + nm_off(bits) + (int)ctx - 1, (run >> (bits - 1 - d)) & 1u, true);
+        }
+    }
+}
+
 // ---- counters --------------------------------------------------------------------------------------------------------
 // predictor.h:53-61 with the family's tuned constants: bit 0 moves towards 4096 - th0, bit 1 towards th1 (arithmetic shifts)
 struct Rates { int t0, a0, t1, a1; };                        // t0 = 4096 - th0, t1 = th1

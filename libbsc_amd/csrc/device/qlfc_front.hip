@@ -259,8 +259,19 @@ int qlfc_front_split(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, int* start
 
 // Runs + ranks of all sub-blocks of dL.  Results in pinned host memory: c->hsym / c->hrank / c->hstart (m entries),
 // run_first[0..nblocks] (run index range per sub-block) and first_run[8][256].
+int qlfc_front_copy_runs(bscgpu_ctx* c, u32 m, HostSlot& slot)
+{
+    // the run arrays of the block whose front end ran last (they live in the sort buffers until the next block's sorter starts)
+    HIP_TRY(c, hipMemcpyAsync(slot.hsym, reinterpret_cast<u8*>(c->vA), m, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(slot.hrank, reinterpret_cast<u8*>(c->vB), m, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(slot.hstart, c->SA, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, ctx_sync(c));
+    prof_collect(c);
+    return BSC_NO_ERROR;
+}
+
 int qlfc_front_runs(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, const int* start, u32* m_out, u32* run_first /*[9]*/,
-                    u32* first_run_host /*[8*256]*/, HostSlot& slot)
+                    u32* first_run_host /*[8*256]*/, HostSlot& slot, bool copy_runs)
 {
     QfSplit sp; sp.nblocks = (u32)nblocks;
     for (int b = 0; b < 9; ++b) sp.start[b] = (b < nblocks) ? (u32)start[b] : n;
@@ -326,10 +337,7 @@ int qlfc_front_runs(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, const int* 
     else       hipLaunchKernelGGL(qf_rank_kernel<false>, dim3((m + WG - 1) / WG), dim3(WG), 0, c->stream, dsym, m, rb, dlut, dmask, dsuper, drank);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(slot.hsym, dsym, m, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(slot.hrank, drank, m, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(slot.hstart, dstart, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, ctx_sync(c));
-    prof_collect(c);
-    return BSC_NO_ERROR;
+    (void)dstart;
+    if (copy_runs) return qlfc_front_copy_runs(c, m, slot);
+    return BSC_NO_ERROR;           // the caller feeds the device coder from the arrays in HBM (and may still ask for the copy)
 }

@@ -275,7 +275,10 @@ struct BlockJob {
     int start[8], size[8];
     u32 run_first[9];
     u32 first_run[8 * 256];
-    HostSlot slot;
+    HostSlot* slot = nullptr;        // pinned landing zones of this block (owned by the context)
+    // device-side static model (devcoder.hip): the host codes from a probability stream instead of run arrays
+    bool use_ps = false; const uint16_t* ps = nullptr; u32 poff[9]; u32 ndec = 0; int sorter = 0;
+    std::atomic<bool> redo{false};   // a sub-block did not compress: the block goes through the host model again (raw sub-blocks need the run arrays)
     bool stored_small = false;       // n <= header size: finished in the GPU stage
     int  result = 0;
     // host stage, split into per-sub-block tasks for the pipe's worker pool
@@ -290,8 +293,13 @@ struct BlockJob {
 using clk = std::chrono::steady_clock;
 static double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
 
-static int gpu_stage(BlockJob& J, int blockSorter)
+// BSC_DEVICE_CODER=0 keeps the static coder's model on the host; BSC_DEVICE_CODER_MIN_N: smallest block that takes the device model
+static bool devcoder_enabled() { static const int v = [] { const char* e = getenv("BSC_DEVICE_CODER"); return e ? atoi(e) : 1; }(); return v != 0; }
+static int  devcoder_min_n() { static const int v = [] { const char* e = getenv("BSC_DEVICE_CODER_MIN_N"); return e ? atoi(e) : (1 << 20); }(); return v; }
+
+static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
 {
+    J.sorter = blockSorter; J.use_ps = false; J.redo.store(false, std::memory_order_relaxed);
     bscgpu_ctx* c = J.c;
     const int n = J.n;
     if (hipSetDevice(c->device) != hipSuccess) return LIBBSC_GPU_ERROR;
@@ -332,8 +340,34 @@ static int gpu_stage(BlockJob& J, int blockSorter)
     rc = qlfc_front_split(c, c->dL, (u32)n, J.nblocks, J.start, J.size);
     if (rc < 0) return rc;
     u32 m = 0;
-    rc = qlfc_front_runs(c, c->dL, (u32)n, J.nblocks, J.start, &m, J.run_first, J.first_run, J.slot);
+    // static coder on a block with several sub-blocks: the adaptive model runs on the GPU too (devcoder.hip) and only the
+    // probability stream crosses PCIe; anything that path declines falls back to the run arrays + host model
+    const bool try_dc = allow_devcoder && devcoder_enabled() && J.coder == LIBBSC_CODER_QLFC_STATIC && J.nblocks > 1 && n >= devcoder_min_n() && !J.lz;
+    rc = qlfc_front_runs(c, c->dL, (u32)n, J.nblocks, J.start, &m, J.run_first, J.first_run, *J.slot, !try_dc);
     if (rc < 0) return rc;
+    if (try_dc) {
+        bool ok = false;
+        if ((double)m <= 0.70 * (double)n) {                        // nearly one run per byte: the sub-blocks will be stored raw anyway
+            int maxr[8];
+            for (int b = 0; b < J.nblocks; ++b) {
+                int nsym = 0;
+                for (int sy = 0; sy < 256; ++sy) nsym += J.first_run[b * 256 + sy] != 0xffffffffu;
+                int k = 0; while ((2 << k) <= nsym - 1) ++k;           // bsr(nsym - 1), 0 for nsym <= 2 (qlfc.cpp:888)
+                maxr[b] = nsym >= 2 ? k : 0;
+            }
+            u32 ndec = 0;
+            const int r2 = devcoder_pstream(c, reinterpret_cast<const u8*>(c->vA), reinterpret_cast<const u8*>(c->vB), c->SA, m, (u32)n, J.nblocks,
+                                            J.run_first, maxr, &ndec, J.poff, nullptr);
+            if (r2 == LIBBSC_NO_ERROR) {
+                if (ctx_ensure_pstream_slot(c, *J.slot, (size_t)ndec + 64) != LIBBSC_NO_ERROR) return LIBBSC_NOT_ENOUGH_MEMORY;
+                if (hipMemcpyAsync(J.slot->hps, devcoder_pstream_ptr(c), (size_t)ndec * 2, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                    ctx_sync(c) != hipSuccess) return LIBBSC_GPU_ERROR;
+                prof_collect(c);
+                J.use_ps = true; J.ps = J.slot->hps; J.ndec = ndec; ok = true;
+            } else if (r2 != LIBBSC_NOT_SUPPORTED) return r2;
+        }
+        if (!ok) { rc = qlfc_front_copy_runs(c, m, *J.slot); if (rc < 0) return rc; }
+    }
     c->stage_ms[2] = ms_since(t0);
     return LIBBSC_NO_ERROR;
 }
@@ -343,7 +377,7 @@ static void host_prepare(BlockJob& J)
     for (int b = 0; b < J.nblocks; ++b) {
         RunView& V = J.views[b];
         V = RunView();
-        V.sym = J.slot.hsym + J.run_first[b]; V.rank = J.slot.hrank + J.run_first[b]; V.start = J.slot.hstart + J.run_first[b];
+        V.sym = J.slot->hsym + J.run_first[b]; V.rank = J.slot->hrank + J.run_first[b]; V.start = J.slot->hstart + J.run_first[b];
         V.count = J.run_first[b + 1] - J.run_first[b];
         V.end = (u32)(J.start[b] + J.size[b]);
         // alphabet in order of first appearance = symbols sorted by the index of their first run
@@ -367,6 +401,13 @@ static void host_encode_sub(BlockJob& J, int b)
 {
     const size_t need = (size_t)J.size[b] + 64;
     if (J.scratch_cap[b] < need) { J.scratch[b].reset(new uint8_t[need + need / 8]); J.scratch_cap[b] = need + need / 8; }
+    if (J.use_ps) {
+        const int r = qlfc_encode_static_pstream(J.views[b].first_seen, J.views[b].nsym, J.size[b], J.ps + J.poff[b], (size_t)(J.poff[b + 1] - J.poff[b]),
+                                                 J.scratch[b].get(), J.size[b]);
+        if (r < 0) J.redo.store(true, std::memory_order_relaxed);      // would be stored raw: that needs the run arrays
+        J.sub_res[b] = (r < 0) ? J.size[b] : r;
+        return;
+    }
     const int r = qlfc_encode_runs(J.views[b], J.size[b], J.scratch[b].get(), J.size[b], J.coder);
     J.sub_res[b] = (r < 0) ? J.size[b] : r;
 }
@@ -459,7 +500,7 @@ static void host_finalize_serial(BlockJob& J)
         if (J.sub_res[b] == J.size[b] && optr + J.size[b] >= n) { incompressible = true; break; }       // coder.cpp:131-134
         optr += J.sub_res[b];
     }
-    if (!exact) { host_code_serially(J); return; }
+    if (!exact) { if (J.use_ps) { J.redo.store(true, std::memory_order_relaxed); return; } host_code_serially(J); return; }
     if (incompressible) write_header_and_trailer(J, LIBBSC_NOT_COMPRESSIBLE);
     else {
         out[0] = (uint8_t)nb;
@@ -477,6 +518,7 @@ static void host_finalize_serial(BlockJob& J)
 
 static void host_finalize(BlockJob& J)
 {
+    if (J.use_ps && J.redo.load(std::memory_order_relaxed)) return;            // finished later by redo_on_host_model()
     if (J.features & LIBBSC_FEATURE_MULTITHREADING) host_finalize_parallel(J); else host_finalize_serial(J);
 }
 
@@ -523,6 +565,20 @@ static int stage_host_h2d(BlockJob& J, bscgpu_ctx* c)
     return LIBBSC_NO_ERROR;
 }
 
+// A block that took the device model but has a sub-block that does not compress (or needs the strictly serial framing) is
+// run again with the model on the host: raw sub-blocks are rebuilt from the run arrays, which that path never copied.  Rare
+// (such blocks are mostly caught before by their run count); the caller must be the thread that owns the context's GPU stage.
+static int redo_on_host_model(BlockJob& J)
+{
+    J.redo.store(false, std::memory_order_relaxed);
+    int rc = LIBBSC_NO_ERROR;
+    if (J.hInput) rc = stage_host_h2d(J, J.c);
+    if (rc >= 0) rc = gpu_stage(J, J.sorter, false);
+    if (rc < 0) { J.result = rc; return rc; }
+    host_stage(J);
+    return J.result;
+}
+
 // bsc_compress (libbsc.cpp:213-338; input == output selects the in-place rules, :83-211): optional LZP on the host, then
 // the same GPU stage + host coder as the device-resident entry point.
 int bsc_compress(const unsigned char* input, unsigned char* output, int n, int lzpHashSize, int lzpMinLen,
@@ -547,7 +603,7 @@ int bsc_compress(const unsigned char* input, unsigned char* output, int n, int l
         if (hipSetDevice(c->device) != hipSuccess) return LIBBSC_GPU_ERROR;
         rc = ctx_ensure_slots(c, user.slot + 1);
         if (rc < 0) return rc;
-        J->slot = c->slots[user.slot];
+        J->slot = &c->slots[user.slot];
         rc = stage_host_h2d(*J, c);
         if (rc < 0) return rc;
         rc = gpu_stage(*J, blockSorter);
@@ -555,6 +611,11 @@ int bsc_compress(const unsigned char* input, unsigned char* output, int n, int l
         if (rc < 0) return rc;
     }
     host_stage(*J);                                             // host coder: overlaps the next caller's GPU stage
+    if (J->redo.load(std::memory_order_relaxed)) {
+        std::lock_guard<std::mutex> g(user.dev->gpu_lock);
+        if (hipSetDevice(c->device) != hipSuccess) return LIBBSC_GPU_ERROR;
+        return redo_on_host_model(*J);
+    }
     return J->result;
 }
 
@@ -588,11 +649,12 @@ int bscgpu_compress_device(bscgpu_ctx* c, const void* dInput, uint8_t* output, i
     std::unique_ptr<BlockJob> J(new BlockJob);
     int rc = prepare_job(*J, c, dInput, output, n, blockSorter, coder, features);
     if (rc < 0) return rc;
-    J->slot = c->slots[0];
+    J->slot = &c->slots[0];
     rc = gpu_stage(*J, blockSorter);
     if (rc < 0) return rc;
     const auto t0 = clk::now();
     host_stage(*J);
+    if (J->redo.load(std::memory_order_relaxed)) redo_on_host_model(*J);
     c->stage_ms[3] = ms_since(t0);
     c->stage_ms[4] = ms_since(t_all);
     return J->result;
@@ -659,9 +721,13 @@ struct bscgpu_pipe {
 static void lane_join(bscgpu_pipe* p, bscgpu_pipe::Lane& L)
 {
     if (!L.busy) return;
-    std::unique_lock<std::mutex> lk(p->mu);
-    p->cv_done.wait(lk, [&] { return L.job->done; });
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv_done.wait(lk, [&] { return L.job->done; });
+    }
     L.busy = false;
+    // lane_join only runs on the pipe's submitting thread (submit / wait / destroy), which owns the GPU stage
+    if (L.job->redo.load(std::memory_order_relaxed) && hipSetDevice(p->c->device) == hipSuccess) redo_on_host_model(*L.job);
 }
 
 int bscgpu_pipe_create(bscgpu_ctx* c, int depth, bscgpu_pipe** out)
@@ -719,7 +785,7 @@ int bscgpu_pipe_submit(bscgpu_pipe* p, const void* dInput, uint8_t* output, int 
     BlockJob& J = *L.job;
     int rc = prepare_job(J, p->c, dInput, output, n, blockSorter, coder, features);
     if (rc < 0) return rc;
-    J.slot = p->c->slots[ticket % p->depth];
+    J.slot = &p->c->slots[ticket % p->depth];
     J.done = false;
     rc = gpu_stage(J, blockSorter);
     J.lz.reset();                                   // the LZP output lives in HBM from here on
@@ -742,7 +808,7 @@ int bscgpu_pipe_submit_host(bscgpu_pipe* p, const uint8_t* input, uint8_t* outpu
     lane_join(p, L);
     BlockJob& J = *L.job;
     J.done = false;
-    J.slot = p->c->slots[ticket % p->depth];
+    J.slot = &p->c->slots[ticket % p->depth];
     if (n <= LIBBSC_HEADER_SIZE) {
         J.c = p->c; J.n = J.n_orig = n; J.output = output; J.lz.reset();
         J.result = bsc_store(input, output, n, features);

@@ -200,3 +200,29 @@ def test_write_combining_scatter_variant(torch_cuda):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_device.py"), "-q", "-x",
                         "-k", "radix_sort_matches or bwt_device_resident_16m"], capture_output=True, text=True, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_device_static_model_matches_oracle_trace(ctx):
+    """bscgpu_qlfc_static_pstream (devcoder.hip): every probability of the static QLFC model computed on the GPU equals the
+    oracle's trace of the reference model (oracle/bsc_oracle.c: encode_model1 with the trace hook), sub-block by sub-block,
+    including the run-start marks; blocks with more than 256 decision types are declined, never approximated."""
+    from libbsc_amd import api
+    from libbsc_amd.gpu import GpuError
+    from oracle.refbind import Oracle, Ref
+    orc, ref = Oracle(), Ref()
+    rng = np.random.default_rng(11)
+    bwt = lambda x: ref.bwt_encode(x)[0]
+    cases = [("text300k", bwt(api.synth_text_v1(3, 300_000))), ("text1m", bwt(api.synth_text_v1(1, 1 << 20))),
+             ("low1m", bwt(rng.integers(0, 3, 1 << 20, dtype=np.uint8))), ("zeros", np.zeros(500_000, np.uint8)),
+             ("sym40", bwt((rng.geometric(0.15, 700_000) % 40).astype(np.uint8))),
+             ("longruns", np.repeat(rng.integers(0, 6, 3000, dtype=np.uint8), rng.integers(1, 3000, 3000)).astype(np.uint8)),
+             ("text3m", bwt(api.synth_text_v1(4, 3 << 20)))]
+    for name, L in cases:
+        ps, st, sz, poff, _ = ctx.qlfc_static_pstream(L)
+        assert poff[0] == 0 and poff[-1] == len(ps), name
+        for b in range(len(st)):
+            tr, _ = orc.static_pstream(L[st[b]:st[b] + sz[b]])
+            assert np.array_equal(tr, ps[poff[b]:poff[b + 1]]), (name, b)
+    with pytest.raises(GpuError) as e:                       # 256 symbols, ranks up to 255: more than 256 decision types
+        ctx.qlfc_static_pstream(rng.integers(0, 256, 1 << 20, dtype=np.uint8))
+    assert e.value.code == -4
