@@ -55,9 +55,10 @@ struct DevCoder {
     u32 *inv_ch = nullptr, *inv_sr = nullptr, *inv_sn = nullptr;
     u8  *ge32 = nullptr;
     u32 *doff[4] = {nullptr, nullptr, nullptr, nullptr};       // per job: sp, ch, sr, sn
-    u16 *events = nullptr;
-    u32 *pos[3] = {nullptr, nullptr, nullptr};
-    u16 *V[3] = {nullptr, nullptr, nullptr};
+    u16 *events[4] = {nullptr, nullptr, nullptr, nullptr};     // per job, chain-major
+    u32 *pos[4] = {nullptr, nullptr, nullptr, nullptr};        // per job: where each decision's event went
+    u16 *V[4] = {nullptr, nullptr, nullptr, nullptr};          // per job: counter value seen by each event
+    size_t nch_cap = 0;                                        // evaluation chunks per job (capacity)
     u16 *ps = nullptr;
     u32 *cnt = nullptr, *rowtot = nullptr, *rowstart = nullptr /*[4][257]*/, *wdec = nullptr, *wdecoff = nullptr;
     u16 *elo = nullptr, *ehi = nullptr, *S = nullptr;
@@ -263,8 +264,57 @@ __device__ __forceinline__ void dc_match(u32 h, bool on, u64 active, u32& mlo, u
     dc_match8(h, active, mlo, mhi);
 }
 
+// rounds whose decisions all have the same type (hence the same row): everything but the mantissa / escape rounds
+__device__ __forceinline__ bool dc_single_row_round(int r) { return r < ROUND_RM || (r >= ROUND_NF && r < ROUND_NM); }
+
 template <int SIDES>
 __device__ __forceinline__ bool dc_round_on_side(int r) { return (r < ROUND_NF) ? (SIDES & 1) != 0 : (SIDES & 2) != 0; }
+
+// The decisions of 64 items, round by round in canonical order, with the case analysis done once per item instead of once per
+// round: single-row rounds (RF, RE s, NF, NE s: one decision type, hence one row, per round) go to es(slot, on, bit) with
+// slot = 0 | 1 + s | 8 | 9 + s; mantissa / escape rounds (several rows per round) go to em(tau, on, bit).  Control flow is
+// wave-uniform; every lane calls with its own `on`.
+constexpr int DC_SLOTS = 40;
+__device__ __forceinline__ int dc_slot_tau(int slot) { return slot == 0 ? TAU_RF : slot < 8 ? TAU_RE + slot - 1 : slot == 8 ? TAU_NF : TAU_NE + slot - 9; }
+
+template <int SIDES, class ES, class EM>
+__device__ __forceinline__ void dc_item_rounds(const Item& it, bool valid, int maxr, ES&& es, EM&& em)
+{
+    if (SIDES & 1) {
+        const u32 rank = it.rank;
+        const bool ge = valid && it.ge32 != 0u, ng = valid && it.ge32 == 0u;
+        const int B = (ng && rank != 1u) ? bsr(rank) : 0;
+        const int e = B ? (B - 1) + (B < maxr ? 1 : 0) : 0;
+        if (__ballot(ng)) es(0, ng, rank != 1u ? 1u : 0u);
+        for (int sx = 0; sx < 7; ++sx) { const bool on = sx < e; if (!__ballot(on)) break; es(1 + sx, on, sx + 1 < B ? 1u : 0u); }
+        for (int d = 0; d < 7; ++d) {
+            const bool on = d < B;
+            if (!__ballot(on)) break;
+            const int tau = on ? TAU_RM + rm_off(B) + (int)(rank >> (B - d)) - 1 : 0;
+            em(tau, on, on ? (rank >> (B - 1 - d)) & 1u : 0u);
+        }
+        if (__ballot(ge)) {
+            for (int d = 0; d < 8; ++d) {
+                const bool on = ge && d <= maxr;
+                if (!__ballot(on)) break;
+                const u32 ctx = on ? ((1u << d) | ((rank >> (maxr + 1 - d)) & ((1u << d) - 1u))) : 1u;
+                em(TAU_RP + (int)ctx - 1, on, on ? (rank >> (maxr - d)) & 1u : 0u);
+            }
+        }
+    }
+    if (SIDES & 2) {
+        const u32 run = it.run;
+        const int nb = (valid && run != 1u) ? bsr(run) : 0;
+        if (__ballot(valid)) es(8, valid, run != 1u ? 1u : 0u);
+        for (int sx = 0; sx < 31; ++sx) { const bool on = sx < nb; if (!__ballot(on)) break; es(9 + sx, on, sx + 1 < nb ? 1u : 0u); }
+        for (int d = 0; d < 31; ++d) {
+            const bool on = d < nb;
+            if (!__ballot(on)) break;
+            const u32 ctx = on ? (nb <= 5 ? (run >> (nb - d)) : (u32)(1 + d)) : 1u;
+            em(on ? TAU_NM + nm_off(nb) + (int)ctx - 1 : 0, on, on ? (run >> (nb - 1 - d)) & 1u : 0u);
+        }
+    }
+}
 
 // 2a. per wave-chunk: decisions per row and in total
 template <int SIDES>
@@ -274,15 +324,13 @@ __global__ __launch_bounds__(WG) void dc_part_count_kernel(const u64* __restrict
 {
     __shared__ u8 shot[NUM_TAU];
     __shared__ u32 hist[WAVES][256];
-    __shared__ u8 srounds[NUM_ROUNDS];
+    (void)rounds; (void)meta;
     for (u32 i = threadIdx.x; i < NUM_TAU; i += WG) shot[i] = hot[i];
     for (u32 i = threadIdx.x; i < WAVES * 256; i += WG) (&hist[0][0])[i] = 0;
-    const u32 nr = meta[DM_NROUNDS];
-    if (threadIdx.x < NUM_ROUNDS) srounds[threadIdx.x] = threadIdx.x < nr ? rounds[threadIdx.x] : 0;
     __syncthreads();
     const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 wc = blockIdx.x * WAVES + w;
-    dc_lds_vu32* vh = (dc_lds_vu32*)&hist[w][0];
+    u32* hw = &hist[w][0];
     const u64 lt = lanemask_lt();
     const u32 lt_lo = (u32)lt, lt_hi = (u32)(lt >> 32);
     u32 total = 0;
@@ -295,22 +343,22 @@ __global__ __launch_bounds__(WG) void dc_part_count_kernel(const u64* __restrict
             const u64 key = valid ? items[i] : 0ull;
             const Item it = item_unpack(key);
             const int maxr = (int)S.maxr[it.sb];
-            for (u32 k = 0; k < nr; ++k) {
-                const int r = srounds[k];
-                if (!dc_round_on_side<SIDES>(r)) continue;
-                u32 bit = 0;
-                const int tau = valid ? decision(it, maxr, r, &bit) : -1;
-                const bool on = tau >= 0;
-                const u64 active = __ballot(on);
-                if (active == 0) continue;
-                const u32 h = on ? (u32)shot[tau] : 0u;
-                u32 mlo, mhi;
-                dc_match(h, on, active, mlo, mhi);
-                const u32 rr = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));
-                const u32 cn = (u32)(__popc(mlo) + __popc(mhi));
-                if (on && rr == cn - 1) vh[h] = vh[h] + cn;               // one lane per row adds the row's count
-                total += (u32)__popcll(active);
-            }
+            dc_item_rounds<SIDES>(it, valid, maxr,
+                [&](int slot, bool on, u32) {
+                    const u32 n1 = (u32)__popcll(__ballot(on));
+                    if (lane == 0) atomicAdd(&hw[shot[dc_slot_tau(slot)]], n1);          // no return value: fire and forget
+                    total += n1;
+                },
+                [&](int tau, bool on, u32) {
+                    const u64 active = __ballot(on);
+                    const u32 h = on ? (u32)shot[tau] : 0u;
+                    u32 mlo, mhi;
+                    dc_match(h, on, active, mlo, mhi);
+                    const u32 rr = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));
+                    const u32 cn = (u32)(__popc(mlo) + __popc(mhi));
+                    if (on && rr == cn - 1) atomicAdd(&hw[h], cn);                         // one lane per row adds the row's count
+                    total += (u32)__popcll(active);
+                });
         }
     }
     __syncthreads();
@@ -362,7 +410,9 @@ __global__ __launch_bounds__(WG) void dc_scan_misc_kernel(const u32* __restrict_
 // 2c. scatter.  One wavefront per wave-chunk walks its items 64 at a time; per canonical round the lanes that have a decision
 // are ranked stably inside their row (same type -> same round, so rows never interleave across rounds) and write
 //   events[row offset]            = X | sub-block << 8 | bit << 11
-//   pos[decision index of item]   = v_base + that offset (index into the family's value array)
+//   pos[decision index of item]   = that offset (index into the job's value array)
+// The running offsets of the 40 single-row types live in one VGPR (lane = slot; v_readlane / v_writelane with a uniform slot),
+// those of the mantissa / escape rows in LDS.
 template <int SIDES>
 __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restrict__ items, DcGeom g, DcSub S, const u8* __restrict__ hot,
                                                              const u8* __restrict__ rounds, const u32* __restrict__ meta,
@@ -372,11 +422,9 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
 {
     __shared__ u8 shot[NUM_TAU];
     __shared__ u32 goff[WAVES][256];
-    __shared__ u8 srounds[NUM_ROUNDS];
+    (void)rounds; (void)v_base; (void)dec_base;
     if (meta[DM_FAIL] != 0u) return;
     for (u32 i = threadIdx.x; i < NUM_TAU; i += WG) shot[i] = hot[i];
-    const u32 nr = meta[DM_NROUNDS];
-    if (threadIdx.x < NUM_ROUNDS) srounds[threadIdx.x] = threadIdx.x < nr ? rounds[threadIdx.x] : 0;
     const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 wc = blockIdx.x * WAVES + w;
     if (wc < g.W) for (u32 h = lane; h < 256; h += 64) goff[w][h] = rowstart[h] + cnt[(size_t)h * g.W + wc];
@@ -385,6 +433,7 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
     dc_lds_vu32* vg = (dc_lds_vu32*)&goff[w][0];
     const u64 lt = lanemask_lt();
     const u32 lt_lo = (u32)lt, lt_hi = (u32)(lt >> 32);
+    int sreg = (lane < (u32)DC_SLOTS) ? (int)goff[w][shot[dc_slot_tau((int)lane)]] : 0;     // running offsets of the single-row types
     const u64 i0 = (u64)wc * g.per_wave;
     u64 i1 = i0 + g.per_wave; if (i1 > g.m) i1 = g.m;
     u32 running = wdecoff[wc];                                        // decision index of the tile's first item
@@ -401,29 +450,34 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
         if (valid) doff[i] = my;
         running += __shfl(incl, 63, 64);
         const u32 sig = (ignoreX ? 0u : item_X(key)) | (it.sb << 8);
+        u32* mypos = pos + my;
         u32 ord = 0;
-        for (u32 k = 0; k < nr; ++k) {
-            const int r = srounds[k];
-            if (!dc_round_on_side<SIDES>(r)) continue;
-            u32 bit = 0;
-            const int tau = valid ? decision(it, maxr, r, &bit) : -1;
-            const bool on = tau >= 0;
-            const u64 active = __ballot(on);
-            if (active == 0) continue;
-            const u32 h = on ? (u32)shot[tau] : 0u;
-            u32 mlo, mhi;
-            dc_match(h, on, active, mlo, mhi);
-            const u32 before = vg[h];
-            const u32 rr  = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));
-            const u32 cn  = (u32)(__popc(mlo) + __popc(mhi));
-            if (on) {
-                const u32 p = before + rr;
-                if (rr == cn - 1) vg[h] = before + cn;                // highest peer publishes
-                events[p] = (u16)(sig | (bit << 11));
-                pos[(size_t)dec_base + my + ord] = v_base + p;
-                ++ord;
-            }
-        }
+        dc_item_rounds<SIDES>(it, valid, maxr,
+            [&](int slot, bool on, u32 bit) {
+                const u64 m = __ballot(on);
+                const u32 bs = (u32)__builtin_amdgcn_readlane(sreg, slot);
+                if (on) {
+                    const u32 p = bs + (u32)(__popc((u32)m & lt_lo) + __popc((u32)(m >> 32) & lt_hi));
+                    events[p] = (u16)(sig | (bit << 11));
+                    mypos[ord++] = p;
+                }
+                if ((int)lane == slot) sreg = (int)(bs + (u32)__popcll(m));
+            },
+            [&](int tau, bool on, u32 bit) {
+                const u64 active = __ballot(on);
+                const u32 h = on ? (u32)shot[tau] : 0u;
+                u32 mlo, mhi;
+                dc_match(h, on, active, mlo, mhi);
+                const u32 before = vg[h];
+                const u32 rr = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));
+                const u32 cn = (u32)(__popc(mlo) + __popc(mhi));
+                if (on) {
+                    const u32 p = before + rr;
+                    if (rr == cn - 1) vg[h] = before + cn;                // highest peer publishes
+                    events[p] = (u16)(sig | (bit << 11));
+                    mypos[ord++] = p;
+                }
+            });
     }
     if (wc == g.W - 1 && lane == 0) doff[g.m] = running;
 }
@@ -500,21 +554,33 @@ __device__ __forceinline__ void dc_walk(const DcEvalJob& J, const ModelParams* _
 // way.  The next batch is in flight while the current one is walked.
 constexpr int DC_EB = 64;                       // events per lane per batch
 constexpr int DC_EROW = DC_EB * 2 + 16;         // LDS row pitch in bytes (padded)
+// all four jobs of a block in one launch (they are independent, and one job alone leaves most SIMDs idle: a lane is a serial chain)
+struct DcEvalAll { DcEvalJob job[4]; u32 wstart[5]; u32 cstart[5]; u16* V[4]; };   // first wavefront / first chunk of each job
+
 template <bool WRITE>
-__global__ __launch_bounds__(64) void dc_eval_wave_kernel(DcEvalJob J, const ModelParams* __restrict__ mp, const u32* __restrict__ meta,
-                                                          u16* __restrict__ elo, u16* __restrict__ ehi, const u16* __restrict__ Sv, u16* __restrict__ Vout)
+__global__ __launch_bounds__(64) void dc_eval_wave_kernel(DcEvalAll A, const ModelParams* __restrict__ mp, const u32* __restrict__ meta,
+                                                          u16* __restrict__ elo_all, u16* __restrict__ ehi_all, const u16* __restrict__ Sv_all)
 {
     __shared__ __attribute__((aligned(16))) u8 sin[64 * DC_EROW];
     __shared__ __attribute__((aligned(16))) u8 sout[WRITE ? 64 * DC_EROW : 16];
     if (meta[DM_FAIL] != 0u) return;
+    int jb = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) if (blockIdx.x >= A.wstart[q]) jb = q;
+    const DcEvalJob J = A.job[jb];
+    u16* const elo = elo_all + A.cstart[jb];
+    u16* const ehi = ehi_all + A.cstart[jb];
+    const u16* const Sv = Sv_all + A.cstart[jb];
+    u16* const Vout = A.V[jb];
+    const u32 wave = blockIdx.x - A.wstart[jb];
     const u32 lane = threadIdx.x;
-    const u32 c = blockIdx.x * 64 + lane;
+    const u32 c = wave * 64 + lane;
     const u64 k0 = (u64)c * DC_EV;
     const bool mine = k0 < J.E;
     const u32 k1 = mine ? (u32)((k0 + DC_EV < J.E) ? k0 + DC_EV : J.E) : 0u;
     // cooperative mapping: instruction i moves 16 bytes of row 8 i + lane / 8, column lane % 8
     const u32 crow = lane >> 3, ccol = lane & 7u;
-    const u64 wave_k0 = (u64)blockIdx.x * 64 * DC_EV;
+    const u64 wave_k0 = (u64)wave * 64 * DC_EV;
 
     u32 row = 0, rowend = 0, prev = 0xffffu;
     int lo = 2048, hi = 2048;
@@ -598,19 +664,6 @@ __global__ __launch_bounds__(64) void dc_eval_wave_kernel(DcEvalJob J, const Mod
     if (!WRITE && mine) { elo[c] = (u16)lo; ehi[c] = (u16)hi; }
 }
 
-__global__ __launch_bounds__(WG) void dc_eval_a_kernel(DcEvalJob J, const ModelParams* __restrict__ mp, const u32* __restrict__ meta,
-                                                       u16* __restrict__ elo, u16* __restrict__ ehi)
-{
-    if (meta[DM_FAIL] != 0u) return;
-    const u32 c = blockIdx.x * WG + threadIdx.x;
-    const u64 k0 = (u64)c * DC_EV;
-    if (k0 >= J.E) return;
-    const u32 k1 = (u32)((k0 + DC_EV < J.E) ? k0 + DC_EV : J.E);
-    int lo, hi;
-    dc_walk<false>(J, mp, (u32)k0, k1, lo, hi, true, nullptr);
-    elo[c] = (u16)lo; ehi[c] = (u16)hi;
-}
-
 __device__ __forceinline__ bool dc_chunk_continues(const DcEvalJob& J, u32 c)
 {
     if (c == 0) return false;
@@ -621,12 +674,19 @@ __device__ __forceinline__ bool dc_chunk_continues(const DcEvalJob& J, u32 c)
     return (((u32)J.events[k0 - 1] ^ (u32)J.events[k0]) & DC_SIGMASK) == 0;
 }
 
-// exact value at the start of every chunk that begins inside a chain
-__global__ __launch_bounds__(WG) void dc_eval_b_kernel(DcEvalJob J, const ModelParams* __restrict__ mp, u32* __restrict__ meta,
-                                                       const u16* __restrict__ elo, const u16* __restrict__ ehi, u16* __restrict__ Sv)
+// exact value at the start of every chunk that begins inside a chain (all jobs in one launch; thread per chunk)
+__global__ __launch_bounds__(WG) void dc_eval_b_kernel(DcEvalAll A, const ModelParams* __restrict__ mp, u32* __restrict__ meta,
+                                                       const u16* __restrict__ elo_all, const u16* __restrict__ ehi_all, u16* __restrict__ Sv_all)
 {
     if (meta[DM_FAIL] != 0u) return;
-    const u32 c = blockIdx.x * WG + threadIdx.x;
+    const u32 g = blockIdx.x * WG + threadIdx.x;
+    if (g >= A.cstart[4]) return;
+    int jb = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) if (g >= A.cstart[q]) jb = q;
+    const DcEvalJob J = A.job[jb];
+    const u16* elo = elo_all + A.cstart[jb]; const u16* ehi = ehi_all + A.cstart[jb]; u16* Sv = Sv_all + A.cstart[jb];
+    const u32 c = g - A.cstart[jb];
     const u64 k0 = (u64)c * DC_EV;
     if (k0 >= J.E) return;
     if (!dc_chunk_continues(J, c)) { Sv[c] = 2048; return; }
@@ -647,18 +707,6 @@ __global__ __launch_bounds__(WG) void dc_eval_b_kernel(DcEvalJob J, const ModelP
     Sv[c] = (u16)lo;
 }
 
-__global__ __launch_bounds__(WG) void dc_eval_c_kernel(DcEvalJob J, const ModelParams* __restrict__ mp, const u32* __restrict__ meta,
-                                                       const u16* __restrict__ Sv, u16* __restrict__ Vout)
-{
-    if (meta[DM_FAIL] != 0u) return;
-    const u32 c = blockIdx.x * WG + threadIdx.x;
-    const u64 k0 = (u64)c * DC_EV;
-    if (k0 >= J.E) return;
-    const u32 k1 = (u32)((k0 + DC_EV < J.E) ? k0 + DC_EV : J.E);
-    int lo = Sv[c], hi = lo;
-    dc_walk<true>(J, mp, (u32)k0, k1, lo, hi, false, Vout);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // 4. probability stream, stream order.  Thread per run.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -666,9 +714,8 @@ struct DcGather {
     const u64* key_ch; u32 m;
     const u32 *inv_ch, *inv_sr, *inv_sn;
     const u32 *doff_sp, *doff_ch, *doff_sr, *doff_sn;
-    const u32 *pos_sp, *pos_ch, *pos_st;
-    const u16 *V_sp, *V_ch, *V_st;
-    u32 dec_base_sn;                                                   // decision-index base of the run-side state job inside pos_st
+    const u32 *pos_sp, *pos_ch, *pos_sr, *pos_sn;
+    const u16 *V_sp, *V_ch, *V_sr, *V_sn;
 };
 __global__ __launch_bounds__(WG) void dc_pstream_kernel(DcGather G, DcSub S, const ModelParams* __restrict__ mp,
                                                         const u32* __restrict__ meta, u16* __restrict__ out, u16* __restrict__ dbg /*[3][D] or null*/, u32 dbgD)
@@ -681,16 +728,15 @@ __global__ __launch_bounds__(WG) void dc_pstream_kernel(DcGather G, DcSub S, con
     const u32 b_sp = G.doff_sp[j];
     const u32* p_sp = G.pos_sp + b_sp;
     const u32* p_ch = G.pos_ch + G.doff_ch[G.inv_ch[j]];
-    const u32* p_sr = G.pos_st + G.doff_sr[G.inv_sr[j]];
-    const u32* p_sn = G.pos_st + (G.doff_sn[G.inv_sn[j]] + G.dec_base_sn);
+    const u32* p_sr = G.pos_sr + G.doff_sr[G.inv_sr[j]];
+    const u32* p_sn = G.pos_sn + G.doff_sn[G.inv_sn[j]];
     u16* o = out + b_sp;
     u32 ord = 0, ord_run = 0;
     enumerate(it, maxr, [&](int tau, u32 bit, bool run_side) {
         const int cls = tau_class(tau);
-        const u32 pst = run_side ? p_sn[ord_run++] : p_sr[ord];
+        const int v_st = run_side ? G.V_sn[p_sn[ord_run++]] : G.V_sr[p_sr[ord]];
         const int v_sp = G.V_sp[p_sp[ord]];
         const int v_ch = G.V_ch[p_ch[ord]];
-        const int v_st = G.V_st[pst];
         const int p = blend(v_ch, v_st, v_sp, mp->lr[cls]);
         o[ord] = (u16)((u32)p | (bit << 12) | (ord == 0 ? (u32)PS_RUN : 0u));
         if (dbg) { dbg[b_sp + ord] = (u16)v_st; dbg[(size_t)dbgD + b_sp + ord] = (u16)v_ch; dbg[2 * (size_t)dbgD + b_sp + ord] = (u16)v_sp; }
@@ -733,13 +779,13 @@ int devcoder_ensure(bscgpu_ctx* c)
         {(void**)&d->key_sn, 8 * M}, {(void**)&d->key_sn_s, 8 * M},
         {(void**)&d->inv_ch, 4 * M}, {(void**)&d->inv_sr, 4 * M}, {(void**)&d->inv_sn, 4 * M}, {(void**)&d->ge32, M},
         {(void**)&d->doff[0], 4 * M}, {(void**)&d->doff[1], 4 * M}, {(void**)&d->doff[2], 4 * M}, {(void**)&d->doff[3], 4 * M},
-        {(void**)&d->events, 2 * D},
-        {(void**)&d->pos[0], 4 * D}, {(void**)&d->pos[1], 4 * D}, {(void**)&d->pos[2], 4 * D},
-        {(void**)&d->V[0], 2 * D}, {(void**)&d->V[1], 2 * D}, {(void**)&d->V[2], 2 * D},
+        {(void**)&d->events[0], 2 * D}, {(void**)&d->events[1], 2 * D}, {(void**)&d->events[2], 2 * D}, {(void**)&d->events[3], 2 * D},
+        {(void**)&d->pos[0], 4 * D}, {(void**)&d->pos[1], 4 * D}, {(void**)&d->pos[2], 4 * D}, {(void**)&d->pos[3], 4 * D},
+        {(void**)&d->V[0], 2 * D}, {(void**)&d->V[1], 2 * D}, {(void**)&d->V[2], 2 * D}, {(void**)&d->V[3], 2 * D},
         {(void**)&d->ps, 2 * D},
         {(void**)&d->cnt, (size_t)256 * DC_WCH_MAX * 4}, {(void**)&d->rowtot, 256 * 4}, {(void**)&d->rowstart, 4 * 260 * 4},
         {(void**)&d->wdec, (DC_WCH_MAX + 8) * 4}, {(void**)&d->wdecoff, (DC_WCH_MAX + 8) * 4},
-        {(void**)&d->elo, 2 * NCH}, {(void**)&d->ehi, 2 * NCH}, {(void**)&d->S, 2 * NCH},
+        {(void**)&d->elo, 2 * 4 * NCH}, {(void**)&d->ehi, 2 * 4 * NCH}, {(void**)&d->S, 2 * 4 * NCH},
         {(void**)&d->present, 64 * 4}, {(void**)&d->hot, 2048}, {(void**)&d->hot2tau, 512}, {(void**)&d->rounds, 256},
         {(void**)&d->meta, DM_COUNT * 4}, {(void**)&d->poff, 16 * 4},
         {(void**)&d->tab_rank, 32768}, {(void**)&d->tab_run, 8192}, {(void**)&d->mp, sizeof(ModelParams)},
@@ -747,7 +793,7 @@ int devcoder_ensure(bscgpu_ctx* c)
     size_t total = 0;
     for (auto& cv : carve) total += dc_align(cv.bytes);
     if (hipMalloc((void**)&d->arena, total) != hipSuccess) { (void)hipGetLastError(); delete d; return BSC_GPU_NOT_ENOUGH_MEMORY; }
-    d->arena_bytes = total;
+    d->arena_bytes = total; d->nch_cap = NCH;
     size_t off = 0;
     for (auto& cv : carve) { *cv.p = d->arena + off; off += dc_align(cv.bytes); }
     if (hipHostMalloc((void**)&d->hmeta, 64 * 4, hipHostMallocDefault) != hipSuccess) { hipFree(d->arena); delete d; return BSC_NOT_ENOUGH_MEMORY; }
@@ -766,8 +812,7 @@ int devcoder_ensure(bscgpu_ctx* c)
 int64_t devcoder_arena_bytes(const bscgpu_ctx* c) { return c->dc ? (int64_t)c->dc->arena_bytes : 0; }
 
 template <int SIDES>
-static void dc_launch_partition(bscgpu_ctx* c, DevCoder* d, const u64* items, u32 m, const DcSub& S, int job, u32 v_base, u32 dec_base,
-                                u32 ignoreX, u32* posarr, u32* doff)
+static void dc_launch_partition(bscgpu_ctx* c, DevCoder* d, const u64* items, u32 m, const DcSub& S, int job, u32 ignoreX)
 {
     const DcGeom g = dc_geom(m);
     const u32 grid = (g.W + WAVES - 1) / WAVES;
@@ -777,7 +822,7 @@ static void dc_launch_partition(bscgpu_ctx* c, DevCoder* d, const u64* items, u3
     hipLaunchKernelGGL(dc_scan_rows_kernel, dim3(256), dim3(WG), 0, c->stream, d->cnt, g.W, d->rowtot);
     hipLaunchKernelGGL(dc_scan_misc_kernel, dim3(1), dim3(WG), 0, c->stream, d->rowtot, rowstart, d->wdec, g.W, d->wdecoff, d->meta, job, (u32)d->Dcap);
     hipLaunchKernelGGL(dc_part_scatter_kernel<SIDES>, dim3(grid), dim3(WG), 0, c->stream, items, g, S, d->hot, d->rounds, d->meta, d->cnt, rowstart,
-                       d->wdecoff, v_base, dec_base, ignoreX, d->events, posarr, doff);
+                       d->wdecoff, 0u, 0u, ignoreX, d->events[job], d->pos[job], d->doff[job]);
     prof_end(c);
 }
 
@@ -820,51 +865,47 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     rc = radix_sort_passes(c, d->key_sn, d->key_sn_s, nullptr, nullptr, m, &top, 1, &in_alt, d->inv_sn);
     if (rc < 0) return rc;
 
-    // families: static (stream order, X ignored), char (symbol-major), state (rank side by rank-state, run side by run-state)
-    // (each job's event count is read back once: the evaluation launches are sized by it)
-    u32 E[4] = {0, 0, 0, 0};
-    u32 vbase_sn = 0;                                                           // the run-side state job's values follow the rank-side job's
-    for (int job = 0; job < 4; ++job) {
-        const u64* items = job == 0 ? d->key_ch : job == 1 ? d->key_ch_s : job == 2 ? d->key_sr_s : d->key_sn_s;
-        const int fam = job == 0 ? FAM_STATIC : job == 1 ? FAM_CHAR : FAM_STATE;
-        const int slot = job == 0 ? 0 : job == 1 ? 1 : 2;                       // pos / V array
-        if (job == 3) vbase_sn = (E[2] + 7u) & ~7u;                             // 16-byte aligned rows for the vector stores
-        const u32 v_base = (job == 3) ? vbase_sn : 0u;
-        const u32 dec_base = (job == 3) ? E[2] : 0u;
-        if (job < 2)       dc_launch_partition<3>(c, d, items, m, S, job, v_base, dec_base, job == 0 ? 1u : 0u, d->pos[slot], d->doff[job]);
-        else if (job == 2) dc_launch_partition<1>(c, d, items, m, S, job, v_base, dec_base, 0u, d->pos[slot], d->doff[job]);
-        else               dc_launch_partition<2>(c, d, items, m, S, job, v_base, dec_base, 0u, d->pos[slot], d->doff[job]);
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipMemcpyAsync(d->hmeta, d->meta, DM_COUNT * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, ctx_sync(c));
-        prof_collect(c);
-        if (d->hmeta[DM_FAIL] != 0) { c->dc_last_fail = (int)d->hmeta[DM_FAIL]; return BSC_NOT_SUPPORTED; }
-        E[job] = d->hmeta[DM_D0 + job];
-        if (E[job] == 0) continue;
-        DcEvalJob J; J.events = d->events; J.E = E[job]; J.rowstart = d->rowstart + 260 * job; J.hot2tau = d->hot2tau; J.fam = fam;
-        const u32 nch = (E[job] + DC_EV - 1) / DC_EV, ge = (nch + WG - 1) / WG;
-        u16* Vout = d->V[slot] + v_base;
-        prof_begin(c, BSCGPU_K_DC_EVAL, (u64)E[job] * 6, E[job]);
-        const u32 gw = (nch + 63) / 64;
-        if (getenv("BSC_DC_SCALAR_EVAL")) {
-            hipLaunchKernelGGL(dc_eval_a_kernel, dim3(ge), dim3(WG), 0, c->stream, J, d->mp, d->meta, d->elo, d->ehi);
-            hipLaunchKernelGGL(dc_eval_b_kernel, dim3(ge), dim3(WG), 0, c->stream, J, d->mp, d->meta, d->elo, d->ehi, d->S);
-            hipLaunchKernelGGL(dc_eval_c_kernel, dim3(ge), dim3(WG), 0, c->stream, J, d->mp, d->meta, d->S, Vout);
-        } else {
-            hipLaunchKernelGGL(dc_eval_wave_kernel<false>, dim3(gw), dim3(64), 0, c->stream, J, d->mp, d->meta, d->elo, d->ehi, (const u16*)nullptr, (u16*)nullptr);
-            hipLaunchKernelGGL(dc_eval_b_kernel, dim3(ge), dim3(WG), 0, c->stream, J, d->mp, d->meta, d->elo, d->ehi, d->S);
-            hipLaunchKernelGGL(dc_eval_wave_kernel<true>, dim3(gw), dim3(64), 0, c->stream, J, d->mp, d->meta, (u16*)nullptr, (u16*)nullptr, d->S, Vout);
+    // families: static (stream order, X ignored), char (symbol-major), state (rank side by rank-state, run side by run-state):
+    // four independent partition jobs, then ONE read-back of their sizes, then all chains of the block in one set of launches
+    dc_launch_partition<3>(c, d, d->key_ch, m, S, 0, 1u);
+    dc_launch_partition<3>(c, d, d->key_ch_s, m, S, 1, 0u);
+    dc_launch_partition<1>(c, d, d->key_sr_s, m, S, 2, 0u);
+    dc_launch_partition<2>(c, d, d->key_sn_s, m, S, 3, 0u);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(d->hmeta, d->meta, DM_COUNT * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, ctx_sync(c));
+    prof_collect(c);
+    if (d->hmeta[DM_FAIL] != 0) { c->dc_last_fail = (int)d->hmeta[DM_FAIL]; return BSC_NOT_SUPPORTED; }
+    u32 E[4];
+    for (int job = 0; job < 4; ++job) E[job] = d->hmeta[DM_D0 + job];
+    if (E[0] != E[1] || E[0] != E[2] + E[3]) return ctx_fail(c, BSC_GPU_ERROR, "device coder: decision counts of the families differ", hipSuccess);
+    {
+        DcEvalAll A;
+        A.wstart[0] = 0; A.cstart[0] = 0;
+        for (int job = 0; job < 4; ++job) {
+            const int fam = job == 0 ? FAM_STATIC : job == 1 ? FAM_CHAR : FAM_STATE;
+            A.job[job].events = d->events[job]; A.job[job].E = E[job]; A.job[job].rowstart = d->rowstart + 260 * job;
+            A.job[job].hot2tau = d->hot2tau; A.job[job].fam = fam;
+            A.V[job] = d->V[job];
+            const u32 nch = (E[job] + DC_EV - 1) / DC_EV;
+            A.wstart[job + 1] = A.wstart[job] + (nch + 63) / 64;
+            A.cstart[job + 1] = A.cstart[job] + (nch + 63) / 64 * 64;           // chunk slots padded to whole wavefronts
+        }
+        if (A.cstart[4] > 4 * d->nch_cap) return ctx_fail(c, BSC_GPU_ERROR, "device coder: chunk table too small", hipSuccess);
+        prof_begin(c, BSCGPU_K_DC_EVAL, (u64)E[0] * 18, (u64)E[0] * 3);
+        if (A.wstart[4] > 0) {
+            hipLaunchKernelGGL(dc_eval_wave_kernel<false>, dim3(A.wstart[4]), dim3(64), 0, c->stream, A, d->mp, d->meta, d->elo, d->ehi, (const u16*)nullptr);
+            hipLaunchKernelGGL(dc_eval_b_kernel, dim3((A.cstart[4] + WG - 1) / WG), dim3(WG), 0, c->stream, A, d->mp, d->meta, d->elo, d->ehi, d->S);
+            hipLaunchKernelGGL(dc_eval_wave_kernel<true>, dim3(A.wstart[4]), dim3(64), 0, c->stream, A, d->mp, d->meta, (u16*)nullptr, (u16*)nullptr, d->S);
         }
         prof_end(c);
     }
-    if (E[0] != E[1] || E[0] != E[2] + E[3]) return ctx_fail(c, BSC_GPU_ERROR, "device coder: decision counts of the families differ", hipSuccess);
 
     DcGather G;
     G.key_ch = d->key_ch; G.m = m; G.inv_ch = d->inv_ch; G.inv_sr = d->inv_sr; G.inv_sn = d->inv_sn;
     G.doff_sp = d->doff[0]; G.doff_ch = d->doff[1]; G.doff_sr = d->doff[2]; G.doff_sn = d->doff[3];
-    G.pos_sp = d->pos[0]; G.pos_ch = d->pos[1]; G.pos_st = d->pos[2];
-    G.V_sp = d->V[0]; G.V_ch = d->V[1]; G.V_st = d->V[2];
-    G.dec_base_sn = E[2];                                                       // index base inside pos[2]
+    G.pos_sp = d->pos[0]; G.pos_ch = d->pos[1]; G.pos_sr = d->pos[2]; G.pos_sn = d->pos[3];
+    G.V_sp = d->V[0]; G.V_ch = d->V[1]; G.V_sr = d->V[2]; G.V_sn = d->V[3];
     prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)E[0] * 26, E[0]);
     hipLaunchKernelGGL(dc_pstream_kernel, dim3(gm), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps, dbg, E[0]);
     hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, d->doff[0], S, m, d->poff);
