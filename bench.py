@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--sorter", type=int, default=1)
     ap.add_argument("--coder", type=int, default=1)
     ap.add_argument("--depth", type=int, default=0, help="blocks in flight per GPU (0 = from the coder pool size); their sub-blocks feed the pool of coder threads")
+    ap.add_argument("--contexts", type=int, default=1, help="GPU contexts (own stream, arena and pipe each) driven concurrently on every GPU: "
+                    "kernels of two blocks interleave on the device, which fills the SIMDs that one block's serial chains leave idle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -65,9 +67,10 @@ def main():
     # host-thread budget of this rank: its share of the CPUs the job may use (affinity and cgroup quota); the native default is
     # "all of them", which is right for one rank per box
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    if "BSCGPU_HOST_THREADS" not in os.environ:
-        os.environ["BSCGPU_HOST_THREADS"] = str(max(4, min(64, effective_cpus() // max(local_world, 1))))
-    coder_threads = int(os.environ["BSCGPU_HOST_THREADS"])
+    ncx = max(1, args.contexts)
+    if "BSCGPU_HOST_THREADS" not in os.environ:         # per pipe: this rank's CPUs are shared by its contexts
+        os.environ["BSCGPU_HOST_THREADS"] = str(max(4, min(64, effective_cpus() // max(local_world, 1) // ncx)))
+    coder_threads = int(os.environ["BSCGPU_HOST_THREADS"]) * ncx
     if args.depth <= 0:                                 # enough sub-block tasks in flight for the pool: 8 per block
         args.depth = max(4, min(8, -(-3 * coder_threads // 16)))
     torch.cuda.set_device(local)
@@ -79,36 +82,55 @@ def main():
     seed = 2 if world == 1 else 10 + rank
     host_in = api.synth_text_v1(seed, n)
     d_in = torch.from_numpy(host_in).to(dev)
-    ctx = GpuContext(local, max_n=n + 4096)
+    ctxs = [GpuContext(local, max_n=n + 4096) for _ in range(ncx)]
+    ctx = ctxs[0]
 
     # rank 0 receives world - 1 compressed blocks per round into one staging tensor; the others stage one block
     gather_buf = torch.empty((n + 64) * (max(world - 1, 1) if rank == 0 else 1), dtype=torch.uint8, device=comm_dev)
 
     from libbsc_amd.multigpu import Concatenator
-    pipe = ctx.pipe(args.depth, reuse_outputs=True)        # compressed blocks land in recycled host buffers
+    import threading
+    pipes = [cx.pipe(args.depth, reuse_outputs=True) for cx in ctxs]        # compressed blocks land in recycled host buffers
     stage = np.zeros(6)
+    stage_lock = threading.Lock()
 
     concat = None
 
-    def finish(ticket):
+    def finish(pipe, ticket):
         blk = pipe.wait(ticket)
         if concat is not None:      # final concatenation on rank 0 over RCCL / xGMI, on a background thread per rank
-            concat.put(blk)
+            with stage_lock:
+                concat.put(blk)
         return blk
 
-    def run(steps, record=False):
-        """`steps` blocks through the pipe: GPU stage of block i+1 overlaps the host coding of block i."""
-        nonlocal stage
+    def run_one(k, steps, record, out):
+        """`steps` blocks through pipe k: GPU stage of block i+1 overlaps the host coding of block i."""
+        pipe, cx = pipes[k], ctxs[k]
         tickets, blk = [], None
+        local_stage = np.zeros(6)
         for _ in range(steps):
             tickets.append(pipe.submit(d_in, n, args.sorter, args.coder, 3))
             if record:
-                stage += np.array(ctx.last_stage_ms())
+                local_stage += np.array(cx.last_stage_ms())
             if len(tickets) >= args.depth:
-                blk = finish(tickets.pop(0))
+                blk = finish(pipe, tickets.pop(0))
         while tickets:
-            blk = finish(tickets.pop(0))
-        return blk
+            blk = finish(pipe, tickets.pop(0))
+        out[k] = blk
+        if record:
+            with stage_lock:
+                stage[:] += local_stage
+
+    def run(steps, record=False):
+        out = [None] * ncx
+        share = [steps // ncx + (1 if k < steps % ncx else 0) for k in range(ncx)]
+        if ncx == 1:
+            run_one(0, steps, record, out)
+        else:
+            ths = [threading.Thread(target=run_one, args=(k, share[k], record, out)) for k in range(ncx)]
+            for t in ths: t.start()
+            for t in ths: t.join()
+        return next(b for b in reversed(out) if b is not None)
 
     def sync():
         if world > 1:
@@ -121,8 +143,9 @@ def main():
     if concat is not None:
         concat.close()
         concat = Concatenator(rank, world, comm_dev, staging=gather_buf)
-    ctx.profile(True)
-    ctx.profile_reset()
+    for cx in ctxs:
+        cx.profile(True)
+        cx.profile_reset()
     sync()
     cpu0 = time.process_time()
     t0 = time.perf_counter()
@@ -136,13 +159,18 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    ctx.profile(False)
+    for cx in ctxs:
+        cx.profile(False)
 
     # ---- outside the timed region: is the output the reference's?  The last block every rank produced in the timed
     # region is checked against the reference output committed in tests/golden/golden_big.json (size + md5; generated
     # from the compiled reference by tests/golden/make_golden_big.py) — no reference is needed on this box.
     verified, verify_note = verify_block(blk, seed, n, args.sorter, args.coder)
-    stats = ctx.profile_get()
+    stats = ctxs[0].profile_get()
+    for cx in ctxs[1:]:
+        for k, v in cx.profile_get().items():
+            for f in ("ms", "launches", "bytes", "records"):
+                stats[k][f] += v[f]
     mine = {"rank": rank, "verified": verified, "gpu_stage_total_ms": round(float(stage[0] + stage[1] + stage[2]) / args.steps, 2),
             "sorter_only_MBps": round(n / 1e6 / max(stage[1] / args.steps / 1e3, 1e-9), 1),
             "cpu_seconds_per_block": round(cpu_used / args.steps, 3), "coder_threads": coder_threads,
@@ -156,7 +184,7 @@ def main():
     if rank == 0:
         value = world * args.steps * n / 1e6 / dt
         sc = stats["radix_scatter"]
-        launches = ctx.scatter_launches(65536)
+        launches = [x for cx in ctxs for x in cx.scatter_launches(65536)]
         big = [(ms, rec) for ms, rec in launches if rec >= (1 << 20)]
         full = [(ms, rec) for ms, rec in launches if rec == n]
         rec_bytes = 12 if args.sorter == 1 else 8
@@ -211,7 +239,7 @@ def main():
             "stage_ms_per_step": {"adler32_gpu": round(stage[0] / args.steps, 2), "sort_transform_gpu": round(stage[1] / args.steps, 2),
                                   "qlfc_front_gpu_and_d2h": round(stage[2] / args.steps, 2),
                                   "gpu_stage_total": round((stage[0] + stage[1] + stage[2]) / args.steps, 2),
-                                  "doubling_rounds": stage[5] / args.steps, "pipeline_depth": args.depth},
+                                  "doubling_rounds": stage[5] / args.steps, "pipeline_depth": args.depth, "contexts_per_gpu": ncx},
             "sorter_only_MBps": round(n / 1e6 / max(stage[1] / args.steps / 1e3, 1e-9), 1),
             "kernels": per_kernel,
             "host": {"cpus": os.cpu_count(), "effective_cpus": effective_cpus(), "coder_threads_per_gpu": coder_threads,

@@ -31,7 +31,8 @@ int ctx_ensure_slots(bscgpu_ctx* c, int count)
     const size_t N = align_up((size_t)c->max_n + 4096, 4096);
     for (; c->nslots < count; ++c->nslots) {
         HostSlot& s = c->slots[c->nslots];
-        bool ok = hipHostMalloc((void**)&s.hsym, N, hipHostMallocDefault) == hipSuccess
+        bool ok = hipEventCreateWithFlags(&s.copy_ev, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess
+               && hipHostMalloc((void**)&s.hsym, N, hipHostMallocDefault) == hipSuccess
                && hipHostMalloc((void**)&s.hrank, N, hipHostMallocDefault) == hipSuccess
                && hipHostMalloc((void**)&s.hstart, 4 * N, hipHostMallocDefault) == hipSuccess;
         if (!ok) return BSC_NOT_ENOUGH_MEMORY;
@@ -73,6 +74,7 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
     memset(c->kstat, 0, sizeof c->kstat);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BSC_GPU_ERROR; }
     if (hipEventCreateWithFlags(&c->sync_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return BSC_GPU_ERROR; }
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { hipEventDestroy(c->sync_ev); hipStreamDestroy(c->stream); delete c; return BSC_GPU_ERROR; }
 
     const size_t N = align_up((size_t)max_n + 4096, 4096);
     struct Carve { void** p; size_t bytes; size_t lead; };
@@ -120,6 +122,7 @@ extern "C" void bscgpu_destroy(bscgpu_ctx* c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) ctx_sync(c);
+    if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     for (auto& p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& e : c->event_pool) hipEventDestroy(e);
     if (c->hscal) hipHostFree(c->hscal);
@@ -132,6 +135,7 @@ extern "C" void bscgpu_destroy(bscgpu_ctx* c)
         if (s.hrank) hipHostFree(s.hrank);
         if (s.hstart) hipHostFree(s.hstart);
         if (s.hps) hipHostFree(s.hps);
+        if (s.copy_ev) hipEventDestroy(s.copy_ev);
     }
     devcoder_destroy(c);
     if (c->arena) hipFree(c->arena);

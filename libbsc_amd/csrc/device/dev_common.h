@@ -59,6 +59,7 @@ struct HostSlot {
     u32* hstart = nullptr;   // run start positions
     u16* hps    = nullptr;   // probability stream of the device coder (allocated when that path is first used)
     size_t hps_cap = 0;      // entries
+    hipEvent_t copy_ev = nullptr;   // recorded on the copy stream behind the block's p-stream copy; the host coder waits on it
 };
 constexpr int MAX_SLOTS = 8;
 
@@ -67,6 +68,9 @@ struct DevCoder;                  // device-side static coder state (devcoder.hi
 struct bscgpu_ctx {
     int          device      = 0;
     hipStream_t  stream      = nullptr;
+    hipStream_t  copy_stream = nullptr;   // D2H of the device coder's p stream, overlapped with the next block's GPU stage
+    hipEvent_t   ps_guard[2] = {nullptr, nullptr};   // last copy out of each device p-stream buffer (not owned: a slot's copy_ev)
+    int          ps_toggle   = 0;
     hipEvent_t   sync_ev     = nullptr;   // blocking-sync event: waiting threads sleep instead of spinning (host CPUs are the scarce resource)
     int64_t      max_n       = 0;
     char*        arena       = nullptr;
@@ -150,8 +154,8 @@ int ctx_ensure_slots(bscgpu_ctx* c, int count);
 int ctx_ensure_pstream_slot(bscgpu_ctx* c, HostSlot& slot, size_t entries);     // pinned landing zone for a block's p stream
 // device-side model of the static QLFC coder (devcoder.hip): probability stream of a whole block from the front end's run arrays
 int  devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* dstart, u32 m, u32 n, int nb, const u32* run_first,
-                      const int* max_rank, u32* D_out, u32* poff_out, u16* dbg);
-const u16* devcoder_pstream_ptr(const bscgpu_ctx* c);
+                      const int* max_rank, u32* D_out, u32* poff_out, u16* dbg, int psbuf = 0);
+const u16* devcoder_pstream_ptr(const bscgpu_ctx* c, int psbuf = 0);
 void devcoder_destroy(bscgpu_ctx* c);
 int64_t devcoder_arena_bytes(const bscgpu_ctx* c);
 

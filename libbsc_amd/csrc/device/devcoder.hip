@@ -59,7 +59,7 @@ struct DevCoder {
     u32 *pos[4] = {nullptr, nullptr, nullptr, nullptr};        // per job: where each decision's event went
     u16 *V[4] = {nullptr, nullptr, nullptr, nullptr};          // per job: counter value seen by each event
     size_t nch_cap = 0;                                        // evaluation chunks per job (capacity)
-    u16 *ps = nullptr;
+    u16 *ps[2] = {nullptr, nullptr};                           // double buffer: block i's copy-out overlaps block i+1's kernels
     u32 *cnt = nullptr, *rowtot = nullptr, *rowstart = nullptr /*[4][257]*/, *wdec = nullptr, *wdecoff = nullptr;
     u16 *elo = nullptr, *ehi = nullptr, *S = nullptr;
     u32 *present = nullptr; u8 *hot = nullptr; u16 *hot2tau = nullptr; u8 *rounds = nullptr; u32 *meta = nullptr; u32 *poff = nullptr;
@@ -717,6 +717,10 @@ struct DcGather {
     const u32 *pos_sp, *pos_ch, *pos_sr, *pos_sn;
     const u16 *V_sp, *V_ch, *V_sr, *V_sn;
 };
+// pos entries of one run are contiguous but only 4-byte aligned: a packed struct makes the compiler use one dwordx4 load
+// (global memory takes dword-aligned multi-dword accesses) instead of four dword loads
+struct __attribute__((packed, aligned(4))) DcU4 { u32 a, b, c, d; };
+
 __global__ __launch_bounds__(WG) void dc_pstream_kernel(DcGather G, DcSub S, const ModelParams* __restrict__ mp,
                                                         const u32* __restrict__ meta, u16* __restrict__ out, u16* __restrict__ dbg /*[3][D] or null*/, u32 dbgD)
 {
@@ -725,23 +729,43 @@ __global__ __launch_bounds__(WG) void dc_pstream_kernel(DcGather G, DcSub S, con
     if (j >= G.m) return;
     const Item it = item_unpack(G.key_ch[j]);
     const int maxr = (int)S.maxr[it.sb];
+    const int n_rank = count_rank_side(it, maxr), n_run = count_run_side(it), nd = n_rank + n_run;
     const u32 b_sp = G.doff_sp[j];
     const u32* p_sp = G.pos_sp + b_sp;
     const u32* p_ch = G.pos_ch + G.doff_ch[G.inv_ch[j]];
     const u32* p_sr = G.pos_sr + G.doff_sr[G.inv_sr[j]];
     const u32* p_sn = G.pos_sn + G.doff_sn[G.inv_sn[j]];
     u16* o = out + b_sp;
-    u32 ord = 0, ord_run = 0;
-    enumerate(it, maxr, [&](int tau, u32 bit, bool run_side) {
-        const int cls = tau_class(tau);
-        const int v_st = run_side ? G.V_sn[p_sn[ord_run++]] : G.V_sr[p_sr[ord]];
-        const int v_sp = G.V_sp[p_sp[ord]];
-        const int v_ch = G.V_ch[p_ch[ord]];
-        const int p = blend(v_ch, v_st, v_sp, mp->lr[cls]);
-        o[ord] = (u16)((u32)p | (bit << 12) | (ord == 0 ? (u32)PS_RUN : 0u));
-        if (dbg) { dbg[b_sp + ord] = (u16)v_st; dbg[(size_t)dbgD + b_sp + ord] = (u16)v_ch; dbg[2 * (size_t)dbgD + b_sp + ord] = (u16)v_sp; }
-        ++ord;
-    });
+    auto emit = [&](int k, u32 q_sp, u32 q_ch, u32 q_st, bool run_side, int tau, u32 bit) {
+        const int v_sp = G.V_sp[q_sp];
+        const int v_ch = G.V_ch[q_ch];
+        const int v_st = run_side ? G.V_sn[q_st] : G.V_sr[q_st];
+        const int p = blend(v_ch, v_st, v_sp, mp->lr[tau_class(tau)]);
+        o[k] = (u16)((u32)p | (bit << 12) | (k == 0 ? (u32)PS_RUN : 0u));
+        if (dbg) { dbg[b_sp + k] = (u16)v_st; dbg[(size_t)dbgD + b_sp + k] = (u16)v_ch; dbg[2 * (size_t)dbgD + b_sp + k] = (u16)v_sp; }
+    };
+    // first 8 decisions: positions by wide loads (the arrays have slack behind their last entry), static register indices
+    u32 qsp[8], qch[8];
+    {
+        const DcU4 a0 = *reinterpret_cast<const DcU4*>(p_sp), a1 = *reinterpret_cast<const DcU4*>(p_sp + 4);
+        const DcU4 c0 = *reinterpret_cast<const DcU4*>(p_ch), c1 = *reinterpret_cast<const DcU4*>(p_ch + 4);
+        qsp[0] = a0.a; qsp[1] = a0.b; qsp[2] = a0.c; qsp[3] = a0.d; qsp[4] = a1.a; qsp[5] = a1.b; qsp[6] = a1.c; qsp[7] = a1.d;
+        qch[0] = c0.a; qch[1] = c0.b; qch[2] = c0.c; qch[3] = c0.d; qch[4] = c1.a; qch[5] = c1.b; qch[6] = c1.c; qch[7] = c1.d;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k < nd) {
+            u32 bit; bool rs;
+            const int tau = nth_decision(it, maxr, n_rank, k, &bit, &rs);
+            const u32 q_st = rs ? p_sn[k - n_rank] : p_sr[k];
+            emit(k, qsp[k], qch[k], q_st, rs, tau, bit);
+        }
+    }
+    for (int k = 8; k < nd; ++k) {
+        u32 bit; bool rs;
+        const int tau = nth_decision(it, maxr, n_rank, k, &bit, &rs);
+        emit(k, p_sp[k], p_ch[k], rs ? p_sn[k - n_rank] : p_sr[k], rs, tau, bit);
+    }
 }
 
 __global__ void dc_poff_kernel(const u32* __restrict__ doff_sp, DcSub S, u32 m, u32* __restrict__ poff)
@@ -782,7 +806,7 @@ int devcoder_ensure(bscgpu_ctx* c)
         {(void**)&d->events[0], 2 * D}, {(void**)&d->events[1], 2 * D}, {(void**)&d->events[2], 2 * D}, {(void**)&d->events[3], 2 * D},
         {(void**)&d->pos[0], 4 * D}, {(void**)&d->pos[1], 4 * D}, {(void**)&d->pos[2], 4 * D}, {(void**)&d->pos[3], 4 * D},
         {(void**)&d->V[0], 2 * D}, {(void**)&d->V[1], 2 * D}, {(void**)&d->V[2], 2 * D}, {(void**)&d->V[3], 2 * D},
-        {(void**)&d->ps, 2 * D},
+        {(void**)&d->ps[0], 2 * D}, {(void**)&d->ps[1], 2 * D},
         {(void**)&d->cnt, (size_t)256 * DC_WCH_MAX * 4}, {(void**)&d->rowtot, 256 * 4}, {(void**)&d->rowstart, 4 * 260 * 4},
         {(void**)&d->wdec, (DC_WCH_MAX + 8) * 4}, {(void**)&d->wdecoff, (DC_WCH_MAX + 8) * 4},
         {(void**)&d->elo, 2 * 4 * NCH}, {(void**)&d->ehi, 2 * 4 * NCH}, {(void**)&d->S, 2 * 4 * NCH},
@@ -831,7 +855,7 @@ static void dc_launch_partition(bscgpu_ctx* c, DevCoder* d, const u64* items, u3
 // device p stream (d->ps) and poff[0..nb] (decision offsets of the sub-blocks) to hmeta[32..]; returns BSC_NOT_SUPPORTED when
 // the block has to go through the host model instead.
 int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* dstart, u32 m, u32 n, int nb, const u32* run_first,
-                     const int* max_rank, u32* D_out, u32* poff_out, u16* dbg)
+                     const int* max_rank, u32* D_out, u32* poff_out, u16* dbg, int psbuf)
 {
     int rc = devcoder_ensure(c);
     if (rc < 0) return rc;
@@ -907,7 +931,8 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     G.pos_sp = d->pos[0]; G.pos_ch = d->pos[1]; G.pos_sr = d->pos[2]; G.pos_sn = d->pos[3];
     G.V_sp = d->V[0]; G.V_ch = d->V[1]; G.V_sr = d->V[2]; G.V_sn = d->V[3];
     prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)E[0] * 26, E[0]);
-    hipLaunchKernelGGL(dc_pstream_kernel, dim3(gm), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps, dbg, E[0]);
+    if (c->ps_guard[psbuf & 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ps_guard[psbuf & 1], 0));     // the buffer's previous copy-out
+    hipLaunchKernelGGL(dc_pstream_kernel, dim3(gm), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, E[0]);
     hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, d->doff[0], S, m, d->poff);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
@@ -922,7 +947,7 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     return BSC_NO_ERROR;
 }
 
-const u16* devcoder_pstream_ptr(const bscgpu_ctx* c) { return c->dc ? c->dc->ps : nullptr; }
+const u16* devcoder_pstream_ptr(const bscgpu_ctx* c, int psbuf) { return c->dc ? c->dc->ps[psbuf & 1] : nullptr; }
 
 // ---- C ABI: the stage on its own (host block in, probability stream out) ---------------------------------------------
 // What a maintainer would call next to bsc_qlfc_transform-style stage functions, and what the parity tests compare with the

@@ -173,6 +173,33 @@ DC_HD void enumerate(const Item& it, int max_rank, F&& f)
     }
 }
 
+// The k-th decision of a run (k counted over both sides, stream order), without walking the ones before it.
+DC_HD int nth_decision(const Item& it, int max_rank, int n_rank, int k, uint32_t* bit, bool* run_side)
+{
+    if (k < n_rank) {
+        const uint32_t rank = it.rank;
+        *run_side = false;
+        if (it.ge32) { return decision(it, max_rank, ROUND_RP + k, bit); }
+        if (k == 0) { *bit = rank != 1u ? 1u : 0u; return TAU_RF; }
+        const int B = bsr(rank);
+        const int e = (B - 1) + (B < max_rank ? 1 : 0);
+        if (k <= e) { const int sx = k - 1; *bit = sx + 1 < B ? 1u : 0u; return TAU_RE + sx; }
+        const int d = k - 1 - e;
+        *bit = (rank >> (B - 1 - d)) & 1u;
+        return TAU_RM + rm_off(B) + (int)(rank >> (B - d)) - 1;
+    }
+    const int kk = k - n_rank;
+    const uint32_t run = it.run;
+    *run_side = true;
+    if (kk == 0) { *bit = run != 1u ? 1u : 0u; return TAU_NF; }
+    const int nb = bsr(run);
+    if (kk <= nb) { const int sx = kk - 1; *bit = sx + 1 < nb ? 1u : 0u; return TAU_NE + sx; }
+    const int d = kk - 1 - nb;
+    const uint32_t ctx = nb <= 5 ? (run >> (nb - d)) : (uint32_t)(1 + d);
+    *bit = (run >> (nb - 1 - d)) & 1u;
+    return TAU_NM + nm_off(nb) + (int)ctx - 1;
+}
+
 // ---- counters --------------------------------------------------------------------------------------------------------
 // predictor.h:53-61 with the family's tuned constants: bit 0 moves towards 4096 - th0, bit 1 towards th1 (arithmetic shifts)
 struct Rates { int t0, a0, t1, a1; };                        // t0 = 4096 - th0, t1 = th1

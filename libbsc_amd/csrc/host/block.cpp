@@ -278,6 +278,7 @@ struct BlockJob {
     HostSlot* slot = nullptr;        // pinned landing zones of this block (owned by the context)
     // device-side static model (devcoder.hip): the host codes from a probability stream instead of run arrays
     bool use_ps = false; const uint16_t* ps = nullptr; u32 poff[9]; u32 ndec = 0; int sorter = 0;
+    hipEvent_t ps_ready = nullptr;   // the p stream's copy to the host (copy stream); coder tasks wait on it
     std::atomic<bool> redo{false};   // a sub-block did not compress: the block goes through the host model again (raw sub-blocks need the run arrays)
     bool stored_small = false;       // n <= header size: finished in the GPU stage
     int  result = 0;
@@ -356,13 +357,17 @@ static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
                 maxr[b] = nsym >= 2 ? k : 0;
             }
             u32 ndec = 0;
+            const int pb = c->ps_toggle;
             const int r2 = devcoder_pstream(c, reinterpret_cast<const u8*>(c->vA), reinterpret_cast<const u8*>(c->vB), c->SA, m, (u32)n, J.nblocks,
-                                            J.run_first, maxr, &ndec, J.poff, nullptr);
+                                            J.run_first, maxr, &ndec, J.poff, nullptr, pb);
             if (r2 == LIBBSC_NO_ERROR) {
+                // the stream has been synchronised behind the last kernel; the copy goes to the copy stream and is NOT waited for
+                // here: the next block's sort overlaps it, the coder tasks wait on the event
                 if (ctx_ensure_pstream_slot(c, *J.slot, (size_t)ndec + 64) != LIBBSC_NO_ERROR) return LIBBSC_NOT_ENOUGH_MEMORY;
-                if (hipMemcpyAsync(J.slot->hps, devcoder_pstream_ptr(c), (size_t)ndec * 2, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                    ctx_sync(c) != hipSuccess) return LIBBSC_GPU_ERROR;
-                prof_collect(c);
+                if (hipMemcpyAsync(J.slot->hps, devcoder_pstream_ptr(c, pb), (size_t)ndec * 2, hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess ||
+                    hipEventRecord(J.slot->copy_ev, c->copy_stream) != hipSuccess) return LIBBSC_GPU_ERROR;
+                c->ps_guard[pb] = J.slot->copy_ev; c->ps_toggle = pb ^ 1;
+                J.ps_ready = J.slot->copy_ev;
                 J.use_ps = true; J.ps = J.slot->hps; J.ndec = ndec; ok = true;
             } else if (r2 != LIBBSC_NOT_SUPPORTED) return r2;
         }
@@ -402,6 +407,7 @@ static void host_encode_sub(BlockJob& J, int b)
     const size_t need = (size_t)J.size[b] + 64;
     if (J.scratch_cap[b] < need) { J.scratch[b].reset(new uint8_t[need + need / 8]); J.scratch_cap[b] = need + need / 8; }
     if (J.use_ps) {
+        if (hipEventSynchronize(J.ps_ready) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); J.sub_res[b] = J.size[b]; return; }
         const int r = qlfc_encode_static_pstream(J.views[b].first_seen, J.views[b].nsym, J.size[b], J.ps + J.poff[b], (size_t)(J.poff[b + 1] - J.poff[b]),
                                                  J.scratch[b].get(), J.size[b]);
         if (r < 0) J.redo.store(true, std::memory_order_relaxed);      // would be stored raw: that needs the run arrays
@@ -410,6 +416,25 @@ static void host_encode_sub(BlockJob& J, int b)
     }
     const int r = qlfc_encode_runs(J.views[b], J.size[b], J.scratch[b].get(), J.size[b], J.coder);
     J.sub_res[b] = (r < 0) ? J.size[b] : r;
+}
+
+// two sub-blocks of a device-model block in one interleaved range-coder loop (b even)
+static void host_encode_pair(BlockJob& J, int b)
+{
+    if (!J.use_ps || b + 1 >= J.nblocks) { host_encode_sub(J, b); if (b + 1 < J.nblocks) host_encode_sub(J, b + 1); return; }
+    PstreamJob P[2];
+    for (int k = 0; k < 2; ++k) {
+        const int q = b + k;
+        const size_t need = (size_t)J.size[q] + 64;
+        if (J.scratch_cap[q] < need) { J.scratch[q].reset(new uint8_t[need + need / 8]); J.scratch_cap[q] = need + need / 8; }
+        P[k] = PstreamJob{J.views[q].first_seen, J.views[q].nsym, J.size[q], J.ps + J.poff[q], (size_t)(J.poff[q + 1] - J.poff[q]), J.scratch[q].get(), J.size[q]};
+    }
+    if (hipEventSynchronize(J.ps_ready) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); J.sub_res[b] = J.size[b]; J.sub_res[b + 1] = J.size[b + 1]; return; }
+    int r0, r1;
+    qlfc_encode_static_pstream_pair(P[0], P[1], &r0, &r1);
+    if (r0 < 0 || r1 < 0) J.redo.store(true, std::memory_order_relaxed);
+    J.sub_res[b] = r0 < 0 ? J.size[b] : r0;
+    J.sub_res[b + 1] = r1 < 0 ? J.size[b + 1] : r1;
 }
 
 static void write_stored(BlockJob& J)
@@ -528,7 +553,8 @@ static void host_stage(BlockJob& J)
     if (J.stored_small) return;
     host_prepare(J);
     if (job_uses_tasks(J)) {
-        run_tasks(J.nblocks, [&J](int b) { host_encode_sub(J, b); });
+        if (J.use_ps) run_tasks(J.nblocks / 2, [&J](int t) { host_encode_pair(J, 2 * t); });
+        else run_tasks(J.nblocks, [&J](int b) { host_encode_sub(J, b); });
         host_finalize(J);
         return;
     }
@@ -710,7 +736,7 @@ struct bscgpu_pipe {
             bool finished = false;
             if (t.sub < 0) { host_stage(J); finished = true; }
             else {
-                host_encode_sub(J, t.sub);
+                if (J.use_ps) host_encode_pair(J, t.sub); else host_encode_sub(J, t.sub);
                 if (J.remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) { host_finalize(J); finished = true; }
             }
             if (finished) { { std::lock_guard<std::mutex> lk(mu); J.done = true; } cv_done.notify_all(); }
@@ -765,8 +791,13 @@ static int pipe_enqueue(bscgpu_pipe* p, bscgpu_pipe::Lane& L, int ticket)
         std::lock_guard<std::mutex> lk(p->mu);
         if (job_uses_tasks(J)) {
             host_prepare(J);
-            J.remaining.store(J.nblocks, std::memory_order_release);
-            for (int b = 0; b < J.nblocks; ++b) p->queue.push_back({&J, b});
+            if (J.use_ps) {                                      // device model: two sub-blocks per task (interleaved range coders)
+                J.remaining.store(J.nblocks / 2, std::memory_order_release);
+                for (int b = 0; b < J.nblocks; b += 2) p->queue.push_back({&J, b});
+            } else {
+                J.remaining.store(J.nblocks, std::memory_order_release);
+                for (int b = 0; b < J.nblocks; ++b) p->queue.push_back({&J, b});
+            }
         } else {
             p->queue.push_back({&J, -1});
         }

@@ -820,6 +820,40 @@ int qlfc_encode_static_pstream(const uint8_t* first_seen, int nsym, int in_size,
     return rc.finish();
 }
 
+void qlfc_encode_static_pstream_pair(const PstreamJob& A, const PstreamJob& B, int* resA, int* resB)
+{
+    RunView HA, HB;
+    HA.nsym = A.nsym; memcpy(HA.first_seen, A.first_seen, (size_t)A.nsym);
+    HB.nsym = B.nsym; memcpy(HB.first_seen, B.first_seen, (size_t)B.nsym);
+    RangeEncoder ra, rb;
+    ra.init(A.out, A.out_size); rb.init(B.out, B.out_size);
+    ra.encode_word((uint32_t)A.in_size); rb.encode_word((uint32_t)B.in_size);
+    (void)encode_alphabet(HA, [&](unsigned b) { ra.encode_half(b); });
+    (void)encode_alphabet(HB, [&](unsigned b) { rb.encode_half(b); });
+    RangeEncoder::Live La = ra.enter(), Lb = rb.enter();
+    const uint16_t* pa = A.ps; const uint16_t* pb = B.ps;
+    const size_t both = A.count < B.count ? A.count : B.count;
+    size_t i = 0;
+    bool fa = false, fb = false;                              // a stream ran out of budget (reference: NOT_COMPRESSIBLE at a run start)
+    for (; i < both; ++i) {
+        const unsigned x = pa[i], y = pb[i];
+        // branch-free test (the budget check belongs to run starts only, qlfc.cpp:894; it practically never fires)
+        const unsigned stop = ((x >> 13) & (unsigned)ra.full()) | ((y >> 13) & (unsigned)rb.full());
+        if (__builtin_expect(stop != 0, 0)) {
+            if ((x & 0x2000u) && ra.full()) { fa = true; break; }
+            fb = true; break;
+        }
+        ra.encode_live<12>(La, (x >> 12) & 1u, (int)(x & 0xfffu));
+        rb.encode_live<12>(Lb, (y >> 12) & 1u, (int)(y & 0xfffu));
+    }
+    // what is left of either stream, singly
+    if (!fa) for (size_t k = i; k < A.count; ++k) { const unsigned x = pa[k]; if ((x & 0x2000u) && ra.full()) { fa = true; break; } ra.encode_live<12>(La, (x >> 12) & 1u, (int)(x & 0xfffu)); }
+    if (!fb) for (size_t k = i; k < B.count; ++k) { const unsigned y = pb[k]; if ((y & 0x2000u) && rb.full()) { fb = true; break; } rb.encode_live<12>(Lb, (y >> 12) & 1u, (int)(y & 0xfffu)); }
+    ra.leave(La); rb.leave(Lb);
+    *resA = fa ? NOT_COMPRESSIBLE : ra.finish();
+    *resB = fb ? NOT_COMPRESSIBLE : rb.finish();
+}
+
 int qlfc_encode_runs(const RunView& R, int in_size, uint8_t* out, int out_size, int coder)
 {
     if (in_size <= 0 || R.count == 0) return BAD_PARAMETER;

@@ -103,6 +103,18 @@ int main(int argc, char** argv)
             }
             if (di != rf[j + 1]) { if (bad++ < 10) printf("sb %d run %zu: %d decisions vs truth %u\n", sb, j, cnt, rf[j + 1] - rf[j]); di = rf[j + 1]; }
             if (cnt != dcm::count_rank_side(it, max_rank) + dcm::count_run_side(it)) { if (bad++ < 10) printf("count mismatch\n"); }
+            {   // nth_decision and enumerate agree with the round order
+                const int n_rank = dcm::count_rank_side(it, max_rank);
+                int k = 0;
+                dcm::enumerate(it, max_rank, [&](int tau, uint32_t bit, bool rs) {
+                    uint32_t b2 = 9; bool rs2 = !rs;
+                    const int t2 = dcm::nth_decision(it, max_rank, n_rank, k, &b2, &rs2);
+                    const Dec& d = D[rf[j] + k];
+                    if (t2 != tau || b2 != bit || rs2 != rs || dcm::tau_class(tau) != d.cls || bit != d.bit) { if (bad++ < 10) printf("nth/enumerate mismatch run %zu k %d\n", j, k); }
+                    ++k;
+                });
+                if (k != cnt) { if (bad++ < 10) printf("enumerate count mismatch\n"); }
+            }
             // context update (qlfc.cpp:978-989, :1063-1068)
             rank_hist[c] = (uint8_t)dcm::bsr(rank);
             avg = dcm::avg_rank_next(avg, rank);
