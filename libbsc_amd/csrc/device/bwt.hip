@@ -25,6 +25,7 @@
 #include "dev_common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 constexpr int SEG_ITEMS = 8;
 constexpr int SEG_TILE  = WG * SEG_ITEMS;      // 2048 records per tile, 8 consecutive per thread
@@ -63,7 +64,8 @@ __global__ __launch_bounds__(WG) void bwt_bytehist_kernel(const u8* __restrict__
 // that raw bytes spend on 8, which removes most of the first doubling round's work.
 // Suffixes whose window crosses the end ("tails", i + w > n, at most w-1 of them) go FIRST in input order, shortest
 // first: the stable sort then leaves them first inside any group of equal padded keys, already in final order.
-struct PackParams { u32 cb; u32 w; u32 tc; u32 low_shift; };
+struct PackParams { u32 cb; u32 w; u32 tc; u32 low_shift; u32 pred_shift; };   // pred_shift: 0 = values are plain suffix indexes,
+                                                                               // else value = index | code(T[i-1]) << pred_shift
 
 __global__ __launch_bounds__(WG) void bwt_pack_kernel(const u8* __restrict__ T, u32 n, PackParams pp,
                                                       const u8* __restrict__ codes, u64* __restrict__ keys, u32* __restrict__ vals)
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(WG) void bwt_pack_kernel(const u8* __restrict__ T, 
     u32 wds[5];
 #pragma unroll
     for (int x = 0; x < 5; ++x) wds[x] = T32[x];
+    u32 pcode = (pp.pred_shift && i0 > 0) ? (u32)lut[T[i0 - 1]] : 0u;        // code of the character in front of suffix i0
     u64 cd[19];                                     // codes of characters i0 .. i0+18 (0 past the end)
 #pragma unroll
     for (u32 t = 0; t < 19; ++t) {
@@ -94,7 +97,8 @@ __global__ __launch_bounds__(WG) void bwt_pack_kernel(const u8* __restrict__ T, 
             const bool tail = (u64)i + pp.w > (u64)n;
             const u32 slot = tail ? (n - 1 - i) : (i + pp.tc);
             keys[slot] = key;
-            vals[slot] = i;
+            vals[slot] = pp.pred_shift ? (i | (pcode << pp.pred_shift)) : i;
+            pcode = (u32)cd[j];                                                 // this suffix's first character precedes the next one
         }
     }
 }
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(WG) void bwt_pack_kernel(const u8* __restrict__ T, 
 // ---------------------------------------------------------------------------------------------
 template <bool INITIAL>
 __global__ __launch_bounds__(WG) void seg_reduce_kernel(const u64* __restrict__ keys, const u32* __restrict__ sa,
-                                                        u32 m, u32 tail_lo, u32 chunk_tiles, u32 num_tiles,
+                                                        u32 m, u32 tail_lo, u32 smask, u32 chunk_tiles, u32 num_tiles,
                                                         u8* __restrict__ flags, u32* __restrict__ segsum /*[2][MAX_CHUNKS]*/)
 {
     __shared__ u32 scr[8];
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(WG) void seg_reduce_kernel(const u64* __restrict__ 
 #pragma unroll
             for (int q = 0; q < SEG_ITEMS + 2; ++q) {
                 const long long x = (long long)j - 1 + q;
-                s[q] = (x >= 0 && x < (long long)m) ? sa[x] : 0;
+                s[q] = (x >= 0 && x < (long long)m) ? (sa[x] & smask) : 0;
             }
         }
         u32 h[SEG_ITEMS + 1];
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(WG) void seg_scan_kernel(const u32* __restrict__ se
 // seg phase C: ranks (position of the group head), SA / ISA write-back, compaction of unsorted records.
 template <bool INITIAL>
 __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ flags, const u32* __restrict__ sa_sorted,
-                                                       const u32* __restrict__ cpos_in, u32 m,
+                                                       const u32* __restrict__ cpos_in, u32 m, u32 smask,
                                                        u32 chunk_tiles, u32 num_tiles, const u32* __restrict__ segoff,
                                                        u32* __restrict__ SA, u32* __restrict__ ISA,
                                                        u32* __restrict__ cpos_out, u32* __restrict__ csa_out,
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
                 if (f[q] & 1u) run = pos[q] + 1;
                 const u32 rank = run - 1;
                 SA[pos[q]] = s[q];
-                ISA[s[q]]  = rank;
+                ISA[s[q] & smask] = rank;                  // SA / csa keep the predecessor code in their high bits
                 if (f[q] & 2u) {
                     cpos_out[kslot] = pos[q];
                     csa_out[kslot]  = s[q];
@@ -276,13 +280,13 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
 // doubling round key build: key = rank << 32 | (ISA[sa + h] + 1, 0 when sa + h == n)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void bwt_gather_kernel(const u32* __restrict__ csa, const u32* __restrict__ cgrp,
-                                                        const u32* __restrict__ ISA, u32 U, u64 h, u64 n, int lo_bits,
+                                                        const u32* __restrict__ ISA, u32 U, u64 h, u64 n, int lo_bits, u32 smask,
                                                         u64* __restrict__ keys, u32* __restrict__ vals)
 {
     const u32 stride = gridDim.x * WG;
     for (u32 k = blockIdx.x * WG + threadIdx.x; k < U; k += stride) {
         const u32 s = csa[k];
-        const u64 p = (u64)s + h;
+        const u64 p = (u64)(s & smask) + h;
         const u32 nxt = (p < n) ? (ISA[p] + 1u) : 0u;
         keys[k] = ((u64)cgrp[k] << lo_bits) | nxt;
         vals[k] = s;
@@ -318,6 +322,33 @@ __global__ __launch_bounds__(WG) void bwt_emit_kernel(const u8* __restrict__ T, 
     else for (u32 q = 0; o0 + q < n; ++q) L[o0 + q] = (u8)(word >> (8 * q));
 }
 
+// The same from values that carry the predecessor's code (SA[j] = index | code(T[index-1]) << pred_shift): no access to T at
+// all, SA is read in order.  decode[code] = byte.
+__global__ __launch_bounds__(WG) void bwt_emit_pred_kernel(const u8* __restrict__ T, const u32* __restrict__ SA, const u32* __restrict__ ISA, u32 n,
+                                                           u32 pred_shift, const u8* __restrict__ decode, u8* __restrict__ L, u32* __restrict__ dscal)
+{
+    __shared__ u8 dec[256];
+    dec[threadIdx.x] = decode[threadIdx.x];
+    __syncthreads();
+    const u32 o0 = 4u * (blockIdx.x * WG + threadIdx.x);
+    if (o0 >= n) return;
+    const u32 p = ISA[0];
+    if (o0 == 0) dscal[1] = p + 1;
+    u32 word = 0;
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+        const u32 o = o0 + q;
+        u32 byte = 0;
+        if (o < n) {
+            if (o == 0) byte = T[n - 1];
+            else { const u32 j = (o <= p) ? (o - 1) : o; byte = dec[SA[j] >> pred_shift]; }
+        }
+        word |= byte << (8 * q);
+    }
+    if (o0 + 4 <= n) *reinterpret_cast<u32*>(L + o0) = word;
+    else for (u32 q = 0; o0 + q < n; ++q) L[o0 + q] = (u8)(word >> (8 * q));
+}
+
 __global__ void bwt_aux_kernel(const u32* __restrict__ ISA, u32 n, u32 r, u32 cnt, u32* __restrict__ I)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -333,20 +364,20 @@ void launch_seg_scan(bscgpu_ctx* c, u32 num_chunks)
 static int bit_length(u64 x) { int b = 0; while (x) { ++b; x >>= 1; } return b; }
 
 template <bool INITIAL>
-static int run_seg(bscgpu_ctx* c, const u64* keys, const u32* sa_sorted, const u32* cpos_in, u32 m, u32 tail_lo,
+static int run_seg(bscgpu_ctx* c, const u64* keys, const u32* sa_sorted, const u32* cpos_in, u32 m, u32 tail_lo, u32 smask,
                    u32* cpos_out, u32* csa_out, u32* cgrp_out, u32* U_out)
 {
     const Chunking ch = make_chunking(m, SEG_TILE);
     prof_begin(c, BSCGPU_K_SEG, (u64)m * (8 + (INITIAL ? 4 : 0) + 1), m);
     hipLaunchKernelGGL(seg_reduce_kernel<INITIAL>, dim3(ch.num_chunks), dim3(WG), 0, c->stream,
-                       keys, sa_sorted, m, tail_lo, ch.chunk_tiles, ch.num_tiles, c->flags, c->segsum);
+                       keys, sa_sorted, m, tail_lo, smask, ch.chunk_tiles, ch.num_tiles, c->flags, c->segsum);
     prof_end(c);
     prof_begin(c, BSCGPU_K_SEG, 0, 0);
     hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(WG), 0, c->stream, c->segsum, ch.num_chunks, c->segoff, c->dscal);
     prof_end(c);
     prof_begin(c, BSCGPU_K_SEG, (u64)m * (1 + 4 + (INITIAL ? 0 : 4) + 4 + 4), m);
     hipLaunchKernelGGL(seg_apply_kernel<INITIAL>, dim3(ch.num_chunks), dim3(WG), 0, c->stream,
-                       c->flags, sa_sorted, cpos_in, m, ch.chunk_tiles, ch.num_tiles, c->segoff,
+                       c->flags, sa_sorted, cpos_in, m, smask, ch.chunk_tiles, ch.num_tiles, c->segoff,
                        c->SA, c->ISA, cpos_out, csa_out, cgrp_out);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
@@ -386,9 +417,19 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
     pp.w = 64 / pp.cb;
     pp.tc = n < pp.w - 1 ? n : pp.w - 1;
     pp.low_shift = 64 - pp.cb * pp.w;
+    // The sort's values have spare high bits when the block is not huge: carry the code of the character in FRONT of the
+    // suffix there, so that the final L = T[SA - 1] needs no random gather from the text (BSC_BWT_PRED=0 keeps the gather)
+    const int idx_bits = bit_length(n - 1);
+    static const int pred_on = [] { const char* e = getenv("BSC_BWT_PRED"); return e ? atoi(e) : 1; }();
+    pp.pred_shift = (pred_on && idx_bits >= 1 && idx_bits + (int)pp.cb <= 32) ? (u32)idx_bits : 0u;
+    const u32 smask = pp.pred_shift ? ((1u << pp.pred_shift) - 1u) : 0xffffffffu;
     const u32 tail_lo = (n >= pp.w) ? (n - (pp.w - 1)) : 0;
     u8* dcodes = reinterpret_cast<u8*>(c->dscal + 560);         // 256 bytes of the scalar area
+    u8* ddecode = reinterpret_cast<u8*>(c->dscal + 720);        // 256 bytes: code -> byte (640..703 is the QLFC front end's symbol table)
+    u8 decode[256]; memset(decode, 0, sizeof decode);
+    for (int b = 255; b >= 0; --b) if (c->hscal[300 + b]) decode[codes[b]] = (u8)b;
     HIP_TRY(c, hipMemcpyAsync(dcodes, codes, 256, hipMemcpyHostToDevice, c->stream));
+    if (pp.pred_shift) HIP_TRY(c, hipMemcpyAsync(ddecode, decode, 256, hipMemcpyHostToDevice, c->stream));
     prof_begin(c, BSCGPU_K_PACK, (u64)n * 13, n);
     hipLaunchKernelGGL(bwt_pack_kernel, dim3((n + 4 * WG - 1) / (4 * WG)), dim3(WG), 0, c->stream,
                        c->dT, n, pp, dcodes, c->kA, c->vA);
@@ -405,7 +446,7 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
 
     int cur = 0;
     u32 U = 0;
-    rc = run_seg<true>(c, ks, vs, nullptr, n, tail_lo, c->cpos[cur], c->csa[cur], c->cgrp[cur], &U);
+    rc = run_seg<true>(c, ks, vs, nullptr, n, tail_lo, smask, c->cpos[cur], c->csa[cur], c->cgrp[cur], &U);
     if (rc < 0) return rc;
 
     const int lo_bits = bit_length(n);          // next-rank field: values 0 .. n
@@ -419,7 +460,7 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
         u32 blocks = (U + WG - 1) / WG; if (blocks > 8192) blocks = 8192;
         prof_begin(c, BSCGPU_K_GATHER, (u64)U * (4 + 4 + 4 + 8 + 4), U);
         hipLaunchKernelGGL(bwt_gather_kernel, dim3(blocks), dim3(WG), 0, c->stream,
-                           c->csa[cur], c->cgrp[cur], c->ISA, U, h, (u64)n, lo_bits, c->kA, c->vA);
+                           c->csa[cur], c->cgrp[cur], c->ISA, U, h, (u64)n, lo_bits, smask, c->kA, c->vA);
         prof_end(c);
 
         RadixPass rp[8]; int np = 0;
@@ -431,7 +472,7 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
         vs = in_alt ? c->vB : c->vA;
 
         u32 U2 = 0;
-        rc = run_seg<false>(c, ks, vs, c->cpos[cur], U, 0, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2);
+        rc = run_seg<false>(c, ks, vs, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2);
         if (rc < 0) return rc;
         cur ^= 1;
         if (dbg) fprintf(stderr, "[bwt] round %d h=%llu U %u -> %u (passes %d)\n", rounds, h, U, U2, np);
@@ -441,8 +482,12 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
     c->stage_ms[5] = rounds;
 
     prof_begin(c, BSCGPU_K_EMIT, (u64)n * 6, n);
-    hipLaunchKernelGGL(bwt_emit_kernel, dim3((n + 4 * WG - 1) / (4 * WG)), dim3(WG), 0, c->stream,
-                       c->dT, c->SA, c->ISA, n, dL_user, c->dscal);
+    if (pp.pred_shift)
+        hipLaunchKernelGGL(bwt_emit_pred_kernel, dim3((n + 4 * WG - 1) / (4 * WG)), dim3(WG), 0, c->stream,
+                           c->dT, c->SA, c->ISA, n, pp.pred_shift, ddecode, dL_user, c->dscal);
+    else
+        hipLaunchKernelGGL(bwt_emit_kernel, dim3((n + 4 * WG - 1) / (4 * WG)), dim3(WG), 0, c->stream,
+                           c->dT, c->SA, c->ISA, n, dL_user, c->dscal);
     prof_end(c);
     u32 cnt = 0;
     if (I_host != nullptr) {

@@ -139,30 +139,47 @@ __global__ __launch_bounds__(WG) void dc_ctx_kernel(const u64* __restrict__ key_
                 ctx_run |= (p.run < 3u ? 1u : 0u) << (k - 1);
             }
         }
-        // symbol-major neighbours: the previous runs of this symbol in this sub-block
+        // symbol-major neighbours: the previous runs of this symbol in this sub-block, nearest first (loaded once)
         const u32 q = inv_ch[j];
         const u64 chain_id = key >> 53;                               // X and sub-block
-        u32 rank_hist = 0;
-        if (q > 0) { const u64 pk = key_ch_s[q - 1]; if ((pk >> 53) == chain_id) rank_hist = (u32)bsr(item_unpack(pk).rank); }
-        // run_hist (qlfc.cpp:981-987): h' = (h + x) >> 2 over the symbol's earlier runs; only min(h, 7) is used, so walk a
-        // two-sided bracket forward from K runs back until both ends give the same clamped value
+        constexpr int NP = 5;
+        u32 prun[NP], prank0 = 0; int np = 0; bool at_start = false;
+#pragma unroll
+        for (int t = 1; t <= NP; ++t) {
+            bool have = false;
+            if (!at_start && q >= (u32)t) {
+                const u64 pk = key_ch_s[q - t];
+                if ((pk >> 53) == chain_id) { const Item pi = item_unpack(pk); prun[t - 1] = pi.run; if (t == 1) prank0 = pi.rank; have = true; np = t; }
+            }
+            if (!have) { at_start = true; prun[t - 1] = 1; }
+        }
+        const u32 rank_hist = np > 0 ? (u32)bsr(prank0) : 0u;
+        // run_hist (qlfc.cpp:981-987): h' = (h + x) >> 2 over the symbol's earlier runs; only min(h, 7) is used.  Walk a two-sided
+        // bracket forward over the loaded predecessors; the start is exact (0) when the chain begins inside the window.
         u32 run_hist = 0;
         {
-            u32 K = 6;
-            for (;;) {
-                u32 lo = 0, hi = 63, first = q;                       // first = oldest predecessor used
-                bool exact = false;
-                for (u32 t = 1; t <= K; ++t) {
-                    if (q < t || (key_ch_s[q - t] >> 53) != chain_id) { exact = true; break; }
-                    first = q - t;
+            u32 lo = 0, hi = at_start ? 0u : 63u;
+#pragma unroll
+            for (int t = NP; t >= 1; --t) if (t <= np) { lo = run_hist_next(lo, prun[t - 1]); hi = run_hist_next(hi, prun[t - 1]); }
+            u32 cl = lo < 7u ? lo : 7u, ch = hi < 7u ? hi : 7u;
+            if (cl != ch) {
+                // rare: look further back (quadrupling) until the clamped values agree or the chain starts
+                u32 K = 4 * NP;
+                for (;;) {
+                    lo = 0; hi = 63; u32 first = q; bool exact = false;
+                    for (u32 t = 1; t <= K; ++t) {
+                        if (q < t || (key_ch_s[q - t] >> 53) != chain_id) { exact = true; break; }
+                        first = q - t;
+                    }
+                    if (exact) hi = 0;
+                    for (u32 p = first; p < q; ++p) { const u32 r = item_unpack(key_ch_s[p]).run; lo = run_hist_next(lo, r); hi = run_hist_next(hi, r); }
+                    cl = lo < 7u ? lo : 7u; ch = hi < 7u ? hi : 7u;
+                    if (cl == ch) break;
+                    if (K >= 4096) { atomicOr(&meta[DM_FAIL], (u32)FAIL_HIST); break; }
+                    K *= 4;
                 }
-                if (exact) hi = 0;
-                for (u32 p = first; p < q; ++p) { const u32 r = item_unpack(key_ch_s[p]).run; lo = run_hist_next(lo, r); hi = run_hist_next(hi, r); }
-                const u32 cl = lo < 7u ? lo : 7u, ch = hi < 7u ? hi : 7u;
-                if (cl == ch) { run_hist = cl; break; }
-                if (K >= 4096) { atomicOr(&meta[DM_FAIL], (u32)FAIL_HIST); run_hist = cl; break; }
-                K *= 4;
             }
+            run_hist = cl;
         }
         const u32 state_rank = tab_rank[rank_state_index(ctx_run, ctx_rank4, rank_hist)];
         const u32 state_run = tab_run[run_state_index(ctx_rank0, ctx_run, it.rank, run_hist)];
@@ -871,7 +888,14 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     const u32 gm = (m + WG - 1) / WG;
 
     prof_begin(c, BSCGPU_K_DC_CTX, (u64)m * 40, m);
-    hipLaunchKernelGGL(dc_avg_kernel, dim3(((m + DC_AVG_CH - 1) / DC_AVG_CH + WG - 1) / WG), dim3(WG), 0, c->stream, drank, m, S, d->ge32, d->meta);
+    // avg' = (124 avg + 4 rank) >> 7 <= max(avg, rank) and rank < nsym <= 2^(max_rank + 1): with at most 32 symbols in every
+    // sub-block the average never reaches 32 and the escape coding (qlfc.cpp:960) cannot occur
+    bool may_escape = false;
+    for (int b = 0; b < nb; ++b) may_escape |= max_rank[b] > 4;
+    if (may_escape)
+        hipLaunchKernelGGL(dc_avg_kernel, dim3(((m + DC_AVG_CH - 1) / DC_AVG_CH + WG - 1) / WG), dim3(WG), 0, c->stream, drank, m, S, d->ge32, d->meta);
+    else
+        HIP_TRY(c, hipMemsetAsync(d->ge32, 0, m, c->stream));
     hipLaunchKernelGGL(dc_items_kernel, dim3(gm), dim3(WG), 0, c->stream, dsym, drank, dstart, d->ge32, m, n, S, d->key_ch);
     prof_end(c);
     RadixPass top; top.shift = 56; top.bits = 8;
