@@ -293,6 +293,89 @@ __global__ __launch_bounds__(WG) void bwt_gather_kernel(const u32* __restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Doubling round as a SEGMENTED sort (what libcubwt does with cub::DeviceSegmentedSort, libcubwt.cu:1691): the compacted
+// records arrive grouped (equal group rank = contiguous, in SA order), so ordering them by (group, next rank) only has to
+// reorder each group internally.  One workgroup takes the groups whose head lies in its tile of RS_T records (plus the tail of
+// the last one, up to RS_G records past the tile), fetches next = ISA[sa + h] + 1 for them (the gather of the round), and
+// ranks every record inside its group by counting (groups are small: 99.9 % of the records of a text block sit in groups of
+// <= 1024, three quarters in groups of <= 8; sum of squares ~ 23 comparisons per record).  Output = the same (key, value)
+// arrays the radix path produced.  A group longer than RS_G raises `fallback` and the round is redone by the radix engine.
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_T = 2048, RS_G = 1024, RS_E = RS_T + RS_G;       // 24 KB of LDS per workgroup: 6 workgroups per CU hide the ISA gather
+
+__global__ __launch_bounds__(WG) void bwt_round_segsort_kernel(const u32* __restrict__ csa, const u32* __restrict__ cgrp, const u32* __restrict__ ISA,
+                                                               u32 U, u64 h, u64 n, int lo_bits, u32 smask,
+                                                               u64* __restrict__ keys_out, u32* __restrict__ vals_out, u32* __restrict__ fallback)
+{
+    __shared__ u32 snext[RS_E];                  // first the group ranks (for the head flags), then the gathered next ranks
+    __shared__ short sgs[RS_E];                  // start of the record's group inside the window, -1: it started before the window
+    __shared__ short sge[RS_E];                  // indexed by a group's start: one past its last record
+    __shared__ u32 scr[8];
+    __shared__ u32 sincl[WG];
+    const u32 t = threadIdx.x;
+    const u64 base = (u64)blockIdx.x * RS_T;
+    const u32 ext = (u32)((base + RS_E <= U) ? (u64)RS_E : (U - base));     // records visible to this workgroup
+    const u32 own = ext < (u32)RS_T ? ext : (u32)RS_T;                      // groups whose head is below `own` are ours
+    const u32 prevg = (base > 0) ? cgrp[base - 1] : 0xffffffffu;            // group ranks are SA slots < n: never 0xffffffff
+    for (u32 i = t; i < ext; i += WG) { snext[i] = cgrp[base + i]; sge[i] = (short)ext; }
+    __syncthreads();
+    // group start of every record = running maximum of head positions; each thread owns PER consecutive records
+    constexpr int PER = RS_E / WG;
+    const u32 i0 = t * PER;
+    u32 hmask = 0;                               // head flags of this thread's records
+    int last_head = -1;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 i = i0 + q;
+        if (i < ext) { const bool head = (i == 0) ? (snext[0] != prevg) : (snext[i] != snext[i - 1]); if (head) { last_head = (int)i; hmask |= 1u << q; } }
+    }
+    u32 totmax;
+    const u32 incl = block_incl_max((u32)(last_head + 1), scr, &totmax);    // 0 = no head so far
+    sincl[t] = incl;
+    __syncthreads();
+    int run = (t > 0) ? (int)sincl[t - 1] - 1 : -1;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 i = i0 + q;
+        if (i < ext) {
+            if (hmask & (1u << q)) { if (run >= 0) sge[run] = (short)i; run = (int)i; }      // a head closes the group before it
+            sgs[i] = (short)run;
+        }
+    }
+    __syncthreads();
+    // a group of ours that is still open at the end of the window (and continues behind it) is too long for this kernel
+    if (t == 0 && base + ext < U) {
+        const int gs = sgs[ext - 1];
+        if (gs >= 0 && (u32)gs < own && cgrp[base + ext] == snext[ext - 1]) atomicOr(fallback, 1u);
+    }
+    __syncthreads();
+    // the round's gather, for the records we own (overwrites the group ranks in LDS; they are re-read from memory at the end)
+    for (u32 i = t; i < ext; i += WG) {
+        const int gs = sgs[i];
+        u32 nx = 0;
+        if (gs >= 0 && (u32)gs < own) {
+            const u64 p = (u64)(csa[base + i] & smask) + h;
+            nx = (p < n) ? (ISA[p] + 1u) : 0u;
+        }
+        snext[i] = nx;
+    }
+    __syncthreads();
+    // rank inside the group by counting (ties keep their order), write to the sorted position
+    for (u32 i = t; i < ext; i += WG) {
+        const int gs = sgs[i];
+        if (gs < 0 || (u32)gs >= own) continue;
+        const u32 mine = snext[i];
+        const u32 ge = (u32)sge[gs];
+        u32 r = 0;
+        for (u32 k = (u32)gs; k < ge; ++k) { const u32 o = snext[k]; r += (u32)((o < mine) || (o == mine && k < i)); }
+        const u64 dst = base + (u32)gs + r;
+        keys_out[dst] = ((u64)cgrp[base + i] << lo_bits) | mine;
+        vals_out[dst] = csa[base + i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // L[0] = T[n-1]; L[o] = T[SA[j]-1] with j = o-1 for o <= ISA[0], j = o for o > ISA[0].
 // ---------------------------------------------------------------------------------------------
@@ -457,19 +540,37 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
     if (dbg) fprintf(stderr, "[bwt] n=%u initial unsorted=%u\n", n, U);
     while (U > 0) {
         if (++rounds > 40) return ctx_fail(c, BSC_GPU_ERROR, "prefix doubling did not converge", hipSuccess);
-        u32 blocks = (U + WG - 1) / WG; if (blocks > 8192) blocks = 8192;
-        prof_begin(c, BSCGPU_K_GATHER, (u64)U * (4 + 4 + 4 + 8 + 4), U);
-        hipLaunchKernelGGL(bwt_gather_kernel, dim3(blocks), dim3(WG), 0, c->stream,
-                           c->csa[cur], c->cgrp[cur], c->ISA, U, h, (u64)n, lo_bits, smask, c->kA, c->vA);
-        prof_end(c);
+        // segmented sort of the grouped records (falls back to the radix engine when a group is too long for one workgroup)
+        static const int segsort_on = [] { const char* e = getenv("BSC_BWT_SEGSORT"); return e ? atoi(e) : 1; }();
+        bool sorted = false;
+        if (segsort_on) {
+            HIP_TRY(c, hipMemsetAsync(c->dscal + 2, 0, 4, c->stream));
+            prof_begin(c, BSCGPU_K_GATHER, (u64)U * (4 + 4 + 4 + 8 + 4), U);
+            hipLaunchKernelGGL(bwt_round_segsort_kernel, dim3((U + RS_T - 1) / RS_T), dim3(WG), 0, c->stream,
+                               c->csa[cur], c->cgrp[cur], c->ISA, U, h, (u64)n, lo_bits, smask, c->kB, c->vB, c->dscal + 2);
+            prof_end(c);
+            HIP_TRY(c, hipMemcpyAsync(c->hscal + 2, c->dscal + 2, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, ctx_sync(c));
+            prof_collect(c);
+            sorted = (c->hscal[2] == 0);
+            ks = c->kB; vs = c->vB;
+        }
+        int np = 0;
+        if (!sorted) {
+            u32 blocks = (U + WG - 1) / WG; if (blocks > 8192) blocks = 8192;
+            prof_begin(c, BSCGPU_K_GATHER, (u64)U * (4 + 4 + 4 + 8 + 4), U);
+            hipLaunchKernelGGL(bwt_gather_kernel, dim3(blocks), dim3(WG), 0, c->stream,
+                               c->csa[cur], c->cgrp[cur], c->ISA, U, h, (u64)n, lo_bits, smask, c->kA, c->vA);
+            prof_end(c);
 
-        RadixPass rp[8]; int np = 0;
-        const int kbits = lo_bits + hi_bits;            // key = (group rank << lo_bits) | next rank : 53 bits at n = 2^26 -> 7 passes
-        for (int s = 0; s < kbits; s += 8) { rp[np].shift = s; rp[np].bits = (kbits - s < 8) ? kbits - s : 8; ++np; }
-        rc = radix_sort_passes(c, c->kA, c->kB, c->vA, c->vB, U, rp, np, &in_alt);
-        if (rc < 0) return rc;
-        ks = in_alt ? c->kB : c->kA;
-        vs = in_alt ? c->vB : c->vA;
+            RadixPass rp[8];
+            const int kbits = lo_bits + hi_bits;            // key = (group rank << lo_bits) | next rank : 53 bits at n = 2^26 -> 7 passes
+            for (int s = 0; s < kbits; s += 8) { rp[np].shift = s; rp[np].bits = (kbits - s < 8) ? kbits - s : 8; ++np; }
+            rc = radix_sort_passes(c, c->kA, c->kB, c->vA, c->vB, U, rp, np, &in_alt);
+            if (rc < 0) return rc;
+            ks = in_alt ? c->kB : c->kA;
+            vs = in_alt ? c->vB : c->vA;
+        }
 
         u32 U2 = 0;
         rc = run_seg<false>(c, ks, vs, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2);
