@@ -2,8 +2,9 @@
 """bench.py — MB/s compress (BWT + QLFC) on 64 MiB blocks, 1/2/4/8 GPU (BASELINE.json metric).
 
 A step = one pass of the hot path over one 64 MiB synthetic block per GPU, input already resident in HBM:
-Adler-32 + forward BWT (prefix-doubling suffix sort on the LSD radix engine) on the MI355X, QLFC static (-e1)
-coder on 8 host threads, block container — i.e. bsc_compress(lzp off, BWT, QLFC_STATIC) — then, for N > 1, the
+Adler-32 + forward BWT (prefix-doubling suffix sort: LSD radix first sort, segmented sorts for the doubling rounds) +
+QLFC front end + the static coder's adaptive model (-e1: every probability, devcoder.hip) on the MI355X, range coding
+on host threads, block container — i.e. bsc_compress(lzp off, BWT, QLFC_STATIC) — then, for N > 1, the
 compressed blocks are concatenated on rank 0 over RCCL/xGMI (send/recv of the variable-size blocks).
 Blocks are independent, so N GPUs = N blocks per step (weak scaling), one process per GPU.
 
@@ -33,7 +34,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 T
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--block", type=int, default=BLOCK)
     ap.add_argument("--sorter", type=int, default=1)
@@ -227,7 +228,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{world} x {n >> 20} MiB synth-text-v1 block(s) per step (seed {'2' if world == 1 else '10..'+str(9+world)}), "
                                    f"bsc_compress(lzp off, sorter={args.sorter}, coder={args.coder}); input resident in HBM; "
-                                   "Adler-32 + BWT + QLFC run/rank front end on GPU, QLFC modelling + range coding on host threads (one per sub-block, 8 per block), "
+                                   "Adler-32 + BWT + QLFC run/rank front end + (static coder) the whole adaptive model on the GPU, "
+                                   "16 bits per binary decision over PCIe, range coding on host threads (two sub-blocks per task, interleaved); "
                                    f"{args.depth} block(s) in flight per GPU feeding a pool of {coder_threads} coder threads; output checked against the reference's (see verified)",
                        "block_bytes": n, "blocks_per_step": world, "sorter": "BWT" if args.sorter == 1 else f"ST{args.sorter}",
                        "coder": {1: "QLFC static (-e1)", 2: "QLFC adaptive (-e2)", 3: "QLFC fast (-e0)"}[args.coder],

@@ -498,6 +498,7 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
     pp.cb = 1; while ((1u << pp.cb) < K) ++pp.cb;
     if (pp.cb < 4) pp.cb = 4;                                   // at most 16 characters per key
     pp.w = 64 / pp.cb;
+    { static const int wmax = [] { const char* e = getenv("BSC_BWT_W"); return e ? atoi(e) : 0; }(); if (wmax >= 2 && (u32)wmax < pp.w) pp.w = (u32)wmax; }   // experiment: shorter first-sort keys
     pp.tc = n < pp.w - 1 ? n : pp.w - 1;
     pp.low_shift = 64 - pp.cb * pp.w;
     // The sort's values have spare high bits when the block is not huge: carry the code of the character in FRONT of the

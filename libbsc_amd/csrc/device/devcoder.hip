@@ -37,7 +37,10 @@
 using namespace dcm;
 
 constexpr int DC_WCH_MAX  = 4096;      // wave-chunks of a partition job (one wavefront walks one chunk of runs)
-constexpr int DC_EV       = 8192;      // events per evaluation chunk
+#ifndef DC_EV_N
+#define DC_EV_N 8192
+#endif
+constexpr int DC_EV       = DC_EV_N;   // events per evaluation chunk
 constexpr int DC_AVG_CH   = 1024;      // runs per avg_rank lane
 constexpr int DC_AVG_WARM = 768;       // warm-up runs in front of an avg_rank chunk
 constexpr u32 DC_SIGMASK  = 0x7ffu;    // event = X | sub-block << 8 | bit << 11
@@ -966,6 +969,7 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     if (d->hmeta[DM_FAIL] != 0) { c->dc_last_fail = (int)d->hmeta[DM_FAIL]; return BSC_NOT_SUPPORTED; }
     c->dc_last_fail = 0;
     c->dc_replays = (int)d->hmeta[DM_REPLAYS];
+    if (getenv("BSCGPU_DEBUG")) fprintf(stderr, "[devcoder] decisions %u, types %u, rounds %u, chunks replayed %u\n", E[0], d->hmeta[DM_NHOT], d->hmeta[DM_NROUNDS], d->hmeta[DM_REPLAYS]);
     *D_out = E[0];
     for (int b = 0; b <= nb; ++b) poff_out[b] = d->hmeta[32 + b];
     return BSC_NO_ERROR;

@@ -205,7 +205,15 @@ DC_HD int nth_decision(const Item& it, int max_rank, int n_rank, int k, uint32_t
 struct Rates { int t0, a0, t1, a1; };                        // t0 = 4096 - th0, t1 = th1
 DC_HD int step(int v, uint32_t bit, const Rates& R)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // both directions with the full-rate 24-bit multiply (|t - v| < 2^13, rates < 2^11: exact), then one select: the plain form
+    // compiles to two exec-masked branches around quarter-rate 32-bit multiplies, twice the cycles of this on the serial chains
+    const int up = v + (__mul24(R.t0 - v, R.a0) >> 12);
+    const int dn = v - (__mul24(v - R.t1, R.a1) >> 12);
+    return bit ? dn : up;
+#else
     return bit ? v - (((v - R.t1) * R.a1) >> 12) : v + (((R.t0 - v) * R.a0) >> 12);
+#endif
 }
 
 // Everything the kernels need from the tuned tables (filled on the host from qlfc_data.inc, passed by value).
@@ -236,7 +244,14 @@ inline void model_params_from_table(const short (*P)[19], ModelParams& M)
         M.lr[c][0] = P[c][16]; M.lr[c][1] = P[c][17]; M.lr[c][2] = P[c][18];
     }
 }
-DC_HD int blend(int v_char, int v_state, int v_static, const short* lr) { return (v_char * lr[0] + v_state * lr[1] + v_static * lr[2]) >> 5; }
+DC_HD int blend(int v_char, int v_state, int v_static, const short* lr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (__mul24(v_char, lr[0]) + __mul24(v_state, lr[1]) + __mul24(v_static, lr[2])) >> 5;
+#else
+    return (v_char * lr[0] + v_state * lr[1] + v_static * lr[2]) >> 5;
+#endif
+}
 
 // ---- contexts of a run (qlfc.cpp:896-903, :978-989, :1063-1068) -------------------------------------------------------
 DC_HD uint32_t avg_rank_next(uint32_t avg, uint32_t rank) { return (avg * 124u + rank * 4u) >> 7; }
