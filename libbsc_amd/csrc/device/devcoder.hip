@@ -44,9 +44,10 @@ constexpr int DC_EV       = DC_EV_N;   // events per evaluation chunk
 constexpr int DC_AVG_CH   = 1024;      // runs per avg_rank lane
 constexpr int DC_AVG_WARM = 768;       // warm-up runs in front of an avg_rank chunk
 constexpr u32 DC_SIGMASK  = 0x7ffu;    // event = X | sub-block << 8 | bit << 11
+constexpr int DC_ROWS     = 1088;      // rows of the chain-major layout = decision types (NUM_TAU = 1080), padded to whole wavefronts
 
 // meta scalars (device u32 array)
-enum { DM_FAIL = 0, DM_NHOT, DM_NROUNDS, DM_AVG_UND, DM_REPLAYS, DM_D0, DM_D1, DM_D2, DM_D3, DM_HIST_FAIL, DM_COUNT = 16 };
+enum { DM_FAIL = 0, DM_NTYPES, DM_NROUNDS, DM_AVG_UND, DM_REPLAYS, DM_D0, DM_D1, DM_D2, DM_D3, DM_HIST_FAIL, DM_COUNT = 16 };
 enum { FAIL_TYPES = 1, FAIL_AVG = 2, FAIL_HIST = 4, FAIL_CAP = 8, FAIL_REPLAY = 16 };
 
 struct DcSub { u32 nb; u32 first[9]; u32 maxr[8]; };            // run index range and max_rank of each sub-block
@@ -65,7 +66,7 @@ struct DevCoder {
     u16 *ps[2] = {nullptr, nullptr};                           // double buffer: block i's copy-out overlaps block i+1's kernels
     u32 *cnt = nullptr, *rowtot = nullptr, *rowstart = nullptr /*[4][257]*/, *wdec = nullptr, *wdecoff = nullptr;
     u16 *elo = nullptr, *ehi = nullptr, *S = nullptr;
-    u32 *present = nullptr; u8 *hot = nullptr; u16 *hot2tau = nullptr; u8 *rounds = nullptr; u32 *meta = nullptr; u32 *poff = nullptr;
+    u32 *present = nullptr; u8 *rounds = nullptr; u32 *meta = nullptr; u32 *poff = nullptr;
     u8  *tab_rank = nullptr, *tab_run = nullptr;
     ModelParams* mp = nullptr;                                 // device copy
     u32 *hmeta = nullptr;                                      // pinned: meta + poff
@@ -214,34 +215,26 @@ __global__ __launch_bounds__(WG) void dc_ctx_kernel(const u64* __restrict__ key_
     for (u32 i = threadIdx.x; i < (NUM_TAU + 31) / 32; i += WG) if (bits[i]) atomicOr(&present[i], bits[i]);
 }
 
-// 1d. dense row ids of the types that occur, and the canonical rounds that occur.  One workgroup.
-__global__ __launch_bounds__(WG) void dc_setup_kernel(const u32* __restrict__ present, u8* __restrict__ hot, u16* __restrict__ hot2tau,
-                                                      u8* __restrict__ rounds, u32* __restrict__ meta)
+// 1d. the canonical rounds that occur (and how many decision types: diagnostics).  One workgroup.
+__global__ __launch_bounds__(WG) void dc_setup_kernel(const u32* __restrict__ present, u8* __restrict__ rounds, u32* __restrict__ meta)
 {
-    __shared__ u32 wpre[(NUM_TAU + 31) / 32 + 1];
     __shared__ u32 rbits[3];
-    constexpr int NW = (NUM_TAU + 31) / 32;
-    if (threadIdx.x == 0) { u32 acc = 0; for (int w = 0; w < NW; ++w) { wpre[w] = acc; acc += __popc(present[w]); } wpre[NW] = acc; }
+    __shared__ u32 ntypes;
     if (threadIdx.x < 3) rbits[threadIdx.x] = 0;
+    if (threadIdx.x == 0) ntypes = 0;
     __syncthreads();
-    const u32 nhot = wpre[NW];
     for (int tau = threadIdx.x; tau < NUM_TAU; tau += WG) {
-        const u32 w = (u32)tau >> 5, b = (u32)tau & 31u, word = present[w];
-        u32 h = 0;
-        if (word & (1u << b)) {
-            h = wpre[w] + __popc(word & ((1u << b) - 1u));
-            if (h < 256u) hot2tau[h] = (u16)tau;
+        if (present[(u32)tau >> 5] & (1u << (tau & 31))) {
             const int r = tau_round(tau);
             atomicOr(&rbits[r >> 5], 1u << (r & 31));
+            atomicAdd(&ntypes, 1u);
         }
-        hot[tau] = (u8)(h < 256u ? h : 255u);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         u32 nr = 0;
         for (int r = 0; r < NUM_ROUNDS; ++r) if (rbits[r >> 5] & (1u << (r & 31))) rounds[nr++] = (u8)r;
-        meta[DM_NHOT] = nhot; meta[DM_NROUNDS] = nr;
-        if (nhot > 256u) atomicOr(&meta[DM_FAIL], (u32)FAIL_TYPES);
+        meta[DM_NTYPES] = ntypes; meta[DM_NROUNDS] = nr;
         if (meta[DM_AVG_UND] != 0u) atomicOr(&meta[DM_FAIL], (u32)FAIL_AVG);
     }
 }
@@ -262,11 +255,11 @@ static DcGeom dc_geom(u32 m)
 typedef __attribute__((address_space(3))) volatile u32 dc_lds_vu32;
 
 // lanes of `active` whose h equals this lane's: (lo, hi) halves of the peer mask
-__device__ __forceinline__ void dc_match8(u32 h, u64 active, u32& mlo, u32& mhi)
+__device__ __forceinline__ void dc_match8(u32 h, u64 active, u32& mlo, u32& mhi)      // (row ids have 11 bits)
 {
     mlo = (u32)active; mhi = (u32)(active >> 32);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < 11; ++b) {
         const int bitm = __builtin_amdgcn_sbfe((int)h, b, 1);
         const u64 bal = __ballot(bitm != 0);
         const u32 nb = ~(u32)bitm;
@@ -338,15 +331,13 @@ __device__ __forceinline__ void dc_item_rounds(const Item& it, bool valid, int m
 
 // 2a. per wave-chunk: decisions per row and in total
 template <int SIDES>
-__global__ __launch_bounds__(WG) void dc_part_count_kernel(const u64* __restrict__ items, DcGeom g, DcSub S, const u8* __restrict__ hot,
+__global__ __launch_bounds__(WG) void dc_part_count_kernel(const u64* __restrict__ items, DcGeom g, DcSub S,
                                                            const u8* __restrict__ rounds, const u32* __restrict__ meta,
-                                                           u32* __restrict__ cnt /*[256][W]*/, u32* __restrict__ wdec)
+                                                           u32* __restrict__ cnt /*[DC_ROWS][W]*/, u32* __restrict__ wdec)
 {
-    __shared__ u8 shot[NUM_TAU];
-    __shared__ u32 hist[WAVES][256];
+    __shared__ u32 hist[WAVES][DC_ROWS];
     (void)rounds; (void)meta;
-    for (u32 i = threadIdx.x; i < NUM_TAU; i += WG) shot[i] = hot[i];
-    for (u32 i = threadIdx.x; i < WAVES * 256; i += WG) (&hist[0][0])[i] = 0;
+    for (u32 i = threadIdx.x; i < WAVES * DC_ROWS; i += WG) (&hist[0][0])[i] = 0;
     __syncthreads();
     const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 wc = blockIdx.x * WAVES + w;
@@ -366,12 +357,12 @@ __global__ __launch_bounds__(WG) void dc_part_count_kernel(const u64* __restrict
             dc_item_rounds<SIDES>(it, valid, maxr,
                 [&](int slot, bool on, u32) {
                     const u32 n1 = (u32)__popcll(__ballot(on));
-                    if (lane == 0) atomicAdd(&hw[shot[dc_slot_tau(slot)]], n1);          // no return value: fire and forget
+                    if (lane == 0) atomicAdd(&hw[dc_slot_tau(slot)], n1);                 // no return value: fire and forget
                     total += n1;
                 },
                 [&](int tau, bool on, u32) {
                     const u64 active = __ballot(on);
-                    const u32 h = on ? (u32)shot[tau] : 0u;
+                    const u32 h = on ? (u32)tau : 0u;
                     u32 mlo, mhi;
                     dc_match(h, on, active, mlo, mhi);
                     const u32 rr = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));
@@ -383,7 +374,7 @@ __global__ __launch_bounds__(WG) void dc_part_count_kernel(const u64* __restrict
     }
     __syncthreads();
     if (wc < g.W) {
-        for (u32 h = lane; h < 256; h += 64) cnt[(size_t)h * g.W + wc] = hist[w][h];
+        for (u32 h = lane; h < (u32)DC_ROWS; h += 64) cnt[(size_t)h * g.W + wc] = hist[w][h];
         if (lane == 0) wdec[wc] = total;
     }
 }
@@ -405,15 +396,22 @@ __global__ __launch_bounds__(WG) void dc_scan_rows_kernel(u32* __restrict__ cnt,
     }
     if (threadIdx.x == 0) rowtot[blockIdx.x] = carry;
 }
-__global__ __launch_bounds__(WG) void dc_scan_misc_kernel(const u32* __restrict__ rowtot, u32* __restrict__ rowstart /*[257]*/,
+__global__ __launch_bounds__(WG) void dc_scan_misc_kernel(const u32* __restrict__ rowtot, u32* __restrict__ rowstart /*[DC_ROWS + 1]*/,
                                                           const u32* __restrict__ wdec, u32 W, u32* __restrict__ wdecoff /*[W+1]*/,
                                                           u32* __restrict__ meta, int job, u32 Dcap)
 {
     __shared__ u32 scr[8];
-    u32 tot;
-    const u32 ex = block_excl_sum(rowtot[threadIdx.x], scr, &tot);
-    rowstart[threadIdx.x] = ex;
-    if (threadIdx.x == 0) { rowstart[256] = tot; meta[DM_D0 + job] = tot; if (tot > Dcap) atomicOr(&meta[DM_FAIL], (u32)FAIL_CAP); }
+    u32 rc = 0;
+    for (u32 base = 0; base < (u32)DC_ROWS; base += WG) {
+        const u32 i = base + threadIdx.x;
+        const u32 v = (i < (u32)DC_ROWS) ? rowtot[i] : 0u;
+        u32 t1;
+        const u32 e1 = block_excl_sum(v, scr, &t1);
+        if (i < (u32)DC_ROWS) rowstart[i] = rc + e1;
+        rc += t1;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { rowstart[DC_ROWS] = rc; meta[DM_D0 + job] = rc; if (rc > Dcap) atomicOr(&meta[DM_FAIL], (u32)FAIL_CAP); }
     u32 carry = 0;
     for (u32 base = 0; base < W; base += WG) {
         const u32 i = base + threadIdx.x;
@@ -434,26 +432,24 @@ __global__ __launch_bounds__(WG) void dc_scan_misc_kernel(const u32* __restrict_
 // The running offsets of the 40 single-row types live in one VGPR (lane = slot; v_readlane / v_writelane with a uniform slot),
 // those of the mantissa / escape rows in LDS.
 template <int SIDES>
-__global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restrict__ items, DcGeom g, DcSub S, const u8* __restrict__ hot,
+__global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restrict__ items, DcGeom g, DcSub S,
                                                              const u8* __restrict__ rounds, const u32* __restrict__ meta,
                                                              const u32* __restrict__ cnt, const u32* __restrict__ rowstart,
                                                              const u32* __restrict__ wdecoff, u32 v_base, u32 dec_base, u32 ignoreX,
                                                              u16* __restrict__ events, u32* __restrict__ pos, u32* __restrict__ doff)
 {
-    __shared__ u8 shot[NUM_TAU];
-    __shared__ u32 goff[WAVES][256];
+    __shared__ u32 goff[WAVES][DC_ROWS];
     (void)rounds; (void)v_base; (void)dec_base;
     if (meta[DM_FAIL] != 0u) return;
-    for (u32 i = threadIdx.x; i < NUM_TAU; i += WG) shot[i] = hot[i];
     const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 wc = blockIdx.x * WAVES + w;
-    if (wc < g.W) for (u32 h = lane; h < 256; h += 64) goff[w][h] = rowstart[h] + cnt[(size_t)h * g.W + wc];
+    if (wc < g.W) for (u32 h = lane; h < (u32)DC_ROWS; h += 64) goff[w][h] = rowstart[h] + cnt[(size_t)h * g.W + wc];
     __syncthreads();
     if (wc >= g.W) return;
     dc_lds_vu32* vg = (dc_lds_vu32*)&goff[w][0];
     const u64 lt = lanemask_lt();
     const u32 lt_lo = (u32)lt, lt_hi = (u32)(lt >> 32);
-    int sreg = (lane < (u32)DC_SLOTS) ? (int)goff[w][shot[dc_slot_tau((int)lane)]] : 0;     // running offsets of the single-row types
+    int sreg = (lane < (u32)DC_SLOTS) ? (int)goff[w][dc_slot_tau((int)lane)] : 0;     // running offsets of the single-row types
     const u64 i0 = (u64)wc * g.per_wave;
     u64 i1 = i0 + g.per_wave; if (i1 > g.m) i1 = g.m;
     u32 running = wdecoff[wc];                                        // decision index of the tile's first item
@@ -485,7 +481,7 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
             },
             [&](int tau, bool on, u32 bit) {
                 const u64 active = __ballot(on);
-                const u32 h = on ? (u32)shot[tau] : 0u;
+                const u32 h = on ? (u32)tau : 0u;
                 u32 mlo, mhi;
                 dc_match(h, on, active, mlo, mhi);
                 const u32 before = vg[h];
@@ -505,11 +501,11 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
 // ---------------------------------------------------------------------------------------------------------------------
 // 3. chain evaluation over chain-major events
 // ---------------------------------------------------------------------------------------------------------------------
-struct DcEvalJob { const u16* events; u32 E; const u32* rowstart; const u16* hot2tau; int fam; };
+struct DcEvalJob { const u16* events; u32 E; const u32* rowstart; int fam; };      // rowstart[DC_ROWS + 1]: row = decision type
 
 __device__ __forceinline__ u32 dc_find_row(const u32* __restrict__ rowstart, u32 k)
 {
-    u32 lo = 0, hi = 256;                                              // largest row with rowstart[row] <= k
+    u32 lo = 0, hi = DC_ROWS;                                          // largest row with rowstart[row] <= k
     while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (rowstart[mid] <= k) lo = mid; else hi = mid; }
     return lo;
 }
@@ -522,16 +518,16 @@ __device__ __forceinline__ void dc_walk(const DcEvalJob& J, const ModelParams* _
 {
     u32 row = dc_find_row(J.rowstart, k0);
     u32 rowend = J.rowstart[row + 1];
-    while (rowend <= k0 && row < 255) { ++row; rowend = J.rowstart[row + 1]; }     // k0 inside an empty-row run: move to its row
-    int cls = tau_class(J.hot2tau[row]);
+    while (rowend <= k0 && row < (u32)DC_ROWS - 1) { ++row; rowend = J.rowstart[row + 1]; }     // k0 inside an empty-row run: move to its row
+    int cls = tau_class((int)row);
     Rates R = mp->rates[cls][J.fam];
     u32 prev = (k0 > J.rowstart[row]) ? ((u32)J.events[k0 - 1] & DC_SIGMASK) : 0xffffu;
     if (bracket) { lo = mp->vmin[cls][J.fam]; hi = mp->vmax[cls][J.fam]; }
     u32 k = k0;
     while (k < k1) {
         if (k == rowend) {
-            do { ++row; rowend = J.rowstart[row + 1]; } while (rowend == k && row < 255);
-            cls = tau_class(J.hot2tau[row]); R = mp->rates[cls][J.fam];
+            do { ++row; rowend = J.rowstart[row + 1]; } while (rowend == k && row < (u32)DC_ROWS - 1);
+            cls = tau_class((int)row); R = mp->rates[cls][J.fam];
             prev = 0xffffu;
         }
         u32 lim = k1 < rowend ? k1 : rowend;
@@ -608,7 +604,7 @@ __global__ __launch_bounds__(64) void dc_eval_wave_kernel(DcEvalAll A, const Mod
     if (mine) {
         row = dc_find_row(J.rowstart, (u32)k0);
         rowend = J.rowstart[row + 1];
-        const int cls = tau_class(J.hot2tau[row]);
+        const int cls = tau_class((int)row);
         R = mp->rates[cls][J.fam];
         prev = (k0 > J.rowstart[row]) ? ((u32)J.events[k0 - 1] & DC_SIGMASK) : 0xffffu;
         if (WRITE) { lo = Sv[c]; hi = lo; } else { lo = mp->vmin[cls][J.fam]; hi = mp->vmax[cls][J.fam]; }
@@ -657,8 +653,8 @@ __global__ __launch_bounds__(64) void dc_eval_wave_kernel(DcEvalAll A, const Mod
                 for (u32 x = 0; x < cnt; ++x) {
                     const u32 k = kb + x;
                     if (k == rowend) {
-                        do { ++row; rowend = J.rowstart[row + 1]; } while (rowend == k && row < 255);
-                        R = mp->rates[tau_class(J.hot2tau[row])][J.fam];
+                        do { ++row; rowend = J.rowstart[row + 1]; } while (rowend == k && row < (u32)DC_ROWS - 1);
+                        R = mp->rates[tau_class((int)row)][J.fam];
                         prev = 0xffffu;
                     }
                     const u32 e = *reinterpret_cast<const u16*>(myrow + 2 * x);
@@ -827,10 +823,10 @@ int devcoder_ensure(bscgpu_ctx* c)
         {(void**)&d->pos[0], 4 * D}, {(void**)&d->pos[1], 4 * D}, {(void**)&d->pos[2], 4 * D}, {(void**)&d->pos[3], 4 * D},
         {(void**)&d->V[0], 2 * D}, {(void**)&d->V[1], 2 * D}, {(void**)&d->V[2], 2 * D}, {(void**)&d->V[3], 2 * D},
         {(void**)&d->ps[0], 2 * D}, {(void**)&d->ps[1], 2 * D},
-        {(void**)&d->cnt, (size_t)256 * DC_WCH_MAX * 4}, {(void**)&d->rowtot, 256 * 4}, {(void**)&d->rowstart, 4 * 260 * 4},
+        {(void**)&d->cnt, (size_t)DC_ROWS * DC_WCH_MAX * 4}, {(void**)&d->rowtot, DC_ROWS * 4}, {(void**)&d->rowstart, 4 * (DC_ROWS + 8) * 4},
         {(void**)&d->wdec, (DC_WCH_MAX + 8) * 4}, {(void**)&d->wdecoff, (DC_WCH_MAX + 8) * 4},
         {(void**)&d->elo, 2 * 4 * NCH}, {(void**)&d->ehi, 2 * 4 * NCH}, {(void**)&d->S, 2 * 4 * NCH},
-        {(void**)&d->present, 64 * 4}, {(void**)&d->hot, 2048}, {(void**)&d->hot2tau, 512}, {(void**)&d->rounds, 256},
+        {(void**)&d->present, 64 * 4}, {(void**)&d->rounds, 256},
         {(void**)&d->meta, DM_COUNT * 4}, {(void**)&d->poff, 16 * 4},
         {(void**)&d->tab_rank, 32768}, {(void**)&d->tab_run, 8192}, {(void**)&d->mp, sizeof(ModelParams)},
     };
@@ -860,12 +856,12 @@ static void dc_launch_partition(bscgpu_ctx* c, DevCoder* d, const u64* items, u3
 {
     const DcGeom g = dc_geom(m);
     const u32 grid = (g.W + WAVES - 1) / WAVES;
-    u32* rowstart = d->rowstart + 260 * job;
+    u32* rowstart = d->rowstart + (DC_ROWS + 8) * job;
     prof_begin(c, BSCGPU_K_DC_PART, (u64)m * 8, m);
-    hipLaunchKernelGGL(dc_part_count_kernel<SIDES>, dim3(grid), dim3(WG), 0, c->stream, items, g, S, d->hot, d->rounds, d->meta, d->cnt, d->wdec);
-    hipLaunchKernelGGL(dc_scan_rows_kernel, dim3(256), dim3(WG), 0, c->stream, d->cnt, g.W, d->rowtot);
+    hipLaunchKernelGGL(dc_part_count_kernel<SIDES>, dim3(grid), dim3(WG), 0, c->stream, items, g, S, d->rounds, d->meta, d->cnt, d->wdec);
+    hipLaunchKernelGGL(dc_scan_rows_kernel, dim3(DC_ROWS), dim3(WG), 0, c->stream, d->cnt, g.W, d->rowtot);
     hipLaunchKernelGGL(dc_scan_misc_kernel, dim3(1), dim3(WG), 0, c->stream, d->rowtot, rowstart, d->wdec, g.W, d->wdecoff, d->meta, job, (u32)d->Dcap);
-    hipLaunchKernelGGL(dc_part_scatter_kernel<SIDES>, dim3(grid), dim3(WG), 0, c->stream, items, g, S, d->hot, d->rounds, d->meta, d->cnt, rowstart,
+    hipLaunchKernelGGL(dc_part_scatter_kernel<SIDES>, dim3(grid), dim3(WG), 0, c->stream, items, g, S, d->rounds, d->meta, d->cnt, rowstart,
                        d->wdecoff, 0u, 0u, ignoreX, d->events[job], d->pos[job], d->doff[job]);
     prof_end(c);
 }
@@ -887,7 +883,6 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
 
     HIP_TRY(c, hipMemsetAsync(d->meta, 0, DM_COUNT * 4, c->stream));
     HIP_TRY(c, hipMemsetAsync(d->present, 0, 64 * 4, c->stream));
-    HIP_TRY(c, hipMemsetAsync(d->hot2tau, 0, 512, c->stream));
     const u32 gm = (m + WG - 1) / WG;
 
     prof_begin(c, BSCGPU_K_DC_CTX, (u64)m * 40, m);
@@ -909,7 +904,7 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     prof_begin(c, BSCGPU_K_DC_CTX, (u64)m * 40, m);
     hipLaunchKernelGGL(dc_ctx_kernel, dim3(gm), dim3(WG), 0, c->stream, d->key_ch, d->key_ch_s, d->inv_ch, m, S, d->tab_rank, d->tab_run,
                        d->key_sr, d->key_sn, d->present, d->meta);
-    hipLaunchKernelGGL(dc_setup_kernel, dim3(1), dim3(WG), 0, c->stream, d->present, d->hot, d->hot2tau, d->rounds, d->meta);
+    hipLaunchKernelGGL(dc_setup_kernel, dim3(1), dim3(WG), 0, c->stream, d->present, d->rounds, d->meta);
     prof_end(c);
     rc = radix_sort_passes(c, d->key_sr, d->key_sr_s, nullptr, nullptr, m, &top, 1, &in_alt, d->inv_sr);
     if (rc < 0) return rc;
@@ -935,8 +930,8 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
         A.wstart[0] = 0; A.cstart[0] = 0;
         for (int job = 0; job < 4; ++job) {
             const int fam = job == 0 ? FAM_STATIC : job == 1 ? FAM_CHAR : FAM_STATE;
-            A.job[job].events = d->events[job]; A.job[job].E = E[job]; A.job[job].rowstart = d->rowstart + 260 * job;
-            A.job[job].hot2tau = d->hot2tau; A.job[job].fam = fam;
+            A.job[job].events = d->events[job]; A.job[job].E = E[job]; A.job[job].rowstart = d->rowstart + (DC_ROWS + 8) * job;
+            A.job[job].fam = fam;
             A.V[job] = d->V[job];
             const u32 nch = (E[job] + DC_EV - 1) / DC_EV;
             A.wstart[job + 1] = A.wstart[job] + (nch + 63) / 64;
@@ -969,7 +964,7 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     if (d->hmeta[DM_FAIL] != 0) { c->dc_last_fail = (int)d->hmeta[DM_FAIL]; return BSC_NOT_SUPPORTED; }
     c->dc_last_fail = 0;
     c->dc_replays = (int)d->hmeta[DM_REPLAYS];
-    if (getenv("BSCGPU_DEBUG")) fprintf(stderr, "[devcoder] decisions %u, types %u, rounds %u, chunks replayed %u\n", E[0], d->hmeta[DM_NHOT], d->hmeta[DM_NROUNDS], d->hmeta[DM_REPLAYS]);
+    if (getenv("BSCGPU_DEBUG")) fprintf(stderr, "[devcoder] decisions %u, types %u, rounds %u, chunks replayed %u\n", E[0], d->hmeta[DM_NTYPES], d->hmeta[DM_NROUNDS], d->hmeta[DM_REPLAYS]);
     *D_out = E[0];
     for (int b = 0; b <= nb; ++b) poff_out[b] = d->hmeta[32 + b];
     return BSC_NO_ERROR;

@@ -108,7 +108,7 @@ class GpuContext:
         """bscgpu_qlfc_static_pstream: (entries u16[D], sub_start, sub_size, poff[nb+1], dbg [3,D] or None); raises GpuError
         with code -4 when the block has to take the host model."""
         a = np.ascontiguousarray(L, dtype=np.uint8)
-        cap = 8 * a.size + 65536
+        cap = 16 * a.size + 65536               # decisions: ~3 per byte on text, ~9 on random bytes
         out = np.empty(cap, np.uint16)
         dbg = np.empty((3, cap), np.uint16) if debug else None
         nb = C.c_int(0); st = (C.c_int * 8)(); sz = (C.c_int * 8)(); poff = (C.c_int64 * 9)()
@@ -117,6 +117,8 @@ class GpuContext:
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         D = f(self.h, N.np_ptr(a), a.size, out.ctypes.data, cap, C.byref(nb), st, sz, poff, dbg.ctypes.data if debug else None)
         self._check(D)
+        if D > cap:
+            raise GpuError(-2, f"{D} decisions exceed the buffer of {cap}")
         k = nb.value
         return out[:D], list(st[:k]), list(sz[:k]), list(poff[:k + 1]), (dbg[:, :D] if debug else None)
 

@@ -205,7 +205,7 @@ def test_write_combining_scatter_variant(torch_cuda):
 def test_device_static_model_matches_oracle_trace(ctx):
     """bscgpu_qlfc_static_pstream (devcoder.hip): every probability of the static QLFC model computed on the GPU equals the
     oracle's trace of the reference model (oracle/bsc_oracle.c: encode_model1 with the trace hook), sub-block by sub-block,
-    including the run-start marks; blocks with more than 256 decision types are declined, never approximated."""
+    including the run-start marks; a block the device path cannot hold (more than 4 decisions per byte) is declined, never approximated."""
     from libbsc_amd import api
     from libbsc_amd.gpu import GpuError
     from oracle.refbind import Oracle, Ref
@@ -216,13 +216,24 @@ def test_device_static_model_matches_oracle_trace(ctx):
              ("low1m", bwt(rng.integers(0, 3, 1 << 20, dtype=np.uint8))), ("zeros", np.zeros(500_000, np.uint8)),
              ("sym40", bwt((rng.geometric(0.15, 700_000) % 40).astype(np.uint8))),
              ("longruns", np.repeat(rng.integers(0, 6, 3000, dtype=np.uint8), rng.integers(1, 3000, 3000)).astype(np.uint8)),
-             ("text3m", bwt(api.synth_text_v1(4, 3 << 20)))]
+             ("text3m", bwt(api.synth_text_v1(4, 3 << 20))),
+             # 224 symbols, text-like structure (each 64 KiB segment in its own 32-symbol band): several hundred decision types
+             ("text224", bwt(((api.synth_text_v1(6, 3 << 20) & 31) + ((np.arange(3 << 20) >> 16) % 7 * 32).astype(np.uint8)).astype(np.uint8))),
+             ("rand600k", rng.integers(0, 256, 600_000, dtype=np.uint8)),           # all 8-bit ranks, escape coding (avg_rank >= 32), ~340 decision types
+             ("skew1m", bwt((rng.geometric(0.02, 1 << 20) % 256).astype(np.uint8)))]
     for name, L in cases:
         ps, st, sz, poff, _ = ctx.qlfc_static_pstream(L)
         assert poff[0] == 0 and poff[-1] == len(ps), name
         for b in range(len(st)):
             tr, _ = orc.static_pstream(L[st[b]:st[b] + sz[b]])
             assert np.array_equal(tr, ps[poff[b]:poff[b + 1]]), (name, b)
-    with pytest.raises(GpuError) as e:                       # 256 symbols, ranks up to 255: more than 256 decision types
-        ctx.qlfc_static_pstream(rng.integers(0, 256, 1 << 20, dtype=np.uint8))
-    assert e.value.code == -4
+    # capacity is the only thing the device path declines on such inputs: 4 decisions per byte of the CONTEXT's block size
+    # (random bytes need ~9 per byte); a context sized for the block itself says LIBBSC_NOT_SUPPORTED, never approximates
+    from libbsc_amd import GpuContext
+    small = GpuContext(0, max_n=(1 << 20) + 4096)
+    try:
+        with pytest.raises(GpuError) as e:
+            small.qlfc_static_pstream(rng.integers(0, 256, 1 << 20, dtype=np.uint8))
+        assert e.value.code == -4
+    finally:
+        small.close()

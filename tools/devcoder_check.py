@@ -23,7 +23,9 @@ cases = [("text300k", bwt(api.synth_text_v1(3, 300_000))),
          ("n100", bwt(api.synth_text_v1(8, 100))),
          ("sym40", bwt((rng.geometric(0.15, 700_000) % 40).astype(np.uint8))),
          ("longruns", np.repeat(rng.integers(0, 6, 3000, dtype=np.uint8), rng.integers(1, 3000, 3000)).astype(np.uint8)),
-         ("text5m", bwt(api.synth_text_v1(4, 5 << 20)))]
+         ("text5m", bwt(api.synth_text_v1(4, 5 << 20))),
+         # 224 symbols with text-like structure: every 64 KiB segment of the text is shifted into its own 32-symbol band
+         ("text224", bwt(((api.synth_text_v1(6, 3 << 20) & 31) + ((np.arange(3 << 20) >> 16) % 7 * 32).astype(np.uint8)).astype(np.uint8)))]
 if mode == "full":
     cases += [("text20m", bwt(api.synth_text_v1(5, 20 << 20))), ("text64m", bwt(api.synth_text_v1(2, 64 << 20))),
               ("rand2m", rng.integers(0, 256, 2 << 20, dtype=np.uint8)), ("skew2m", bwt((rng.geometric(0.02, 2 << 20) % 256).astype(np.uint8)))]
