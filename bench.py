@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--sorter", type=int, default=1)
     ap.add_argument("--coder", type=int, default=1)
     ap.add_argument("--depth", type=int, default=0, help="blocks in flight per GPU (0 = from the coder pool size); their sub-blocks feed the pool of coder threads")
-    ap.add_argument("--contexts", type=int, default=1, help="GPU contexts (own stream, arena and pipe each) driven concurrently on every GPU: "
+    ap.add_argument("--contexts", type=int, default=4, help="GPU contexts (own stream, arena and pipe each) driven concurrently on every GPU: "
                     "kernels of two blocks interleave on the device, which fills the SIMDs that one block's serial chains leave idle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -72,8 +72,8 @@ def main():
     if "BSCGPU_HOST_THREADS" not in os.environ:         # per pipe: this rank's CPUs are shared by its contexts
         os.environ["BSCGPU_HOST_THREADS"] = str(max(4, min(64, effective_cpus() // max(local_world, 1) // ncx)))
     coder_threads = int(os.environ["BSCGPU_HOST_THREADS"]) * ncx
-    if args.depth <= 0:                                 # enough sub-block tasks in flight for the pool: 8 per block
-        args.depth = max(4, min(8, -(-3 * coder_threads // 16)))
+    if args.depth <= 0:                                 # blocks in flight per context: 8 per GPU in total keep the coder pool and the GPU busy
+        args.depth = max(2, min(4, 8 // ncx))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
