@@ -57,6 +57,11 @@ BSCGPU_API int64_t bscgpu_bwt_aux(bscgpu_ctx* ctx, const uint8_t* T, uint8_t* L,
  * (r ignored when I is NULL).  Returns the primary index. */
 BSCGPU_API int64_t bscgpu_bwt_device(bscgpu_ctx* ctx, const void* dT, void* dL, int64_t n, int64_t r, uint32_t* I);
 
+/* ---- inverse BWT (libcubwt_unbwt's role, libcubwt.cuh:91-104; reached from bsc_bwt_decode, bwt.cpp:233-281) ---------- */
+/* L[0..n) and the 1-based primary index as bsc_bwt_encode writes them -> T[0..n); host pointers, may alias; synchronous.
+ * Returns 0, LIBBSC_DATA_CORRUPT (-6) when the rows do not form one cycle through the sentinel row, or another libbsc code. */
+BSCGPU_API int bscgpu_unbwt(bscgpu_ctx* ctx, const uint8_t* L, uint8_t* T, int64_t n, int64_t index);
+
 /* ---- Sort Transform (order k = 3..8) ----------------------------------------------------- */
 /* In place on host T[0..n).  Returns the 0-based primary index like bsc_st_encode (st.cpp:990). */
 BSCGPU_API int bscgpu_st_encode(bscgpu_ctx* ctx, uint8_t* T, int n, int k);

@@ -197,6 +197,16 @@ int bsc_bwt_encode(unsigned char* T, int n, unsigned char* num_indexes, int* ind
     return (int)bscgpu_bwt(c, T, T, n);
 }
 
+// inverse BWT on the default GPU context (decode.cpp calls this for large blocks; < 0 other than DATA_CORRUPT = not available,
+// the caller continues on the host)
+int bsc_bwt_decode_gpu(unsigned char* T, int n, int index)
+{
+    DefaultGpuUser user(n, false);
+    if (user.rc != LIBBSC_NO_ERROR) return user.rc;
+    std::lock_guard<std::mutex> g(user.dev->gpu_lock);
+    return bscgpu_unbwt(user.c, T, T, n, index);
+}
+
 int bsc_st_encode(unsigned char* T, int n, int k, int features)
 {
     (void)features;

@@ -99,10 +99,19 @@ static int aux_rate_of(int n)          // largest power of two <= n / 8 (>= 1), 
     return mod + 1;
 }
 
+int bsc_bwt_decode_gpu(unsigned char* T, int n, int index);            // block.cpp: the default GPU context's bscgpu_unbwt
+
 int bsc_bwt_decode(unsigned char* T, int n, int index, unsigned char num_indexes, int* indexes, int features)
 {
     if (T == nullptr || n < 0 || index <= 0 || index > n) return LIBBSC_BAD_PARAMETER;     // bwt.cpp:285
     if (n <= 1) return LIBBSC_NO_ERROR;
+    // large blocks: the GPU walks n/128 pieces of the LF cycle at once (unbwt.hip; the reference's hook is libcubwt_unbwt,
+    // bwt.cpp:233-281).  Like the reference, the CPU walk below remains for small blocks and for machines without a GPU.
+    static const int gpu_min = [] { const char* e = getenv("BSC_GPU_UNBWT_MIN_N"); return e ? atoi(e) : (1 << 20); }();
+    if (gpu_min > 0 && n >= gpu_min) {
+        const int r = bsc_bwt_decode_gpu(T, n, index);
+        if (r == LIBBSC_NO_ERROR || r == LIBBSC_DATA_CORRUPT) return r;
+    }
     const size_t N = (size_t)n;
     // 8 bytes per row, written once below: no zero fill
     struct FreeRaw { void operator()(void* q) const { free(q); } };

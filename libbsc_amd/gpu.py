@@ -71,6 +71,16 @@ class GpuContext:
         rc = self._check(self.L.bscgpu_bwt(self.h, N.np_ptr(T), N.np_ptr(Lout), n))
         return Lout[:n], int(rc), None
 
+    def unbwt(self, L, index):
+        """bscgpu_unbwt: inverse BWT of L (np.uint8) with the 1-based primary index -> (text np.uint8, rc)"""
+        a = np.ascontiguousarray(L, dtype=np.uint8)
+        out = np.empty(max(a.size, 1), np.uint8)
+        f = self.L.bscgpu_unbwt
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
+        rc = f(self.h, N.np_ptr(a), N.np_ptr(out), a.size, int(index))
+        return out[:a.size], int(rc)
+
     def st_encode(self, data, k):
         T = np.array(np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else data, copy=True)
         rc = self._check(self.L.bscgpu_st_encode(self.h, N.np_ptr(T), T.size, k))

@@ -237,3 +237,28 @@ def test_device_static_model_matches_oracle_trace(ctx):
         assert e.value.code == -4
     finally:
         small.close()
+
+
+def test_gpu_inverse_bwt(ctx, ref):
+    """bscgpu_unbwt (unbwt.hip): LF mapping from one radix pass with destination positions, the LF cycle cut at ~n/128 marked rows
+    and walked in parallel.  Against the texts the reference's forward BWT came from; wrong primary indexes and damaged columns
+    must come back as DATA_CORRUPT or as a different text, never hang."""
+    from libbsc_amd.synth import synth_text_v1, synth_repeat_v1
+    rng = np.random.default_rng(3)
+    cases = [synth_text_v1(7, n) for n in (1, 2, 3, 17, 127, 128, 129, 1000, 65536, 300_000, (1 << 20) + 17, 5 << 20)]
+    cases += [rng.integers(0, 256, 200_000, dtype=np.uint8), np.zeros(70_000, np.uint8), (np.arange(100_000) % 2).astype(np.uint8),
+              synth_repeat_v1(3, 2 << 20, 50_000), np.full(5, 255, np.uint8)]
+    for T in cases:
+        L, idx, _ = ref.bwt_encode(T, aux=False)
+        back, rc = ctx.unbwt(L, idx)
+        assert rc == 0 and np.array_equal(back, T), (T.size, rc)
+    T = synth_text_v1(9, 400_000)
+    L, idx, _ = ref.bwt_encode(T, aux=False)
+    for bad in (1, idx - 1, idx + 1, T.size):
+        if bad == idx or bad < 1 or bad > T.size:
+            continue
+        back, rc = ctx.unbwt(L, bad)
+        assert rc == -6 or (rc == 0 and not np.array_equal(back, T)), bad
+    L2 = L.copy(); L2[1000:1100] = L2[5000:5100]                # damaged column: symbol counts change, cycles break
+    back, rc = ctx.unbwt(L2, idx)
+    assert rc == -6 or (rc == 0 and not np.array_equal(back, T))
