@@ -219,6 +219,26 @@ int main(int argc, char** argv)
                 printf("rc, two interleaved streams: %d + %d bytes, %.1f ms, %.2f ns/decision\n", sa, sb, ms, ms * 1e6 / (2 * half));
             }
         }
+        {   // four streams interleaved
+            std::vector<uint8_t> o[4]; for (auto& v : o) v.resize(size[0] + 1024);
+            for (int rep = 0; rep < 2; ++rep) {
+                auto t0 = std::chrono::steady_clock::now();
+                RangeEncoder r0, r1, r2, r3; r0.init(o[0].data(), (int)o[0].size()); r1.init(o[1].data(), (int)o[1].size()); r2.init(o[2].data(), (int)o[2].size()); r3.init(o[3].data(), (int)o[3].size());
+                RangeEncoder::Live L0 = r0.enter(), L1 = r1.enter(), L2 = r2.enter(), L3 = r3.enter();
+                const uint16_t* ps = pstream.data(); const size_t nd = pstream.size(), q = nd / 4;
+                for (size_t i = 0; i < q; ++i) {
+                    const unsigned a = ps[i], b = ps[q + i], c = ps[2 * q + i], d = ps[3 * q + i];
+                    r0.encode_live<12>(L0, a >> 15, (int)(a & 0xfff));
+                    r1.encode_live<12>(L1, b >> 15, (int)(b & 0xfff));
+                    r2.encode_live<12>(L2, c >> 15, (int)(c & 0xfff));
+                    r3.encode_live<12>(L3, d >> 15, (int)(d & 0xfff));
+                }
+                r0.leave(L0); r1.leave(L1); r2.leave(L2); r3.leave(L3);
+                const int s0 = r0.finish() + r1.finish() + r2.finish() + r3.finish();
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                printf("rc, four interleaved streams: %d bytes, %.1f ms, %.2f ns/decision\n", s0, ms, ms * 1e6 / (4 * q));
+            }
+        }
         std::vector<uint8_t> out2(size[0] + 1024);
         auto t0 = std::chrono::steady_clock::now();
         const int sz2 = qlfc_encode_runs(R.view, size[0], out2.data(), size[0], CODER_STATIC);
