@@ -51,6 +51,7 @@ enum { DM_FAIL = 0, DM_NTYPES, DM_NROUNDS, DM_AVG_UND, DM_REPLAYS, DM_D0, DM_D1,
 enum { FAIL_TYPES = 1, FAIL_AVG = 2, FAIL_HIST = 4, FAIL_CAP = 8, FAIL_REPLAY = 16 };
 
 struct DcSub { u32 nb; u32 first[9]; u32 maxr[8]; };            // run index range and max_rank of each sub-block
+struct DcRowBins { u16 lo1, hi1, lo2, hi2; };                   // counting pass: count(row) = P[hi1] - P[lo1] + P[hi2] - P[lo2] over bin prefix sums
 
 struct DevCoder {
     size_t Mcap = 0, Dcap = 0;
@@ -67,6 +68,7 @@ struct DevCoder {
     u32 *cnt = nullptr, *rowtot = nullptr, *rowstart = nullptr /*[4][257]*/, *wdec = nullptr, *wdecoff = nullptr;
     u16 *elo = nullptr, *ehi = nullptr, *S = nullptr;
     u32 *present = nullptr; u8 *rounds = nullptr; u32 *meta = nullptr; u32 *poff = nullptr;
+    DcRowBins* rowbins = nullptr;                              // row -> bin ranges of the counting pass
     u8  *tab_rank = nullptr, *tab_run = nullptr;
     ModelParams* mp = nullptr;                                 // device copy
     u32 *hmeta = nullptr;                                      // pinned: meta + poff
@@ -254,34 +256,36 @@ static DcGeom dc_geom(u32 m)
 
 typedef __attribute__((address_space(3))) volatile u32 dc_lds_vu32;
 
-// Peer mask inside a mantissa / escape round: the rows of one round differ only in a short key (rank length and tree path,
-// <= 9 bits), so match on that key instead of the 11-bit row id; first the common case that every active lane has the same key.
-// (A loop that skips the bits on which all lanes agree was measured slower than the fixed unrolled one: 5.3 vs 4.7 ms per block.)
-__device__ __forceinline__ void dc_match(u32 key, int kbits, bool on, u64 active, u32& mlo, u32& mhi)
+// Lanes among `on` whose NB-bit key equals this lane's: (lo, hi) halves of the peer mask.
+template <int NB>
+__device__ __forceinline__ void dc_peers(u32 key, bool on, u32& mlo, u32& mhi)
 {
-    (void)kbits;
-    mlo = (u32)active; mhi = (u32)(active >> 32);
-    const u32 k0 = (u32)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(active));
-    if (__ballot(on && key != k0) == 0) return;
+    const u64 act = __ballot(on);
+    mlo = (u32)act; mhi = (u32)(act >> 32);
 #pragma unroll
-    for (int b = 0; b < 9; ++b) {
-        const int bitm = __builtin_amdgcn_sbfe((int)key, b, 1);
+    for (int b = 0; b < NB; ++b) {
+        const int bitm = __builtin_amdgcn_sbfe((int)key, b, 1);              // 0 or -1
         const u64 bal = __ballot(bitm != 0);
-        const u32 nb = ~(u32)bitm;
-        mlo &= (u32)bal ^ nb;
-        mhi &= (u32)(bal >> 32) ^ nb;
+        const u32 nbm = ~(u32)bitm;
+        mlo &= (u32)bal ^ nbm;
+        mhi &= (u32)(bal >> 32) ^ nbm;
     }
 }
-
-// rounds whose decisions all have the same type (hence the same row): everything but the mantissa / escape rounds
-__device__ __forceinline__ bool dc_single_row_round(int r) { return r < ROUND_RM || (r >= ROUND_NF && r < ROUND_NM); }
-
-template <int SIDES>
-__device__ __forceinline__ bool dc_round_on_side(int r) { return (r < ROUND_NF) ? (SIDES & 1) != 0 : (SIDES & 2) != 0; }
+// One level down a code tree: of the peers keep those that coded the same bit (`keep` = all ones: no refinement for this lane).
+__device__ __forceinline__ void dc_refine(u32 bit, u32 keep, u32& mlo, u32& mhi)
+{
+    const u64 bal = __ballot(bit != 0);
+    const u32 nbm = bit ? 0u : ~0u;
+    mlo &= ((u32)bal ^ nbm) | keep;
+    mhi &= ((u32)(bal >> 32) ^ nbm) | keep;
+}
 
 // The decisions of 64 items, round by round in canonical order, with the case analysis done once per item instead of once per
 // round: single-row rounds (RF, RE s, NF, NE s: one decision type, hence one row, per round) go to es(slot, on, bit) with
-// slot = 0 | 1 + s | 8 | 9 + s; mantissa / escape rounds (several rows per round) go to em(tau, on, bit).  Control flow is
+// slot = 0 | 1 + s | 8 | 9 + s; mantissa / escape rounds (several rows per round) go to em(tau, on, bit, peers) where peers is
+// the mask of the lanes whose decision of this round has the same type.  The rows of such a round are the nodes of one level
+// of a code tree: two lanes are peers at depth d + 1 iff they were peers at depth d and coded the same bit there, so the mask
+// costs one ballot per round after a single match on the tree's id (rank length B / run-length bits).  Control flow is
 // wave-uniform; every lane calls with its own `on`.
 constexpr int DC_SLOTS = 40;
 __device__ __forceinline__ int dc_slot_tau(int slot) { return slot == 0 ? TAU_RF : slot < 8 ? TAU_RE + slot - 1 : slot == 8 ? TAU_NF : TAU_NE + slot - 9; }
@@ -296,19 +300,29 @@ __device__ __forceinline__ void dc_item_rounds(const Item& it, bool valid, int m
         const int e = B ? (B - 1) + (B < maxr ? 1 : 0) : 0;
         if (__ballot(ng)) es(0, ng, rank != 1u ? 1u : 0u);
         for (int sx = 0; sx < 7; ++sx) { const bool on = sx < e; if (!__ballot(on)) break; es(1 + sx, on, sx + 1 < B ? 1u : 0u); }
-        for (int d = 0; d < 7; ++d) {
-            const bool on = d < B;
-            if (!__ballot(on)) break;
-            const u32 ctx = on ? (rank >> (B - d)) : 1u;
-            const int tau = on ? TAU_RM + rm_off(B) + (int)ctx - 1 : 0;
-            em(tau, on, on ? (rank >> (B - 1 - d)) & 1u : 0u, ((u32)B << d) | (ctx & ((1u << d) - 1u)), 3 + d);
+        if (__ballot(B != 0)) {
+            u32 mlo, mhi;
+            dc_peers<3>((u32)B, B != 0, mlo, mhi);
+            for (int d = 0; d < 7; ++d) {
+                const bool on = d < B;
+                const u64 act = __ballot(on);
+                if (!act) break;
+                const u32 ctx = on ? (rank >> (B - d)) : 1u;
+                const u32 bit = on ? (rank >> (B - 1 - d)) & 1u : 0u;
+                em(on ? TAU_RM + rm_off(B) + (int)ctx - 1 : 0, on, bit, mlo & (u32)act, mhi & (u32)(act >> 32));
+                dc_refine(bit, 0u, mlo, mhi);
+            }
         }
         if (__ballot(ge)) {
+            u32 mlo = ~0u, mhi = ~0u;                                           // depth 0: one row (ctx = 1)
             for (int d = 0; d < 8; ++d) {
                 const bool on = ge && d <= maxr;
-                if (!__ballot(on)) break;
+                const u64 act = __ballot(on);
+                if (!act) break;
                 const u32 ctx = on ? ((1u << d) | ((rank >> (maxr + 1 - d)) & ((1u << d) - 1u))) : 1u;
-                em(TAU_RP + (int)ctx - 1, on, on ? (rank >> (maxr - d)) & 1u : 0u, ctx & ((1u << d) - 1u), d);
+                const u32 bit = on ? (rank >> (maxr - d)) & 1u : 0u;
+                em(TAU_RP + (int)ctx - 1, on, bit, mlo & (u32)act, mhi & (u32)(act >> 32));
+                dc_refine(bit, 0u, mlo, mhi);
             }
         }
     }
@@ -317,65 +331,80 @@ __device__ __forceinline__ void dc_item_rounds(const Item& it, bool valid, int m
         const int nb = (valid && run != 1u) ? bsr(run) : 0;
         if (__ballot(valid)) es(8, valid, run != 1u ? 1u : 0u);
         for (int sx = 0; sx < 31; ++sx) { const bool on = sx < nb; if (!__ballot(on)) break; es(9 + sx, on, sx + 1 < nb ? 1u : 0u); }
-        for (int d = 0; d < 31; ++d) {
-            const bool on = d < nb;
-            if (!__ballot(on)) break;
-            const u32 ctx = on ? (nb <= 5 ? (run >> (nb - d)) : (u32)(1 + d)) : 1u;
-            const u32 key = d < 5 ? (((u32)nb << d) | (nb <= 5 ? (ctx & ((1u << d) - 1u)) : 0u)) : (u32)nb;      // what tells this round's rows apart
-            em(on ? TAU_NM + nm_off(nb) + (int)ctx - 1 : 0, on, on ? (run >> (nb - 1 - d)) & 1u : 0u, key, d < 5 ? 5 + d : 5);
+        if (__ballot(nb != 0)) {
+            u32 mlo, mhi;
+            dc_peers<5>((u32)nb, nb != 0, mlo, mhi);
+            const u32 keep = nb > 5 ? ~0u : 0u;                                 // more than 5 bits: one row per depth, no tree
+            for (int d = 0; d < 31; ++d) {
+                const bool on = d < nb;
+                const u64 act = __ballot(on);
+                if (!act) break;
+                const u32 ctx = on ? (nb <= 5 ? (run >> (nb - d)) : (u32)(1 + d)) : 1u;
+                const u32 bit = on ? (run >> (nb - 1 - d)) & 1u : 0u;
+                em(on ? TAU_NM + nm_off(nb) + (int)ctx - 1 : 0, on, bit, mlo & (u32)act, mhi & (u32)(act >> 32));
+                dc_refine(bit, keep, mlo, mhi);
+            }
         }
     }
 }
 
-// 2a. per wave-chunk: decisions per row and in total
+// 2a. per wave-chunk: decisions per row and in total.  Which rows a run contributes to is a function of (rank, B < max_rank)
+// on the rank side and of the run length's class on the run side, and every row collects a contiguous range of those values
+// (a tree node = a prefix of the value): so the wavefront only histograms its runs into DC_BINS bins (two LDS atomics per run)
+// and turns the prefix sums of the bins into row counts at the end through a table built on the host from the model itself
+// (dc_build_rowbins).  Runs under escape coding (avg_rank >= 32; their rows depend on max_rank) are counted directly.
+constexpr int DC_BIN_RUN = 512;        // bins [0, 256): rank, B >= max_rank or rank < 2; [256, 512): rank, B < max_rank; [512, 608): run classes
+constexpr int DC_BINS = 640;           // padded to 10 per lane
+__host__ __device__ __forceinline__ u32 dc_rank_bin(u32 rank, int maxr) { const int B = rank != 1u ? bsr(rank) : 0; return rank | ((B != 0 && B < maxr) ? 256u : 0u); }
+__host__ __device__ __forceinline__ u32 dc_run_bin(u32 run) { return (u32)DC_BIN_RUN + (run < 64u ? run : 64u + (u32)bsr(run)); }
+
 template <int SIDES>
-__global__ __launch_bounds__(WG) void dc_part_count_kernel(const u64* __restrict__ items, DcGeom g, DcSub S,
-                                                           const u8* __restrict__ rounds, const u32* __restrict__ meta,
+__global__ __launch_bounds__(WG) void dc_part_count_kernel(const u64* __restrict__ items, DcGeom g, DcSub S, const DcRowBins* __restrict__ rowbins,
                                                            u32* __restrict__ cnt /*[DC_ROWS][W]*/, u32* __restrict__ wdec)
 {
-    __shared__ u32 hist[WAVES][DC_ROWS];
-    (void)rounds; (void)meta;
-    for (u32 i = threadIdx.x; i < WAVES * DC_ROWS; i += WG) (&hist[0][0])[i] = 0;
+    __shared__ u32 bins[WAVES][DC_BINS + 8];
+    __shared__ u32 hrp[WAVES][256];                                             // escape rows (TAU_RP + ctx - 1), counted directly
+    for (u32 i = threadIdx.x; i < WAVES * (DC_BINS + 8); i += WG) (&bins[0][0])[i] = 0;
+    for (u32 i = threadIdx.x; i < WAVES * 256; i += WG) (&hrp[0][0])[i] = 0;
     __syncthreads();
     const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 wc = blockIdx.x * WAVES + w;
-    u32* hw = &hist[w][0];
-    const u64 lt = lanemask_lt();
-    const u32 lt_lo = (u32)lt, lt_hi = (u32)(lt >> 32);
+    u32* bw = &bins[w][0];
     u32 total = 0;
     if (wc < g.W) {
         const u64 i0 = (u64)wc * g.per_wave;
         u64 i1 = i0 + g.per_wave; if (i1 > g.m) i1 = g.m;
-        u64 knext = (i0 + lane < i1) ? items[i0 + lane] : 0ull;          // the next tile's items are requested one tile ahead
-        for (u64 base = i0; base < i1; base += 64) {
-            const u64 i = base + lane;
-            const bool valid = i < i1;
-            const u64 key = knext;
-            knext = (i + 64 < i1) ? items[i + 64] : 0ull;
-            const Item it = item_unpack(key);
+        for (u64 i = i0 + lane; i < i1; i += 64) {
+            const Item it = item_unpack(items[i]);
             const int maxr = (int)S.maxr[it.sb];
-            dc_item_rounds<SIDES>(it, valid, maxr,
-                [&](int slot, bool on, u32) {
-                    const u32 n1 = (u32)__popcll(__ballot(on));
-                    if (lane == 0) atomicAdd(&hw[dc_slot_tau(slot)], n1);                 // no return value: fire and forget
-                    total += n1;
-                },
-                [&](int tau, bool on, u32, u32 key, int kbits) {
-                    const u64 active = __ballot(on);
-                    const u32 h = on ? (u32)tau : 0u;
-                    u32 mlo, mhi;
-                    dc_match(key, kbits, on, active, mlo, mhi);
-                    const u32 rr = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));
-                    const u32 cn = (u32)(__popc(mlo) + __popc(mhi));
-                    if (on && rr == cn - 1) atomicAdd(&hw[h], cn);                         // one lane per row adds the row's count
-                    total += (u32)__popcll(active);
-                });
+            if (SIDES & 1) {
+                total += (u32)count_rank_side(it, maxr);
+                if (it.ge32) {
+                    for (int d = 0; d <= maxr; ++d) atomicAdd(&hrp[w][((1u << d) | ((it.rank >> (maxr + 1 - d)) & ((1u << d) - 1u))) - 1u], 1u);
+                } else atomicAdd(&bw[dc_rank_bin(it.rank, maxr)], 1u);
+            }
+            if (SIDES & 2) { total += (u32)count_run_side(it); atomicAdd(&bw[dc_run_bin(it.run)], 1u); }
         }
     }
     __syncthreads();
+    {   // exclusive prefix sums of the wave's bins, 10 consecutive bins per lane
+        u32 loc[DC_BINS / 64], sum = 0;
+#pragma unroll
+        for (int q = 0; q < DC_BINS / 64; ++q) { loc[q] = bw[lane * (DC_BINS / 64) + q]; sum += loc[q]; }
+        u32 run = wave_incl_sum(sum) - sum;
+#pragma unroll
+        for (int q = 0; q < DC_BINS / 64; ++q) { bw[lane * (DC_BINS / 64) + q] = run; run += loc[q]; }
+    }
+    total = wave_incl_sum(total);
+    __syncthreads();
     if (wc < g.W) {
-        for (u32 h = lane; h < (u32)DC_ROWS; h += 64) cnt[(size_t)h * g.W + wc] = hist[w][h];
-        if (lane == 0) wdec[wc] = total;
+        for (u32 h = lane; h < (u32)DC_ROWS; h += 64) {
+            const DcRowBins rb = rowbins[h];
+            u32 v = bw[rb.hi1] - bw[rb.lo1] + bw[rb.hi2] - bw[rb.lo2];
+            if (h >= (u32)TAU_RP && h < (u32)TAU_NF) v += hrp[w][h - TAU_RP];
+            cnt[(size_t)h * g.W + wc] = v;
+        }
+        if (lane == 63) wdec[wc] = total;
     }
 }
 
@@ -429,17 +458,22 @@ __global__ __launch_bounds__(WG) void dc_scan_misc_kernel(const u32* __restrict_
 // are ranked stably inside their row (same type -> same round, so rows never interleave across rounds) and write
 //   events[row offset]            = X | sub-block << 8 | bit << 11
 //   pos[decision index of item]   = that offset (index into the job's value array)
-// The running offsets of the 40 single-row types live in one VGPR (lane = slot; v_readlane / v_writelane with a uniform slot),
-// those of the mantissa / escape rows in LDS.
+// The running offsets of the 40 single-row types live in one VGPR (lane = slot; v_readlane with a uniform slot), those of the
+// mantissa / escape rows in LDS.  pos is item-major, i.e. every lane owns a short run of it and a direct store per round would
+// touch ~20 lines per wavefront instruction (the address path, not the bytes, was the kernel's limit): the tile's entries are
+// collected in LDS and leave as whole lines when the tile is done (a tile with more decisions than the stage holds stores directly).
+#ifndef DC_POS_STAGE_N
+#define DC_POS_STAGE_N 1280
+#endif
+constexpr u32 DC_POS_STAGE = DC_POS_STAGE_N;
 template <int SIDES>
-__global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restrict__ items, DcGeom g, DcSub S,
-                                                             const u8* __restrict__ rounds, const u32* __restrict__ meta,
+__global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restrict__ items, DcGeom g, DcSub S, const u32* __restrict__ meta,
                                                              const u32* __restrict__ cnt, const u32* __restrict__ rowstart,
-                                                             const u32* __restrict__ wdecoff, u32 v_base, u32 dec_base, u32 ignoreX,
+                                                             const u32* __restrict__ wdecoff, u32 ignoreX,
                                                              u16* __restrict__ events, u32* __restrict__ pos, u32* __restrict__ doff)
 {
     __shared__ u32 goff[WAVES][DC_ROWS];
-    (void)rounds; (void)v_base; (void)dec_base;
+    __shared__ u32 spos[WAVES][DC_POS_STAGE];
     if (meta[DM_FAIL] != 0u) return;
     const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 wc = blockIdx.x * WAVES + w;
@@ -447,6 +481,7 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
     __syncthreads();
     if (wc >= g.W) return;
     dc_lds_vu32* vg = (dc_lds_vu32*)&goff[w][0];
+    dc_lds_vu32* sp = (dc_lds_vu32*)&spos[w][0];
     const u64 lt = lanemask_lt();
     const u32 lt_lo = (u32)lt, lt_hi = (u32)(lt >> 32);
     int sreg = (lane < (u32)DC_SLOTS) ? (int)goff[w][dc_slot_tau((int)lane)] : 0;     // running offsets of the single-row types
@@ -464,12 +499,14 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
         u32 nd = 0;
         if (valid) { if (SIDES & 1) nd += (u32)count_rank_side(it, maxr); if (SIDES & 2) nd += (u32)count_run_side(it); }
         const u32 incl = wave_incl_sum(nd);
-        const u32 my = running + incl - nd;
-        if (valid) doff[i] = my;
-        running += __shfl(incl, 63, 64);
+        const u32 loc = incl - nd;                                    // first decision of this item inside the tile
+        if (valid) doff[i] = running + loc;
+        const u32 tile_total = (u32)__shfl((int)incl, 63, 64);
+        const bool staged = tile_total <= DC_POS_STAGE;               // wave-uniform
         const u32 sig = (ignoreX ? 0u : item_X(key)) | (it.sb << 8);
-        u32* mypos = pos + my;
+        u32* mypos = pos + running + loc;
         u32 ord = 0;
+        auto put = [&](u32 p) { if (staged) sp[loc + ord] = p; else mypos[ord] = p; ++ord; };
         dc_item_rounds<SIDES>(it, valid, maxr,
             [&](int slot, bool on, u32 bit) {
                 const u64 m = __ballot(on);
@@ -477,15 +514,12 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
                 if (on) {
                     const u32 p = bs + (u32)(__popc((u32)m & lt_lo) + __popc((u32)(m >> 32) & lt_hi));
                     events[p] = (u16)(sig | (bit << 11));
-                    mypos[ord++] = p;
+                    put(p);
                 }
                 if ((int)lane == slot) sreg = (int)(bs + (u32)__popcll(m));
             },
-            [&](int tau, bool on, u32 bit, u32 key, int kbits) {
-                const u64 active = __ballot(on);
+            [&](int tau, bool on, u32 bit, u32 mlo, u32 mhi) {
                 const u32 h = on ? (u32)tau : 0u;
-                u32 mlo, mhi;
-                dc_match(key, kbits, on, active, mlo, mhi);
                 const u32 before = vg[h];
                 const u32 rr = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));
                 const u32 cn = (u32)(__popc(mlo) + __popc(mhi));
@@ -493,9 +527,11 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
                     const u32 p = before + rr;
                     if (rr == cn - 1) vg[h] = before + cn;                // highest peer publishes
                     events[p] = (u16)(sig | (bit << 11));
-                    mypos[ord++] = p;
+                    put(p);
                 }
             });
+        if (staged) for (u32 t = lane; t < tile_total; t += 64) pos[running + t] = sp[t];
+        running += tile_total;
     }
     if (wc == g.W - 1 && lane == 0) doff[g.m] = running;
 }
@@ -795,6 +831,48 @@ __global__ void dc_poff_kernel(const u32* __restrict__ doff_sp, DcSub S, u32 m, 
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
+// Row -> bin ranges of the counting pass, derived from the model's own case analysis (the one dc_item_rounds walks): for every
+// bin the rows a run of that bin contributes to, then per row the (at most two) ranges of consecutive bins.  Returns false if a
+// row ever needed more — the layout of the bins would be wrong, and the device coder is then not offered at all.
+static bool dc_build_rowbins(DcRowBins* T)
+{
+    static unsigned char member[DC_ROWS][DC_BINS];
+    memset(member, 0, sizeof member);
+    for (int lt = 0; lt < 2; ++lt) {
+        for (u32 rank = 0; rank < 256; ++rank) {
+            const int B = rank != 1u ? bsr(rank) : 0;
+            if (lt && B == 0) continue;                                         // dc_rank_bin never produces these
+            const u32 bin = rank | (lt ? 256u : 0u);
+            const int e = B ? (B - 1) + lt : 0;
+            member[TAU_RF][bin] = 1;
+            for (int sx = 0; sx < e && sx < 7; ++sx) member[TAU_RE + sx][bin] = 1;
+            for (int d = 0; d < B; ++d) member[TAU_RM + rm_off(B) + (int)(rank >> (B - d)) - 1][bin] = 1;
+        }
+    }
+    for (u32 cls = 1; cls < 96; ++cls) {
+        if (cls >= 64 && (cls < 70 || cls > 94)) continue;                      // run lengths below 64 have their own bin; 2^31 > run
+        const u32 run = cls < 64 ? cls : 1u << (cls - 64);
+        const u32 bin = dc_run_bin(run);
+        if (bin != DC_BIN_RUN + cls) return false;
+        const int nb = run != 1u ? bsr(run) : 0;
+        member[TAU_NF][bin] = 1;
+        for (int sx = 0; sx < nb; ++sx) member[TAU_NE + sx][bin] = 1;
+        for (int d = 0; d < nb; ++d) member[TAU_NM + nm_off(nb) + (int)(nb <= 5 ? (run >> (nb - d)) : (u32)(1 + d)) - 1][bin] = 1;
+    }
+    for (int h = 0; h < DC_ROWS; ++h) {
+        u16 r[4] = {0, 0, 0, 0}; int nr = 0;
+        for (int b = 0; b < DC_BINS;) {
+            if (!member[h][b]) { ++b; continue; }
+            int e = b; while (e < DC_BINS && member[h][e]) ++e;
+            if (nr == 2) return false;
+            r[2 * nr] = (u16)b; r[2 * nr + 1] = (u16)e; ++nr;
+            b = e;
+        }
+        T[h].lo1 = r[0]; T[h].hi1 = r[1]; T[h].lo2 = r[2]; T[h].hi2 = r[3];
+    }
+    return true;
+}
+
 static size_t dc_align(size_t x) { return (x + 255) / 256 * 256; }
 
 void devcoder_destroy(bscgpu_ctx* c)
@@ -831,6 +909,7 @@ int devcoder_ensure(bscgpu_ctx* c)
         {(void**)&d->present, 64 * 4}, {(void**)&d->rounds, 256},
         {(void**)&d->meta, DM_COUNT * 4}, {(void**)&d->poff, 16 * 4},
         {(void**)&d->tab_rank, 32768}, {(void**)&d->tab_run, 8192}, {(void**)&d->mp, sizeof(ModelParams)},
+        {(void**)&d->rowbins, DC_ROWS * sizeof(DcRowBins)},
     };
     size_t total = 0;
     for (auto& cv : carve) total += dc_align(cv.bytes);
@@ -840,11 +919,15 @@ int devcoder_ensure(bscgpu_ctx* c)
     for (auto& cv : carve) { *cv.p = d->arena + off; off += dc_align(cv.bytes); }
     if (hipHostMalloc((void**)&d->hmeta, 64 * 4, hipHostMallocDefault) != hipSuccess) { hipFree(d->arena); delete d; return BSC_NOT_ENOUGH_MEMORY; }
     ModelParams mp; model_params_from_table(bschost::qlfc_static_params(), mp);
+    static DcRowBins rowbins[DC_ROWS];
+    static const bool rowbins_ok = dc_build_rowbins(rowbins);
+    if (!rowbins_ok) { (void)hipFree(d->arena); (void)hipHostFree(d->hmeta); delete d; return ctx_fail(c, BSC_GPU_ERROR, "device coder: bin layout", hipSuccess); }
     const bschost::QlfcTables& QT = bschost::qlfc_tables();
     const uint8_t *rs = QT.rank_state, *ns = QT.run_state;
     const bool ok = hipMemcpyAsync(d->mp, &mp, sizeof mp, hipMemcpyHostToDevice, c->stream) == hipSuccess
                  && hipMemcpyAsync(d->tab_rank, rs, 32768, hipMemcpyHostToDevice, c->stream) == hipSuccess
                  && hipMemcpyAsync(d->tab_run, ns, 8192, hipMemcpyHostToDevice, c->stream) == hipSuccess
+                 && hipMemcpyAsync(d->rowbins, rowbins, sizeof rowbins, hipMemcpyHostToDevice, c->stream) == hipSuccess
                  && ctx_sync(c) == hipSuccess;                      // mp is a stack object: the copies must have finished
     if (!ok) { hipFree(d->arena); hipHostFree(d->hmeta); delete d; return ctx_fail(c, BSC_GPU_ERROR, "device coder tables", hipSuccess); }
     c->dc = d;
@@ -860,11 +943,11 @@ static void dc_launch_partition(bscgpu_ctx* c, DevCoder* d, const u64* items, u3
     const u32 grid = (g.W + WAVES - 1) / WAVES;
     u32* rowstart = d->rowstart + (DC_ROWS + 8) * job;
     prof_begin(c, BSCGPU_K_DC_PART, (u64)m * 8, m);
-    hipLaunchKernelGGL(dc_part_count_kernel<SIDES>, dim3(grid), dim3(WG), 0, c->stream, items, g, S, d->rounds, d->meta, d->cnt, d->wdec);
+    hipLaunchKernelGGL(dc_part_count_kernel<SIDES>, dim3(grid), dim3(WG), 0, c->stream, items, g, S, d->rowbins, d->cnt, d->wdec);
     hipLaunchKernelGGL(dc_scan_rows_kernel, dim3(DC_ROWS), dim3(WG), 0, c->stream, d->cnt, g.W, d->rowtot);
     hipLaunchKernelGGL(dc_scan_misc_kernel, dim3(1), dim3(WG), 0, c->stream, d->rowtot, rowstart, d->wdec, g.W, d->wdecoff, d->meta, job, (u32)d->Dcap);
-    hipLaunchKernelGGL(dc_part_scatter_kernel<SIDES>, dim3(grid), dim3(WG), 0, c->stream, items, g, S, d->rounds, d->meta, d->cnt, rowstart,
-                       d->wdecoff, 0u, 0u, ignoreX, d->events[job], d->pos[job], d->doff[job]);
+    hipLaunchKernelGGL(dc_part_scatter_kernel<SIDES>, dim3(grid), dim3(WG), 0, c->stream, items, g, S, d->meta, d->cnt, rowstart,
+                       d->wdecoff, ignoreX, d->events[job], d->pos[job], d->doff[job]);
     prof_end(c);
 }
 
