@@ -172,6 +172,22 @@ def main():
         for k, v in cx.profile_get().items():
             for f in ("ms", "launches", "bytes", "records"):
                 stats[k][f] += v[f]
+    launches_timed = [x for cx in ctxs for x in cx.scatter_launches(65536)]
+    # ---- roofline leg.  With several contexts per GPU the kernels of different blocks run side by side in the timed region, so
+    # the HIP-event duration of one launch there measures how the chip was shared, not the kernel.  The kernel's own rate is
+    # therefore taken from a second, untimed pass of the same workload through ONE context (same block, same pipe, HIP events on
+    # the context's stream); the timed region's (contended) numbers are reported next to it.  One context: the timed region itself.
+    stats_iso, launches_iso, iso_blocks = stats, launches_timed, args.steps
+    if ncx > 1 and rank == 0:
+        iso_blocks = max(2, min(8, args.steps))
+        concat = None                                   # (N > 1: these blocks are not part of the job's output)
+        ctxs[0].profile(True)
+        ctxs[0].profile_reset()
+        run_one(0, iso_blocks, False, [None] * ncx)
+        torch.cuda.synchronize()
+        ctxs[0].profile(False)
+        stats_iso = ctxs[0].profile_get()
+        launches_iso = ctxs[0].scatter_launches(65536)
     mine = {"rank": rank, "verified": verified, "gpu_stage_total_ms": round(float(stage[0] + stage[1] + stage[2]) / args.steps, 2),
             "sorter_only_MBps": round(n / 1e6 / max(stage[1] / args.steps / 1e3, 1e-9), 1),
             "cpu_seconds_per_block": round(cpu_used / args.steps, 3), "coder_threads": coder_threads,
@@ -184,14 +200,21 @@ def main():
 
     if rank == 0:
         value = world * args.steps * n / 1e6 / dt
-        sc = stats["radix_scatter"]
-        launches = [x for cx in ctxs for x in cx.scatter_launches(65536)]
-        big = [(ms, rec) for ms, rec in launches if rec >= (1 << 20)]
-        full = [(ms, rec) for ms, rec in launches if rec == n]
         rec_bytes = 12 if args.sorter == 1 else 8
-        tot_ms = sum(ms for ms, _ in big) or 1e-9
-        tot_bytes = sum(2 * rec_bytes * rec for _, rec in big)
-        achieved = tot_bytes / 1e6 / tot_ms                                  # GB/s
+
+        def scatter_rate(launches):
+            big = [(ms, rec) for ms, rec in launches if rec >= (1 << 20)]
+            full = [(ms, rec) for ms, rec in launches if rec == n]
+            tot_ms = sum(ms for ms, _ in big) or 1e-9
+            tot_bytes = sum(2 * rec_bytes * rec for _, rec in big)
+            return big, full, tot_ms, tot_bytes, tot_bytes / 1e6 / tot_ms     # ..., GB/s
+
+        def pass_rate(st):
+            # the whole digit pass = rs_hist + rs_scan + rs_scatter: the same algorithmic bytes over the time of all three kernels
+            ms = sum(st[k]["ms"] for k in ("radix_hist", "radix_scan", "radix_scatter") if k in st)
+            return st["radix_scatter"]["bytes"] / 1e6 / max(ms, 1e-9)
+
+        big, full, tot_ms, tot_bytes, achieved = scatter_rate(launches_iso)
         # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
         # runs, tools/profile_round.sh): per full-size launch, corrected as MI355X_MICROARCH.md prescribes
         # (KiB units; FETCH_SIZE x2 on gfx950 for wide coalesced loads).  Static artefact, not measured in this run.
@@ -202,15 +225,15 @@ def main():
                 traffic = pm["rs_scatter_pairs"]["traffic_bytes_per_launch"]
         except Exception:
             pass
-        # the whole digit pass = rs_hist + rs_scan + rs_scatter: the same algorithmic bytes over the time of all three kernels
-        pass_ms = sum(stats[k]["ms"] for k in ("radix_hist", "radix_scan", "radix_scatter") if k in stats)
-        pass_bytes = stats["radix_scatter"]["bytes"]
-        pass_achieved = pass_bytes / 1e6 / max(pass_ms, 1e-9)
+        pass_achieved = pass_rate(stats_iso)
         roofline = {
             "bound": "hbm", "kernel": "rs_scatter_kernel (one 8-bit LSD digit pass: read + scatter of u64 key + u32 value)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "pass_frac": round(pass_achieved / HBM_PEAK_GBPS, 4), "pass_achieved": round(pass_achieved, 1),
-            "pass_note": "whole digit pass (histogram + scan + scatter kernels, every launch of the timed region) charged with the scatter's algorithmic bytes",
+            "pass_note": "whole digit pass (histogram + scan + scatter kernels, every launch of the measured region) charged with the scatter's algorithmic bytes",
+            "measured_on": ("the timed region (one context per GPU: launches do not overlap)" if ncx == 1 else
+                            f"{iso_blocks} more blocks of the same workload through ONE context right after the timed region (HIP events on its stream); in the timed "
+                            f"region {ncx} contexts run side by side, so a launch's duration there measures sharing of the chip, see timed_region"),
             "traffic": traffic, "traffic_note": "bytes per full-size launch = 2 x FETCH_SIZE + WRITE_SIZE from profiles/pmc_traffic.json "
                                                 "(rocprofv3 PMC passes; algorithmic bytes per full-size launch = %d)" % (2 * rec_bytes * n),
             "launches": len(big), "avg_launch_ms": round(tot_ms / max(len(big), 1), 4),
@@ -220,8 +243,12 @@ def main():
                                     "GBps": round(2 * rec_bytes * n / 1e6 / float(np.mean([m for m, _ in full])), 1) if full else None},
             "frac_of_copy_ceiling_6290": round(achieved / 6290.0, 4),
         }
-        per_kernel = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "GBps": round(v["bytes"] / 1e6 / v["ms"], 1) if v["ms"] > 0 else None}
-                      for k, v in stats.items() if v["launches"]}
+        if ncx > 1:
+            _, _, t_ms, _, t_ach = scatter_rate(launches_timed)
+            roofline["timed_region"] = {"achieved": round(t_ach, 1), "frac": round(t_ach / HBM_PEAK_GBPS, 4), "pass_frac": round(pass_rate(stats) / HBM_PEAK_GBPS, 4),
+                                        "note": f"per-launch durations while {ncx} contexts share the GPU (launches overlap; sum of durations > wall time)"}
+        per_kernel = {k: {"ms_per_block": round(v["ms"] / iso_blocks, 3), "GBps": round(v["bytes"] / 1e6 / v["ms"], 1) if v["ms"] > 0 else None}
+                      for k, v in stats_iso.items() if v["launches"]}
         out = {
             "metric": "MB/s compress (BWT+QLFC) on 64 MiB blocks", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
@@ -244,6 +271,7 @@ def main():
                                   "doubling_rounds": stage[5] / args.steps, "pipeline_depth": args.depth, "contexts_per_gpu": ncx},
             "sorter_only_MBps": round(n / 1e6 / max(stage[1] / args.steps / 1e3, 1e-9), 1),
             "kernels": per_kernel,
+            "kernels_note": "HIP-event time per kernel class and block, from the region named in roofline.measured_on",
             "host": {"cpus": os.cpu_count(), "effective_cpus": effective_cpus(), "coder_threads_per_gpu": coder_threads,
                      "cpu_seconds_per_block_rank0": round(cpu_used / args.steps, 3),
                      "cpu_busy_fraction_of_effective": round(cpu_used / (dt * max(effective_cpus() / max(local_world, 1), 1)), 3)},

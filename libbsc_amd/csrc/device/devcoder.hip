@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 using namespace dcm;
 
@@ -40,7 +41,7 @@ constexpr int DC_WCH_MAX  = 4096;      // wave-chunks of a partition job (one wa
 #ifndef DC_EV_N
 #define DC_EV_N 8192
 #endif
-constexpr int DC_EV       = DC_EV_N;   // events per evaluation chunk
+constexpr int DC_EV       = DC_EV_N;   // events per evaluation chunk: the minimum (see devcoder_pstream: long enough for the brackets to meet)
 constexpr int DC_AVG_CH   = 1024;      // runs per avg_rank lane
 constexpr int DC_AVG_WARM = 768;       // warm-up runs in front of an avg_rank chunk
 constexpr u32 DC_SIGMASK  = 0x7ffu;    // event = X | sub-block << 8 | bit << 11
@@ -69,6 +70,7 @@ struct DevCoder {
     u16 *elo = nullptr, *ehi = nullptr, *S = nullptr;
     u32 *present = nullptr; u8 *rounds = nullptr; u32 *meta = nullptr; u32 *poff = nullptr;
     DcRowBins* rowbins = nullptr;                              // row -> bin ranges of the counting pass
+    u16* sink = nullptr;                                       // where stores past the end of an array go (1 KB)
     u8  *tab_rank = nullptr, *tab_run = nullptr;
     ModelParams* mp = nullptr;                                 // device copy
     u32 *hmeta = nullptr;                                      // pinned: meta + poff
@@ -132,7 +134,6 @@ __global__ __launch_bounds__(WG) void dc_ctx_kernel(const u64* __restrict__ key_
     if (j < m) {
         const u64 key = key_ch[j];
         const Item it = item_unpack(key);
-        const u32 c = item_X(key);
         const u32 j0 = S.first[it.sb];
         // window contexts: previous runs of the same sub-block (qlfc.cpp:1063-1068)
         u32 ctx_rank0 = 0, ctx_rank4 = 0, ctx_run = 0;
@@ -541,7 +542,8 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
 // ---------------------------------------------------------------------------------------------------------------------
 struct DcEvalJob { const u16* events; u32 E; const u32* rowstart; int fam; };      // rowstart[DC_ROWS + 1]: row = decision type
 
-__device__ __forceinline__ u32 dc_find_row(const u32* __restrict__ rowstart, u32 k)
+template <class P>
+__device__ __forceinline__ u32 dc_find_row(P rowstart, u32 k)
 {
     u32 lo = 0, hi = DC_ROWS;                                          // largest row with rowstart[row] <= k
     while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (rowstart[mid] <= k) lo = mid; else hi = mid; }
@@ -564,7 +566,7 @@ __device__ __forceinline__ void dc_walk(const DcEvalJob& J, const ModelParams* _
     u32 k = k0;
     while (k < k1) {
         if (k == rowend) {
-            do { ++row; rowend = J.rowstart[row + 1]; } while (rowend == k && row < (u32)DC_ROWS - 1);
+            row = dc_find_row(J.rowstart, k); rowend = J.rowstart[row + 1];                 // the next non-empty row (empty ones in between: most types never occur)
             cls = tau_class((int)row); R = mp->rates[cls][J.fam];
             prev = 0xffffu;
         }
@@ -606,69 +608,132 @@ __device__ __forceinline__ void dc_walk(const DcEvalJob& J, const ModelParams* _
 // full lines — for every batch of 64 events per lane the wavefront loads the 64 lanes' 128-byte pieces cooperatively
 // (8 x 16 B per lane, eight rows per instruction), transposes them through LDS, and (phase c) writes the values back the same
 // way.  The next batch is in flight while the current one is walked.
+#ifndef DC_EVAL_TIMING
+#define DC_EVAL_TIMING 0
+#endif
 constexpr int DC_EB = 64;                       // events per lane per batch
 constexpr int DC_EROW = DC_EB * 2 + 16;         // LDS row pitch in bytes (padded)
 // all four jobs of a block in one launch (they are independent, and one job alone leaves most SIMDs idle: a lane is a serial chain)
-struct DcEvalAll { DcEvalJob job[4]; u32 wstart[5]; u32 cstart[5]; u16* V[4]; };   // first wavefront / first chunk of each job
+struct DcEvalAll { DcEvalJob job[4]; u32 wstart[5]; u32 cstart[5]; u16* V[4]; u16* sink; u32 ev; };   // first wavefront / first chunk of each job; events per chunk
+
+// First event of every non-empty row gets DC_ROWMARK: inside the rows of one class (same update rates) a walk then needs no row
+// bookkeeping at all — a chain ends where the signature changes or a marked event begins.
+constexpr u32 DC_ROWMARK = 0x1000u;
+__global__ __launch_bounds__(WG) void dc_mark_rows_kernel(DcEvalAll A)
+{
+    const u32 g = blockIdx.x * WG + threadIdx.x;
+    if (g >= 4u * DC_ROWS) return;
+    const DcEvalJob J = A.job[g / DC_ROWS];
+    const u32 r = g % DC_ROWS;
+    const u32 rs = J.rowstart[r], re = J.rowstart[r + 1];
+    if (re > rs) const_cast<u16*>(J.events)[rs] |= (u16)DC_ROWMARK;
+}
+// first row of each class, and one past the last
+__device__ __forceinline__ int dc_class_first_row(int cls)
+{
+    return cls == CLS_RF ? TAU_RF : cls == CLS_RE ? TAU_RE : cls == CLS_RM ? TAU_RM : cls == CLS_RP ? TAU_RP : cls == CLS_NF ? TAU_NF
+         : cls == CLS_NE ? TAU_NE : cls == CLS_NM ? TAU_NM : DC_ROWS;
+}
+
+// A wavefront is self-contained here (its own LDS slices, no workgroup barrier); four of them form a workgroup only so that the
+// hardware puts them on the four SIMDs of one CU — launched as single-wave workgroups, a tenth of the ~1000 wavefronts ended up
+// two to a SIMD while other SIMDs stayed empty, and the kernel took 1.6 x as long as its median wavefront.
+constexpr int DC_EVAL_WAVES = 4;
+constexpr int DC_EVAL_LDS_WAVE = 2 * 64 * DC_EROW;                                             // sin + sout
+constexpr int DC_EVAL_LDS = DC_EVAL_WAVES * (DC_EVAL_LDS_WAVE + NUM_CLS * 4 + NUM_CLS * 16);   // + class ends, rates
+__device__ __forceinline__ void dc_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // LDS operations of one wavefront execute in order: only the compiler has to be told
+    __builtin_amdgcn_wave_barrier();
+}
 
 template <bool WRITE>
-__global__ __launch_bounds__(64) void dc_eval_wave_kernel(DcEvalAll A, const ModelParams* __restrict__ mp, const u32* __restrict__ meta,
-                                                          u16* __restrict__ elo_all, u16* __restrict__ ehi_all, const u16* __restrict__ Sv_all)
+__global__ __launch_bounds__(64 * DC_EVAL_WAVES) void dc_eval_wave_kernel(DcEvalAll A, const ModelParams* __restrict__ mp, const u32* __restrict__ meta,
+                                                          u16* __restrict__ elo_all, u16* __restrict__ ehi_all, const u16* __restrict__ Sv_all, u32* __restrict__ tdbg)
 {
-    __shared__ __attribute__((aligned(16))) u8 sin[64 * DC_EROW];
-    __shared__ __attribute__((aligned(16))) u8 sout[WRITE ? 64 * DC_EROW : 16];
-    if (meta[DM_FAIL] != 0u) return;
+#if DC_EVAL_TIMING
+    const u64 t_begin = wall_clock64();
+    u32 slow_batches = 0;
+#endif
+    extern __shared__ __attribute__((aligned(16))) u8 dc_eval_lds[];
+    const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    u8* const sin = dc_eval_lds + wv * DC_EVAL_LDS_WAVE;
+    u8* const sout = sin + 64 * DC_EROW;
+    // where each class's rows end (in events) and the family's rates per class: all a walk needs besides the events themselves
+    u32* const sclsend = reinterpret_cast<u32*>(dc_eval_lds + DC_EVAL_WAVES * DC_EVAL_LDS_WAVE) + wv * NUM_CLS;
+    Rates* const srate = reinterpret_cast<Rates*>(dc_eval_lds + DC_EVAL_WAVES * (DC_EVAL_LDS_WAVE + NUM_CLS * 4)) + wv * NUM_CLS;
+    const u32 gw = blockIdx.x * DC_EVAL_WAVES + wv;                    // this wavefront among all of the launch
+    if (meta[DM_FAIL] != 0u || gw >= A.wstart[4]) return;
     int jb = 0;
 #pragma unroll
-    for (int q = 1; q < 4; ++q) if (blockIdx.x >= A.wstart[q]) jb = q;
+    for (int q = 1; q < 4; ++q) if (gw >= A.wstart[q]) jb = q;
     const DcEvalJob J = A.job[jb];
+    if (lane < (u32)NUM_CLS) {
+        srate[lane] = mp->rates[lane][J.fam];
+        sclsend[lane] = J.rowstart[dc_class_first_row((int)lane + 1)];
+    }
+    dc_wave_sync();
     u16* const elo = elo_all + A.cstart[jb];
     u16* const ehi = ehi_all + A.cstart[jb];
     const u16* const Sv = Sv_all + A.cstart[jb];
     u16* const Vout = A.V[jb];
-    const u32 wave = blockIdx.x - A.wstart[jb];
-    const u32 lane = threadIdx.x;
+    const u32 wave = gw - A.wstart[jb];
     const u32 c = wave * 64 + lane;
-    const u64 k0 = (u64)c * DC_EV;
+    const u32 EV = A.ev;                                               // multiple of DC_EB
+    const u64 k0 = (u64)c * EV;
     const bool mine = k0 < J.E;
-    const u32 k1 = mine ? (u32)((k0 + DC_EV < J.E) ? k0 + DC_EV : J.E) : 0u;
+    const u32 k1 = mine ? (u32)((k0 + EV < J.E) ? k0 + EV : J.E) : 0u;
     // cooperative mapping: instruction i moves 16 bytes of row 8 i + lane / 8, column lane % 8
     const u32 crow = lane >> 3, ccol = lane & 7u;
-    const u64 wave_k0 = (u64)wave * 64 * DC_EV;
+    const u64 wave_k0 = (u64)wave * 64 * EV;
 
-    u32 row = 0, rowend = 0, prev = 0xffffu;
+    u32 cls = 0, clsend = 0, prev = 0xffffu;
     int lo = 2048, hi = 2048;
-    Rates R = mp->rates[0][J.fam];
+    Rates R = srate[0];
     if (mine) {
-        row = dc_find_row(J.rowstart, (u32)k0);
-        rowend = J.rowstart[row + 1];
-        const int cls = tau_class((int)row);
-        R = mp->rates[cls][J.fam];
-        prev = (k0 > J.rowstart[row]) ? ((u32)J.events[k0 - 1] & DC_SIGMASK) : 0xffffu;
+        while (cls + 1 < (u32)NUM_CLS && sclsend[cls] <= (u32)k0) ++cls;                     // class of the row that owns event k0
+        clsend = sclsend[cls];
+        R = srate[cls];
+        // a chunk that starts a row starts with a marked event; otherwise the chain may continue from the event before
+        prev = (k0 > 0) ? ((u32)J.events[k0 - 1] & DC_SIGMASK) : 0xffffu;
         if (WRITE) { lo = Sv[c]; hi = lo; } else { lo = mp->vmin[cls][J.fam]; hi = mp->vmax[cls][J.fam]; }
     }
     auto fetch = [&](u32 b, uint4* q) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const u64 kk = wave_k0 + (u64)(8 * i + crow) * DC_EV + (u64)b * DC_EB + ccol * 8;
-            q[i] = (kk < J.E) ? *reinterpret_cast<const uint4*>(J.events + kk) : make_uint4(0, 0, 0, 0);
+            // no branch around a global load or store in this kernel (past the end: a clamped address / a sink slot): the compiler
+            // then knows how many are outstanding and waits for the prefetched batch with an exact vmcnt, not for the stores behind it
+            const u64 kk = wave_k0 + (u64)(8 * i + crow) * EV + (u64)b * DC_EB + ccol * 8;
+            const u64 ka = kk < J.E ? kk : 0ull;
+            const uint4 val = *reinterpret_cast<const uint4*>(J.events + ka);
+            q[i].x = val.x; q[i].y = val.y; q[i].z = val.z; q[i].w = val.w;          // (member-wise: a whole-vector copy through the select made the array live in scratch)
+        }
+    };
+    auto store_out = [&](u32 b) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const u64 kk = wave_k0 + (u64)(8 * i + crow) * EV + (u64)b * DC_EB + ccol * 8;
+            *reinterpret_cast<uint4*>(kk < J.E ? Vout + kk : A.sink + lane * 8) = *reinterpret_cast<const uint4*>(sout + (8 * i + crow) * DC_EROW + ccol * 16);
         }
     };
     uint4 nxt[8];
     fetch(0, nxt);
-    constexpr u32 NB = DC_EV / DC_EB;
+    const u32 NB = EV / DC_EB;
     for (u32 b = 0; b < NB; ++b) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(sin + (8 * i + crow) * DC_EROW + ccol * 16) = nxt[i];
-        __syncthreads();
-        if (b + 1 < NB) fetch(b + 1, nxt);
+        dc_wave_sync();
+        // the values of the batch before leave now, a whole walk ahead of the next wait on the memory counter (the loads below are
+        // waited for at the top of the next iteration, and the counter is in order: stores issued after them would be waited for too)
+        if (WRITE && b > 0) store_out(b - 1);
+        fetch(b + 1 < NB ? b + 1 : b, nxt);                            // (the last batch is simply fetched again)
         const u32 kb = (u32)k0 + b * DC_EB;
         if (mine && kb < k1) {
             const u8* myrow = sin + lane * DC_EROW;
-            u8* orow = sout + (WRITE ? lane * DC_EROW : 0);
-            const u32 lim = k1 < rowend ? k1 : rowend;
+            u8* orow = sout + lane * DC_EROW;
+            const u32 lim = k1 < clsend ? k1 : clsend;
             if (kb + DC_EB <= lim) {
-                // whole batch inside the current row: straight-line walk from registers
+                // whole batch inside one class (one set of rates): straight-line walk from registers
 #pragma unroll
                 for (int g8 = 0; g8 < 8; ++g8) {
                     const uint4 q = *reinterpret_cast<const uint4*>(myrow + g8 * 16);
@@ -677,27 +742,32 @@ __global__ __launch_bounds__(64) void dc_eval_wave_kernel(DcEvalAll A, const Mod
 #pragma unroll
                     for (int x = 0; x < 8; ++x) {
                         const u32 e = (wds[x >> 1] >> (16 * (x & 1))) & 0xffffu;
-                        const u32 sig = e & DC_SIGMASK;
-                        if (sig != prev) { lo = 2048; hi = 2048; prev = sig; }
-                        const u32 bt = (e >> 11) & 1u;
+                        const u32 sigm = e & (DC_SIGMASK | DC_ROWMARK);                      // a marked event never equals prev
+                        if (sigm != prev) { lo = 2048; hi = 2048; }
+                        prev = e & DC_SIGMASK;
+                        // dcm::step with the target, rate and rounding picked by the bit first, so that both ends of the bracket
+                        // share the selects: bit 1 is v - (((v - t1) a1) >> 12) = v + (((t1 - v) a1 + 4095) >> 12) (floor of a
+                        // negated quotient = minus its ceiling), bit 0 is v + (((t0 - v) a0) >> 12)
+                        const bool b1 = (e & 0x800u) != 0u;
+                        const int T = b1 ? R.t1 : R.t0, Aa = b1 ? R.a1 : R.a0, rr = b1 ? 4095 : 0;
                         if (WRITE) outw[x >> 1] |= (u32)lo << (16 * (x & 1));
-                        lo = step(lo, bt, R);
-                        if (!WRITE) hi = step(hi, bt, R);
+                        lo += (__mul24(T - lo, Aa) + rr) >> 12;
+                        if (!WRITE) hi += (__mul24(T - hi, Aa) + rr) >> 12;
                     }
                     if (WRITE) *reinterpret_cast<uint4*>(orow + g8 * 16) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
                 }
             } else {
+                // a class boundary or the end of the chunk inside the batch (a handful of batches per launch)
+#if DC_EVAL_TIMING
+                ++slow_batches;
+#endif
                 const u32 cnt = (k1 - kb < (u32)DC_EB) ? k1 - kb : (u32)DC_EB;
                 for (u32 x = 0; x < cnt; ++x) {
                     const u32 k = kb + x;
-                    if (k == rowend) {
-                        do { ++row; rowend = J.rowstart[row + 1]; } while (rowend == k && row < (u32)DC_ROWS - 1);
-                        R = mp->rates[tau_class((int)row)][J.fam];
-                        prev = 0xffffu;
-                    }
+                    while (k >= clsend && cls + 1 < (u32)NUM_CLS) { ++cls; clsend = sclsend[cls]; R = srate[cls]; }
                     const u32 e = *reinterpret_cast<const u16*>(myrow + 2 * x);
-                    const u32 sig = e & DC_SIGMASK;
-                    if (sig != prev) { lo = 2048; hi = 2048; prev = sig; }
+                    if ((e & (DC_SIGMASK | DC_ROWMARK)) != prev) { lo = 2048; hi = 2048; }
+                    prev = e & DC_SIGMASK;
                     const u32 bt = (e >> 11) & 1u;
                     if (WRITE) *reinterpret_cast<u16*>(orow + 2 * x) = (u16)lo;
                     lo = step(lo, bt, R);
@@ -705,23 +775,23 @@ __global__ __launch_bounds__(64) void dc_eval_wave_kernel(DcEvalAll A, const Mod
                 }
             }
         }
-        __syncthreads();
-        if (WRITE) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const u64 kk = wave_k0 + (u64)(8 * i + crow) * DC_EV + (u64)b * DC_EB + ccol * 8;
-                if (kk < J.E) *reinterpret_cast<uint4*>(Vout + kk) = *reinterpret_cast<const uint4*>(sout + (8 * i + crow) * DC_EROW + ccol * 16);
-            }
-            __syncthreads();
-        }
+        dc_wave_sync();
     }
+    if (WRITE) store_out(NB - 1);
     if (!WRITE && mine) { elo[c] = (u16)lo; ehi[c] = (u16)hi; }
+#if DC_EVAL_TIMING
+    {
+        u32 sb = slow_batches;
+        for (int d = 32; d >= 1; d >>= 1) { const u32 o = (u32)__shfl_xor((int)sb, d, 64); sb = sb > o ? sb : o; }
+        if (lane == 0) { tdbg[3 * gw] = (u32)(t_begin & 0xffffffffu); tdbg[3 * gw + 1] = (u32)(wall_clock64() - t_begin); tdbg[3 * gw + 2] = sb | ((u32)jb << 16); }
+    }
+#endif
 }
 
-__device__ __forceinline__ bool dc_chunk_continues(const DcEvalJob& J, u32 c)
+__device__ __forceinline__ bool dc_chunk_continues(const DcEvalJob& J, u32 c, u32 EV)
 {
     if (c == 0) return false;
-    const u32 k0 = c * DC_EV;
+    const u32 k0 = c * EV;
     u32 row = dc_find_row(J.rowstart, k0);
     if (J.rowstart[row] == k0) return false;                          // a row (hence a chain) starts exactly here
     // (an empty row cannot own k0: dc_find_row returns the last row starting at or before k0, which then is non-empty or k0 >= E)
@@ -741,23 +811,24 @@ __global__ __launch_bounds__(WG) void dc_eval_b_kernel(DcEvalAll A, const ModelP
     const DcEvalJob J = A.job[jb];
     const u16* elo = elo_all + A.cstart[jb]; const u16* ehi = ehi_all + A.cstart[jb]; u16* Sv = Sv_all + A.cstart[jb];
     const u32 c = g - A.cstart[jb];
-    const u64 k0 = (u64)c * DC_EV;
+    const u32 EV = A.ev;
+    const u64 k0 = (u64)c * EV;
     if (k0 >= J.E) return;
-    if (!dc_chunk_continues(J, c)) { Sv[c] = 2048; return; }
+    if (!dc_chunk_continues(J, c, EV)) { Sv[c] = 2048; return; }
     if (elo[c - 1] == ehi[c - 1]) { Sv[c] = elo[c - 1]; return; }
     // the predecessor did not coalesce: replay from the nearest chunk whose start value is known
     u32 j = c - 1;
     int start = 2048;
     u32 depth = 1;
     for (;;) {
-        if (!dc_chunk_continues(J, j)) { start = 2048; break; }
+        if (!dc_chunk_continues(J, j, EV)) { start = 2048; break; }
         if (elo[j - 1] == ehi[j - 1]) { start = elo[j - 1]; break; }
         --j; ++depth;
         if (depth > 64) { atomicOr(&meta[DM_FAIL], (u32)FAIL_REPLAY); Sv[c] = 2048; return; }
     }
     atomicAdd(&meta[DM_REPLAYS], depth);
     int lo = start, hi = start;
-    dc_walk<false>(J, mp, j * DC_EV, c * DC_EV, lo, hi, false, nullptr);          // exact walk (lo == hi throughout), no output
+    dc_walk<false>(J, mp, j * EV, c * EV, lo, hi, false, nullptr);          // exact walk (lo == hi throughout), no output
     Sv[c] = (u16)lo;
 }
 
@@ -909,7 +980,7 @@ int devcoder_ensure(bscgpu_ctx* c)
         {(void**)&d->present, 64 * 4}, {(void**)&d->rounds, 256},
         {(void**)&d->meta, DM_COUNT * 4}, {(void**)&d->poff, 16 * 4},
         {(void**)&d->tab_rank, 32768}, {(void**)&d->tab_run, 8192}, {(void**)&d->mp, sizeof(ModelParams)},
-        {(void**)&d->rowbins, DC_ROWS * sizeof(DcRowBins)},
+        {(void**)&d->rowbins, DC_ROWS * sizeof(DcRowBins)}, {(void**)&d->sink, 4096},
     };
     size_t total = 0;
     for (auto& cv : carve) total += dc_align(cv.bytes);
@@ -919,6 +990,12 @@ int devcoder_ensure(bscgpu_ctx* c)
     for (auto& cv : carve) { *cv.p = d->arena + off; off += dc_align(cv.bytes); }
     if (hipHostMalloc((void**)&d->hmeta, 64 * 4, hipHostMallocDefault) != hipSuccess) { hipFree(d->arena); delete d; return BSC_NOT_ENOUGH_MEMORY; }
     ModelParams mp; model_params_from_table(bschost::qlfc_static_params(), mp);
+    // more than 64 KB of dynamic LDS is a per-device attribute of the function: set for every context's device
+    if (hipFuncSetAttribute((const void*)dc_eval_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DC_EVAL_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)dc_eval_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DC_EVAL_LDS) != hipSuccess) {
+        (void)hipFree(d->arena); (void)hipHostFree(d->hmeta); delete d;
+        return ctx_fail(c, BSC_GPU_ERROR, "device coder: LDS attribute", hipSuccess);
+    }
     static DcRowBins rowbins[DC_ROWS];
     static const bool rowbins_ok = dc_build_rowbins(rowbins);
     if (!rowbins_ok) { (void)hipFree(d->arena); (void)hipHostFree(d->hmeta); delete d; return ctx_fail(c, BSC_GPU_ERROR, "device coder: bin layout", hipSuccess); }
@@ -1012,22 +1089,32 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     if (E[0] != E[1] || E[0] != E[2] + E[3]) return ctx_fail(c, BSC_GPU_ERROR, "device coder: decision counts of the families differ", hipSuccess);
     {
         DcEvalAll A;
-        A.wstart[0] = 0; A.cstart[0] = 0;
+        A.wstart[0] = 0; A.cstart[0] = 0; A.sink = d->sink;
+        // One lane is one serial chain, so the walks are VALU-issue bound with ONE wavefront per SIMD (1024 of them); a few
+        // wavefronts more than that and some SIMDs get two, which doubles the kernel's time.  Chunks are therefore DC_EV events
+        // (what the brackets need to meet) or as many as it takes to stay at <= 1000 wavefronts (+ <= 4 of padding) per launch.
+        {
+            const u64 Etot = (u64)E[0] + E[1] + E[2] + E[3];
+            u64 ev = (Etot + 64ull * 1000 - 1) / (64ull * 1000);
+            ev = (ev + DC_EB - 1) / DC_EB * DC_EB;
+            A.ev = ev < (u64)DC_EV ? (u32)DC_EV : (u32)ev;
+        }
         for (int job = 0; job < 4; ++job) {
             const int fam = job == 0 ? FAM_STATIC : job == 1 ? FAM_CHAR : FAM_STATE;
             A.job[job].events = d->events[job]; A.job[job].E = E[job]; A.job[job].rowstart = d->rowstart + (DC_ROWS + 8) * job;
             A.job[job].fam = fam;
             A.V[job] = d->V[job];
-            const u32 nch = (E[job] + DC_EV - 1) / DC_EV;
+            const u32 nch = (E[job] + A.ev - 1) / A.ev;
             A.wstart[job + 1] = A.wstart[job] + (nch + 63) / 64;
             A.cstart[job + 1] = A.cstart[job] + (nch + 63) / 64 * 64;           // chunk slots padded to whole wavefronts
         }
         if (A.cstart[4] > 4 * d->nch_cap) return ctx_fail(c, BSC_GPU_ERROR, "device coder: chunk table too small", hipSuccess);
         prof_begin(c, BSCGPU_K_DC_EVAL, (u64)E[0] * 18, (u64)E[0] * 3);
         if (A.wstart[4] > 0) {
-            hipLaunchKernelGGL(dc_eval_wave_kernel<false>, dim3(A.wstart[4]), dim3(64), 0, c->stream, A, d->mp, d->meta, d->elo, d->ehi, (const u16*)nullptr);
+            hipLaunchKernelGGL(dc_mark_rows_kernel, dim3((4 * DC_ROWS + WG - 1) / WG), dim3(WG), 0, c->stream, A);
+            hipLaunchKernelGGL(dc_eval_wave_kernel<false>, dim3((A.wstart[4] + DC_EVAL_WAVES - 1) / DC_EVAL_WAVES), dim3(64 * DC_EVAL_WAVES), DC_EVAL_LDS, c->stream, A, d->mp, d->meta, d->elo, d->ehi, (const u16*)nullptr, d->cnt);
             hipLaunchKernelGGL(dc_eval_b_kernel, dim3((A.cstart[4] + WG - 1) / WG), dim3(WG), 0, c->stream, A, d->mp, d->meta, d->elo, d->ehi, d->S);
-            hipLaunchKernelGGL(dc_eval_wave_kernel<true>, dim3(A.wstart[4]), dim3(64), 0, c->stream, A, d->mp, d->meta, (u16*)nullptr, (u16*)nullptr, d->S);
+            hipLaunchKernelGGL(dc_eval_wave_kernel<true>, dim3((A.wstart[4] + DC_EVAL_WAVES - 1) / DC_EVAL_WAVES), dim3(64 * DC_EVAL_WAVES), DC_EVAL_LDS, c->stream, A, d->mp, d->meta, (u16*)nullptr, (u16*)nullptr, d->S, d->cnt + 3 * 4096);
         }
         prof_end(c);
     }
@@ -1049,6 +1136,19 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     if (d->hmeta[DM_FAIL] != 0) { c->dc_last_fail = (int)d->hmeta[DM_FAIL]; return BSC_NOT_SUPPORTED; }
     c->dc_last_fail = 0;
     c->dc_replays = (int)d->hmeta[DM_REPLAYS];
+#if DC_EVAL_TIMING
+    {
+        std::vector<u32> h(6 * 4096);
+        (void)hipMemcpy(h.data(), d->cnt, h.size() * 4, hipMemcpyDeviceToHost);
+        const u32 nw = 1100;
+        for (int pass = 0; pass < 2; ++pass) {
+            const u32* t = h.data() + pass * 3 * 4096;
+            u32 t0 = 0xffffffffu; for (u32 i = 0; i < nw && i < 4096; ++i) if (t[3 * i + 1] && t[3 * i] < t0) t0 = t[3 * i];
+            fprintf(stderr, "[eval timing pass %d] wave: start(us) dur(us) maxslowbatches job\n", pass);
+            for (u32 i = 0; i < nw && i < 4096; ++i) if (t[3 * i + 1]) fprintf(stderr, "  %u %.1f %.1f %u %u\n", i, (t[3 * i] - t0) / 100.0, t[3 * i + 1] / 100.0, t[3 * i + 2] & 0xffff, t[3 * i + 2] >> 16);
+        }
+    }
+#endif
     if (getenv("BSCGPU_DEBUG")) fprintf(stderr, "[devcoder] decisions %u, types %u, rounds %u, chunks replayed %u\n", E[0], d->hmeta[DM_NTYPES], d->hmeta[DM_NROUNDS], d->hmeta[DM_REPLAYS]);
     *D_out = E[0];
     for (int b = 0; b <= nb; ++b) poff_out[b] = d->hmeta[32 + b];

@@ -146,70 +146,131 @@ struct QfRuns { u32 nblocks; u32 first[9]; };      // run index range of each su
 // the last run of a symbol in its sub-block, all distinct symbols that still follow); the last run of a sub-block is 1
 // (qlfc.cpp:249 / :449).  One lane per run walks forward: inside its own 256-run tile from an LDS copy, then over whole
 // tiles / super tiles whose set does not contain its symbol, then inside the tile that holds the next occurrence.
+// The walk lengths are extremely uneven (a frequent symbol comes back within a few runs, a rare one after thousands), and a
+// wavefront is as slow as its slowest lane: so every lane first walks at most QF_SHORT runs; the few that are still looking
+// are compacted through LDS and finished by the first wavefront(s) of the workgroup, lane per unfinished run, while the others
+// leave.  The long walks read the tile sets four at a time and the destination tile sixteen symbols per load.
+template <bool DENSE> struct QfSet;
+template <> struct QfSet<true> {
+    u64 a = 0;
+    __device__ __forceinline__ void add(u32 s) { a |= 1ull << s; }
+    __device__ __forceinline__ void merge(const u64* p) { a |= p[0]; }
+    __device__ __forceinline__ static bool has(const u64* p, u32 c) { return (p[0] >> c) & 1ull; }
+    __device__ __forceinline__ u32 count() const { return (u32)__popcll(a); }
+    __device__ __forceinline__ void store(u64* q) const { q[0] = a; }
+    __device__ __forceinline__ void load(const u64* q) { a = q[0]; }
+};
+template <> struct QfSet<false> {
+    u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    __device__ __forceinline__ void add(u32 s) {
+        const u64 bit = 1ull << (s & 63);
+        const u32 w = s >> 6;
+        a0 |= (w == 0) ? bit : 0; a1 |= (w == 1) ? bit : 0; a2 |= (w == 2) ? bit : 0; a3 |= (w == 3) ? bit : 0;
+    }
+    __device__ __forceinline__ void merge(const u64* p) { a0 |= p[0]; a1 |= p[1]; a2 |= p[2]; a3 |= p[3]; }
+    __device__ __forceinline__ static bool has(const u64* p, u32 c) { return (p[c >> 6] >> (c & 63)) & 1ull; }
+    __device__ __forceinline__ u32 count() const { return (u32)(__popcll(a0) + __popcll(a1) + __popcll(a2) + __popcll(a3)); }
+    __device__ __forceinline__ void store(u64* q) const { q[0] = a0; q[1] = a1; q[2] = a2; q[3] = a3; }
+    __device__ __forceinline__ void load(const u64* q) { a0 = q[0]; a1 = q[1]; a2 = q[2]; a3 = q[3]; }
+};
+#ifndef QF_SHORT_N
+#define QF_SHORT_N 48
+#endif
+constexpr u32 QF_SHORT = QF_SHORT_N;
+
 template <bool DENSE>
 __global__ __launch_bounds__(WG) void qf_rank_kernel(const u8* __restrict__ sym, u32 m, QfRuns rb, const u8* __restrict__ lut,
                                                      const u64* __restrict__ masks, const u64* __restrict__ super,
                                                      u8* __restrict__ rank)
 {
+    constexpr int W = DENSE ? 1 : 4;
     __shared__ u8 scode[WG];
     __shared__ u8 slut[256];
+    __shared__ u32 qn;
+    __shared__ u8 qt[WG];
+    __shared__ u16 qi[WG];
+    __shared__ u64 qset[WG * W];
     const u32 base = blockIdx.x * WG, t = threadIdx.x;
-    const u32 j = base + t;
     if (DENSE) slut[t] = lut[t];
-    const u32 raw = (j < m) ? sym[j] : 0u;
-    __syncthreads();
-    scode[t] = (u8)(DENSE ? slut[raw] : raw);
-    __syncthreads();
-    if (j >= m) return;
-    u32 re = m;
-#pragma unroll
-    for (int b = 8; b >= 1; --b) if ((u32)b <= rb.nblocks && j < rb.first[b]) re = rb.first[b];
-    if (j + 1 == re) { rank[j] = 1; return; }
-    const u32 c = scode[t];
-    u32 i = j + 1;
-    bool found = false;
-    if (DENSE) {
-        u64 set = 0;
-        const u64 cbit = 1ull << c;
-        while (i < re && (i & 255u) != 0) { const u32 s = scode[i - base]; if (s == c) { found = true; break; } set |= 1ull << s; ++i; }
-        if (!found) {
-            while (i + 256 <= re) {
-                if ((i & 65535u) == 0 && i + 65536 <= re) {
-                    const u64 sm = super[i >> 16];
-                    if (!(sm & cbit)) { set |= sm; i += 65536; continue; }
-                }
-                const u64 tm = masks[i >> 8];
-                if (tm & cbit) break;
-                set |= tm;
-                i += 256;
-            }
-            while (i < re) { const u32 s = slut[sym[i]]; if (s == c) break; set |= 1ull << s; ++i; }
-        }
-        rank[j] = (u8)__popcll(set);
-    } else {
-        u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        auto add = [&](u32 s) {
-            const u64 bit = 1ull << (s & 63);
-            const u32 w = s >> 6;
-            s0 |= (w == 0) ? bit : 0; s1 |= (w == 1) ? bit : 0; s2 |= (w == 2) ? bit : 0; s3 |= (w == 3) ? bit : 0;
-        };
-        const u32 cw = c >> 6; const u64 cbit = 1ull << (c & 63);
-        while (i < re && (i & 255u) != 0) { const u32 s = scode[i - base]; if (s == c) { found = true; break; } add(s); ++i; }
-        if (!found) {
-            while (i + 256 <= re) {
-                if ((i & 65535u) == 0 && i + 65536 <= re) {
-                    const u64* sm = super + (size_t)(i >> 16) * 4;
-                    if (!(sm[cw] & cbit)) { s0 |= sm[0]; s1 |= sm[1]; s2 |= sm[2]; s3 |= sm[3]; i += 65536; continue; }
-                }
-                const u64* tm = masks + (size_t)(i >> 8) * 4;
-                if (tm[cw] & cbit) break;
-                s0 |= tm[0]; s1 |= tm[1]; s2 |= tm[2]; s3 |= tm[3];
-                i += 256;
-            }
-            while (i < re) { const u32 s = sym[i]; if (s == c) break; add(s); ++i; }
-        }
-        rank[j] = (u8)(__popcll(s0) + __popcll(s1) + __popcll(s2) + __popcll(s3));
+    if (t == 0) qn = 0;
+    {
+        const u32 j = base + t;
+        const u32 raw = (j < m) ? sym[j] : 0u;
+        __syncthreads();
+        scode[t] = (u8)(DENSE ? slut[raw] : raw);
     }
+    __syncthreads();
+    auto sub_end = [&](u32 j) {
+        u32 re = m;
+#pragma unroll
+        for (int b = 8; b >= 1; --b) if ((u32)b <= rb.nblocks && j < rb.first[b]) re = rb.first[b];
+        return re;
+    };
+    {   // every lane: at most QF_SHORT runs ahead, inside the tile
+        const u32 j = base + t;
+        if (j < m) {
+            const u32 re = sub_end(j);
+            if (j + 1 == re) rank[j] = 1;
+            else {
+                const u32 c = scode[t];
+                u32 lim = re < base + WG ? re : base + WG;
+                if (lim > j + 1 + QF_SHORT) lim = j + 1 + QF_SHORT;
+                QfSet<DENSE> set;
+                u32 i = j + 1;
+                bool found = false;
+                while (i < lim) { const u32 s = scode[i - base]; if (s == c) { found = true; break; } set.add(s); ++i; }
+                if (found || i == re) rank[j] = (u8)set.count();
+                else {
+                    const u32 slot = atomicAdd(&qn, 1u);
+                    qt[slot] = (u8)t; qi[slot] = (u16)(i - base); set.store(&qset[slot * W]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (t >= qn) return;
+    // the unfinished runs, one per lane
+    const u32 tt = qt[t];
+    const u32 j = base + tt;
+    const u32 re = sub_end(j);
+    const u32 c = scode[tt];
+    u32 i = base + qi[t];
+    QfSet<DENSE> set; set.load(&qset[t * W]);
+    bool found = false;
+    while (i < re && (i & 255u) != 0) { const u32 s = scode[i - base]; if (s == c) { found = true; break; } set.add(s); ++i; }
+    if (!found) {
+        while (i + 256 <= re) {
+            if ((i & 65535u) == 0 && i + 65536 <= re) {
+                const u64* sm = super + (size_t)(i >> 16) * W;
+                if (!QfSet<DENSE>::has(sm, c)) { set.merge(sm); i += 65536; continue; }
+            }
+            if (DENSE && (i & 1023u) == 0 && i + 1024 <= re) {                 // four one-word tile sets per 32 bytes
+                const ulonglong2 x = *reinterpret_cast<const ulonglong2*>(masks + (i >> 8));
+                const ulonglong2 y = *reinterpret_cast<const ulonglong2*>(masks + (i >> 8) + 2);
+                const u64 all = x.x | x.y | y.x | y.y;
+                if (!QfSet<DENSE>::has(&all, c)) { set.merge(&all); i += 1024; continue; }
+            }
+            const u64* tm = masks + (size_t)(i >> 8) * W;
+            if (QfSet<DENSE>::has(tm, c)) break;
+            set.merge(tm);
+            i += 256;
+        }
+        // the destination tile (or the sub-block's last, partial one): i is a multiple of 256, sixteen symbols per load
+        while (i < re) {
+            const uint4 q = *reinterpret_cast<const uint4*>(sym + i);
+            const u32 wds[4] = {q.x, q.y, q.z, q.w};
+            bool hit = false;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const u32 raw = (wds[b >> 2] >> (8 * (b & 3))) & 0xffu;
+                const u32 s = DENSE ? slut[raw] : raw;
+                if (!hit && i + b < re) { if (s == c) hit = true; else set.add(s); }
+            }
+            if (hit) break;
+            i += 16;
+        }
+    }
+    rank[j] = (u8)set.count();
 }
 
 // -------------------------------------------------------------------------------------------------
