@@ -27,6 +27,7 @@
 //    reordered through LDS (32 / 64 KB staging) so that every bucket leaves as one contiguous run:
 //    consecutive lanes store consecutive addresses.  Integer/index work only — no MFMA.
 #include "dev_common.h"
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -52,6 +53,16 @@ typedef __attribute__((address_space(3))) volatile u32 lds_vu32;
 #ifndef RS_WC_DEFAULT
 #define RS_WC_DEFAULT 0        // default of BSC_RS_WC (write-combining scatter for large inputs)
 #endif
+// Phase timing (debug builds, -DRS_PHASE_TIMING=1): thread 0 of every workgroup stamps s_memtime at the phase boundaries of
+// its first 32 tiles into the context's scratch buffer; radix_sort_passes dumps the last pass to gpurun_out/phase_timing.bin.
+#ifndef RS_PHASE_TIMING
+#define RS_PHASE_TIMING 0
+#endif
+#if RS_PHASE_TIMING
+#define RS_PH(i) do { if (t == 0 && tile_no < 32u) tdbg[((size_t)blockIdx.x * 32 + tile_no) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RS_PH(i) do { } while (0)
+#endif
 constexpr int RS_WAVES = RS_WG / 64;
 #ifndef RS_ITEMS_N
 #define RS_ITEMS_N 16
@@ -66,6 +77,9 @@ constexpr int RS_MAX_CHUNKS = 256 * (1024 / RS_WG);       // all workgroups resi
 #endif
 #ifndef RSB_ITEMS_N
 #define RSB_ITEMS_N 8
+#endif
+#ifndef RSB_PIPE
+#define RSB_PIPE 1      // software-pipelined loads in the 1024 x 8 shape (A/B builds: 0)
 #endif
 constexpr int RSB_WG = 1024, RSB_ITEMS = RSB_ITEMS_N, RSB_SPAN = 4;
 constexpr int RSB_LDS = RSB_WG * RSB_ITEMS * 8 + (RSB_WG / 64) * 256 * 4 + 3 * 256 * 4 + 16 * 4;      // 85,056 B -> 1 WG (16 waves) / CU
@@ -83,11 +97,12 @@ static inline Chunking rs_chunking(u64 n) {
 
 // Exclusive sum over the first 256 threads' values (one per digit); every thread of the workgroup calls it
 // (threads >= 256 pass 0).  scr: RS_WAVES u32.
-template <int WAVES = RS_WAVES>
+// LEAD_BARRIER = false: the caller guarantees that nobody still reads scr from an earlier call.
+template <int WAVES = RS_WAVES, bool LEAD_BARRIER = true>
 __device__ __forceinline__ u32 rs_digit_excl_sum(u32 v, u32* scr, u32* total) {
     const u32 incl = wave_incl_sum(v);
     const u32 w = threadIdx.x >> 6, l = lane_id();
-    __syncthreads();
+    if (LEAD_BARRIER) __syncthreads();
     if (l == 63) scr[w] = incl;
     __syncthreads();
     u32 base = 0, tot = 0;
@@ -95,6 +110,77 @@ __device__ __forceinline__ u32 rs_digit_excl_sum(u32 v, u32* scr, u32* total) {
     for (int i = 0; i < WAVES; ++i) { const u32 t = scr[i]; if ((u32)i < w) base += t; tot += t; }
     *total = tot;
     return base + incl - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// In-wave match on an 8-bit digit: (mlo, mhi) = mask of the lanes whose digit equals this lane's.  Per digit bit: one
+// sign-extended bit extract (t = all-ones if the bit is set), one compare that IS the ballot (it writes an SGPR pair), and
+// one 3-input boolean op per 32-bit half, m &= ~(ballot ^ t) (v_bitop3 table 0x90) — 32 VALU instructions per record.
+// Written as one asm block because the compiler's own lowering of the same expression takes ~8 instructions per bit
+// (shift, compare, not, arithmetic shift, two xors, two 3-input ands), and the ranking loop is what the scatter kernels'
+// VALU time goes into.  gfx950 needs two wait states between a VALU write of an SGPR and a VALU read of it, so two SGPR
+// pairs (vcc and s[98:99]) alternate and every ballot is consumed three or more instructions after it was produced.
+// All 64 lanes must be active.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rs_match8(const u32 d, u32& mlo, u32& mhi)
+{
+    u32 lo = ~0u, hi = ~0u, t0, t1, t2;
+    asm volatile(
+        "v_bfe_i32 %2, %5, 0, 1\n\t"
+        "v_bfe_i32 %3, %5, 1, 1\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %2\n\t"
+        "v_cmp_ne_u32_e64 s[98:99], 0, %3\n\t"
+        "v_bfe_i32 %4, %5, 2, 1\n\t"
+        "v_bitop3_b32 %0, %0, vcc_lo, %2 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, vcc_hi, %2 bitop3:0x90\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %4\n\t"
+        "v_bfe_i32 %2, %5, 3, 1\n\t"
+        "v_bitop3_b32 %0, %0, s98, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s99, %3 bitop3:0x90\n\t"
+        "v_cmp_ne_u32_e64 s[98:99], 0, %2\n\t"
+        "v_bfe_i32 %3, %5, 4, 1\n\t"
+        "v_bitop3_b32 %0, %0, vcc_lo, %4 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, vcc_hi, %4 bitop3:0x90\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %3\n\t"
+        "v_bfe_i32 %4, %5, 5, 1\n\t"
+        "v_bitop3_b32 %0, %0, s98, %2 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s99, %2 bitop3:0x90\n\t"
+        "v_cmp_ne_u32_e64 s[98:99], 0, %4\n\t"
+        "v_bfe_i32 %2, %5, 6, 1\n\t"
+        "v_bitop3_b32 %0, %0, vcc_lo, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, vcc_hi, %3 bitop3:0x90\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %2\n\t"
+        "v_bfe_i32 %3, %5, 7, 1\n\t"
+        "v_bitop3_b32 %0, %0, s98, %4 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s99, %4 bitop3:0x90\n\t"
+        "v_cmp_ne_u32_e64 s[98:99], 0, %3\n\t"
+        "v_bitop3_b32 %0, %0, vcc_lo, %2 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, vcc_hi, %2 bitop3:0x90\n\t"
+        "v_bitop3_b32 %0, %0, s98, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s99, %3 bitop3:0x90"
+        : "+v"(lo), "+v"(hi), "=&v"(t0), "=&v"(t1), "=&v"(t2)
+        : "v"(d)
+        : "vcc", "s98", "s99");
+    mlo = lo; mhi = hi;
+}
+
+// Stable rank of ITEMS records per lane inside the wave's 64 * ITEMS records (item-major order: item i of all lanes comes
+// before item i + 1), by digit: rk[i] = number of earlier records of the wave with the same digit.  wh = the wave's 256
+// digit counters in LDS (zeroed by the caller), left holding the wave's digit histogram.
+template <int ITEMS>
+__device__ __forceinline__ void rs_rank_wave(const u64 (&k)[ITEMS], const int shift, const u32 mask, lds_vu32* wh, u32 (&rk)[ITEMS])
+{
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const u32 d = (u32)(k[i] >> shift) & mask;
+        u32 mlo, mhi;
+        rs_match8(d, mlo, mhi);
+        const u32 before = wh[d];                   // records of digit d seen by this wave so far
+        const u32 r      = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));   // peers in lower lanes
+        const u32 cnt    = (u32)(__popc(mlo) + __popc(mhi));
+        rk[i] = before + r;
+        if (r == cnt - 1) wh[d] = before + cnt;     // highest peer lane publishes
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -179,7 +265,11 @@ __global__ __launch_bounds__(WG) void rs_scan_kernel(u32* __restrict__ counts, u
 //            first-sort pass 0.447 -> 0.410 ms, whole BWT 11.5 -> 10.8 ms; keys-only (ST) is 6 % slower with it.
 // EMIT_POS: also write, for every input record (in input order, coalesced), the index it lands on — the inverse of the
 // pass's permutation, which the device coder needs to find a run inside its sorted copies (devcoder.hip).
-template <bool HAS_VAL, int WGSZ, int ITEMS, int SPAN, bool EMIT_POS = false>
+// PIPE (the 1024 x 8 shape): the next tile's keys are requested as soon as this tile's keys sit in the staging area, its
+// values as soon as this tile's values do — ahead of the tile's stores in the wave's memory queue, into the registers the
+// current tile has just given up.  Phase stamps (RS_PHASE_TIMING) showed a one-workgroup-per-CU tile spending 60 % of its time
+// waiting: first for the previous tile's stores to drain before its own loads could even issue, then for those loads.
+template <bool HAS_VAL, int WGSZ, int ITEMS, int SPAN, bool EMIT_POS = false, bool PIPE = false>
 __global__ __launch_bounds__(WGSZ, 4) void rs_scatter_kernel(const u64* __restrict__ kin, u64* __restrict__ kout,
                                                         const u32* __restrict__ vin, u32* __restrict__ vout,
                                                         u32 n, int shift, u32 mask,
@@ -189,7 +279,7 @@ __global__ __launch_bounds__(WGSZ, 4) void rs_scatter_kernel(const u64* __restri
                                                         u32* __restrict__ dstpos = nullptr)
 {
     constexpr int WG = WGSZ, WAVES = WGSZ / 64, TILE = WGSZ * ITEMS;
-    (void)sink;
+    u64* const tdbg = sink; (void)tdbg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* skeys  = reinterpret_cast<u64*>(smem);                       // [TILE] staging (reused as u32 for values)
     u32* whist  = reinterpret_cast<u32*>(smem + TILE * 8);            // [WAVES][256] per-wave digit counts / prefixes
@@ -200,27 +290,237 @@ __global__ __launch_bounds__(WGSZ, 4) void rs_scatter_kernel(const u64* __restri
     lds_vu32* vwh = (lds_vu32*)whist;
 
     const u32 t = threadIdx.x, w = t >> 6, lane = t & 63;
-    const u64 lt = lanemask_lt();
 
     {   // global offset of this chunk's first record of digit t
         u32 tot;
         const u32 base = rs_digit_excl_sum<WAVES>(t < 256 ? rowtot[t] : 0u, scr, &tot);
         if (t < 256) goff[t] = base + offsets[(size_t)t * num_chunks + (size_t)blockIdx.x * SPAN];
     }
+    // every wave owns (and re-zeroes, see below) its 256 counters
+#pragma unroll
+    for (int i = 0; i < 4; ++i) whist[w * 256 + i * 64 + lane] = 0;
     __syncthreads();
 
-    // this workgroup's records: SPAN consecutive rs_hist chunks (chunk_tiles tiles of RS_TILE records each)
-    const u64 rec0 = (u64)blockIdx.x * SPAN * chunk_tiles * RS_TILE;
-    u64 rec1 = rec0 + (u64)SPAN * chunk_tiles * RS_TILE;
-    if (rec1 > n) rec1 = n;
+    // this workgroup's records: SPAN consecutive rs_hist chunks (chunk_tiles tiles of RS_TILE records each); n < 2^32 - 2^20
+    const u32 rec0 = (u32)((u64)blockIdx.x * SPAN * chunk_tiles * RS_TILE);
+    u32 rec1;
+    { const u64 e = (u64)rec0 + (u64)SPAN * chunk_tiles * RS_TILE; rec1 = e > n ? n : (u32)e; }
+
+    // wave-striped ownership: wave w holds records [w*64*ITEMS, (w+1)*64*ITEMS) of the tile, item i = 64 consecutive records
+    const u32 wbase = w * (64 * ITEMS) + lane;
+    u64 k[ITEMS];
+    u32 v[ITEMS];
+    // PIPE loads never sit behind a branch: a lane past the end of the workgroup's records reads its first record instead
+    // (one cache line for the whole wave) and the value is replaced where it is used.
+    auto prefetch_keys = [&](const u32 tb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) { u32 e = tb + wbase + i * 64; e = e < rec1 ? e : rec0; k[i] = __builtin_nontemporal_load(&kin[e]); }
+    };
+    auto prefetch_vals = [&](const u32 tb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) { u32 e = tb + wbase + i * 64; e = e < rec1 ? e : rec0; v[i] = __builtin_nontemporal_load(&vin[e]); }
+    };
+    if (PIPE) { prefetch_keys(rec0); if (HAS_VAL) prefetch_vals(rec0); }
 
     // Full tiles run without any branch around a global load or store, so the compiler can wait with exact vmcnt values
-    // (a guarded memory instruction makes the number of outstanding operations unknown and every later wait vmcnt(0));
+    // (a guarded memory instruction makes the number of outstanding operations unknown and later waits conservative);
     // the one partial tile of the whole input is handled by a second, guarded instantiation after the loop.
+    // Barriers per tile: after ranking, inside and after the digit scan, after the staging writes, and two around the value
+    // staging.  None at the end of a tile: what the next tile writes first (its own wave's counters, then — behind its first
+    // barrier — adj / goff) is not read by anyone still in this tile's write-out.
+    auto do_tile = [&](const u32 tbase, const u32 nvalid, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const u32 tile_no = (tbase - rec0) / TILE; (void)tile_no;
+        RS_PH(0);
+
+        if (!PIPE) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const u32 idx = wbase + i * 64;
+                if (FULL) k[i] = __builtin_nontemporal_load(&kin[(u64)tbase + idx]);
+                else k[i] = (idx < nvalid) ? __builtin_nontemporal_load(&kin[(u64)tbase + idx]) : ~0ull;
+            }
+        } else if (!FULL) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) if (wbase + i * 64 >= nvalid) k[i] = ~0ull;       // padding sorts last
+        }
+        RS_PH(1);
+
+        // ---- stable in-wave ranking by ballot match (rs_rank_wave) --------------------------------
+        u32 rk[ITEMS];
+        rs_rank_wave<ITEMS>(k, shift, mask, vwh + w * 256, rk);
+        RS_PH(2);
+        // values are fetched only now (they are not needed for ranking): keeps the ranking loop's
+        // register footprint at 4 waves/SIMD, and the loads fly under the bucket scan + key reorder.
+        if (HAS_VAL && !PIPE) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const u32 idx = wbase + i * 64;
+                if (FULL) v[i] = __builtin_nontemporal_load(&vin[(u64)tbase + idx]);
+                else v[i] = (idx < nvalid) ? __builtin_nontemporal_load(&vin[(u64)tbase + idx]) : 0u;
+            }
+        }
+        __syncthreads();
+        RS_PH(3);
+
+        // ---- per digit: wave prefixes, tile-local bucket start, global adjust -------------------
+        {
+            u32 c[WAVES];
+            u32 tot = 0;
+            if (t < 256) {
+#pragma unroll
+                for (int i = 0; i < WAVES; ++i) { c[i] = whist[i * 256 + t]; tot += c[i]; }
+            }
+            u32 all;
+            const u32 ds = rs_digit_excl_sum<WAVES, false>(tot, scr, &all);
+            if (t < 256) {
+                u32 run = ds;
+#pragma unroll
+                for (int i = 0; i < WAVES; ++i) { whist[i * 256 + t] = run; run += c[i]; }
+                const u32 g = goff[t];
+                adj[t]  = g - ds;
+                goff[t] = g + tot;
+            }
+        }
+        __syncthreads();
+        RS_PH(4);
+
+        // ---- local reorder through LDS --------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const u32 d = (u32)(k[i] >> shift) & mask;
+            const u32 pos = whist[w * 256 + d] + rk[i];
+            rk[i] = pos;
+            skeys[pos] = k[i];
+            if (EMIT_POS) { const u32 idx = wbase + i * 64; if (FULL || idx < nvalid) dstpos[(u64)tbase + idx] = adj[d] + pos; }
+        }
+        if (PIPE) prefetch_keys(tbase + TILE);
+        RS_PH(5);
+        __syncthreads();
+        RS_PH(6);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) whist[w * 256 + i * 64 + lane] = 0;       // for the next tile's ranking (own wave's counters only)
+
+        u32 dd[ITEMS / 4];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 q = j * WG + t;
+            const u64 key = skeys[q];
+            const u32 d = (u32)(key >> shift) & mask;
+            if ((j & 3) == 0) dd[j >> 2] = d; else dd[j >> 2] |= d << (8 * (j & 3));
+            if (FULL || q < nvalid) kout[adj[d] + q] = key;
+        }
+        RS_PH(7);
+
+        if (HAS_VAL) {
+            __syncthreads();
+            u32* svals = reinterpret_cast<u32*>(skeys);
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) svals[rk[i]] = v[i];
+            if (PIPE) prefetch_vals(tbase + TILE);
+            __syncthreads();
+            RS_PH(8);
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const u32 q = j * WG + t;
+                const u32 d = (dd[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                if (FULL || q < nvalid) vout[adj[d] + q] = svals[q];
+            }
+        }
+        RS_PH(9);
+        RS_PH(10);
+        };
+    u32 tbase = rec0;
+    for (; tbase + TILE <= rec1; tbase += TILE) do_tile(tbase, (u32)TILE, std::true_type());
+    if (tbase < rec1) do_tile(tbase, rec1 - tbase, std::false_type());
+}
+
+// ---------------------------------------------------------------------------------------------
+// rs_scatter_wc: the digit pass with write combining (large inputs).
+//
+// What limits rs_scatter above on uniform digits is not bytes but write *requests*: a tile leaves 256 runs of ~32
+// records, i.e. ~256 B of keys and ~128 B of values at arbitrary 8-/4-byte alignment, so every run touches two
+// partially written 128-B lines per array (tools/ubench.hip: pairs in aligned full lines 5.1 TB/s, the same bytes as
+// misaligned 16-record runs 2.4 TB/s, aligned 128-B key lines with 64-B value half-lines 3.8-4.1 TB/s; HBM byte counters
+// stay at the algorithmic volume in all cases).  Here a workgroup keeps, per digit, the records that do not yet fill a
+// line: keys are written only as whole 16-key groups on 16-key boundaries of the output (one full 128-B line), values
+// only as whole 32-value groups on 32-value boundaries (one full line); the unaligned head of a (chunk, digit) segment
+// and its tail are written once each.  Output is identical to rs_scatter (same stable order).
+//
+// Shape: the 1024 x 8 shape of rs_scatter (8192-record tiles, one workgroup per CU walking four of rs_hist's chunks), so
+// that the fixed per-tile work (digit scan, flushes, barriers) is spread over 8 records per lane; the first version of
+// this kernel (4096-record tiles, 32-record groups for both arrays = 96 KB of pending records) was VALU-issue-bound.
+// Pending records live in LDS rings indexed by the OUTPUT position (slot = position mod group size): a record never
+// moves between becoming pending and being written.  State per digit (one thread each, in registers): E = output
+// position behind the last record seen, gk / gv = first key / value position not yet written (gk = max(segment start,
+// E rounded down to 16), gv likewise with 32).
+// ---------------------------------------------------------------------------------------------
+constexpr int WC_WG = 1024, WC_WAVES = WC_WG / 64, WC_ITEMS = 8, WC_TILE = WC_WG * WC_ITEMS, WC_GK = 16, WC_GV = 32, WC_SPAN = 4;
+constexpr int WC_LDS_KEYS  = WC_TILE * 8 + 256 * WC_GK * 8 + WC_WAVES * 256 * 4 + 4 * 256 * 4 + 16 * 4;
+constexpr int WC_LDS_PAIRS = WC_LDS_KEYS + 256 * WC_GV * 4 + 3 * 256 * 4;
+static_assert(WC_LDS_PAIRS <= 160 * 1024, "rs_scatter_wc does not fit the CU's LDS");
+
+template <bool HAS_VAL>
+__global__ __launch_bounds__(WC_WG) void rs_scatter_wc_kernel(const u64* __restrict__ kin, u64* __restrict__ kout,
+                                                              const u32* __restrict__ vin, u32* __restrict__ vout,
+                                                              u32 n, int shift, u32 mask,
+                                                              u32 chunk_tiles, u32 num_chunks,
+                                                              const u32* __restrict__ offsets,
+                                                              const u32* __restrict__ rowtot, u64* __restrict__ tdbg)
+{
+    (void)tdbg;
+    constexpr int WG = WC_WG, WAVES = WC_WAVES, ITEMS = WC_ITEMS, TILE = WC_TILE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* skeys = reinterpret_cast<u64*>(smem);                        // [TILE] staging (reused as u32 for values)
+    u64* pendK = skeys + TILE;                                        // [256][16] pending keys, ring by output position
+    u32* whist = reinterpret_cast<u32*>(pendK + 256 * WC_GK);         // [16][256] per-wave digit counts / prefixes
+    u32* infoA = whist + WAVES * 256;                                 // [256] staging slot q of digit d is output position q + A
+    u32* infoK = infoA + 256;                                         // [256] (first slot that stays pending) | (end of valid slots) << 16, keys
+    u32* fkS   = infoK + 256;                                         // [256] old pending keys to write this tile: positions [fkS, fkE)
+    u32* fkE   = fkS + 256;
+    u32* scr   = fkE + 256;                                           // [16]
+    u32* pendV = scr + 16;                                            // [256][32] pending values (pairs only)
+    u32* infoV = pendV + 256 * WC_GV;                                 // [256] as infoK, values
+    u32* fvS   = infoV + 256;
+    u32* fvE   = fvS + 256;
+    lds_vu32* vwh = (lds_vu32*)whist;
+
+    const u32 t = threadIdx.x, w = t >> 6, lane = t & 63;
+
+    u32 E = 0, gk = 0, gv = 0;              // digit state of thread t < 256
+    {
+        u32 tot;
+        const u32 base = rs_digit_excl_sum<WAVES>(t < 256 ? rowtot[t] : 0u, scr, &tot);
+        if (t < 256) { E = base + offsets[(size_t)t * num_chunks + (size_t)blockIdx.x * WC_SPAN]; gk = gv = E; }
+    }
+    __syncthreads();
+
+    const u64 rec0 = (u64)blockIdx.x * WC_SPAN * chunk_tiles * RS_TILE;
+    u64 rec1 = rec0 + (u64)WC_SPAN * chunk_tiles * RS_TILE;
+    if (rec1 > n) rec1 = n;
+
+    // old pending records of the digits that reached a group boundary: 16 lanes per digit (keys), 32 per digit (values)
+    auto flush_pending = [&]() __attribute__((always_inline)) {
+#pragma unroll 2
+        for (int s = 0; s < 256 / (WG / WC_GK); ++s) {
+            const u32 b = s * (WG / WC_GK) + (t >> 4);
+            const u32 pos = fkS[b] + (t & (WC_GK - 1));
+            if (pos < fkE[b]) kout[pos] = pendK[b * WC_GK + (pos & (WC_GK - 1))];
+        }
+        if (HAS_VAL) {
+#pragma unroll 2
+            for (int s = 0; s < 256 / (WG / WC_GV); ++s) {
+                const u32 b = s * (WG / WC_GV) + (t >> 5);
+                const u32 pos = fvS[b] + (t & (WC_GV - 1));
+                if (pos < fvE[b]) vout[pos] = pendV[b * WC_GV + (pos & (WC_GV - 1))];
+            }
+        }
+    };
+
     auto do_tile = [&](const u64 tbase, const u32 nvalid, auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
-
-        // ---- wave-striped loads: wave w owns records [w*1024, w*1024+1024) of the tile -------
+        const u32 tile_no = (u32)((tbase - rec0) / TILE); (void)tile_no;
+        RS_PH(0);
         u64 k[ITEMS];
         u32 v[ITEMS];
         const u32 wbase = w * (64 * ITEMS) + lane;
@@ -232,33 +532,12 @@ __global__ __launch_bounds__(WGSZ, 4) void rs_scatter_kernel(const u64* __restri
         }
         for (u32 i = t; i < (u32)WAVES * 256; i += WG) whist[i] = 0;
         __syncthreads();
+        RS_PH(1);
 
-        // ---- stable in-wave ranking by ballot match ---------------------------------------------
-        // peers(lane) = lanes whose digit equals this lane's.  Per digit bit: nb = all-ones if this lane's bit is
-        // clear; the lanes agreeing with us on that bit are (ballot ^ nb), so the running mask is one 3-input
-        // boolean op per 32-bit half (v_bitop3 on gfx950).
+        // ---- stable in-wave ranking by ballot match (rs_rank_wave) --------------------------------
         u32 rk[ITEMS];
-        const u32 lt_lo = (u32)lt, lt_hi = (u32)(lt >> 32);
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const u32 d = (u32)(k[i] >> shift) & mask;
-            u32 mlo = ~0u, mhi = ~0u;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int bitm = __builtin_amdgcn_sbfe((int)d, b, 1);         // -1 if bit b set, else 0
-                const u64 bal = __ballot(bitm != 0);
-                const u32 nb = ~(u32)bitm;
-                mlo &= (u32)bal ^ nb;
-                mhi &= (u32)(bal >> 32) ^ nb;
-            }
-            const u32 before = vwh[w * 256 + d];       // records of digit d seen by this wave so far
-            const u32 r      = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));   // peers in lower lanes
-            const u32 cnt    = (u32)(__popc(mlo) + __popc(mhi));
-            rk[i] = before + r;
-            if (r == cnt - 1) vwh[w * 256 + d] = before + cnt;   // highest peer lane publishes
-        }
-        // values are fetched only now (they are not needed for ranking): keeps the ranking loop's
-        // register footprint at 4 waves/SIMD, and the loads fly under the bucket scan + key reorder.
+        rs_rank_wave<ITEMS>(k, shift, mask, vwh + w * 256, rk);
+        RS_PH(2);
         if (HAS_VAL) {
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
@@ -268,8 +547,9 @@ __global__ __launch_bounds__(WGSZ, 4) void rs_scatter_kernel(const u64* __restri
             }
         }
         __syncthreads();
+        RS_PH(3);
 
-        // ---- per digit: wave prefixes, tile-local bucket start, global adjust -------------------
+        // ---- per digit: wave prefixes, tile-local start, what is written / kept this tile ----------
         {
             u32 c[WAVES];
             u32 tot = 0;
@@ -283,23 +563,35 @@ __global__ __launch_bounds__(WGSZ, 4) void rs_scatter_kernel(const u64* __restri
                 u32 run = ds;
 #pragma unroll
                 for (int i = 0; i < WAVES; ++i) { whist[i * 256 + t] = run; run += c[i]; }
-                const u32 g = goff[t];
-                adj[t]  = g - ds;
-                goff[t] = g + tot;
+                const u32 cv = tot - ((!FULL && t == mask) ? ((u32)TILE - nvalid) : 0u);      // padding records sort last
+                const u32 E0 = E, E1 = E0 + cv;
+                const u32 ak = E1 & ~(u32)(WC_GK - 1), av = E1 & ~(u32)(WC_GV - 1);
+                const u32 Fk = ak > gk ? ak : gk, Fv = av > gv ? av : gv;          // first positions still unwritten after this tile
+                infoA[t] = E0 - ds;
+                infoK[t] = (ds + (Fk > E0 ? Fk - E0 : 0u)) | ((ds + cv) << 16);
+                fkS[t] = gk; fkE[t] = (Fk > gk) ? E0 : gk;                         // a boundary was reached: everything pending leaves
+                if (HAS_VAL) {
+                    infoV[t] = (ds + (Fv > E0 ? Fv - E0 : 0u)) | ((ds + cv) << 16);
+                    fvS[t] = gv; fvE[t] = (Fv > gv) ? E0 : gv;
+                }
+                gk = Fk; gv = Fv; E = E1;
             }
         }
         __syncthreads();
+        RS_PH(4);
 
-        // ---- local reorder through LDS --------------------------------------------------------
+        // ---- local reorder of the keys; old pending records of the digits that flush leave now -------
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const u32 d = (u32)(k[i] >> shift) & mask;
             const u32 pos = whist[w * 256 + d] + rk[i];
             rk[i] = pos;
             skeys[pos] = k[i];
-            if (EMIT_POS) { const u32 idx = wbase + i * 64; if (FULL || idx < nvalid) dstpos[tbase + idx] = adj[d] + pos; }
         }
+        flush_pending();
+        RS_PH(5);
         __syncthreads();
+        RS_PH(6);
 
         u32 dd[ITEMS / 4];
 #pragma unroll
@@ -308,8 +600,11 @@ __global__ __launch_bounds__(WGSZ, 4) void rs_scatter_kernel(const u64* __restri
             const u64 key = skeys[q];
             const u32 d = (u32)(key >> shift) & mask;
             if ((j & 3) == 0) dd[j >> 2] = d; else dd[j >> 2] |= d << (8 * (j & 3));
-            if (FULL || q < nvalid) kout[adj[d] + q] = key;
+            const u32 B = infoK[d], pos = q + infoA[d];
+            if (q < (B & 0xffffu)) kout[pos] = key;
+            else if (q < (B >> 16)) pendK[d * WC_GK + (pos & (WC_GK - 1))] = key;
         }
+        RS_PH(7);
 
         if (HAS_VAL) {
             __syncthreads();
@@ -317,233 +612,27 @@ __global__ __launch_bounds__(WGSZ, 4) void rs_scatter_kernel(const u64* __restri
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) svals[rk[i]] = v[i];
             __syncthreads();
+            RS_PH(8);
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
                 const u32 q = j * WG + t;
                 const u32 d = (dd[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                if (FULL || q < nvalid) vout[adj[d] + q] = svals[q];
+                const u32 B = infoV[d], pos = q + infoA[d];
+                const u32 val = svals[q];
+                if (q < (B & 0xffffu)) vout[pos] = val;
+                else if (q < (B >> 16)) pendV[d * WC_GV + (pos & (WC_GV - 1))] = val;
             }
         }
+        RS_PH(9);
         __syncthreads();
-        };
+        RS_PH(10);
+    };
     u64 tbase = rec0;
     for (; tbase + TILE <= rec1; tbase += TILE) do_tile(tbase, (u32)TILE, std::true_type());
     if (tbase < rec1) do_tile(tbase, (u32)(rec1 - tbase), std::false_type());
-}
-
-// ---------------------------------------------------------------------------------------------
-// rs_scatter_wc: the digit pass with write combining (large inputs).
-//
-// What limits rs_scatter above on uniform digits is not bytes but write *requests*: a tile leaves 256 runs of ~16
-// records, i.e. ~128 B of keys and ~64 B of values at arbitrary 8-/4-byte alignment, so almost every run touches two
-// partially written 128-B lines (tools/ubench.hip: pairs in aligned full lines 5.1 TB/s, the same bytes as misaligned
-// 16-record runs 2.4 TB/s; HBM byte counters stay at the algorithmic volume in both cases).  Here every workgroup
-// keeps, per digit, up to 31 not-yet-written records in LDS and only ever writes whole 32-record groups that start on
-// a 32-record boundary of the output (2 full key lines + 1 full value line); the unaligned head of a (chunk, digit)
-// segment and its tail are written once each.  Output is identical to rs_scatter (same stable order).
-//
-// Price: 96 KB of LDS for the pending records (150 KB per workgroup with staging), so one workgroup of 1024 threads
-// per CU (16 waves, 4 records per lane and tile) that walks four of rs_hist's chunks; the next tile's records are
-// loaded into registers before the current one is ranked, so the loads fly under the LDS phases.
-// ---------------------------------------------------------------------------------------------
-constexpr int WC_WG = 1024, WC_WAVES = WC_WG / 64, WC_ITEMS = RS_TILE / WC_WG, WC_GRP = 32, WC_SPAN = 4;
-constexpr int WC_LDS_KEYS  = RS_TILE * 8 + 256 * WC_GRP * 8 + WC_WAVES * 256 * 4 + 7 * 256 * 4 + 16 * 4;
-constexpr int WC_LDS_PAIRS = WC_LDS_KEYS + 256 * WC_GRP * 4;
-
-// exclusive sum over the digit values held by threads 0..255 (waves 0..3) of a 1024-thread workgroup
-__device__ __forceinline__ u32 wc_digit_excl_sum(u32 v, u32* scr)
-{
-    const u32 incl = wave_incl_sum(v);
-    const u32 w = threadIdx.x >> 6, l = lane_id();
-    __syncthreads();
-    if (l == 63 && w < 4) scr[w] = incl;
-    __syncthreads();
-    u32 base = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) if ((u32)i < w) base += scr[i];
-    return base + incl - v;
-}
-
-template <bool HAS_VAL>
-__global__ __launch_bounds__(WC_WG) void rs_scatter_wc_kernel(const u64* __restrict__ kin, u64* __restrict__ kout,
-                                                              const u32* __restrict__ vin, u32* __restrict__ vout,
-                                                              u32 n, int shift, u32 mask,
-                                                              u32 chunk_tiles, u32 num_chunks, u32 num_tiles,
-                                                              const u32* __restrict__ offsets,
-                                                              const u32* __restrict__ rowtot, u64* __restrict__ sink)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* skeys = reinterpret_cast<u64*>(smem);                        // [RS_TILE] staging (reused as u32 for values)
-    u64* pendK = skeys + RS_TILE;                                     // [256][32] pending keys per digit
-    u32* whist = reinterpret_cast<u32*>(pendK + 256 * WC_GRP);        // [16][256] per-wave digit counts / prefixes
-    u32* gofs  = whist + WC_WAVES * 256;                              // [256] output position of the first unwritten record
-    u32* pcnt  = gofs + 256;                                          // [256] pending records
-    u32* infoA = pcnt + 256;                                          // [256] staging slot q of digit d goes to kout[q + A]
-    u32* infoB = infoA + 256;                                         // [256] (first pending slot) | (end of valid slots) << 16
-    u32* infoC = infoB + 256;                                         // [256] ... or to pend[d][q + C]
-    u32* fcnt  = infoC + 256;                                         // [256] old pending records written this tile
-    u32* gold  = fcnt + 256;                                          // [256] their output position
-    u32* scr   = gold + 256;                                          // [16]
-    u32* pendV = scr + 16;                                            // [256][32] pending values (pairs only)
-    lds_vu32* vwh = (lds_vu32*)whist;
-
-    const u32 t = threadIdx.x, w = t >> 6, lane = t & 63;
-    const u64 lt = lanemask_lt();
-    const u32 lt_lo = (u32)lt, lt_hi = (u32)(lt >> 32);
-
-    {
-        const u32 base = wc_digit_excl_sum(t < 256 ? rowtot[t] : 0u, scr);
-        if (t < 256) { gofs[t] = base + offsets[(size_t)t * num_chunks + (size_t)blockIdx.x * WC_SPAN]; pcnt[t] = 0; }
-    }
-    __syncthreads();
-
-    const u32 tile0 = blockIdx.x * WC_SPAN * chunk_tiles;
-    u32 tile1 = tile0 + WC_SPAN * chunk_tiles;
-    if (tile1 > num_tiles) tile1 = num_tiles;
-
-    // wave-striped ownership: wave w holds records [w*256, w*256+256) of the tile, item i = 64 consecutive records
-    const u32 wbase = w * (64 * WC_ITEMS) + lane;
-    u64 k[WC_ITEMS], kn[WC_ITEMS];
-    u32 v[WC_ITEMS], vn[WC_ITEMS];
-    auto fetch = [&](u32 tile, u64* kk, u32* vv) {
-        const u64 tbase = (u64)tile * RS_TILE;
-        const u32 rem = (u32)((u64)n - tbase);
-        const u32 nv = rem < (u32)RS_TILE ? rem : (u32)RS_TILE;
-#pragma unroll
-        for (int i = 0; i < WC_ITEMS; ++i) {
-            // every lane always loads (a clamped address when it is past the end) and every lane always stores below (to
-            // a private sink slot when it has nothing to write): with no branch around a memory instruction the compiler
-            // knows how many are outstanding and can wait for the prefetched tile with an exact vmcnt instead of vmcnt(0),
-            // which would stall every tile on the stores it has just issued and on the loads for the tile after it.
-            const u32 idx = wbase + i * 64;
-            const u64 a = tbase + (idx < nv ? idx : nv - 1);
-            const u64 kv = __builtin_nontemporal_load(&kin[a]);
-            kk[i] = (idx < nv) ? kv : ~0ull;
-            if (HAS_VAL) vv[i] = __builtin_nontemporal_load(&vin[a]);
-        }
-    };
-    u64* const ksink = sink + (size_t)blockIdx.x * WC_WG + t;
-    u32* const vsink = reinterpret_cast<u32*>(ksink);
-    // write the first fcnt[b] pending records of every digit b to gold[b]..: half a wave per digit
-    auto flush_pending = [&]() {
-#pragma unroll
-        for (int s = 0; s < 256 / (WC_WG / WC_GRP); ++s) {
-            const u32 b = s * (WC_WG / WC_GRP) + (t >> 5), i = t & 31;
-            const bool on = i < fcnt[b];
-            const u32 o = gold[b] + i;
-            *(on ? &kout[o] : ksink) = pendK[b * WC_GRP + i];
-            if (HAS_VAL) *(on ? &vout[o] : vsink) = pendV[b * WC_GRP + i];
-        }
-    };
-
-    if (tile0 < tile1) fetch(tile0, k, v);
-    for (u32 tile = tile0; tile < tile1; ++tile) {
-        const u32 rem = (u32)((u64)n - (u64)tile * RS_TILE);
-        const u32 nvalid = rem < (u32)RS_TILE ? rem : (u32)RS_TILE;
-        fetch(tile + 1 < tile1 ? tile + 1 : tile, kn, vn);             // in flight during everything below
-
-        for (u32 i = t; i < (u32)WC_WAVES * 256; i += WC_WG) whist[i] = 0;
-        __syncthreads();
-
-        // ---- stable in-wave ranking by ballot match (as in rs_scatter) ---------------------------
-        u32 rk[WC_ITEMS];
-#pragma unroll
-        for (int i = 0; i < WC_ITEMS; ++i) {
-            const u32 d = (u32)(k[i] >> shift) & mask;
-            u32 mlo = ~0u, mhi = ~0u;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int bitm = __builtin_amdgcn_sbfe((int)d, b, 1);
-                const u64 bal = __ballot(bitm != 0);
-                const u32 nb = ~(u32)bitm;
-                mlo &= (u32)bal ^ nb;
-                mhi &= (u32)(bal >> 32) ^ nb;
-            }
-            const u32 before = vwh[w * 256 + d];
-            const u32 r      = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));
-            const u32 cnt    = (u32)(__popc(mlo) + __popc(mhi));
-            rk[i] = before + r;
-            if (r == cnt - 1) vwh[w * 256 + d] = before + cnt;
-        }
-        __syncthreads();
-
-        // ---- per digit: wave prefixes, tile-local start, and what to write / keep this tile ----------
-        {
-            u32 c[WC_WAVES];
-            u32 tot = 0;
-            if (t < 256) {
-#pragma unroll
-                for (int i = 0; i < WC_WAVES; ++i) { c[i] = whist[i * 256 + t]; tot += c[i]; }
-            }
-            const u32 ds = wc_digit_excl_sum(t < 256 ? tot : 0u, scr);
-            if (t < 256) {
-                u32 run = ds;
-#pragma unroll
-                for (int i = 0; i < WC_WAVES; ++i) { whist[i * 256 + t] = run; run += c[i]; }
-                const u32 cv = tot - ((t == mask) ? ((u32)RS_TILE - nvalid) : 0u);      // padding records sort last
-                const u32 pc = pcnt[t], g = gofs[t];
-                const u32 E = g + pc + cv, F = E & ~(u32)(WC_GRP - 1);
-                const bool fl = F > g;                                  // at least one group boundary reached
-                const u32 nn = fl ? (F - g - pc) : 0u;                  // new records written straight from staging
-                infoA[t] = g + pc - ds;
-                infoB[t] = (ds + nn) | ((ds + cv) << 16);
-                infoC[t] = (fl ? (0u - nn) : pc) - ds;
-                fcnt[t]  = fl ? pc : 0u;
-                gold[t]  = g;
-                gofs[t]  = fl ? F : g;
-                pcnt[t]  = fl ? (E - F) : (pc + cv);
-            }
-        }
-        __syncthreads();
-
-        // ---- local reorder of the keys; old pending records of the digits that flush leave now -------
-#pragma unroll
-        for (int i = 0; i < WC_ITEMS; ++i) {
-            const u32 d = (u32)(k[i] >> shift) & mask;
-            const u32 pos = whist[w * 256 + d] + rk[i];
-            rk[i] = pos;
-            skeys[pos] = k[i];
-        }
-        flush_pending();
-        __syncthreads();
-
-        u32 dd = 0;
-#pragma unroll
-        for (int j = 0; j < WC_ITEMS; ++j) {
-            const u32 q = j * WC_WG + t;
-            const u64 key = skeys[q];
-            const u32 d = (u32)(key >> shift) & mask;
-            dd |= d << (8 * j);
-            const u32 B = infoB[d];
-            const bool direct = q < (B & 0xffffu);
-            *(direct ? &kout[infoA[d] + q] : ksink) = key;
-            if (!direct && q < (B >> 16)) pendK[d * WC_GRP + q + infoC[d]] = key;
-        }
-
-        if (HAS_VAL) {
-            __syncthreads();
-            u32* svals = reinterpret_cast<u32*>(skeys);
-#pragma unroll
-            for (int i = 0; i < WC_ITEMS; ++i) svals[rk[i]] = v[i];
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < WC_ITEMS; ++j) {
-                const u32 q = j * WC_WG + t;
-                const u32 d = (dd >> (8 * j)) & 0xffu;
-                const u32 B = infoB[d];
-                const bool direct = q < (B & 0xffffu);
-                const u32 val = svals[q];
-                *(direct ? &vout[infoA[d] + q] : vsink) = val;
-                if (!direct && q < (B >> 16)) pendV[d * WC_GRP + q + infoC[d]] = val;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < WC_ITEMS; ++i) { k[i] = kn[i]; if (HAS_VAL) v[i] = vn[i]; }
-    }
 
     // tails of this workgroup's segments
-    if (t < 256) { fcnt[t] = pcnt[t]; gold[t] = gofs[t]; }
+    if (t < 256) { fkS[t] = gk; fkE[t] = E; if (HAS_VAL) { fvS[t] = gv; fvE[t] = E; } }
     __syncthreads();
     flush_pending();
 }
@@ -560,13 +649,12 @@ int radix_engine_setup(bscgpu_ctx* c)
 {
     const char* e = getenv("BSC_RS_WC");
     int mode = e ? atoi(e) : RS_WC_DEFAULT;
-    if (WC_LDS_PAIRS > 160 * 1024 ||
-        hipFuncSetAttribute((const void*)rs_scatter_wc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_LDS_PAIRS) != hipSuccess ||
+    if (hipFuncSetAttribute((const void*)rs_scatter_wc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_LDS_PAIRS) != hipSuccess ||
         hipFuncSetAttribute((const void*)rs_scatter_wc_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WC_LDS_KEYS) != hipSuccess) {
         mode = 0;
         (void)hipGetLastError();               // do not leave a sticky error behind
     }
-    HIP_TRY(c, hipFuncSetAttribute((const void*)rs_scatter_kernel<true, RSB_WG, RSB_ITEMS, RSB_SPAN>, hipFuncAttributeMaxDynamicSharedMemorySize, RSB_LDS));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)rs_scatter_kernel<true, RSB_WG, RSB_ITEMS, RSB_SPAN, false, RSB_PIPE != 0>, hipFuncAttributeMaxDynamicSharedMemorySize, RSB_LDS));
     c->rs_wc_mode = mode;
     return BSC_NO_ERROR;
 }
@@ -577,7 +665,7 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
     if (emit_pos != nullptr && (npasses != 1 || vals != nullptr)) return BSC_BAD_PARAMETER;     // inverse of ONE keys-only pass
     *in_alt = 0;
     if (n == 0 || npasses == 0) return BSC_NO_ERROR;
-    if (n >= 0xffffffffull) return BSC_BAD_PARAMETER;
+    if (n >= 0xfff00000ull) return BSC_BAD_PARAMETER;          // record indexes are u32, with headroom for a tile past the end
     if ((((uintptr_t)keys) | ((uintptr_t)keys_alt)) & 15) return ctx_fail(c, BSC_BAD_PARAMETER, "radix keys not 16B aligned", hipSuccess);
 
     const Chunking ch = rs_chunking(n);
@@ -608,13 +696,13 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
             if (has_val)
                 hipLaunchKernelGGL(rs_scatter_wc_kernel<true>, dim3(grid), dim3(WC_WG), WC_LDS_PAIRS, c->stream,
                                    ksrc, kdst, vsrc, vdst, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks,
-                                   ch.num_tiles, c->counts, c->rowtot, c->wc_sink);
+                                   c->counts, c->rowtot, c->wc_sink);
             else
                 hipLaunchKernelGGL(rs_scatter_wc_kernel<false>, dim3(grid), dim3(WC_WG), WC_LDS_KEYS, c->stream,
                                    ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, shift, mask,
-                                   ch.chunk_tiles, ch.num_chunks, ch.num_tiles, c->counts, c->rowtot, c->wc_sink);
+                                   ch.chunk_tiles, ch.num_chunks, c->counts, c->rowtot, c->wc_sink);
         } else if (has_val && big_pairs) {
-            hipLaunchKernelGGL((rs_scatter_kernel<true, RSB_WG, RSB_ITEMS, RSB_SPAN>), dim3((ch.num_chunks + RSB_SPAN - 1) / RSB_SPAN), dim3(RSB_WG), RSB_LDS, c->stream,
+            hipLaunchKernelGGL((rs_scatter_kernel<true, RSB_WG, RSB_ITEMS, RSB_SPAN, false, RSB_PIPE != 0>), dim3((ch.num_chunks + RSB_SPAN - 1) / RSB_SPAN), dim3(RSB_WG), RSB_LDS, c->stream,
                                ksrc, kdst, vsrc, vdst, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks,
                                ch.num_tiles, c->counts, c->rowtot, c->wc_sink);
         } else if (has_val)
@@ -635,6 +723,14 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
         u64* tk = ksrc; ksrc = kdst; kdst = tk;
         u32* tv = vsrc; vsrc = vdst; vdst = tv;
     }
+#if RS_PHASE_TIMING
+    if (n >= (1u << 24)) {      // debug builds: phase stamps of the last pass
+        static std::vector<u64> host(256 * 32 * 16);
+        if (hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(host.data(), c->wc_sink, host.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE* f = fopen("gpurun_out/phase_timing.bin", "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+        }
+    }
+#endif
     *in_alt = (npasses & 1);
     return BSC_NO_ERROR;
 }

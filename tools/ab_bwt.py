@@ -30,7 +30,9 @@ libs = sys.argv[1:]
 res = {l: [] for l in libs}
 for rnd in range(2):
     for l in libs:
-        env = dict(os.environ, BSC_LIB_OVERRIDE=os.path.abspath(l))
+        path, _, extra = l.partition(":")
+        env = dict(os.environ, BSC_LIB_OVERRIDE=os.path.abspath(path))
+        env.update(kv.split("=", 1) for kv in extra.split(",") if kv)
         r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=env)
         line = [x for x in r.stdout.splitlines() if x.startswith("RESULT ")]
         if not line:
@@ -39,4 +41,4 @@ for rnd in range(2):
 for l in libs:
     if not res[l]: continue
     best = {k: min(r[k] for r in res[l]) for k in res[l][0]}
-    print(os.path.basename(l).ljust(24), "  ".join(f"{k}={v:.3f}" if isinstance(v, float) else f"{k}={v}" for k, v in best.items()))
+    print(os.path.basename(l).ljust(40), "  ".join(f"{k}={v:.3f}" if isinstance(v, float) else f"{k}={v}" for k, v in best.items()))

@@ -1,5 +1,5 @@
 """A/B timing of radix-engine variants on ONE box (box-to-box spread on the pool is ~20 %, so variants are only comparable
-inside one gpurun call): python tools/ab_radix.py libA.so libB.so ...  — alternates the libraries, 2 rounds each."""
+inside one gpurun call): python tools/ab_radix.py libA.so libB.so[:ENV=VAL,...] ...  — alternates the variants, 2 rounds each."""
 import os, subprocess, sys, json
 import numpy as np
 CHILD = r'''
@@ -31,7 +31,9 @@ libs = sys.argv[1:]
 res = {l: [] for l in libs}
 for rnd in range(2):
     for l in libs:
-        env = dict(os.environ, BSC_LIB_OVERRIDE=os.path.abspath(l))
+        path, _, extra = l.partition(":")
+        env = dict(os.environ, BSC_LIB_OVERRIDE=os.path.abspath(path))
+        env.update(kv.split("=", 1) for kv in extra.split(",") if kv)
         r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=env)
         line = [x for x in r.stdout.splitlines() if x.startswith("RESULT ")]
         if not line:
@@ -40,4 +42,4 @@ for rnd in range(2):
 for l in libs:
     if not res[l]: continue
     keys = res[l][0].keys()
-    print(os.path.basename(l).ljust(28), "  ".join(f"{k}: {min(r[k] for r in res[l]):.3f} ms ({(24 if 'pairs' in k else 16) * (64 << 20) / 1e6 / min(r[k] for r in res[l]):.0f} GB/s)" for k in keys))
+    print(os.path.basename(l).ljust(40), "  ".join(f"{k}: {min(r[k] for r in res[l]):.3f} ms ({(24 if 'pairs' in k else 16) * (64 << 20) / 1e6 / min(r[k] for r in res[l]):.0f} GB/s)" for k in keys))
