@@ -109,10 +109,13 @@ __global__ __launch_bounds__(WG) void bwt_pack_kernel(const u8* __restrict__ T, 
 //   uns(x)   = !(head(x) && head(x+1)), head(m) = 1
 //   flags[x] = head | uns << 1
 // ---------------------------------------------------------------------------------------------
+//   grp (rounds on text keys, see bwt_round_textsort_kernel): the group rank of every record is a separate array and a head is
+//   also where it changes: head(x) |= grp[x] != grp[x-1]
 template <bool INITIAL>
 __global__ __launch_bounds__(WG) void seg_reduce_kernel(const u64* __restrict__ keys, const u32* __restrict__ sa,
                                                         u32 m, u32 tail_lo, u32 smask, u32 chunk_tiles, u32 num_tiles,
-                                                        u8* __restrict__ flags, u32* __restrict__ segsum /*[2][MAX_CHUNKS]*/)
+                                                        u8* __restrict__ flags, u32* __restrict__ segsum /*[2][MAX_CHUNKS]*/,
+                                                        const u32* __restrict__ grp = nullptr)
 {
     __shared__ u32 scr[8];
     const u32 t = threadIdx.x;
@@ -145,6 +148,12 @@ __global__ __launch_bounds__(WG) void seg_reduce_kernel(const u64* __restrict__ 
                 const long long x = (long long)j - 1 + q;
                 s[q] = (x >= 0 && x < (long long)m) ? (sa[x] & smask) : 0;
             }
+        } else if (grp != nullptr) {
+#pragma unroll
+            for (int q = 0; q < SEG_ITEMS + 2; ++q) {
+                const long long x = (long long)j - 1 + q;
+                s[q] = (x >= 0 && x < (long long)m) ? grp[x] : 0;
+            }
         }
         u32 h[SEG_ITEMS + 1];
 #pragma unroll
@@ -155,6 +164,7 @@ __global__ __launch_bounds__(WG) void seg_reduce_kernel(const u64* __restrict__ 
             else {
                 hd = (k[q + 1] != k[q]);
                 if (INITIAL) hd = hd || (s[q + 1] >= tail_lo) || (s[q] >= tail_lo);
+                else if (grp != nullptr) hd = hd || (s[q + 1] != s[q]);
             }
             h[q] = hd ? 1u : 0u;
         }
@@ -214,7 +224,8 @@ __global__ __launch_bounds__(WG) void seg_scan_kernel(const u32* __restrict__ se
 }
 
 // seg phase C: ranks (position of the group head), SA / ISA write-back, compaction of unsorted records.
-template <bool INITIAL>
+// WRITE_ISA = false (rounds on text keys): nobody reads ISA, the random 4-byte scatter is skipped.
+template <bool INITIAL, bool WRITE_ISA>
 __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ flags, const u32* __restrict__ sa_sorted,
                                                        const u32* __restrict__ cpos_in, u32 m, u32 smask,
                                                        u32 chunk_tiles, u32 num_tiles, const u32* __restrict__ segoff,
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
                 if (f[q] & 1u) run = pos[q] + 1;
                 const u32 rank = run - 1;
                 SA[pos[q]] = s[q];
-                ISA[s[q] & smask] = rank;                  // SA / csa keep the predecessor code in their high bits
+                if (WRITE_ISA) ISA[s[q] & smask] = rank;   // SA / csa keep the predecessor code in their high bits
                 if (f[q] & 2u) {
                     cpos_out[kslot] = pos[q];
                     csa_out[kslot]  = s[q];
@@ -377,16 +388,148 @@ __global__ __launch_bounds__(WG) void bwt_round_segsort_kernel(const u32* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// A refinement round WITHOUT the inverse suffix array.  Prefix doubling orders the suffixes of a group (equal first h
+// characters) by the rank of suffix s + h, which needs ISA — a random 4-byte scatter of n entries after the first sort
+// (1.7 ms per 64 MiB block, 5.6 GB of HBM writes for 0.27 GB of payload: the second-largest kernel of the sorter) and a random
+// 4-byte gather per unsorted suffix.  But right after the first sort the rank of suffix s + h is just the order of ITS first
+// a characters, and those can be read from the text: the round's key is the packed codes of T[s+h .. s+h+a) (zero padded
+// past the end) with, in the low 4 bits, min(n - (s+h), a) — "a proper prefix sorts first" among equal padded keys, 0 for the
+// empty suffix.  The text is 1/4 of ISA's size and the 16 bytes a record needs are one or two cache lines.  Such a round
+// advances the sorted depth by a characters instead of doubling it, so it is used while it pays: text blocks are done after
+// two of them (27.8 M unsorted -> 7 155 -> 0 on the bench block) and never build ISA at all; a block that does not converge
+// (long repeats) or has a group too long for one workgroup builds ISA once from the current order (bwt_isa_fill / _fix) and
+// continues with the doubling rounds below.  Same structure as bwt_round_segsort_kernel; the group rank of a record is not
+// part of the output key (cgrp stays valid: records only move inside their group), seg_reduce takes it as a second array.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void bwt_round_textsort_kernel(const u8* __restrict__ T, const u8* __restrict__ codes,
+                                                                const u32* __restrict__ csa, const u32* __restrict__ cgrp,
+                                                                u32 U, u64 h, u32 n, u32 smask, u32 cb, u32 a,
+                                                                u64* __restrict__ keys_out, u32* __restrict__ vals_out, u32* __restrict__ fallback)
+{
+    __shared__ u64 snext[RS_E];                  // first (as u32) the group ranks for the head flags, then the round keys
+    __shared__ short sgs[RS_E];
+    __shared__ short sge[RS_E];
+    __shared__ u32 scr[8];
+    __shared__ u32 sincl[WG];
+    __shared__ u8 lut[256];
+    u32* sgrp = reinterpret_cast<u32*>(snext);
+    const u32 t = threadIdx.x;
+    lut[t] = codes[t];
+    const u64 base = (u64)blockIdx.x * RS_T;
+    const u32 ext = (u32)((base + RS_E <= U) ? (u64)RS_E : (U - base));
+    const u32 own = ext < (u32)RS_T ? ext : (u32)RS_T;
+    const u32 prevg = (base > 0) ? cgrp[base - 1] : 0xffffffffu;
+    for (u32 i = t; i < ext; i += WG) { sgrp[i] = cgrp[base + i]; sge[i] = (short)ext; }
+    __syncthreads();
+    constexpr int PER = RS_E / WG;
+    const u32 i0 = t * PER;
+    u32 hmask = 0;
+    int last_head = -1;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 i = i0 + q;
+        if (i < ext) { const bool head = (i == 0) ? (sgrp[0] != prevg) : (sgrp[i] != sgrp[i - 1]); if (head) { last_head = (int)i; hmask |= 1u << q; } }
+    }
+    u32 totmax;
+    const u32 incl = block_incl_max((u32)(last_head + 1), scr, &totmax);
+    sincl[t] = incl;
+    __syncthreads();
+    int run = (t > 0) ? (int)sincl[t - 1] - 1 : -1;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 i = i0 + q;
+        if (i < ext) {
+            if (hmask & (1u << q)) { if (run >= 0) sge[run] = (short)i; run = (int)i; }
+            sgs[i] = (short)run;
+        }
+    }
+    __syncthreads();
+    if (t == 0 && base + ext < U) {
+        const int gs = sgs[ext - 1];
+        if (gs >= 0 && (u32)gs < own && cgrp[base + ext] == sgrp[ext - 1]) atomicOr(fallback, 1u);
+    }
+    __syncthreads();
+    // the round's keys, from the text (overwrites the group ranks in LDS)
+    const u32* T32 = reinterpret_cast<const u32*>(T);
+    for (u32 i = t; i < ext; i += WG) {
+        const int gs = sgs[i];
+        u64 key = 0;
+        if (gs >= 0 && (u32)gs < own) {
+            const u64 p64 = (u64)(csa[base + i] & smask) + h;
+            if (p64 < n) {
+                const u32 p = (u32)p64, off = p & 3u;
+                const u32* q = T32 + (p >> 2);                  // T is 4-byte aligned at T[0] and zero padded for 32 bytes past n
+                const u32 d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                const u32 x[4] = { __builtin_amdgcn_alignbyte(d1, d0, off), __builtin_amdgcn_alignbyte(d2, d1, off),
+                                   __builtin_amdgcn_alignbyte(d3, d2, off), __builtin_amdgcn_alignbyte(d4, d3, off) };
+                const u32 left = n - p;                          // characters the suffix has
+#pragma unroll
+                for (u32 c = 0; c < 15; ++c) {
+                    if (c < a) {
+                        const u32 byte = (x[c >> 2] >> (8 * (c & 3))) & 0xffu;
+                        const u64 code = (c < left) ? (u64)lut[byte] : 0ull;
+                        key |= code << (64 - cb * (c + 1));
+                    }
+                }
+                key |= (u64)(left < a ? left : a);
+            }
+        }
+        snext[i] = key;
+    }
+    __syncthreads();
+    for (u32 i = t; i < ext; i += WG) {
+        const int gs = sgs[i];
+        if (gs < 0 || (u32)gs >= own) continue;
+        const u64 mine = snext[i];
+        const u32 ge = (u32)sge[gs];
+        u32 r = 0;
+        for (u32 k = (u32)gs; k < ge; ++k) { const u64 o = snext[k]; r += (u32)((o < mine) || (o == mine && k < i)); }
+        const u64 dst = base + (u32)gs + r;
+        keys_out[dst] = mine;
+        vals_out[dst] = csa[base + i];
+    }
+}
+
+// ISA from the current order (when the text rounds hand over to prefix doubling): every suffix gets its SA slot, then the
+// still unsorted ones the rank of their group (the slot of the group's head).
+__global__ __launch_bounds__(WG) void bwt_isa_fill_kernel(const u32* __restrict__ SA, u32 n, u32 smask, u32* __restrict__ ISA)
+{
+    const u32 stride = gridDim.x * WG;
+    for (u32 x = blockIdx.x * WG + threadIdx.x; x < n; x += stride) ISA[SA[x] & smask] = x;
+}
+__global__ __launch_bounds__(WG) void bwt_isa_fix_kernel(const u32* __restrict__ csa, const u32* __restrict__ cgrp, u32 U, u32 smask, u32* __restrict__ ISA)
+{
+    const u32 stride = gridDim.x * WG;
+    for (u32 k = blockIdx.x * WG + threadIdx.x; k < U; k += stride) ISA[csa[k] & smask] = cgrp[k];
+}
+
+// Primary index and aux indexes straight from SA (no ISA needed): dscal[1] = j + 1 where SA[j] = 0,
+// dscal[8 + t] = j + 1 where SA[j] = t * r (libsais_bwt_aux semantics: I[t] = ISA[t * r] + 1).
+__global__ __launch_bounds__(WG) void bwt_find_kernel(const u32* __restrict__ SA, u32 n, u32 smask, u32 rmask, u32 rshift, u32 cnt, u32* __restrict__ dscal)
+{
+    const u32 j0 = 4u * (blockIdx.x * WG + threadIdx.x);
+    if (j0 >= n) return;
+    u32 sv[4];
+    if (j0 + 4 <= n) { const uint4 q = *reinterpret_cast<const uint4*>(SA + j0); sv[0] = q.x; sv[1] = q.y; sv[2] = q.z; sv[3] = q.w; }
+    else { for (u32 q = 0; q < 4; ++q) sv[q] = (j0 + q < n) ? SA[j0 + q] : 0xffffffffu; }
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+        if (j0 + q >= n) continue;
+        const u32 sfx = sv[q] & smask;
+        if (sfx == 0) dscal[1] = j0 + q + 1;
+        if (cnt != 0 && (sfx & rmask) == 0 && (sfx >> rshift) < cnt) dscal[8 + (sfx >> rshift)] = j0 + q + 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // L[0] = T[n-1]; L[o] = T[SA[j]-1] with j = o-1 for o <= ISA[0], j = o for o > ISA[0].
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void bwt_emit_kernel(const u8* __restrict__ T, const u32* __restrict__ SA,
-                                                      const u32* __restrict__ ISA, u32 n, u8* __restrict__ L,
-                                                      u32* __restrict__ dscal)
+                                                      u32 n, u8* __restrict__ L, const u32* __restrict__ dscal)
 {
     const u32 o0 = 4u * (blockIdx.x * WG + threadIdx.x);
     if (o0 >= n) return;
-    const u32 p = ISA[0];
-    if (o0 == 0) dscal[1] = p + 1;
+    const u32 p = dscal[1] - 1;                  // ISA[0], from bwt_find_kernel
     u32 word = 0;
 #pragma unroll
     for (u32 q = 0; q < 4; ++q) {
@@ -407,16 +550,15 @@ __global__ __launch_bounds__(WG) void bwt_emit_kernel(const u8* __restrict__ T, 
 
 // The same from values that carry the predecessor's code (SA[j] = index | code(T[index-1]) << pred_shift): no access to T at
 // all, SA is read in order.  decode[code] = byte.
-__global__ __launch_bounds__(WG) void bwt_emit_pred_kernel(const u8* __restrict__ T, const u32* __restrict__ SA, const u32* __restrict__ ISA, u32 n,
-                                                           u32 pred_shift, const u8* __restrict__ decode, u8* __restrict__ L, u32* __restrict__ dscal)
+__global__ __launch_bounds__(WG) void bwt_emit_pred_kernel(const u8* __restrict__ T, const u32* __restrict__ SA, u32 n,
+                                                           u32 pred_shift, const u8* __restrict__ decode, u8* __restrict__ L, const u32* __restrict__ dscal)
 {
     __shared__ u8 dec[256];
     dec[threadIdx.x] = decode[threadIdx.x];
     __syncthreads();
     const u32 o0 = 4u * (blockIdx.x * WG + threadIdx.x);
     if (o0 >= n) return;
-    const u32 p = ISA[0];
-    if (o0 == 0) dscal[1] = p + 1;
+    const u32 p = dscal[1] - 1;                  // ISA[0], from bwt_find_kernel
     u32 word = 0;
 #pragma unroll
     for (u32 q = 0; q < 4; ++q) {
@@ -432,12 +574,6 @@ __global__ __launch_bounds__(WG) void bwt_emit_pred_kernel(const u8* __restrict_
     else for (u32 q = 0; o0 + q < n; ++q) L[o0 + q] = (u8)(word >> (8 * q));
 }
 
-__global__ void bwt_aux_kernel(const u32* __restrict__ ISA, u32 n, u32 r, u32 cnt, u32* __restrict__ I)
-{
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < cnt) I[t] = ISA[(u64)t * r] + 1u;
-}
-
 void launch_seg_scan(bscgpu_ctx* c, u32 num_chunks)
 {
     hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(WG), 0, c->stream, c->segsum, num_chunks, c->segoff, c->dscal);
@@ -446,20 +582,20 @@ void launch_seg_scan(bscgpu_ctx* c, u32 num_chunks)
 // ---------------------------------------------------------------------------------------------
 static int bit_length(u64 x) { int b = 0; while (x) { ++b; x >>= 1; } return b; }
 
-template <bool INITIAL>
+template <bool INITIAL, bool WRITE_ISA>
 static int run_seg(bscgpu_ctx* c, const u64* keys, const u32* sa_sorted, const u32* cpos_in, u32 m, u32 tail_lo, u32 smask,
-                   u32* cpos_out, u32* csa_out, u32* cgrp_out, u32* U_out)
+                   u32* cpos_out, u32* csa_out, u32* cgrp_out, u32* U_out, const u32* grp_in = nullptr)
 {
     const Chunking ch = make_chunking(m, SEG_TILE);
     prof_begin(c, BSCGPU_K_SEG, (u64)m * (8 + (INITIAL ? 4 : 0) + 1), m);
     hipLaunchKernelGGL(seg_reduce_kernel<INITIAL>, dim3(ch.num_chunks), dim3(WG), 0, c->stream,
-                       keys, sa_sorted, m, tail_lo, smask, ch.chunk_tiles, ch.num_tiles, c->flags, c->segsum);
+                       keys, sa_sorted, m, tail_lo, smask, ch.chunk_tiles, ch.num_tiles, c->flags, c->segsum, grp_in);
     prof_end(c);
     prof_begin(c, BSCGPU_K_SEG, 0, 0);
     hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(WG), 0, c->stream, c->segsum, ch.num_chunks, c->segoff, c->dscal);
     prof_end(c);
     prof_begin(c, BSCGPU_K_SEG, (u64)m * (1 + 4 + (INITIAL ? 0 : 4) + 4 + 4), m);
-    hipLaunchKernelGGL(seg_apply_kernel<INITIAL>, dim3(ch.num_chunks), dim3(WG), 0, c->stream,
+    hipLaunchKernelGGL((seg_apply_kernel<INITIAL, WRITE_ISA>), dim3(ch.num_chunks), dim3(WG), 0, c->stream,
                        c->flags, sa_sorted, cpos_in, m, smask, ch.chunk_tiles, ch.num_tiles, c->segoff,
                        c->SA, c->ISA, cpos_out, csa_out, cgrp_out);
     prof_end(c);
@@ -528,19 +664,59 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
     const u64* ks = in_alt ? c->kB : c->kA;
     const u32* vs = in_alt ? c->vB : c->vA;
 
+    // Rounds on text keys (bwt_round_textsort_kernel) need a characters + 4 bits in 64: a = w where the first-sort key leaves
+    // 4 bits spare, else w - 1.  BSC_BWT_TEXTROUNDS=0 keeps the round-1 flow (ISA built by the first seg, doubling from h = w).
+    static const int text_on = [] { const char* e = getenv("BSC_BWT_TEXTROUNDS"); return e ? atoi(e) : 1; }();
+    const u32 ta = (pp.cb * pp.w + 4 <= 64) ? pp.w : pp.w - 1;
+    bool isa_valid = !(text_on && ta >= 2 && ta <= 15);
     int cur = 0;
     u32 U = 0;
-    rc = run_seg<true>(c, ks, vs, nullptr, n, tail_lo, smask, c->cpos[cur], c->csa[cur], c->cgrp[cur], &U);
+    if (isa_valid) rc = run_seg<true, true >(c, ks, vs, nullptr, n, tail_lo, smask, c->cpos[cur], c->csa[cur], c->cgrp[cur], &U);
+    else           rc = run_seg<true, false>(c, ks, vs, nullptr, n, tail_lo, smask, c->cpos[cur], c->csa[cur], c->cgrp[cur], &U);
     if (rc < 0) return rc;
 
     const int lo_bits = bit_length(n);          // next-rank field: values 0 .. n
     const int hi_bits = bit_length(n - 1);      // group rank field: values 0 .. n-1
     u64 h = pp.w;
-    int rounds = 0;
+    int rounds = 0, text_rounds = 0;
     const bool dbg = getenv("BSCGPU_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[bwt] n=%u initial unsorted=%u\n", n, U);
     while (U > 0) {
-        if (++rounds > 40) return ctx_fail(c, BSC_GPU_ERROR, "prefix doubling did not converge", hipSuccess);
+        if (++rounds > 60) return ctx_fail(c, BSC_GPU_ERROR, "prefix doubling did not converge", hipSuccess);
+        if (!isa_valid) {
+            // a round on text keys; it hands over to doubling when a group does not fit a workgroup or the round did not pay
+            HIP_TRY(c, hipMemsetAsync(c->dscal + 2, 0, 4, c->stream));
+            prof_begin(c, BSCGPU_K_GATHER, (u64)U * (4 + 4 + 16 + 8 + 4), U);
+            hipLaunchKernelGGL(bwt_round_textsort_kernel, dim3((U + RS_T - 1) / RS_T), dim3(WG), 0, c->stream,
+                               c->dT, dcodes, c->csa[cur], c->cgrp[cur], U, h, n, smask, pp.cb, ta, c->kB, c->vB, c->dscal + 2);
+            prof_end(c);
+            HIP_TRY(c, hipMemcpyAsync(c->hscal + 2, c->dscal + 2, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, ctx_sync(c));
+            prof_collect(c);
+            if (c->hscal[2] == 0) {
+                u32 U2 = 0;
+                rc = run_seg<false, false>(c, c->kB, c->vB, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2, c->cgrp[cur]);
+                if (rc < 0) return rc;
+                cur ^= 1;
+                ++text_rounds;
+                h += ta;
+                if (dbg) fprintf(stderr, "[bwt] text round %d depth %llu U %u -> %u\n", rounds, (unsigned long long)h, U, U2);
+                const bool pays = U2 < 65536u || U2 <= U / 4;
+                U = U2;
+                if (U == 0 || (pays && text_rounds < 8)) continue;
+            } else if (dbg) fprintf(stderr, "[bwt] text round %d: group too long, handing over\n", rounds);
+            // hand over: ISA from the current order
+            u32 blocks = (n + WG - 1) / WG; if (blocks > 8192) blocks = 8192;
+            prof_begin(c, BSCGPU_K_SEG, (u64)n * 8, n);
+            hipLaunchKernelGGL(bwt_isa_fill_kernel, dim3(blocks), dim3(WG), 0, c->stream, c->SA, n, smask, c->ISA);
+            prof_end(c);
+            u32 fb = (U + WG - 1) / WG; if (fb > 8192) fb = 8192;
+            prof_begin(c, BSCGPU_K_SEG, (u64)U * 12, U);
+            hipLaunchKernelGGL(bwt_isa_fix_kernel, dim3(fb), dim3(WG), 0, c->stream, c->csa[cur], c->cgrp[cur], U, smask, c->ISA);
+            prof_end(c);
+            isa_valid = true;
+            if (c->hscal[2] == 0) continue;          // the round itself was done; the next one doubles
+        }
         // segmented sort of the grouped records (falls back to the radix engine when a group is too long for one workgroup)
         static const int segsort_on = [] { const char* e = getenv("BSC_BWT_SEGSORT"); return e ? atoi(e) : 1; }();
         bool sorted = false;
@@ -574,30 +750,35 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
         }
 
         u32 U2 = 0;
-        rc = run_seg<false>(c, ks, vs, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2);
+        rc = run_seg<false, true>(c, ks, vs, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2);
         if (rc < 0) return rc;
         cur ^= 1;
-        if (dbg) fprintf(stderr, "[bwt] round %d h=%llu U %u -> %u (passes %d)\n", rounds, h, U, U2, np);
+        if (dbg) fprintf(stderr, "[bwt] round %d h=%llu U %u -> %u (passes %d)\n", rounds, (unsigned long long)h, U, U2, np);
         U = U2;
         h <<= 1;
     }
     c->stage_ms[5] = rounds;
 
-    prof_begin(c, BSCGPU_K_EMIT, (u64)n * 6, n);
-    if (pp.pred_shift)
-        hipLaunchKernelGGL(bwt_emit_pred_kernel, dim3((n + 4 * WG - 1) / (4 * WG)), dim3(WG), 0, c->stream,
-                           c->dT, c->SA, c->ISA, n, pp.pred_shift, ddecode, dL_user, c->dscal);
-    else
-        hipLaunchKernelGGL(bwt_emit_kernel, dim3((n + 4 * WG - 1) / (4 * WG)), dim3(WG), 0, c->stream,
-                           c->dT, c->SA, c->ISA, n, dL_user, c->dscal);
-    prof_end(c);
-    u32 cnt = 0;
+    // primary index and aux indexes from SA, then the last column
+    u32 cnt = 0, rshift = 0;
     if (I_host != nullptr) {
         if (r <= 0 || (r & (r - 1)) != 0) return BSC_BAD_PARAMETER;
         cnt = (u32)((n64 - 1) / r) + 1;
         if (cnt > 256) return BSC_BAD_PARAMETER;
-        hipLaunchKernelGGL(bwt_aux_kernel, dim3(1), dim3(256), 0, c->stream, c->ISA, n, (u32)r, cnt, c->dscal + 8);
+        while ((1ll << rshift) < r) ++rshift;
     }
+    prof_begin(c, BSCGPU_K_EMIT, (u64)n * 4, n);
+    hipLaunchKernelGGL(bwt_find_kernel, dim3((n + 4 * WG - 1) / (4 * WG)), dim3(WG), 0, c->stream,
+                       c->SA, n, smask, cnt ? (u32)(r - 1) : 0u, rshift, cnt, c->dscal);
+    prof_end(c);
+    prof_begin(c, BSCGPU_K_EMIT, (u64)n * 6, n);
+    if (pp.pred_shift)
+        hipLaunchKernelGGL(bwt_emit_pred_kernel, dim3((n + 4 * WG - 1) / (4 * WG)), dim3(WG), 0, c->stream,
+                           c->dT, c->SA, n, pp.pred_shift, ddecode, dL_user, c->dscal);
+    else
+        hipLaunchKernelGGL(bwt_emit_kernel, dim3((n + 4 * WG - 1) / (4 * WG)), dim3(WG), 0, c->stream,
+                           c->dT, c->SA, n, dL_user, c->dscal);
+    prof_end(c);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->hscal, c->dscal, (8 + 256) * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, ctx_sync(c));
