@@ -72,8 +72,16 @@ def main():
     if "BSCGPU_HOST_THREADS" not in os.environ:         # per pipe: this rank's CPUs are shared by its contexts
         os.environ["BSCGPU_HOST_THREADS"] = str(max(4, min(64, effective_cpus() // max(local_world, 1) // ncx)))
     coder_threads = int(os.environ["BSCGPU_HOST_THREADS"]) * ncx
+    # Range coding on the host: pairs of sub-blocks per thread (0.235 CPU-s per block, 0.05 s latency) when this rank's CPUs can
+    # keep its GPU busy that way (~62 blocks/s x 0.235 s = 15 CPUs), else all eight sub-blocks of a block in AVX2 lanes on one
+    # thread (0.145 CPU-s per block, 0.12 s latency: more blocks in flight).  BSC_RC_X8 in the environment overrides.
+    cpus_rank = effective_cpus() // max(local_world, 1)
+    if "BSC_RC_X8" not in os.environ:
+        os.environ["BSC_RC_X8"] = "1" if (args.coder == 1 and cpus_rank < 14) else "0"
+    rc_x8 = os.environ["BSC_RC_X8"] == "1"
     if args.depth <= 0:                                 # blocks in flight per context: 8 per GPU in total keep the coder pool and the GPU busy
         args.depth = max(2, min(4, 8 // ncx))
+        if rc_x8: args.depth = max(2, min(4, -(-int(min(62.0, cpus_rank / 0.145) * 0.25 + 1) // ncx)))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
@@ -273,6 +281,7 @@ def main():
             "kernels": per_kernel,
             "kernels_note": "HIP-event time per kernel class and block, from the region named in roofline.measured_on",
             "host": {"cpus": os.cpu_count(), "effective_cpus": effective_cpus(), "coder_threads_per_gpu": coder_threads,
+                     "range_coder": "8 sub-blocks per thread in AVX2 lanes" if rc_x8 else "2 sub-blocks per thread, interleaved",
                      "cpu_seconds_per_block_rank0": round(cpu_used / args.steps, 3),
                      "cpu_busy_fraction_of_effective": round(cpu_used / (dt * max(effective_cpus() / max(local_world, 1), 1)), 3)},
         }

@@ -66,6 +66,9 @@ int qlfc_encode_static_pstream(const uint8_t* first_seen, int nsym, int in_size,
 // bound, two chains in flight nearly double a core's rate (1.9 -> 1.1 ns per decision on an EPYC 9575F).  res[k] as above.
 struct PstreamJob { const uint8_t* first_seen; int nsym; int in_size; const uint16_t* ps; size_t count; uint8_t* out; int out_size; };
 void qlfc_encode_static_pstream_pair(const PstreamJob& A, const PstreamJob& B, int* resA, int* resB);
+// Eight sub-blocks, one per AVX2 lane (J[8], res[8]).  false = not done (a stream reached its output budget, or no AVX2):
+// the caller codes the sub-blocks with the functions above.
+bool qlfc_encode_static_pstream_x8(const PstreamJob* J, int* res);
 // Encode one sub-block (what coder.cpp:61 dispatches to).  Returns bytes written or NOT_COMPRESSIBLE.
 int qlfc_encode_block(const uint8_t* in, uint8_t* out, int in_size, int out_size, int coder);
 // Decode one sub-block; returns the decoded size or an error.

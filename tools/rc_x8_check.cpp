@@ -1,0 +1,67 @@
+// rc_x8_check.cpp — CPU check + timing of the 8-lane AVX2 range coder against the scalar one (not part of the product).
+//   g++ -O2 -std=c++17 -march=x86-64-v3 -I libbsc_amd/csrc/host -I include tools/rc_x8_check.cpp -o /tmp/rc_x8_check && /tmp/rc_x8_check
+#include "../libbsc_amd/csrc/host/qlfc.cpp"
+#include <chrono>
+#include <cstdio>
+#include <random>
+using namespace bschost;
+
+int main(int argc, char** argv)
+{
+    const size_t base = argc > 1 ? (size_t)atol(argv[1]) : 4000000;
+    std::mt19937_64 rng(7);
+    std::vector<uint16_t> ps[8];
+    uint8_t first_seen[8][256]; int nsym[8];
+    for (int l = 0; l < 8; ++l) {
+        const size_t cnt = base + (rng() % (base / 20 + 1)) - (l == 3 ? base / 50 : 0);
+        ps[l].resize(cnt);
+        for (size_t i = 0; i < cnt; ++i) {
+            // skewed probabilities like the model's: mostly confident predictions
+            unsigned p = 1 + (unsigned)(rng() % 4095);
+            if (rng() & 3) p = (rng() & 1) ? 1 + p / 16 : 4095 - p / 16;
+            const unsigned bit = ((rng() % 4096) >= p) ? 1u : 0u;        // P(bit = 0) = p / 4096
+            ps[l][i] = (uint16_t)(p | (bit << 12) | ((i % 7 == 0) ? 0x2000u : 0u));
+        }
+        nsym[l] = 20 + l;
+        for (int s = 0; s < nsym[l]; ++s) first_seen[l][s] = (uint8_t)(s * 3 + l);
+    }
+    int bad = 0;
+    for (int mode = 0; mode < 2; ++mode) {          // 0: roomy outputs, 1: lane 5 too small (must give up)
+        std::vector<uint8_t> oa[8], ob[8];
+        PstreamJob J[8];
+        int ra[8], rb[8];
+        for (int l = 0; l < 8; ++l) {
+            const int osz = (mode == 1 && l == 5) ? 4096 : (int)ps[l].size() * 2 + 1024;
+            oa[l].assign(osz + 64, 0); ob[l].assign(osz + 64, 0);
+            J[l] = PstreamJob{first_seen[l], nsym[l], (int)ps[l].size(), ps[l].data(), ps[l].size(), ob[l].data(), osz};
+            ra[l] = qlfc_encode_static_pstream(first_seen[l], nsym[l], (int)ps[l].size(), ps[l].data(), ps[l].size(), oa[l].data(), osz);
+        }
+        auto t0 = std::chrono::steady_clock::now();
+        const bool ok = qlfc_encode_static_pstream_x8(J, rb);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        size_t total = 0; for (int l = 0; l < 8; ++l) total += ps[l].size();
+        printf("mode %d: x8 %s, %.1f ms, %.3f ns/decision\n", mode, ok ? "done" : "gave up", ms, ms * 1e6 / total);
+        if (mode == 0) {
+            if (!ok) { printf("FAIL: x8 gave up with roomy outputs\n"); ++bad; }
+            else for (int l = 0; l < 8; ++l) {
+                if (ra[l] != rb[l] || memcmp(oa[l].data(), ob[l].data(), (size_t)(ra[l] > 0 ? ra[l] : 0)) != 0) { printf("FAIL lane %d: scalar %d bytes, x8 %d bytes\n", l, ra[l], rb[l]); ++bad; }
+            }
+        } else {
+            if (ok && rb[5] != ra[5]) { printf("FAIL: budget case, scalar %d x8 %d\n", ra[5], rb[5]); ++bad; }
+            printf("  scalar result of the small lane: %d\n", ra[5]);
+        }
+    }
+    // scalar pair timing for comparison
+    {
+        std::vector<uint8_t> o0(ps[0].size() * 2 + 1024), o1(ps[1].size() * 2 + 1024);
+        PstreamJob A{first_seen[0], nsym[0], (int)ps[0].size(), ps[0].data(), ps[0].size(), o0.data(), (int)o0.size() - 64};
+        PstreamJob B{first_seen[1], nsym[1], (int)ps[1].size(), ps[1].data(), ps[1].size(), o1.data(), (int)o1.size() - 64};
+        int r0, r1;
+        auto t0 = std::chrono::steady_clock::now();
+        qlfc_encode_static_pstream_pair(A, B, &r0, &r1);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        printf("scalar pair: %.1f ms, %.3f ns/decision\n", ms, ms * 1e6 / (ps[0].size() + ps[1].size()));
+    }
+    printf(bad ? "FAILED\n" : "all equal\n");
+    return bad != 0;
+}
