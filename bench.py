@@ -76,9 +76,10 @@ def main():
     # keep its GPU busy that way (~62 blocks/s x 0.235 s = 15 CPUs), else all eight sub-blocks of a block in AVX2 lanes on one
     # thread (0.145 CPU-s per block, 0.12 s latency: more blocks in flight).  BSC_RC_X8 in the environment overrides.
     cpus_rank = effective_cpus() // max(local_world, 1)
-    if "BSC_RC_X8" not in os.environ:
-        os.environ["BSC_RC_X8"] = "1" if (args.coder == 1 and cpus_rank < 14) else "0"
-    rc_x8 = os.environ["BSC_RC_X8"] == "1"
+    if "BSC_RC_SIMD" not in os.environ:
+        os.environ["BSC_RC_SIMD"] = "8" if (os.environ.get("BSC_RC_X8") == "1" or (args.coder == 1 and cpus_rank < 14)) else "0"
+    rc_simd = int(os.environ["BSC_RC_SIMD"])
+    rc_x8 = rc_simd == 8
     if args.depth <= 0:                                 # blocks in flight per context: 8 per GPU in total keep the coder pool and the GPU busy
         args.depth = max(2, min(4, 8 // ncx))
         if rc_x8: args.depth = max(2, min(4, -(-int(min(62.0, cpus_rank / 0.145) * 0.25 + 1) // ncx)))

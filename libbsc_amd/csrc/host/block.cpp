@@ -454,26 +454,38 @@ static void host_encode_pair(BlockJob& J, int b)
 }
 
 // All eight sub-blocks of a device-model block in the lanes of one AVX2 range-coder loop (qlfc_encode_static_pstream_x8):
-// 0.115 s on one thread instead of 4 x 0.052 s on four (EPYC 9575F) — 40 % less CPU time per block (0.235 -> 0.145 s with
-// framing), twice the latency.  It is the mode for hosts where the coder threads are the bottleneck (many GPUs per CPU quota),
-// and needs more blocks in flight to keep a GPU busy; the default stays the pairs.  BSC_RC_X8=1 selects it (bench.py does when
-// a rank's share of the CPUs cannot keep its GPU busy with pairs).
-static bool ps_x8_enabled() { static const bool on = [] { const char* e = getenv("BSC_RC_X8"); return e ? atoi(e) != 0 : false; }(); return on; }
-static bool ps_x8_capable(const BlockJob& J) { return J.use_ps && J.nblocks == 8 && ps_x8_enabled(); }
-static void host_encode_x8(BlockJob& J)
+// one task of 0.115 s instead of four of 0.052 s (EPYC 9575F) — 40 % less CPU time per block (0.238 -> 0.144 s with framing),
+// twice the latency, so more blocks have to be in flight to keep a GPU busy.  It is the mode for hosts whose coder threads are
+// the bottleneck (many GPUs per CPU quota); the default stays the pairs.  BSC_RC_SIMD=8 (or BSC_RC_X8=1) selects it; bench.py
+// does when a rank's share of the CPUs cannot keep its GPU busy with pairs.
+static int ps_simd_mode()
 {
+    static const int mode = [] {
+        if (const char* e = getenv("BSC_RC_SIMD")) return atoi(e) == 8 ? 8 : 0;
+        if (const char* e = getenv("BSC_RC_X8")) return atoi(e) != 0 ? 8 : 0;
+        return 0;
+    }();
+    return mode;
+}
+static int ps_group(const BlockJob& J) { return (J.use_ps && J.nblocks == 8 && ps_simd_mode() == 8) ? 8 : 2; }
+// sub-blocks b .. b + g - 1 of a device-model block, g = ps_group(J)
+static void host_encode_group(BlockJob& J, int b)
+{
+    const int g = ps_group(J);
+    if (g == 2) { host_encode_pair(J, b); return; }
     PstreamJob P[8];
-    for (int q = 0; q < 8; ++q) {
+    for (int k = 0; k < g; ++k) {
+        const int q = b + k;
         const size_t need = (size_t)J.size[q] + 64;
         if (J.scratch_cap[q] < need) { J.scratch[q].reset(new uint8_t[need + need / 8]); J.scratch_cap[q] = need + need / 8; }
-        P[q] = PstreamJob{J.views[q].first_seen, J.views[q].nsym, J.size[q], J.ps + J.poff[q], (size_t)(J.poff[q + 1] - J.poff[q]), J.scratch[q].get(), J.size[q]};
+        P[k] = PstreamJob{J.views[q].first_seen, J.views[q].nsym, J.size[q], J.ps + J.poff[q], (size_t)(J.poff[q + 1] - J.poff[q]), J.scratch[q].get(), J.size[q]};
     }
-    if (hipEventSynchronize(J.ps_ready) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); for (int q = 0; q < 8; ++q) J.sub_res[q] = J.size[q]; return; }
+    if (hipEventSynchronize(J.ps_ready) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); for (int k = 0; k < g; ++k) J.sub_res[b + k] = J.size[b + k]; return; }
     int r[8];
-    if (!qlfc_encode_static_pstream_x8(P, r)) { for (int q = 0; q < 8; q += 2) host_encode_pair(J, q); return; }      // a stream near its budget: the exact scalar coders
-    for (int q = 0; q < 8; ++q) {
-        if (r[q] < 0) J.redo.store(true, std::memory_order_relaxed);
-        J.sub_res[q] = r[q] < 0 ? J.size[q] : r[q];
+    if (!qlfc_encode_static_pstream_x8(P, r)) { for (int k = 0; k < g; k += 2) host_encode_pair(J, b + k); return; }      // a stream near its budget: the exact scalar coders
+    for (int k = 0; k < g; ++k) {
+        if (r[k] < 0) J.redo.store(true, std::memory_order_relaxed);
+        J.sub_res[b + k] = r[k] < 0 ? J.size[b + k] : r[k];
     }
 }
 
@@ -593,8 +605,7 @@ static void host_stage(BlockJob& J)
     if (J.stored_small) return;
     host_prepare(J);
     if (job_uses_tasks(J)) {
-        if (ps_x8_capable(J)) host_encode_x8(J);
-        else if (J.use_ps) run_tasks(J.nblocks / 2, [&J](int t) { host_encode_pair(J, 2 * t); });
+        if (J.use_ps) { const int g = ps_group(J); run_tasks(J.nblocks / g, [&J, g](int t) { host_encode_group(J, g * t); }); }
         else run_tasks(J.nblocks, [&J](int b) { host_encode_sub(J, b); });
         host_finalize(J);
         return;
@@ -757,8 +768,7 @@ struct bscgpu_pipe {
     int next_ticket = 0;
     struct Lane { std::unique_ptr<BlockJob> job; int ticket = -1; bool busy = false; };
     Lane lanes[MAX_SLOTS];
-    struct Task { BlockJob* job; int sub; };          // sub = -1: whole host stage of the block as one task; -2: all eight sub-blocks
-                                                      // of a device-model block in AVX2 lanes (BSC_RC_X8=1)
+    struct Task { BlockJob* job; int sub; };          // sub = -1: whole host stage of the block as one task; else first sub-block of the task
     std::mutex mu; std::condition_variable cv_work, cv_done;
     std::deque<Task> queue;
     std::vector<std::thread> workers;
@@ -778,9 +788,7 @@ struct bscgpu_pipe {
             bool finished = false;
             if (t.sub == -1) { host_stage(J); finished = true; }
             else {
-                if (t.sub == -2) host_encode_x8(J);
-                else if (J.use_ps) host_encode_pair(J, t.sub);
-                else host_encode_sub(J, t.sub);
+                if (J.use_ps) host_encode_group(J, t.sub); else host_encode_sub(J, t.sub);
                 if (J.remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) { host_finalize(J); finished = true; }
             }
             if (finished) { { std::lock_guard<std::mutex> lk(mu); J.done = true; } cv_done.notify_all(); }
@@ -835,12 +843,10 @@ static int pipe_enqueue(bscgpu_pipe* p, bscgpu_pipe::Lane& L, int ticket)
         std::lock_guard<std::mutex> lk(p->mu);
         if (job_uses_tasks(J)) {
             host_prepare(J);
-            if (ps_x8_capable(J)) {                              // device model, eight sub-blocks in AVX2 lanes: one task
-                J.remaining.store(1, std::memory_order_release);
-                p->queue.push_back({&J, -2});
-            } else if (J.use_ps) {                               // device model: two sub-blocks per task (interleaved range coders)
-                J.remaining.store(J.nblocks / 2, std::memory_order_release);
-                for (int b = 0; b < J.nblocks; b += 2) p->queue.push_back({&J, b});
+            if (J.use_ps) {                                      // device model: 2 (interleaved scalar) or 8 (AVX2 lanes) sub-blocks per task
+                const int g = ps_group(J);
+                J.remaining.store(J.nblocks / g, std::memory_order_release);
+                for (int b = 0; b < J.nblocks; b += g) p->queue.push_back({&J, b});
             } else {
                 J.remaining.store(J.nblocks, std::memory_order_release);
                 for (int b = 0; b < J.nblocks; ++b) p->queue.push_back({&J, b});

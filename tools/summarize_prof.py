@@ -5,7 +5,11 @@ root = sys.argv[1]
 def find(pattern):
     return sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
 
-print("== rocprofv3 --kernel-trace --stats of: python bench.py --steps 3 --warmup 1 (4 blocks of 64 MiB incl. warm-up)")
+cmd = sys.argv[2] if len(sys.argv) > 2 else "python bench.py --steps 8 --warmup 2 --no-cpu-baseline"
+print(f"== rocprofv3 --kernel-trace --stats of: {cmd}")
+print("   (4 GPU contexts run side by side in the timed region, so per-launch durations there measure sharing of the chip; the")
+print("    'solo' table below keeps only launches that no launch of another queue overlaps = bench.py's single-context leg, the")
+print("    region its roofline numbers are measured on)")
 for f in find("*kernel_stats.csv"):
     rows = list(csv.DictReader(open(f)))
     print(f"-- {os.path.relpath(f, root)}")
@@ -26,6 +30,25 @@ for f in find("*kernel_trace.csv"):
         print(f"-- {os.path.relpath(f, root)}: rs_scatter<pairs> launches={len(d)}; launches > 300 us: {len(big)} avg {sum(big)/max(len(big),1):.1f} us")
         if big:
             print(f"   => full 64 Mi-record pass: 24 B x 67108864 / {sum(big)/len(big):.1f} us = {24*67108864/(sum(big)/len(big))/1e3:.0f} GB/s")
+# launches not overlapped by any launch of another queue: per-kernel medians (what one block costs on an otherwise idle GPU)
+import statistics
+for f in find("*kernel_trace.csv"):
+    if "pmc" in f:
+        continue
+    rows = list(csv.DictReader(open(f)))
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"].split("(")[0][:64], int(r["Grid_Size_X"])) for r in rows)
+    solo = collections.defaultdict(list)
+    for i, (s0, e0, q0, nm, g) in enumerate(ev):
+        if any(q1 != q0 and s1 < e0 and e1 > s0 for (s1, e1, q1, _, _) in ev[max(0, i - 48):i + 48]):
+            continue
+        solo[nm].append((e0 - s0) / 1e3)
+    print(f"-- {os.path.relpath(f, root)}: launches no other queue overlaps")
+    print(f"{'kernel':66s} {'n':>4s} {'median_us':>10s} {'mean_us':>10s} {'min_us':>9s}")
+    for nm, v in sorted(solo.items(), key=lambda kv: -sum(kv[1]))[:40]:
+        print(f"{nm:66s} {len(v):4d} {statistics.median(v):10.1f} {sum(v)/len(v):10.1f} {min(v):9.1f}")
+    full = [x for nm, v in solo.items() if nm.startswith("void rs_scatter_kernel<true, 1024") for x in v if x > 250]
+    if full:
+        print(f"   => solo full-size rs_scatter<pairs, 1024 x 8> launches: {len(full)}, mean {sum(full)/len(full):.1f} us -> 24 B x 67108864 / mean = {24*67108864/(sum(full)/len(full))/1e3:.0f} GB/s")
 print()
 print("== PMC passes (one 64 MiB BWT; counters per dispatch, summed per kernel; FETCH_SIZE/WRITE_SIZE in KiB units as reported)")
 for tag, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
