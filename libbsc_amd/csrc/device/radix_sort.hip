@@ -9,21 +9,23 @@
 //    input), rs_scan (256 workgroups, one per digit: exclusive scan over chunks), rs_scatter (the
 //    graded kernel).  There is NO inter-workgroup communication inside a launch: on MI355X the eight
 //    XCD L2s are not coherent and an agent-scope hand-off costs ~1-3 us under streaming load
-//    (MI355X_MICROARCH.md, handoff rows), while a chip at 5 TB/s retires a 96 KB tile every ~20 ns —
-//    a decoupled-look-back chain ("onesweep") would serialise on that latency.  The price is one
-//    extra streaming read of the keys per pass (8 B/record, rs_hist); the scatter pass itself moves
-//    exactly the algorithmic 2*(8+4) B/record.
+//    (MI355X_MICROARCH.md, handoff rows; 4.6 us per hop in tools/ubench.hip), while the chip retires a
+//    196 KB tile every ~50 ns: with 256 tiles in flight a decoupled look-back ("onesweep") finds its
+//    nearest finished predecessor 40-60 tiles back and has to sum that many 1 KB aggregate rows per tile
+//    through L2-bypassing loads — the bytes rs_hist reads (64 KB per tile), plus the latency.
+//    The price paid instead is one extra streaming read of the keys per pass (8 B/record, rs_hist, at
+//    4.5 TB/s); the scatter pass itself moves exactly the algorithmic 2*(8+4) B/record.
 //  * <= 1024 chunks for rs_hist (one 256-thread workgroup each, 4 per CU, all resident; block b runs on XCD b % 8 so
 //    every XCD streams an equal contiguous share).  rs_scatter comes in two shapes: 256 threads x 16 records (4096-
 //    record tiles, one chunk per workgroup) for keys-only passes and small inputs, and 1024 threads x 8 records
 //    (8192-record tiles, one workgroup per CU walking four chunks) for large (key, value) passes, where the longer
 //    per-digit runs halve the number of partially written lines.  A workgroup walks its records tile by tile keeping
 //    its 256 running global bucket offsets in LDS, so the per-chunk offsets table is only 256 x 1024 u32.
-//  * rs_scatter_wc (opt-in, BSC_RS_WC=1) additionally keeps up to 31 pending records per digit in LDS and writes only
-//    whole aligned 32-record groups; see its header for why it is not the default.
+//  * rs_scatter_wc (large (key, value) passes; BSC_RS_WC) additionally keeps the records of a digit that do not yet
+//    fill a 128-B line in LDS and writes keys only as whole 16-key lines, values as whole 32-value lines.
 //  * Inside a tile: wave-striped coalesced loads (each wave64 load instruction covers 512 contiguous
-//    bytes of keys), 8-bit digit, stable in-wave ranking by wave64 ballot match (8 ballots -> peer
-//    mask, popcount of lower peers), per-wave 256-bin histograms in LDS, then the tile is locally
+//    bytes of keys), 8-bit digit, stable in-wave ranking by wave64 ballot match (rs_match8: 8 ballots -> peer
+//    mask, 32 hand-scheduled VALU instructions per record), per-wave 256-bin histograms in LDS, then the tile is locally
 //    reordered through LDS (32 / 64 KB staging) so that every bucket leaves as one contiguous run:
 //    consecutive lanes store consecutive addresses.  Integer/index work only — no MFMA.
 #include "dev_common.h"
@@ -51,7 +53,7 @@ typedef volatile u32 lds_vu32;
 typedef __attribute__((address_space(3))) volatile u32 lds_vu32;
 #endif
 #ifndef RS_WC_DEFAULT
-#define RS_WC_DEFAULT 0        // default of BSC_RS_WC (write-combining scatter for large inputs)
+#define RS_WC_DEFAULT 1        // default of BSC_RS_WC: write-combining scatter for large (key, value) passes
 #endif
 // Phase timing (debug builds, -DRS_PHASE_TIMING=1): thread 0 of every workgroup stamps s_memtime at the phase boundaries of
 // its first 32 tiles into the context's scratch buffer; radix_sort_passes dumps the last pass to gpurun_out/phase_timing.bin.
@@ -493,11 +495,29 @@ __global__ __launch_bounds__(WC_WG) void rs_scatter_wc_kernel(const u64* __restr
         const u32 base = rs_digit_excl_sum<WAVES>(t < 256 ? rowtot[t] : 0u, scr, &tot);
         if (t < 256) { E = base + offsets[(size_t)t * num_chunks + (size_t)blockIdx.x * WC_SPAN]; gk = gv = E; }
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) whist[w * 256 + i * 64 + lane] = 0;          // every wave owns (and re-zeroes) its 256 counters
     __syncthreads();
 
-    const u64 rec0 = (u64)blockIdx.x * WC_SPAN * chunk_tiles * RS_TILE;
-    u64 rec1 = rec0 + (u64)WC_SPAN * chunk_tiles * RS_TILE;
-    if (rec1 > n) rec1 = n;
+    const u32 rec0 = (u32)((u64)blockIdx.x * WC_SPAN * chunk_tiles * RS_TILE);
+    u32 rec1;
+    { const u64 e = (u64)rec0 + (u64)WC_SPAN * chunk_tiles * RS_TILE; rec1 = e > n ? n : (u32)e; }
+
+    // as in the 1024 x 8 shape of rs_scatter: the next tile's keys / values are requested as soon as this tile's sit in the
+    // staging area, ahead of the tile's stores; a lane past the end reads the workgroup's first record instead
+    const u32 wbase = w * (64 * ITEMS) + lane;
+    u64 k[ITEMS];
+    u32 v[ITEMS];
+    auto prefetch_keys = [&](const u32 tb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) { u32 e = tb + wbase + i * 64; e = e < rec1 ? e : rec0; k[i] = __builtin_nontemporal_load(&kin[e]); }
+    };
+    auto prefetch_vals = [&](const u32 tb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) { u32 e = tb + wbase + i * 64; e = e < rec1 ? e : rec0; v[i] = __builtin_nontemporal_load(&vin[e]); }
+    };
+    prefetch_keys(rec0);
+    if (HAS_VAL) prefetch_vals(rec0);
 
     // old pending records of the digits that reached a group boundary: 16 lanes per digit (keys), 32 per digit (values)
     auto flush_pending = [&]() __attribute__((always_inline)) {
@@ -517,35 +537,20 @@ __global__ __launch_bounds__(WC_WG) void rs_scatter_wc_kernel(const u64* __restr
         }
     };
 
-    auto do_tile = [&](const u64 tbase, const u32 nvalid, auto full_tag) __attribute__((always_inline)) {
+    auto do_tile = [&](const u32 tbase, const u32 nvalid, auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
-        const u32 tile_no = (u32)((tbase - rec0) / TILE); (void)tile_no;
+        const u32 tile_no = (tbase - rec0) / TILE; (void)tile_no;
         RS_PH(0);
-        u64 k[ITEMS];
-        u32 v[ITEMS];
-        const u32 wbase = w * (64 * ITEMS) + lane;
+        if (!FULL) {
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const u32 idx = wbase + i * 64;
-            if (FULL) k[i] = __builtin_nontemporal_load(&kin[tbase + idx]);
-            else k[i] = (idx < nvalid) ? __builtin_nontemporal_load(&kin[tbase + idx]) : ~0ull;
+            for (int i = 0; i < ITEMS; ++i) if (wbase + i * 64 >= nvalid) k[i] = ~0ull;       // padding sorts last
         }
-        for (u32 i = t; i < (u32)WAVES * 256; i += WG) whist[i] = 0;
-        __syncthreads();
         RS_PH(1);
 
         // ---- stable in-wave ranking by ballot match (rs_rank_wave) --------------------------------
         u32 rk[ITEMS];
         rs_rank_wave<ITEMS>(k, shift, mask, vwh + w * 256, rk);
         RS_PH(2);
-        if (HAS_VAL) {
-#pragma unroll
-            for (int i = 0; i < ITEMS; ++i) {
-                const u32 idx = wbase + i * 64;
-                if (FULL) v[i] = __builtin_nontemporal_load(&vin[tbase + idx]);
-                else v[i] = (idx < nvalid) ? __builtin_nontemporal_load(&vin[tbase + idx]) : 0u;
-            }
-        }
         __syncthreads();
         RS_PH(3);
 
@@ -558,7 +563,7 @@ __global__ __launch_bounds__(WC_WG) void rs_scatter_wc_kernel(const u64* __restr
                 for (int i = 0; i < WAVES; ++i) { c[i] = whist[i * 256 + t]; tot += c[i]; }
             }
             u32 all;
-            const u32 ds = rs_digit_excl_sum<WAVES>(tot, scr, &all);
+            const u32 ds = rs_digit_excl_sum<WAVES, false>(tot, scr, &all);
             if (t < 256) {
                 u32 run = ds;
 #pragma unroll
@@ -588,10 +593,13 @@ __global__ __launch_bounds__(WC_WG) void rs_scatter_wc_kernel(const u64* __restr
             rk[i] = pos;
             skeys[pos] = k[i];
         }
+        prefetch_keys(tbase + TILE);
         flush_pending();
         RS_PH(5);
         __syncthreads();
         RS_PH(6);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) whist[w * 256 + i * 64 + lane] = 0;       // for the next tile's ranking (own wave's counters only)
 
         u32 dd[ITEMS / 4];
 #pragma unroll
@@ -611,6 +619,7 @@ __global__ __launch_bounds__(WC_WG) void rs_scatter_wc_kernel(const u64* __restr
             u32* svals = reinterpret_cast<u32*>(skeys);
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) svals[rk[i]] = v[i];
+            prefetch_vals(tbase + TILE);
             __syncthreads();
             RS_PH(8);
 #pragma unroll
@@ -624,14 +633,14 @@ __global__ __launch_bounds__(WC_WG) void rs_scatter_wc_kernel(const u64* __restr
             }
         }
         RS_PH(9);
-        __syncthreads();
-        RS_PH(10);
+        RS_PH(10);            // no barrier here: the next tile's first writes (own counters; tables behind its first barrier) hurt nobody
     };
-    u64 tbase = rec0;
+    u32 tbase = rec0;
     for (; tbase + TILE <= rec1; tbase += TILE) do_tile(tbase, (u32)TILE, std::true_type());
-    if (tbase < rec1) do_tile(tbase, (u32)(rec1 - tbase), std::false_type());
+    if (tbase < rec1) do_tile(tbase, rec1 - tbase, std::false_type());
 
     // tails of this workgroup's segments
+    __syncthreads();
     if (t < 256) { fkS[t] = gk; fkE[t] = E; if (HAS_VAL) { fvS[t] = gv; fvE[t] = E; } }
     __syncthreads();
     flush_pending();
@@ -643,8 +652,7 @@ __global__ __launch_bounds__(WC_WG) void rs_scatter_wc_kernel(const u64* __restr
 // Per-context (= per-device) setup, called from bscgpu_create with the context's device current: the dynamic-LDS limits
 // of the large-tile kernels are a per-device attribute of the function, so every device that gets a context must be told
 // (a process-wide `static` here would configure only the first device and race between threads).
-// BSC_RS_WC: 0 = plain scatter (default), 1 = write-combining scatter for inputs that fill the chip (>= 2 tiles per rs_hist
-// chunk at the full chunk count), 2 = force it whenever there are >= 4 chunks (tests).
+// BSC_RS_WC: see radix_sort_passes.
 int radix_engine_setup(bscgpu_ctx* c)
 {
     const char* e = getenv("BSC_RS_WC");
@@ -669,12 +677,15 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
     if ((((uintptr_t)keys) | ((uintptr_t)keys_alt)) & 15) return ctx_fail(c, BSC_BAD_PARAMETER, "radix keys not 16B aligned", hipSuccess);
 
     const Chunking ch = rs_chunking(n);
+    const bool has_val = (vals != nullptr);
     const int wc_mode = c->rs_wc_mode;          // BSC_RS_WC, read once per context (radix_engine_setup)
     const bool big_pairs = RS_BIG_PAIRS && ch.num_chunks >= 512 && ch.chunk_tiles >= 2;   // enough records for 8192-record tiles on every CU
-    const bool use_wc = emit_pos == nullptr && ((wc_mode == 2 && ch.num_chunks >= 4) || (wc_mode == 1 && ch.num_chunks >= 512 && ch.chunk_tiles >= 2));
+    // BSC_RS_WC: 0 = never, 1 (default) = large (key, value) passes — on the BWT's keys 0.370 ms per pass against 0.389 ms, the gain
+    // sits in the two lowest digits (0.47 -> 0.40, 0.42 -> 0.38), the others tie; keys-only passes stay on the plain kernel (text-
+    // skewed ST digits: 0.189 against 0.221 ms) —, 2 = every pass with >= 4 chunks (tests)
+    const bool use_wc = emit_pos == nullptr && ((wc_mode == 2 && ch.num_chunks >= 4) || (wc_mode == 1 && has_val && ch.num_chunks >= 512 && ch.chunk_tiles >= 2));
     u64 *ksrc = keys, *kdst = keys_alt;
     u32 *vsrc = vals, *vdst = vals_alt;
-    const bool has_val = (vals != nullptr);
     const u64 rec_bytes = 8 + (has_val ? 4 : 0);
 
     for (int p = 0; p < npasses; ++p) {
