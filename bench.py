@@ -2,7 +2,7 @@
 """bench.py — MB/s compress (BWT + QLFC) on 64 MiB blocks, 1/2/4/8 GPU (BASELINE.json metric).
 
 A step = one pass of the hot path over one 64 MiB synthetic block per GPU, input already resident in HBM:
-Adler-32 + forward BWT (prefix-doubling suffix sort: LSD radix first sort, segmented sorts for the doubling rounds) +
+Adler-32 + forward BWT (LSD radix first sort on 12-character keys, refinement rounds as segmented sorts on text keys) +
 QLFC front end + the static coder's adaptive model (-e1: every probability, devcoder.hip) on the MI355X, range coding
 on host threads, block container — i.e. bsc_compress(lzp off, BWT, QLFC_STATIC) — then, for N > 1, the
 compressed blocks are concatenated on rank 0 over RCCL/xGMI (send/recv of the variable-size blocks).
@@ -34,7 +34,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 T
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--block", type=int, default=BLOCK)
     ap.add_argument("--sorter", type=int, default=1)
@@ -236,7 +236,8 @@ def main():
             pass
         pass_achieved = pass_rate(stats_iso)
         roofline = {
-            "bound": "hbm", "kernel": "rs_scatter_kernel (one 8-bit LSD digit pass: read + scatter of u64 key + u32 value)",
+            "bound": "hbm", "kernel": "rs_scatter_wc_kernel<true> (one 8-bit LSD digit pass of the BWT's first sort: read + scatter of u64 key + u32 value; "
+                                     "write-combining 1024 x 8 shape of rs_scatter)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "pass_frac": round(pass_achieved / HBM_PEAK_GBPS, 4), "pass_achieved": round(pass_achieved, 1),
             "pass_note": "whole digit pass (histogram + scan + scatter kernels, every launch of the measured region) charged with the scatter's algorithmic bytes",
