@@ -79,9 +79,20 @@ __global__ __launch_bounds__(WG) void qf_apply_kernel(const u8* __restrict__ L, 
                                                       u32* __restrict__ first_run /*[8][256]*/)
 {
     __shared__ u32 scr[8];
+    // first run of every symbol per sub-block: minima in LDS first (a chunk of n / 1024 bytes touches at most two sub-blocks),
+    // one global atomicMin per (sub-block, symbol) the workgroup has seen — not one L2 round trip per run
+    __shared__ u32 fmin[2 * 256];
+    for (u32 i = threadIdx.x; i < 2 * 256; i += WG) fmin[i] = 0xffffffffu;
     const u32 tile0 = blockIdx.x * chunk_tiles;
     u32 tile1 = tile0 + chunk_tiles; if (tile1 > num_tiles) tile1 = num_tiles;
+    u32 b_first = 0;
+    {
+        const u32 p0 = tile0 * QF_TILE;
+#pragma unroll
+        for (int q = 1; q < 8; ++q) if ((u32)q < sp.nblocks && p0 >= sp.start[q]) b_first = q;
+    }
     u32 off = segoff[blockIdx.x];
+    __syncthreads();
     for (u32 tile = tile0; tile < tile1; ++tile) {
         const u32 i0 = tile * QF_TILE + threadIdx.x * QF_BYTES;
         uint4 bytes = make_uint4(0, 0, 0, 0);
@@ -90,21 +101,24 @@ __global__ __launch_bounds__(WG) void qf_apply_kernel(const u8* __restrict__ L, 
         u32 tot;
         u32 j = off + block_excl_sum(__popc(mask), scr, &tot);
         const u32 w[4] = {bytes.x, bytes.y, bytes.z, bytes.w};
+        // sub-block of this thread's 16 bytes: the chunk's first one, or the next when a boundary has been passed
+        const u32 b_next_start = (b_first + 1 < sp.nblocks) ? sp.start[b_first + 1 < 8 ? b_first + 1 : 7] : 0xffffffffu;
         while (mask) {
             const u32 p = __ffs(mask) - 1; mask &= mask - 1;
             const u32 c = (w[p >> 2] >> (8 * (p & 3))) & 0xffu;
             const u32 pos = i0 + p;
             sym[j] = (u8)c;
             start[j] = pos;
-            u32 b = 0;
-#pragma unroll
-            for (int q = 1; q < 8; ++q) if ((u32)q < sp.nblocks && pos >= sp.start[q]) b = q;
-            u32* fr = first_run + b * 256 + c;
-            if (j < __hip_atomic_load(fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(fr, j);   // cheap filter before the atomic
+            atomicMin(&fmin[(pos >= b_next_start ? 256u : 0u) + c], j);
             ++j;
         }
         off += tot;
         __syncthreads();
+    }
+    for (u32 i = threadIdx.x; i < 2 * 256; i += WG) {
+        const u32 v = fmin[i];
+        const u32 b = b_first + (i >> 8);
+        if (v != 0xffffffffu && b < 8) atomicMin(first_run + b * 256 + (i & 255u), v);
     }
 }
 

@@ -179,7 +179,13 @@ int adler32_device(bscgpu_ctx* c, const u8* d, int64_t n, u32* out)
 {
     if (n < 0) return BSC_BAD_PARAMETER;
     if (n == 0) { *out = 1; return BSC_NO_ERROR; }
-    if (((uintptr_t)d) & 15) return ctx_fail(c, BSC_BAD_PARAMETER, "adler32 input not 16B aligned", hipSuccess);
+    if (((uintptr_t)d) & 15) {
+        // the kernel reads 16 bytes per lane: an unaligned input (a slice of a caller's tensor) goes through the context's
+        // aligned text buffer first (the sorters copy the block there anyway, after this call)
+        if (n > c->max_n) return ctx_fail(c, BSC_BAD_PARAMETER, "adler32: unaligned input larger than the context", hipSuccess);
+        HIP_TRY(c, hipMemcpyAsync(c->dT, d, (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+        d = c->dT;
+    }
     const Chunking ch = make_chunking((u64)n, ADLER_TILE);
     prof_begin(c, BSCGPU_K_MISC, (u64)n, 0);
     hipLaunchKernelGGL(adler_kernel, dim3(ch.num_chunks), dim3(WG), 0, c->stream, d, (u64)n, ch.chunk_tiles, c->adler_part);

@@ -99,6 +99,18 @@ def test_adler32_device(ctx, torch_cuda):
             assert ctx.adler32_device(d, n) == (zlib.adler32(data.tobytes()) & 0xffffffff), n
 
 
+def test_adler32_device_unaligned_input(ctx, torch_cuda):
+    """A device pointer at an odd offset (slice of a caller's tensor) is accepted: the kernel's 16-byte loads run over the
+    context's aligned copy."""
+    import zlib
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, 300_007, dtype=np.uint8)
+    d = torch.from_numpy(a).cuda()
+    for off in (1, 3, 8, 13):
+        assert ctx.adler32_device(d[off:], a.size - off) == zlib.adler32(a[off:].tobytes())
+
+
 def test_bwt_matches_reference(ctx, ref):
     rng = np.random.default_rng(11)
     bad = []
