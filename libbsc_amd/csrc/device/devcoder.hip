@@ -122,13 +122,16 @@ __global__ __launch_bounds__(WG) void dc_items_kernel(const u8* __restrict__ sym
     key_ch[j] = item_pack(sym[j], dc_sb_of(j, S), ge32[j], rank[j], dc_run_len(start, j, m, n));
 }
 
-// 1c. context states + the state family's items + which decision types occur.  Thread per run (stream order).
+// kinds of run for the "which decision types occur" bitmap: 8 sub-blocks x escape flag x 256 ranks, then 96 run-length classes
+constexpr u32 DC_KIND_RUN = 8 * 512, DC_KIND_WORDS = (DC_KIND_RUN + 96 + 31) / 32;
+
+// 1c. context states + the state family's items + which kinds of run occur.  Thread per run (stream order).
 __global__ __launch_bounds__(WG) void dc_ctx_kernel(const u64* __restrict__ key_ch, const u64* __restrict__ key_ch_s, const u32* __restrict__ inv_ch,
                                                     u32 m, DcSub S, const u8* __restrict__ tab_rank, const u8* __restrict__ tab_run,
                                                     u64* __restrict__ key_sr, u64* __restrict__ key_sn, u32* __restrict__ present, u32* __restrict__ meta)
 {
-    __shared__ u32 bits[(NUM_TAU + 31) / 32];
-    for (u32 i = threadIdx.x; i < (NUM_TAU + 31) / 32; i += WG) bits[i] = 0;
+    __shared__ u32 bits[DC_KIND_WORDS];
+    for (u32 i = threadIdx.x; i < DC_KIND_WORDS; i += WG) bits[i] = 0;
     __syncthreads();
     const u32 j = blockIdx.x * WG + threadIdx.x;
     if (j < m) {
@@ -194,37 +197,54 @@ __global__ __launch_bounds__(WG) void dc_ctx_kernel(const u64* __restrict__ key_
         key_sr[j] = ((u64)state_rank << 56) | info;
         key_sn[j] = ((u64)state_run << 56) | info;
 
-        // decision types of this run
-        const int maxr = (int)S.maxr[it.sb];
-        auto mark = [&](int tau) { const u32 w = (u32)tau >> 5, b = 1u << (tau & 31); if (!(bits[w] & b)) atomicOr(&bits[w], b); };
-        if (it.ge32) { for (int d = 0; d <= maxr; ++d) { u32 bit; mark(decision(it, maxr, ROUND_RP + d, &bit)); } }
-        else {
-            mark(TAU_RF);
-            if (it.rank != 1u) {
-                const int B = bsr(it.rank);
-                for (int s = 0; s <= B - 2; ++s) mark(TAU_RE + s);
-                if (B < maxr) mark(TAU_RE + B - 1);
-                for (int d = 0; d < B; ++d) { u32 bit; mark(decision(it, maxr, ROUND_RM + d, &bit)); }
-            }
-        }
-        mark(TAU_NF);
-        if (it.run != 1u) {
-            const int nb = bsr(it.run);
-            for (int s = 0; s < nb; ++s) mark(TAU_NE + s);
-            for (int d = 0; d < nb; ++d) { u32 bit; mark(decision(it, maxr, ROUND_NM + d, &bit)); }
-        }
+        // which kinds of run occur: the decision types of a run are a function of (sub-block, escape flag, rank) on the rank side
+        // and of the run-length class on the run side (dc_setup_kernel expands the kinds that occur into types)
+        auto mark = [&](u32 k) { const u32 w = k >> 5, b = 1u << (k & 31); if (!(bits[w] & b)) atomicOr(&bits[w], b); };
+        mark((it.sb << 9) | (it.ge32 << 8) | it.rank);
+        mark(DC_KIND_RUN + (it.run < 64u ? it.run : 64u + (u32)bsr(it.run)));
     }
     __syncthreads();
-    for (u32 i = threadIdx.x; i < (NUM_TAU + 31) / 32; i += WG) if (bits[i]) atomicOr(&present[i], bits[i]);
+    for (u32 i = threadIdx.x; i < DC_KIND_WORDS; i += WG) if (bits[i]) atomicOr(&present[i], bits[i]);
 }
 
 // 1d. the canonical rounds that occur (and how many decision types: diagnostics).  One workgroup.
-__global__ __launch_bounds__(WG) void dc_setup_kernel(const u32* __restrict__ present, u8* __restrict__ rounds, u32* __restrict__ meta)
+__global__ __launch_bounds__(WG) void dc_setup_kernel(const u32* __restrict__ kinds, DcSub S, u8* __restrict__ rounds, u32* __restrict__ meta)
 {
+    __shared__ u32 present[(NUM_TAU + 31) / 32];
     __shared__ u32 rbits[3];
     __shared__ u32 ntypes;
+    for (u32 i = threadIdx.x; i < (NUM_TAU + 31) / 32; i += WG) present[i] = 0;
     if (threadIdx.x < 3) rbits[threadIdx.x] = 0;
     if (threadIdx.x == 0) ntypes = 0;
+    __syncthreads();
+    auto mark = [&](int tau) { atomicOr(&present[(u32)tau >> 5], 1u << (tau & 31)); };
+    for (u32 k = threadIdx.x; k < DC_KIND_RUN + 96; k += WG) {
+        if (!(kinds[k >> 5] & (1u << (k & 31)))) continue;
+        Item it; it.sb = 0; it.ge32 = 0; it.rank = 1; it.run = 1;
+        if (k < DC_KIND_RUN) {                                                    // the rank side of a run of this kind
+            it.sb = k >> 9; it.ge32 = (k >> 8) & 1u; it.rank = k & 255u;
+            const int maxr = (int)S.maxr[it.sb];
+            if (it.ge32) { for (int d = 0; d <= maxr; ++d) { u32 bit; mark(decision(it, maxr, ROUND_RP + d, &bit)); } }
+            else {
+                mark(TAU_RF);
+                if (it.rank != 1u) {
+                    const int B = bsr(it.rank);
+                    for (int s = 0; s <= B - 2; ++s) mark(TAU_RE + s);
+                    if (B < maxr) mark(TAU_RE + B - 1);
+                    for (int d = 0; d < B; ++d) { u32 bit; mark(decision(it, maxr, ROUND_RM + d, &bit)); }
+                }
+            }
+        } else {                                                                  // the run side: a representative length of the class
+            const u32 cls = k - DC_KIND_RUN;
+            it.run = cls < 64u ? cls : 1u << (cls - 64u);
+            mark(TAU_NF);
+            if (it.run != 1u) {
+                const int nb = bsr(it.run);
+                for (int s = 0; s < nb; ++s) mark(TAU_NE + s);
+                for (int d = 0; d < nb; ++d) { u32 bit; mark(decision(it, 0, ROUND_NM + d, &bit)); }
+            }
+        }
+    }
     __syncthreads();
     for (int tau = threadIdx.x; tau < NUM_TAU; tau += WG) {
         if (present[(u32)tau >> 5] & (1u << (tau & 31))) {
@@ -977,7 +997,7 @@ int devcoder_ensure(bscgpu_ctx* c)
         {(void**)&d->cnt, (size_t)DC_ROWS * DC_WCH_MAX * 4}, {(void**)&d->rowtot, DC_ROWS * 4}, {(void**)&d->rowstart, 4 * (DC_ROWS + 8) * 4},
         {(void**)&d->wdec, (DC_WCH_MAX + 8) * 4}, {(void**)&d->wdecoff, (DC_WCH_MAX + 8) * 4},
         {(void**)&d->elo, 2 * 4 * NCH}, {(void**)&d->ehi, 2 * 4 * NCH}, {(void**)&d->S, 2 * 4 * NCH},
-        {(void**)&d->present, 64 * 4}, {(void**)&d->rounds, 256},
+        {(void**)&d->present, (size_t)DC_KIND_WORDS * 4}, {(void**)&d->rounds, 256},
         {(void**)&d->meta, DM_COUNT * 4}, {(void**)&d->poff, 16 * 4},
         {(void**)&d->tab_rank, 32768}, {(void**)&d->tab_run, 8192}, {(void**)&d->mp, sizeof(ModelParams)},
         {(void**)&d->rowbins, DC_ROWS * sizeof(DcRowBins)}, {(void**)&d->sink, 4096},
@@ -1044,7 +1064,7 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     for (int b = 0; b < 8; ++b) S.maxr[b] = (b < nb) ? (u32)max_rank[b] : 0u;
 
     HIP_TRY(c, hipMemsetAsync(d->meta, 0, DM_COUNT * 4, c->stream));
-    HIP_TRY(c, hipMemsetAsync(d->present, 0, 64 * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(d->present, 0, (size_t)DC_KIND_WORDS * 4, c->stream));
     const u32 gm = (m + WG - 1) / WG;
 
     prof_begin(c, BSCGPU_K_DC_CTX, (u64)m * 40, m);
@@ -1066,7 +1086,7 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     prof_begin(c, BSCGPU_K_DC_CTX, (u64)m * 40, m);
     hipLaunchKernelGGL(dc_ctx_kernel, dim3(gm), dim3(WG), 0, c->stream, d->key_ch, d->key_ch_s, d->inv_ch, m, S, d->tab_rank, d->tab_run,
                        d->key_sr, d->key_sn, d->present, d->meta);
-    hipLaunchKernelGGL(dc_setup_kernel, dim3(1), dim3(WG), 0, c->stream, d->present, d->rounds, d->meta);
+    hipLaunchKernelGGL(dc_setup_kernel, dim3(1), dim3(WG), 0, c->stream, d->present, S, d->rounds, d->meta);
     prof_end(c);
     rc = radix_sort_passes(c, d->key_sr, d->key_sr_s, nullptr, nullptr, m, &top, 1, &in_alt, d->inv_sr);
     if (rc < 0) return rc;
