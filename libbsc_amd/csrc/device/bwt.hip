@@ -226,10 +226,10 @@ __global__ __launch_bounds__(WG) void seg_scan_kernel(const u32* __restrict__ se
 // seg phase C: ranks (position of the group head), SA / ISA write-back, compaction of unsorted records.
 // WRITE_ISA = false (rounds on text keys): nobody reads ISA, the random 4-byte scatter is skipped.
 template <bool INITIAL, bool WRITE_ISA>
-__global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ flags, const u32* __restrict__ sa_sorted,
+__global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ flags, const u32* sa_sorted,
                                                        const u32* __restrict__ cpos_in, u32 m, u32 smask,
                                                        u32 chunk_tiles, u32 num_tiles, const u32* __restrict__ segoff,
-                                                       u32* __restrict__ SA, u32* __restrict__ ISA,
+                                                       u32* SA, u32* __restrict__ ISA,
                                                        u32* __restrict__ cpos_out, u32* __restrict__ csa_out,
                                                        u32* __restrict__ cgrp_out)
 {
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
             if (x < m) {
                 if (f[q] & 1u) run = pos[q] + 1;
                 const u32 rank = run - 1;
-                SA[pos[q]] = s[q];
+                if (!INITIAL || SA != sa_sorted) SA[pos[q]] = s[q];          // the first seg may run in place: SA = the sort's value array
                 if (WRITE_ISA) ISA[s[q] & smask] = rank;   // SA / csa keep the predecessor code in their high bits
                 if (f[q] & 2u) {
                     cpos_out[kslot] = pos[q];
@@ -584,7 +584,7 @@ static int bit_length(u64 x) { int b = 0; while (x) { ++b; x >>= 1; } return b; 
 
 template <bool INITIAL, bool WRITE_ISA>
 static int run_seg(bscgpu_ctx* c, const u64* keys, const u32* sa_sorted, const u32* cpos_in, u32 m, u32 tail_lo, u32 smask,
-                   u32* cpos_out, u32* csa_out, u32* cgrp_out, u32* U_out, const u32* grp_in = nullptr)
+                   u32* cpos_out, u32* csa_out, u32* cgrp_out, u32* U_out, u32* SA, const u32* grp_in = nullptr)
 {
     const Chunking ch = make_chunking(m, SEG_TILE);
     prof_begin(c, BSCGPU_K_SEG, (u64)m * (8 + (INITIAL ? 4 : 0) + 1), m);
@@ -597,7 +597,7 @@ static int run_seg(bscgpu_ctx* c, const u64* keys, const u32* sa_sorted, const u
     prof_begin(c, BSCGPU_K_SEG, (u64)m * (1 + 4 + (INITIAL ? 0 : 4) + 4 + 4), m);
     hipLaunchKernelGGL((seg_apply_kernel<INITIAL, WRITE_ISA>), dim3(ch.num_chunks), dim3(WG), 0, c->stream,
                        c->flags, sa_sorted, cpos_in, m, smask, ch.chunk_tiles, ch.num_tiles, c->segoff,
-                       c->SA, c->ISA, cpos_out, csa_out, cgrp_out);
+                       SA, c->ISA, cpos_out, csa_out, cgrp_out);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->hscal, c->dscal, 4, hipMemcpyDeviceToHost, c->stream));
@@ -671,8 +671,10 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
     bool isa_valid = !(text_on && ta >= 2 && ta <= 15);
     int cur = 0;
     u32 U = 0;
-    if (isa_valid) rc = run_seg<true, true >(c, ks, vs, nullptr, n, tail_lo, smask, c->cpos[cur], c->csa[cur], c->cgrp[cur], &U);
-    else           rc = run_seg<true, false>(c, ks, vs, nullptr, n, tail_lo, smask, c->cpos[cur], c->csa[cur], c->cgrp[cur], &U);
+    // SA: the sort's value array itself when the rounds do not write to it (they put their output into kB / vB), else a copy
+    u32* SA = (vs == c->vA) ? c->vA : c->SA;
+    if (isa_valid) rc = run_seg<true, true >(c, ks, vs, nullptr, n, tail_lo, smask, c->cpos[cur], c->csa[cur], c->cgrp[cur], &U, SA);
+    else           rc = run_seg<true, false>(c, ks, vs, nullptr, n, tail_lo, smask, c->cpos[cur], c->csa[cur], c->cgrp[cur], &U, SA);
     if (rc < 0) return rc;
 
     const int lo_bits = bit_length(n);          // next-rank field: values 0 .. n
@@ -695,7 +697,7 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
             prof_collect(c);
             if (c->hscal[2] == 0) {
                 u32 U2 = 0;
-                rc = run_seg<false, false>(c, c->kB, c->vB, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2, c->cgrp[cur]);
+                rc = run_seg<false, false>(c, c->kB, c->vB, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2, SA, c->cgrp[cur]);
                 if (rc < 0) return rc;
                 cur ^= 1;
                 ++text_rounds;
@@ -708,7 +710,7 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
             // hand over: ISA from the current order
             u32 blocks = (n + WG - 1) / WG; if (blocks > 8192) blocks = 8192;
             prof_begin(c, BSCGPU_K_SEG, (u64)n * 8, n);
-            hipLaunchKernelGGL(bwt_isa_fill_kernel, dim3(blocks), dim3(WG), 0, c->stream, c->SA, n, smask, c->ISA);
+            hipLaunchKernelGGL(bwt_isa_fill_kernel, dim3(blocks), dim3(WG), 0, c->stream, SA, n, smask, c->ISA);
             prof_end(c);
             u32 fb = (U + WG - 1) / WG; if (fb > 8192) fb = 8192;
             prof_begin(c, BSCGPU_K_SEG, (u64)U * 12, U);
@@ -734,6 +736,10 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
         }
         int np = 0;
         if (!sorted) {
+            if (SA == c->vA) {                       // the radix engine is about to use vA: SA moves to its own buffer
+                HIP_TRY(c, hipMemcpyAsync(c->SA, c->vA, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));
+                SA = c->SA;
+            }
             u32 blocks = (U + WG - 1) / WG; if (blocks > 8192) blocks = 8192;
             prof_begin(c, BSCGPU_K_GATHER, (u64)U * (4 + 4 + 4 + 8 + 4), U);
             hipLaunchKernelGGL(bwt_gather_kernel, dim3(blocks), dim3(WG), 0, c->stream,
@@ -750,7 +756,7 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
         }
 
         u32 U2 = 0;
-        rc = run_seg<false, true>(c, ks, vs, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2);
+        rc = run_seg<false, true>(c, ks, vs, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2, SA);
         if (rc < 0) return rc;
         cur ^= 1;
         if (dbg) fprintf(stderr, "[bwt] round %d h=%llu U %u -> %u (passes %d)\n", rounds, (unsigned long long)h, U, U2, np);
@@ -769,15 +775,15 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
     }
     prof_begin(c, BSCGPU_K_EMIT, (u64)n * 4, n);
     hipLaunchKernelGGL(bwt_find_kernel, dim3((n + 4 * WG - 1) / (4 * WG)), dim3(WG), 0, c->stream,
-                       c->SA, n, smask, cnt ? (u32)(r - 1) : 0u, rshift, cnt, c->dscal);
+                       SA, n, smask, cnt ? (u32)(r - 1) : 0u, rshift, cnt, c->dscal);
     prof_end(c);
     prof_begin(c, BSCGPU_K_EMIT, (u64)n * 6, n);
     if (pp.pred_shift)
         hipLaunchKernelGGL(bwt_emit_pred_kernel, dim3((n + 4 * WG - 1) / (4 * WG)), dim3(WG), 0, c->stream,
-                           c->dT, c->SA, n, pp.pred_shift, ddecode, dL_user, c->dscal);
+                           c->dT, SA, n, pp.pred_shift, ddecode, dL_user, c->dscal);
     else
         hipLaunchKernelGGL(bwt_emit_kernel, dim3((n + 4 * WG - 1) / (4 * WG)), dim3(WG), 0, c->stream,
-                           c->dT, c->SA, n, dL_user, c->dscal);
+                           c->dT, SA, n, dL_user, c->dscal);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->hscal, c->dscal, (8 + 256) * 4, hipMemcpyDeviceToHost, c->stream));
