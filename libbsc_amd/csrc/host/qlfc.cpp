@@ -127,6 +127,16 @@ public:
         L.low  += (uint64_t)(r & m);
         L.range = r + (m & (L.range - r - r));
     }
+    // the same, keeping `is_full` (= full(), which only changes inside shift()) in a caller's register: the run-start budget test of
+    // the p-stream coders costs three loads and a compare per decision otherwise
+    template <int P> __attribute__((always_inline)) inline void encode_live_f(Live& L, unsigned bit, int p, unsigned& is_full)
+    {
+        if (__builtin_expect(L.range < 0x10000u, 0)) { low_ = L.low; shift(); L.low = low_; L.range <<= 16; is_full = (unsigned)full(); }
+        const uint32_t r = (L.range >> P) * (uint32_t)p;
+        const uint32_t m = 0u - bit;
+        L.low  += (uint64_t)(r & m);
+        L.range = r + (m & (L.range - r - r));
+    }
     template <int P> __attribute__((always_inline)) inline void encode(unsigned bit, int p)
     {
         if (__builtin_expect(range_ < 0x10000u, 0)) { shift(); range_ <<= 16; }
@@ -849,20 +859,21 @@ void qlfc_encode_static_pstream_pair(const PstreamJob& A, const PstreamJob& B, i
     const size_t both = A.count < B.count ? A.count : B.count;
     size_t i = 0;
     bool fa = false, fb = false;                              // a stream ran out of budget (reference: NOT_COMPRESSIBLE at a run start)
+    unsigned fulla = (unsigned)ra.full(), fullb = (unsigned)rb.full();     // kept current by encode_live_f
     for (; i < both; ++i) {
         const unsigned x = pa[i], y = pb[i];
         // branch-free test (the budget check belongs to run starts only, qlfc.cpp:894; it practically never fires)
-        const unsigned stop = ((x >> 13) & (unsigned)ra.full()) | ((y >> 13) & (unsigned)rb.full());
+        const unsigned stop = ((x >> 13) & fulla) | ((y >> 13) & fullb);
         if (__builtin_expect(stop != 0, 0)) {
-            if ((x & 0x2000u) && ra.full()) { fa = true; break; }
+            if ((x & 0x2000u) && fulla) { fa = true; break; }
             fb = true; break;
         }
-        ra.encode_live<12>(La, (x >> 12) & 1u, (int)(x & 0xfffu));
-        rb.encode_live<12>(Lb, (y >> 12) & 1u, (int)(y & 0xfffu));
+        ra.encode_live_f<12>(La, (x >> 12) & 1u, (int)(x & 0xfffu), fulla);
+        rb.encode_live_f<12>(Lb, (y >> 12) & 1u, (int)(y & 0xfffu), fullb);
     }
     // what is left of either stream, singly
-    if (!fa) for (size_t k = i; k < A.count; ++k) { const unsigned x = pa[k]; if ((x & 0x2000u) && ra.full()) { fa = true; break; } ra.encode_live<12>(La, (x >> 12) & 1u, (int)(x & 0xfffu)); }
-    if (!fb) for (size_t k = i; k < B.count; ++k) { const unsigned y = pb[k]; if ((y & 0x2000u) && rb.full()) { fb = true; break; } rb.encode_live<12>(Lb, (y >> 12) & 1u, (int)(y & 0xfffu)); }
+    if (!fa) for (size_t k = i; k < A.count; ++k) { const unsigned x = pa[k]; if ((x & 0x2000u) && fulla) { fa = true; break; } ra.encode_live_f<12>(La, (x >> 12) & 1u, (int)(x & 0xfffu), fulla); }
+    if (!fb) for (size_t k = i; k < B.count; ++k) { const unsigned y = pb[k]; if ((y & 0x2000u) && fullb) { fb = true; break; } rb.encode_live_f<12>(Lb, (y >> 12) & 1u, (int)(y & 0xfffu), fullb); }
     ra.leave(La); rb.leave(Lb);
     *resA = fa ? NOT_COMPRESSIBLE : ra.finish();
     *resB = fb ? NOT_COMPRESSIBLE : rb.finish();
