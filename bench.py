@@ -34,7 +34,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 T
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=192)
+    ap.add_argument("--steps", type=int, default=320)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--block", type=int, default=BLOCK)
     ap.add_argument("--sorter", type=int, default=1)
@@ -72,17 +72,23 @@ def main():
     if "BSCGPU_HOST_THREADS" not in os.environ:         # per pipe: this rank's CPUs are shared by its contexts
         os.environ["BSCGPU_HOST_THREADS"] = str(max(4, min(64, effective_cpus() // max(local_world, 1) // ncx)))
     coder_threads = int(os.environ["BSCGPU_HOST_THREADS"]) * ncx
-    # Range coding on the host: pairs of sub-blocks per thread (0.235 CPU-s per block, 0.05 s latency) when this rank's CPUs can
-    # keep its GPU busy that way (~62 blocks/s x 0.235 s = 15 CPUs), else all eight sub-blocks of a block in AVX2 lanes on one
-    # thread (0.145 CPU-s per block, 0.12 s latency: more blocks in flight).  BSC_RC_X8 in the environment overrides.
+    # Range coding on the host: all eight sub-blocks of a block in SIMD lanes on one thread (0.118 CPU-s per block
+    # with AVX-512VL, 0.141 with AVX2, ~0.1 s latency: three blocks in flight per context) or pairs of sub-blocks per thread
+    # (0.228 CPU-s per block, 0.05 s latency: two blocks in flight).  Same MB/s on this box either way once the GPU is the
+    # limit; the lanes leave half of the CPUs idle, so they are the default where the CPU has AVX-512VL, and in any case when this
+    # rank's share of the CPUs could not feed its GPU with pairs (~64 blocks/s x 0.228 s = 15 CPUs).  BSC_RC_SIMD overrides.
     cpus_rank = effective_cpus() // max(local_world, 1)
+    try:
+        has_avx512vl = "avx512vl" in open("/proc/cpuinfo").read()
+    except OSError:
+        has_avx512vl = False
     if "BSC_RC_SIMD" not in os.environ:
-        os.environ["BSC_RC_SIMD"] = "8" if (os.environ.get("BSC_RC_X8") == "1" or (args.coder == 1 and cpus_rank < 14)) else "0"
+        os.environ["BSC_RC_SIMD"] = "8" if (os.environ.get("BSC_RC_X8") == "1" or (args.coder == 1 and (has_avx512vl or cpus_rank < 14))) else "0"
     rc_simd = int(os.environ["BSC_RC_SIMD"])
     rc_x8 = rc_simd == 8
-    if args.depth <= 0:                                 # blocks in flight per context: 8 per GPU in total keep the coder pool and the GPU busy
+    if args.depth <= 0:                                 # blocks in flight per context
         args.depth = max(2, min(4, 8 // ncx))
-        if rc_x8: args.depth = max(2, min(4, -(-int(min(62.0, cpus_rank / 0.145) * 0.25 + 1) // ncx)))
+        if rc_x8: args.depth = max(2, min(4, 12 // ncx)) if has_avx512vl else 4
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
@@ -283,7 +289,7 @@ def main():
             "kernels": per_kernel,
             "kernels_note": "HIP-event time per kernel class and block, from the region named in roofline.measured_on",
             "host": {"cpus": os.cpu_count(), "effective_cpus": effective_cpus(), "coder_threads_per_gpu": coder_threads,
-                     "range_coder": "8 sub-blocks per thread in AVX2 lanes" if rc_x8 else "2 sub-blocks per thread, interleaved",
+                     "range_coder": ("8 sub-blocks per thread in SIMD lanes (" + ("AVX-512VL" if has_avx512vl else "AVX2") + ")") if rc_x8 else "2 sub-blocks per thread, interleaved",
                      "cpu_seconds_per_block_rank0": round(cpu_used / args.steps, 3),
                      "cpu_busy_fraction_of_effective": round(cpu_used / (dt * max(effective_cpus() / max(local_world, 1), 1)), 3)},
         }

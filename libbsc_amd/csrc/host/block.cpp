@@ -293,6 +293,7 @@ struct BlockJob {
     u32 first_run[8 * 256];
     HostSlot* slot = nullptr;        // pinned landing zones of this block (owned by the context)
     // device-side static model (devcoder.hip): the host codes from a probability stream instead of run arrays
+    bool pipelined = false;        // submitted through a pipe (several blocks in flight): throughput over latency
     bool use_ps = false; const uint16_t* ps = nullptr; u32 poff[9]; u32 ndec = 0; int sorter = 0;
     hipEvent_t ps_ready = nullptr;   // the p stream's copy to the host (copy stream); coder tasks wait on it
     std::atomic<bool> redo{false};   // a sub-block did not compress: the block goes through the host model again (raw sub-blocks need the run arrays)
@@ -453,21 +454,30 @@ static void host_encode_pair(BlockJob& J, int b)
     J.sub_res[b + 1] = r1 < 0 ? J.size[b + 1] : r1;
 }
 
-// All eight sub-blocks of a device-model block in the lanes of one AVX2 range-coder loop (qlfc_encode_static_pstream_x8):
-// one task of 0.115 s instead of four of 0.052 s (EPYC 9575F) — 40 % less CPU time per block (0.238 -> 0.144 s with framing),
-// twice the latency, so more blocks have to be in flight to keep a GPU busy.  It is the mode for hosts whose coder threads are
-// the bottleneck (many GPUs per CPU quota); the default stays the pairs.  BSC_RC_SIMD=8 (or BSC_RC_X8=1) selects it; bench.py
-// does when a rank's share of the CPUs cannot keep its GPU busy with pairs.
-static int ps_simd_mode()
+// All eight sub-blocks of a device-model block in the lanes of one SIMD range-coder loop (qlfc_encode_static_pstream_x8): one
+// task instead of four.  EPYC 9575F, CPU-seconds per 64 MiB block with framing: pairs 0.228 (4 x 0.052 s), eight lanes with
+// AVX-512VL 0.118 (one task of ~0.09 s), with AVX2 0.141 (~0.115 s).  Half the CPU time, not quite twice the latency: a pipe needs
+// three blocks in flight per context instead of two to keep the GPU busy, and then moves the same MB/s.
+//   BSC_RC_SIMD=8 / 0   eight lanes / pairs everywhere
+//   unset               eight lanes for pipelined blocks (bscgpu_pipe_*) on CPUs with AVX-512VL, pairs otherwise and for the
+//                       synchronous entry points (one block at a time: latency counts)
+static int ps_simd_env()
 {
     static const int mode = [] {
         if (const char* e = getenv("BSC_RC_SIMD")) return atoi(e) == 8 ? 8 : 0;
         if (const char* e = getenv("BSC_RC_X8")) return atoi(e) != 0 ? 8 : 0;
-        return 0;
+        return -1;
     }();
     return mode;
 }
-static int ps_group(const BlockJob& J) { return (J.use_ps && J.nblocks == 8 && ps_simd_mode() == 8) ? 8 : 2; }
+static bool cpu_has_avx512vl() { static const bool has = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl"); return has; }
+static int ps_group(const BlockJob& J)
+{
+    if (!J.use_ps || J.nblocks != 8) return 2;
+    const int env = ps_simd_env();
+    if (env >= 0) return env == 8 ? 8 : 2;
+    return (J.pipelined && cpu_has_avx512vl()) ? 8 : 2;
+}
 // sub-blocks b .. b + g - 1 of a device-model block, g = ps_group(J)
 static void host_encode_group(BlockJob& J, int b)
 {
@@ -839,6 +849,7 @@ static int pipe_enqueue(bscgpu_pipe* p, bscgpu_pipe::Lane& L, int ticket)
 {
     BlockJob& J = *L.job;
     L.ticket = ticket; L.busy = true;
+    J.pipelined = p->depth >= 3;
     {
         std::lock_guard<std::mutex> lk(p->mu);
         if (job_uses_tasks(J)) {
