@@ -31,12 +31,22 @@ int ctx_ensure_slots(bscgpu_ctx* c, int count)
     const size_t N = align_up((size_t)c->max_n + 4096, 4096);
     for (; c->nslots < count; ++c->nslots) {
         HostSlot& s = c->slots[c->nslots];
-        bool ok = hipEventCreateWithFlags(&s.copy_ev, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess
-               && hipHostMalloc((void**)&s.hsym, N, hipHostMallocDefault) == hipSuccess
-               && hipHostMalloc((void**)&s.hrank, N, hipHostMallocDefault) == hipSuccess
-               && hipHostMalloc((void**)&s.hstart, 4 * N, hipHostMallocDefault) == hipSuccess;
-        if (!ok) return BSC_NOT_ENOUGH_MEMORY;
+        // the landing zones themselves (6 N bytes of run arrays, 8 N of probability stream) are pinned on first use: a block of
+        // the device model never copies its run arrays, a block of the host model has no probability stream
+        (void)N;
+        if (hipEventCreateWithFlags(&s.copy_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) return BSC_NOT_ENOUGH_MEMORY;
     }
+    return BSC_NO_ERROR;
+}
+
+int ctx_ensure_run_slot(bscgpu_ctx* c, HostSlot& s)
+{
+    if (s.hsym && s.hrank && s.hstart) return BSC_NO_ERROR;
+    const size_t N = align_up((size_t)c->max_n + 4096, 4096);
+    const bool ok = (s.hsym   || hipHostMalloc((void**)&s.hsym, N, hipHostMallocDefault) == hipSuccess)
+                 && (s.hrank  || hipHostMalloc((void**)&s.hrank, N, hipHostMallocDefault) == hipSuccess)
+                 && (s.hstart || hipHostMalloc((void**)&s.hstart, 4 * N, hipHostMallocDefault) == hipSuccess);
+    if (!ok) { (void)hipGetLastError(); return BSC_NOT_ENOUGH_MEMORY; }
     return BSC_NO_ERROR;
 }
 

@@ -152,6 +152,7 @@ int qlfc_front_runs(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, const int* 
 int qlfc_front_copy_runs(bscgpu_ctx* c, u32 m, HostSlot& slot);
 int ctx_ensure_slots(bscgpu_ctx* c, int count);
 int ctx_ensure_pstream_slot(bscgpu_ctx* c, HostSlot& slot, size_t entries);     // pinned landing zone for a block's p stream
+int ctx_ensure_run_slot(bscgpu_ctx* c, HostSlot& slot);                           // pinned landing zone for a block's run arrays
 // device-side model of the static QLFC coder (devcoder.hip): probability stream of a whole block from the front end's run arrays
 int  devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* dstart, u32 m, u32 n, int nb, const u32* run_first,
                       const int* max_rank, u32* D_out, u32* poff_out, u16* dbg, int psbuf = 0);

@@ -337,6 +337,7 @@ int qlfc_front_split(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, int* start
 int qlfc_front_copy_runs(bscgpu_ctx* c, u32 m, HostSlot& slot)
 {
     // the run arrays of the block whose front end ran last (they live in the sort buffers until the next block's sorter starts)
+    { const int rc = ctx_ensure_run_slot(c, slot); if (rc < 0) return ctx_fail(c, rc, "pinned host memory for the run arrays", hipSuccess); }
     HIP_TRY(c, hipMemcpyAsync(slot.hsym, reinterpret_cast<u8*>(c->vA), m, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(slot.hrank, reinterpret_cast<u8*>(c->vB), m, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(slot.hstart, c->SA, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
