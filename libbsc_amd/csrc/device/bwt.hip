@@ -1,5 +1,6 @@
-// bwt.hip — forward Burrows-Wheeler transform of one block on MI355X: suffix sort by prefix doubling on
-// the LSD radix engine (radix_sort.hip), then the BWT byte gather.
+// bwt.hip — forward Burrows-Wheeler transform of one block on MI355X: suffix sort = one LSD radix sort on packed prefix
+// keys (radix_sort.hip), refinement rounds as segmented sorts on text keys, prefix doubling only for blocks with long repeats;
+// then the BWT byte emit.
 //
 // Result contract (what bsc_bwt_encode returns, bwt.cpp:178-231, via libsais_bwt_aux, libsais.c:6704):
 //   SA  = suffixes of T[0..n) in lexicographic order, a proper prefix sorting first;
@@ -8,20 +9,21 @@
 // The reference GPU path (libcubwt.cu:2031-2223: DC3 2/3 sample + 64-bit prefix sort + segmented sort
 // + merge) is NOT followed; this is a different algorithm with the same result:
 //
-//   1. bwt_pack:   key[s] = the first w characters of suffix i as dense alphabet codes (w = 8..16), value = i.  The < w "tail" suffixes
-//                  whose window crosses the block end are placed FIRST in input order,
-//                  shortest first; the LSD sort is stable, so inside a group of equal padded keys
-//                  they come out first and already in final order ("proper prefix is smaller"),
-//                  and seg marks each of them as a finished singleton.
+//   1. bwt_pack:   key[s] = the first w characters of suffix i as dense alphabet codes (w = 8..16), value = i (+ the code of
+//                  the character in front of it in the spare high bits).  The < w "tail" suffixes whose window crosses the
+//                  block end are placed FIRST in input order, shortest first; the LSD sort is stable, so inside a group of
+//                  equal padded keys they come out first and already in final order ("proper prefix is smaller"), and seg
+//                  marks each of them as a finished singleton.
 //   2. <= 8 radix passes over (u64 key, u32 suffix) -> order by w-character prefix.
-//   3. seg (reduce / scan / apply): group heads, rank = position of the group head (so ranks are valid
-//      SA slots and only ever grow under refinement), ISA scatter, and stream compaction of every
-//      suffix still sharing its rank ("unsorted").
-//   4. doubling round h = w, 2w, ...: key = (rank << bits(n)) | (ISA[sa+h]+1, or 0 when sa+h == n),
-//      radix-sort the compacted set on the used bits only, seg again (new heads where the 64-bit
-//      key changes), write SA/ISA back through the saved slot list, compact again.  One 4-byte
-//      D2H + stream sync per round for the loop test (libcubwt does the same, libcubwt.cu:1383).
-//   5. bwt_emit:   L from SA/T, aux indexes from ISA.
+//   3. seg (reduce / scan / apply): group heads, rank = position of the group head (so ranks are valid SA slots and only
+//      ever grow under refinement), stream compaction of every suffix still sharing its rank ("unsorted").
+//   4. rounds on text keys (bwt_round_textsort_kernel): the groups are refined by the next a characters of the text behind
+//      the h characters they share — no inverse suffix array; h += a.  Blocks that converge this way (text: two rounds)
+//      never build ISA.
+//   5. otherwise ISA is built once from the current order and the rounds double h (bwt_round_segsort_kernel on ISA[sa+h],
+//      radix fallback for groups longer than a workgroup sorts).  One 4-byte D2H + stream sync per round for the loop
+//      test (libcubwt does the same, libcubwt.cu:1383).
+//   6. bwt_find / bwt_emit: primary and aux indexes from a scan of SA, L from SA (predecessor codes) or SA/T.
 #include "dev_common.h"
 #include <cstdio>
 #include <cstdlib>
