@@ -237,6 +237,7 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
 {
     __shared__ u32 scr[8];
     __shared__ u32 sprev[WG];
+    __shared__ u32 cstage[3 * SEG_TILE];            // SA slot, suffix, group rank of the tile's unsorted records
     const u32 t = threadIdx.x;
     const u32 tile0 = blockIdx.x * chunk_tiles;
     u32 tile1 = tile0 + chunk_tiles; if (tile1 > num_tiles) tile1 = num_tiles;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
         __syncthreads();
         u32 run = (t > 0) ? sprev[t - 1] : 0u;       // exclusive max over lower threads
         if (carry > run) run = carry;
-        u32 kslot = off + block_excl_sum(lcnt, scr, &totcnt);
+        u32 kslot = block_excl_sum(lcnt, scr, &totcnt);          // compacted index inside the tile
 #pragma unroll
         for (int q = 0; q < SEG_ITEMS; ++q) {
             const u32 x = j + q;
@@ -275,13 +276,15 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
                 const u32 rank = run - 1;
                 if (!INITIAL || SA != sa_sorted) SA[pos[q]] = s[q];          // the first seg may run in place: SA = the sort's value array
                 if (WRITE_ISA) ISA[s[q] & smask] = rank;   // SA / csa keep the predecessor code in their high bits
-                if (f[q] & 2u) {
-                    cpos_out[kslot] = pos[q];
-                    csa_out[kslot]  = s[q];
-                    cgrp_out[kslot] = rank;
-                    ++kslot;
-                }
+                if (f[q] & 2u) { cstage[kslot] = pos[q]; cstage[SEG_TILE + kslot] = s[q]; cstage[2 * SEG_TILE + kslot] = rank; ++kslot; }
             }
+        }
+        __syncthreads();
+        // the tile's unsorted records leave through LDS: consecutive lanes write consecutive slots of the three arrays
+        for (u32 i = t; i < totcnt; i += WG) {
+            cpos_out[off + i] = cstage[i];
+            csa_out[off + i]  = cstage[SEG_TILE + i];
+            cgrp_out[off + i] = cstage[2 * SEG_TILE + i];
         }
         carry = (carry > totmax) ? carry : totmax;
         off += totcnt;
