@@ -73,7 +73,7 @@ def main():
         os.environ["BSCGPU_HOST_THREADS"] = str(max(4, min(64, effective_cpus() // max(local_world, 1) // ncx)))
     coder_threads = int(os.environ["BSCGPU_HOST_THREADS"]) * ncx
     # Range coding on the host: all eight sub-blocks of a block in SIMD lanes on one thread (0.118 CPU-s per block
-    # with AVX-512VL, 0.141 with AVX2, ~0.1 s latency: three blocks in flight per context) or pairs of sub-blocks per thread
+    # with AVX-512VL, 0.141 with AVX2, ~0.1 s latency: four blocks in flight per context) or pairs of sub-blocks per thread
     # (0.228 CPU-s per block, 0.05 s latency: two blocks in flight).  Same MB/s on this box either way once the GPU is the
     # limit; the lanes leave half of the CPUs idle, so they are the default where the CPU has AVX-512VL, and in any case when this
     # rank's share of the CPUs could not feed its GPU with pairs (~64 blocks/s x 0.228 s = 15 CPUs).  BSC_RC_SIMD overrides.
@@ -88,7 +88,7 @@ def main():
     rc_x8 = rc_simd == 8
     if args.depth <= 0:                                 # blocks in flight per context
         args.depth = max(2, min(4, 8 // ncx))
-        if rc_x8: args.depth = max(2, min(4, 12 // ncx)) if has_avx512vl else 4
+        if rc_x8: args.depth = max(2, min(4, 16 // ncx))      # one longer task per block: 16 blocks in flight per GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
