@@ -82,6 +82,8 @@ __global__ __launch_bounds__(WG) void qf_apply_kernel(const u8* __restrict__ L, 
     // first run of every symbol per sub-block: minima in LDS first (a chunk of n / 1024 bytes touches at most two sub-blocks),
     // one global atomicMin per (sub-block, symbol) the workgroup has seen — not one L2 round trip per run
     __shared__ u32 fmin[2 * 256];
+    __shared__ u32 sstart[QF_TILE];                 // the tile's runs (a tile of QF_TILE bytes has at most QF_TILE runs)
+    __shared__ u8  ssym[QF_TILE];
     for (u32 i = threadIdx.x; i < 2 * 256; i += WG) fmin[i] = 0xffffffffu;
     const u32 tile0 = blockIdx.x * chunk_tiles;
     u32 tile1 = tile0 + chunk_tiles; if (tile1 > num_tiles) tile1 = num_tiles;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(WG) void qf_apply_kernel(const u8* __restrict__ L, 
         u32 mask = 0;
         if (i0 < n) mask = qf_heads16(L, i0, n, sp, bytes);
         u32 tot;
-        u32 j = off + block_excl_sum(__popc(mask), scr, &tot);
+        u32 lj = block_excl_sum(__popc(mask), scr, &tot);      // run index inside the tile
         const u32 w[4] = {bytes.x, bytes.y, bytes.z, bytes.w};
         // sub-block of this thread's 16 bytes: the chunk's first one, or the next when a boundary has been passed
         const u32 b_next_start = (b_first + 1 < sp.nblocks) ? sp.start[b_first + 1 < 8 ? b_first + 1 : 7] : 0xffffffffu;
@@ -107,11 +109,14 @@ __global__ __launch_bounds__(WG) void qf_apply_kernel(const u8* __restrict__ L, 
             const u32 p = __ffs(mask) - 1; mask &= mask - 1;
             const u32 c = (w[p >> 2] >> (8 * (p & 3))) & 0xffu;
             const u32 pos = i0 + p;
-            sym[j] = (u8)c;
-            start[j] = pos;
-            atomicMin(&fmin[(pos >= b_next_start ? 256u : 0u) + c], j);
-            ++j;
+            ssym[lj] = (u8)c;
+            sstart[lj] = pos;
+            atomicMin(&fmin[(pos >= b_next_start ? 256u : 0u) + c], off + lj);
+            ++lj;
         }
+        __syncthreads();
+        // the tile's runs leave through LDS: consecutive lanes write consecutive entries of both arrays
+        for (u32 i = threadIdx.x; i < tot; i += WG) { sym[off + i] = ssym[i]; start[off + i] = sstart[i]; }
         off += tot;
         __syncthreads();
     }
