@@ -10,9 +10,10 @@
 //    graded kernel).  There is NO inter-workgroup communication inside a launch: on MI355X the eight
 //    XCD L2s are not coherent and an agent-scope hand-off costs ~1-3 us under streaming load
 //    (MI355X_MICROARCH.md, handoff rows; 4.6 us per hop in tools/ubench.hip), while the chip retires a
-//    196 KB tile every ~50 ns: with 256 tiles in flight a decoupled look-back ("onesweep") finds its
-//    nearest finished predecessor 40-60 tiles back and has to sum that many 1 KB aggregate rows per tile
-//    through L2-bypassing loads — the bytes rs_hist reads (64 KB per tile), plus the latency.
+//    196 KB tile every ~50 ns: with 256 tiles in flight a decoupled look-back ("onesweep") has to sum ~20
+//    predecessor rows per tile through L2-bypassing loads; measured under streaming load it adds 0.07-0.09 ms
+//    per pass on the tiles' critical path (tools/ubench_lookback.hip) and gives up the chunk-contiguous
+//    output segments write combining needs.
 //    The price paid instead is one extra streaming read of the keys per pass (8 B/record, rs_hist, at
 //    4.5 TB/s); the scatter pass itself moves exactly the algorithmic 2*(8+4) B/record.
 //  * <= 1024 chunks for rs_hist (one 256-thread workgroup each, 4 per CU, all resident; block b runs on XCD b % 8 so
