@@ -13,7 +13,10 @@
 typedef unsigned long long u64; typedef unsigned int u32;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
-template <int MODE>
+// ORDER 0: workgroup b owns `tiles` consecutive tiles (what rs_scatter does); 1: tiles interleaved over the workgroups so that at
+// any time an XCD (workgroups b % 8) works on 32 consecutive tiles — neighbouring runs of a stream are written at about the same
+// time by CUs that share an L2
+template <int MODE, int ORDER = 0>
 __global__ __launch_bounds__(1024) void k_wc(const u64* __restrict__ kin, const u32* __restrict__ vin, u64* __restrict__ kout, u32* __restrict__ vout,
                                              u32 n, u32 tiles, u32 pk, u32 pv)
 {
@@ -22,13 +25,14 @@ __global__ __launch_bounds__(1024) void k_wc(const u64* __restrict__ kin, const 
     const u32 shift = (MODE == 2) ? 5u : 0u;    // a regular 2 MB stride would put every stream on the same memory channel
 #define STREAM(b) ((u64)(b) * per_bucket + ((((b) * 2654435761u) >> 21) & 2047u) * 32u)
     for (u32 tt = 0; tt < tiles; ++tt) {
-        const u64 tb = ((u64)blockIdx.x * tiles + tt) * 8192;
+        const u32 tile = ORDER == 0 ? blockIdx.x * tiles + tt : tt * 256 + (blockIdx.x & 7) * 32 + (blockIdx.x >> 3);
+        const u64 tb = (u64)tile * 8192;
         u64 k[8]; u32 v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) k[j] = __builtin_nontemporal_load(&kin[tb + j * 1024 + t]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(&vin[tb + j * 1024 + t]);
-        const u32 run0 = (blockIdx.x * tiles + tt) * 32 + shift;        // this tile's offset inside every stream
+        const u32 run0 = tile * 32 + shift;                              // this tile's offset inside every stream
         if (MODE == 1) {
             // flush-shaped instructions: keys 16 lanes per stream (4 steps), values 32 lanes per stream (8 steps)
 #pragma unroll
@@ -72,5 +76,9 @@ int main() {
     }
     ms = timeit([&] { hipLaunchKernelGGL(k_wc<2>, dim3(256), dim3(1024), 0, 0, ka, va, kb, vb, n, tiles, 0u, 0u); });
     printf("1024x8 pairs, runs misaligned by 5 records: %.3f ms -> %.0f GB/s\n", ms, 24.0 * n / 1e6 / ms);
+    ms = timeit([&] { hipLaunchKernelGGL((k_wc<0, 1>), dim3(256), dim3(1024), 0, 0, ka, va, kb, vb, n, tiles, 0u, 0u); });
+    printf("tiles interleaved per XCD, full aligned lines: %.3f ms -> %.0f GB/s\n", ms, 24.0 * n / 1e6 / ms);
+    ms = timeit([&] { hipLaunchKernelGGL((k_wc<2, 1>), dim3(256), dim3(1024), 0, 0, ka, va, kb, vb, n, tiles, 0u, 0u); });
+    printf("tiles interleaved per XCD, runs misaligned by 5 records: %.3f ms -> %.0f GB/s\n", ms, 24.0 * n / 1e6 / ms);
     return 0;
 }
