@@ -132,6 +132,7 @@ extern "C" void bscgpu_destroy(bscgpu_ctx* c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) ctx_sync(c);
+    if (c->tile_counts) { (void)hipFree(c->tile_counts); c->tile_counts = nullptr; }
     if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     for (auto& p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& e : c->event_pool) hipEventDestroy(e);

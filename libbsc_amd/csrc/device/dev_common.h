@@ -94,6 +94,7 @@ struct bscgpu_ctx {
     u32* dscal  = nullptr;   // small device scalars (64 u32)
     u64* dscal64 = nullptr;  // small device u64 scalars (16)
     u64* adler_part = nullptr; // [MAX_CHUNKS][2]
+    u32* tile_counts = nullptr; size_t tile_counts_cap = 0;   // [256][tiles of 8192 records]: BSC_RS_ORDER=1 experiment, allocated on first use
     u64* wc_sink = nullptr;  // [512 * 1024] write sink for predicated-off lanes of rs_scatter_wc
     // pinned host
     u32* hscal  = nullptr;   // 64 u32

@@ -439,6 +439,135 @@ __global__ __launch_bounds__(WGSZ, 4) void rs_scatter_kernel(const u64* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// rs_scatter_tiled (large (key, value) passes; BSC_RS_ORDER): the 1024 x 8 digit pass with the tiles INTERLEAVED over the workgroups instead
+// of one contiguous range per workgroup: in round it workgroup b takes tile it * 256 + (b % 8) * 32 + b / 8, so an XCD
+// (workgroups b % 8) always works on 32 consecutive tiles.  Neighbouring runs of a digit are then written at about the same
+// time by CUs that share an L2, which can merge their partial lines, and the reads of a round cover one contiguous 50 MB
+// stretch (tools/ubench_wc.hip: misaligned runs 0.541 -> 0.445 ms; tools/ubench_lookback.hip: tile copy 6.05 against 5.33 TB/s).
+// The price: offsets per TILE instead of per chunk (counts table [256][tiles], rs_hist launched with one tile per workgroup),
+// fetched per tile (one round ahead), and no state carried from tile to tile (no write combining).
+// ---------------------------------------------------------------------------------------------
+constexpr int RST_LDS = RSB_WG * RSB_ITEMS * 8 + (RSB_WG / 64) * 256 * 4 + 3 * 256 * 4 + 16 * 4;
+
+template <bool HAS_VAL>
+__global__ __launch_bounds__(RSB_WG) void rs_scatter_tiled_kernel(const u64* __restrict__ kin, u64* __restrict__ kout,
+                                                                  const u32* __restrict__ vin, u32* __restrict__ vout,
+                                                                  u32 n, int shift, u32 mask, u32 num_tiles,
+                                                                  const u32* __restrict__ offsets /*[256][num_tiles]*/,
+                                                                  const u32* __restrict__ rowtot)
+{
+    constexpr int WG = RSB_WG, WAVES = RSB_WG / 64, ITEMS = RSB_ITEMS, TILE = RSB_WG * RSB_ITEMS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* skeys  = reinterpret_cast<u64*>(smem);
+    u32* whist  = reinterpret_cast<u32*>(smem + TILE * 8);
+    u32* adj    = whist + WAVES * 256;
+    u32* scr    = adj + 3 * 256;
+    lds_vu32* vwh = (lds_vu32*)whist;
+    const u32 t = threadIdx.x, w = t >> 6, lane = t & 63;
+
+    u32 dbase;                                            // first output position of digit t & 255
+    {
+        u32 tot;
+        dbase = rs_digit_excl_sum<WAVES>(t < 256 ? rowtot[t] : 0u, scr, &tot);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) whist[w * 256 + i * 64 + lane] = 0;
+    __syncthreads();
+
+    const u32 wbase = w * (64 * ITEMS) + lane;
+    u64 k[ITEMS];
+    u32 v[ITEMS];
+    auto prefetch_keys = [&](const u32 tile) __attribute__((always_inline)) {
+        const u32 tb = tile * (u32)TILE;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) { u32 e = tb + wbase + i * 64; e = (tile < num_tiles && e < n) ? e : 0u; k[i] = __builtin_nontemporal_load(&kin[e]); }
+    };
+    auto prefetch_vals = [&](const u32 tile) __attribute__((always_inline)) {
+        const u32 tb = tile * (u32)TILE;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) { u32 e = tb + wbase + i * 64; e = (tile < num_tiles && e < n) ? e : 0u; v[i] = __builtin_nontemporal_load(&vin[e]); }
+    };
+    auto fetch_offset = [&](const u32 tile) __attribute__((always_inline)) -> u32 {          // every thread loads (no branch around a load)
+        return offsets[(size_t)(t & 255u) * num_tiles + (tile < num_tiles ? tile : num_tiles - 1)];
+    };
+    const u32 first = (blockIdx.x & 7u) * 32u + (blockIdx.x >> 3);
+    u32 off_next = fetch_offset(first);
+    prefetch_keys(first);
+    if (HAS_VAL) prefetch_vals(first);
+
+    auto do_tile = [&](const u32 tile, const u32 nvalid, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const u32 tbase = tile * (u32)TILE;
+        const u32 off_cur = off_next;
+        off_next = fetch_offset(tile + 256);
+        if (!FULL) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) if (wbase + i * 64 >= nvalid) k[i] = ~0ull;
+        }
+        u32 rk[ITEMS];
+        rs_rank_wave<ITEMS>(k, shift, mask, vwh + w * 256, rk);
+        __syncthreads();
+        {
+            u32 c[WAVES];
+            u32 tot = 0;
+            if (t < 256) {
+#pragma unroll
+                for (int i = 0; i < WAVES; ++i) { c[i] = whist[i * 256 + t]; tot += c[i]; }
+            }
+            u32 all;
+            const u32 ds = rs_digit_excl_sum<WAVES, false>(tot, scr, &all);
+            if (t < 256) {
+                u32 run = ds;
+#pragma unroll
+                for (int i = 0; i < WAVES; ++i) { whist[i * 256 + t] = run; run += c[i]; }
+                adj[t] = dbase + off_cur - ds;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const u32 d = (u32)(k[i] >> shift) & mask;
+            const u32 pos = whist[w * 256 + d] + rk[i];
+            rk[i] = pos;
+            skeys[pos] = k[i];
+        }
+        prefetch_keys(tile + 256);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) whist[w * 256 + i * 64 + lane] = 0;
+        u32 dd[ITEMS / 4];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 q = j * WG + t;
+            const u64 key = skeys[q];
+            const u32 d = (u32)(key >> shift) & mask;
+            if ((j & 3) == 0) dd[j >> 2] = d; else dd[j >> 2] |= d << (8 * (j & 3));
+            if (FULL || q < nvalid) kout[adj[d] + q] = key;
+        }
+        if (HAS_VAL) {
+            __syncthreads();
+            u32* svals = reinterpret_cast<u32*>(skeys);
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) svals[rk[i]] = v[i];
+            prefetch_vals(tile + 256);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const u32 q = j * WG + t;
+                const u32 d = (dd[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                if (FULL || q < nvalid) vout[adj[d] + q] = svals[q];
+            }
+        }
+        (void)tbase;
+    };
+    for (u32 tile = first; tile < num_tiles; tile += 256) {
+        const u32 left = n - tile * (u32)TILE;
+        if (left >= (u32)TILE) do_tile(tile, (u32)TILE, std::true_type());
+        else do_tile(tile, left, std::false_type());
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // rs_scatter_wc: the digit pass with write combining (large inputs).
 //
 // What limits rs_scatter above on uniform digits is not bytes but write *requests*: a tile leaves 256 runs of ~32
@@ -692,11 +821,46 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
     u64 *ksrc = keys, *kdst = keys_alt;
     u32 *vsrc = vals, *vdst = vals_alt;
     const u64 rec_bytes = 8 + (has_val ? 4 : 0);
+    // XCD-interleaved tiles for large (key, value) passes (rs_scatter_tiled_kernel): BSC_RS_ORDER=1 (default); 0 = one contiguous
+    // range per workgroup (the write-combining / plain kernels below); 2 = also for large keys-only passes (A/B)
+    static const int order_mode = [] { const char* e = getenv("BSC_RS_ORDER"); return e ? atoi(e) : 1; }();
+    const u32 num_tiles8k = (u32)((n + 8191) / 8192);
+    const bool tiled = emit_pos == nullptr && big_pairs && wc_mode != 2 && ((order_mode >= 1 && has_val) || order_mode == 2);
+    if (tiled && c->tile_counts_cap < (size_t)256 * num_tiles8k) {
+        if (c->tile_counts) (void)hipFree(c->tile_counts);
+        c->tile_counts = nullptr; c->tile_counts_cap = 0;
+        const size_t want = (size_t)256 * ((size_t)(c->max_n > (int64_t)n ? c->max_n : (int64_t)n) / 8192 + 2);
+        if (hipMalloc((void**)&c->tile_counts, want * 4) != hipSuccess) return ctx_fail(c, BSC_GPU_NOT_ENOUGH_MEMORY, "tile count table", hipSuccess);
+        c->tile_counts_cap = want;
+        HIP_TRY(c, hipFuncSetAttribute((const void*)rs_scatter_tiled_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RST_LDS));
+        HIP_TRY(c, hipFuncSetAttribute((const void*)rs_scatter_tiled_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RST_LDS));
+    }
 
     for (int p = 0; p < npasses; ++p) {
         const int shift = passes[p].shift;
         const u32 mask  = (passes[p].bits >= 8) ? 0xffu : ((1u << passes[p].bits) - 1u);
 
+        if (tiled) {
+            prof_begin(c, BSCGPU_K_RADIX_HIST, n * 8, n);
+            hipLaunchKernelGGL(rs_hist_kernel, dim3(num_tiles8k), dim3(RS_WG), 0, c->stream,
+                               ksrc, (u32)n, shift, mask, 2u, num_tiles8k, c->tile_counts);
+            prof_end(c);
+            prof_begin(c, BSCGPU_K_RADIX_SCAN, (u64)256 * num_tiles8k * 8, 0);
+            hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(WG), 0, c->stream, c->tile_counts, num_tiles8k, c->rowtot);
+            prof_end(c);
+            prof_begin(c, BSCGPU_K_RADIX_SCATTER, 2 * n * rec_bytes, n);
+            if (has_val)
+                hipLaunchKernelGGL(rs_scatter_tiled_kernel<true>, dim3(256), dim3(RSB_WG), RST_LDS, c->stream,
+                                   ksrc, kdst, vsrc, vdst, (u32)n, shift, mask, num_tiles8k, c->tile_counts, c->rowtot);
+            else
+                hipLaunchKernelGGL(rs_scatter_tiled_kernel<false>, dim3(256), dim3(RSB_WG), RST_LDS, c->stream,
+                                   ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, shift, mask, num_tiles8k, c->tile_counts, c->rowtot);
+            prof_end(c);
+            HIP_TRY(c, hipGetLastError());
+            u64* tk = ksrc; ksrc = kdst; kdst = tk;
+            u32* tv = vsrc; vsrc = vdst; vdst = tv;
+            continue;
+        }
         prof_begin(c, BSCGPU_K_RADIX_HIST, n * 8, n);
         hipLaunchKernelGGL(rs_hist_kernel, dim3(ch.num_chunks), dim3(RS_WG), 0, c->stream,
                            ksrc, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks, c->counts);
