@@ -246,8 +246,8 @@ def main():
             pass
         pass_achieved = pass_rate(stats_iso)
         roofline = {
-            "bound": "hbm", "kernel": "rs_scatter_wc_kernel<true> (one 8-bit LSD digit pass of the BWT's first sort: read + scatter of u64 key + u32 value; "
-                                     "write-combining 1024 x 8 shape of rs_scatter)",
+            "bound": "hbm", "kernel": "rs_scatter_tiled_kernel<true> (one 8-bit LSD digit pass of the BWT's first sort: read + scatter of u64 key + u32 value; "
+                                     "1024 x 8 shape, tiles interleaved per XCD)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "pass_frac": round(pass_achieved / HBM_PEAK_GBPS, 4), "pass_achieved": round(pass_achieved, 1),
             "pass_note": "whole digit pass (histogram + scan + scatter kernels, every launch of the measured region) charged with the scatter's algorithmic bytes",

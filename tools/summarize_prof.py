@@ -23,7 +23,7 @@ for f in find("*kernel_trace.csv"):
     if "pmc" in f:
         continue
     rows = list(csv.DictReader(open(f)))
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "rs_scatter_kernel<true" in r["Kernel_Name"] or "rs_scatter_wc_kernel<true" in r["Kernel_Name"]]
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "rs_scatter_kernel<true" in r["Kernel_Name"] or "rs_scatter_wc_kernel<true" in r["Kernel_Name"] or "rs_scatter_tiled_kernel<true" in r["Kernel_Name"]]
     if d:
         d.sort(reverse=True)
         big = [x for x in d if x > 300]
@@ -46,9 +46,9 @@ for f in find("*kernel_trace.csv"):
     print(f"{'kernel':66s} {'n':>4s} {'median_us':>10s} {'mean_us':>10s} {'min_us':>9s}")
     for nm, v in sorted(solo.items(), key=lambda kv: -sum(kv[1]))[:40]:
         print(f"{nm:66s} {len(v):4d} {statistics.median(v):10.1f} {sum(v)/len(v):10.1f} {min(v):9.1f}")
-    full = [x for nm, v in solo.items() if nm.startswith(("void rs_scatter_kernel<true, 1024", "void rs_scatter_wc_kernel<true")) for x in v if x > 250]
+    full = [x for nm, v in solo.items() if nm.startswith(("void rs_scatter_kernel<true, 1024", "void rs_scatter_wc_kernel<true", "void rs_scatter_tiled_kernel<true")) for x in v if x > 250]
     if full:
-        print(f"   => solo full-size (key, value) digit passes (rs_scatter_wc / rs_scatter 1024 x 8): {len(full)} launches, mean {sum(full)/len(full):.1f} us -> 24 B x 67108864 / mean = {24*67108864/(sum(full)/len(full))/1e3:.0f} GB/s")
+        print(f"   => solo full-size (key, value) digit passes (rs_scatter_tiled / rs_scatter_wc / rs_scatter 1024 x 8): {len(full)} launches, mean {sum(full)/len(full):.1f} us -> 24 B x 67108864 / mean = {24*67108864/(sum(full)/len(full))/1e3:.0f} GB/s")
 print()
 print("== PMC passes (one 64 MiB BWT; counters per dispatch, summed per kernel; FETCH_SIZE/WRITE_SIZE in KiB units as reported)")
 for tag, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
@@ -74,8 +74,8 @@ def per_launch(tag, cname, kname):
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r.get("Counter_Name") == cname and kname in r["Kernel_Name"]]
         return vals
     return []
-fe = per_launch("pmc_fetch", "FETCH_SIZE", "rs_scatter_wc_kernel<true") or per_launch("pmc_fetch", "FETCH_SIZE", "rs_scatter_kernel<true")
-wr = per_launch("pmc_write", "WRITE_SIZE", "rs_scatter_wc_kernel<true") or per_launch("pmc_write", "WRITE_SIZE", "rs_scatter_kernel<true")
+fe = per_launch("pmc_fetch", "FETCH_SIZE", "rs_scatter_tiled_kernel<true") or per_launch("pmc_fetch", "FETCH_SIZE", "rs_scatter_wc_kernel<true") or per_launch("pmc_fetch", "FETCH_SIZE", "rs_scatter_kernel<true")
+wr = per_launch("pmc_write", "WRITE_SIZE", "rs_scatter_tiled_kernel<true") or per_launch("pmc_write", "WRITE_SIZE", "rs_scatter_wc_kernel<true") or per_launch("pmc_write", "WRITE_SIZE", "rs_scatter_kernel<true")
 if fe and wr:
     nfull = 8
     fetch_kib = sum(fe[:nfull]) / nfull; write_kib = sum(wr[:nfull]) / nfull
