@@ -22,8 +22,11 @@
 //    (8192-record tiles, one workgroup per CU walking four chunks) for large (key, value) passes, where the longer
 //    per-digit runs halve the number of partially written lines.  A workgroup walks its records tile by tile keeping
 //    its 256 running global bucket offsets in LDS, so the per-chunk offsets table is only 256 x 1024 u32.
-//  * rs_scatter_wc (large (key, value) passes; BSC_RS_WC) additionally keeps the records of a digit that do not yet
-//    fill a 128-B line in LDS and writes keys only as whole 16-key lines, values as whole 32-value lines.
+//  * rs_scatter_tiled (large (key, value) passes, the default; BSC_RS_ORDER) gives up the contiguous range per workgroup:
+//    the tiles are interleaved so that an XCD always works on 32 consecutive tiles, neighbouring runs of a digit are written
+//    at the same time by CUs that share an L2, and the offsets are per tile.  0.60-0.62 of 8 TB/s on the BWT's keys.
+//  * rs_scatter_wc (BSC_RS_ORDER=0) keeps the contiguous ranges and additionally holds the records of a digit that do not yet
+//    fill a 128-B line in LDS: keys leave only as whole 16-key lines, values as whole 32-value lines (0.55).
 //  * Inside a tile: wave-striped coalesced loads (each wave64 load instruction covers 512 contiguous
 //    bytes of keys), 8-bit digit, stable in-wave ranking by wave64 ballot match (rs_match8: 8 ballots -> peer
 //    mask, 32 hand-scheduled VALU instructions per record), per-wave 256-bin histograms in LDS, then the tile is locally
@@ -814,7 +817,7 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
     const bool has_val = (vals != nullptr);
     const int wc_mode = c->rs_wc_mode;          // BSC_RS_WC, read once per context (radix_engine_setup)
     const bool big_pairs = RS_BIG_PAIRS && ch.num_chunks >= 512 && ch.chunk_tiles >= 2;   // enough records for 8192-record tiles on every CU
-    // BSC_RS_WC: 0 = never, 1 (default) = large (key, value) passes — on the BWT's keys 0.370 ms per pass against 0.389 ms, the gain
+    // (with BSC_RS_ORDER=0) BSC_RS_WC: 0 = never, 1 (default) = large (key, value) passes — on the BWT's keys 0.370 ms per pass against 0.389 ms, the gain
     // sits in the two lowest digits (0.47 -> 0.40, 0.42 -> 0.38), the others tie; keys-only passes stay on the plain kernel (text-
     // skewed ST digits: 0.189 against 0.221 ms) —, 2 = every pass with >= 4 chunks (tests)
     const bool use_wc = emit_pos == nullptr && ((wc_mode == 2 && ch.num_chunks >= 4) || (wc_mode == 1 && has_val && ch.num_chunks >= 512 && ch.chunk_tiles >= 2));

@@ -201,17 +201,19 @@ def test_error_paths_and_two_contexts(torch_cuda, ref):
         a.close(); b.close()
 
 
-def test_write_combining_scatter_variant(torch_cuda):
-    """The opt-in write-combining digit pass (BSC_RS_WC, radix_sort.hip) must produce the same stable order: run the
-    radix parity cases in a child process with the variant forced on for every size that has >= 4 chunks."""
+def test_contiguous_range_scatter_variants(torch_cuda):
+    """The digit-pass kernels that give a workgroup one contiguous tile range (BSC_RS_ORDER=0: the write-combining kernel, forced
+    on for every size with >= 4 chunks by BSC_RS_WC=2, and the plain 1024 x 8 kernel, BSC_RS_WC=0) must produce the same stable
+    order as the default XCD-interleaved kernel: the radix parity cases and a 16 MiB BWT in child processes."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BSC_RS_WC="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_device.py"), "-q", "-x",
-                        "-k", "radix_sort_matches or bwt_device_resident_16m"], capture_output=True, text=True, env=env, cwd=root)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for wc in ("2", "0"):
+        env = dict(os.environ, BSC_RS_WC=wc, BSC_RS_ORDER="0")
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_device.py"), "-q", "-x",
+                            "-k", "radix_sort_matches or bwt_device_resident_16m"], capture_output=True, text=True, env=env, cwd=root)
+        assert r.returncode == 0, (wc, r.stdout[-2000:] + r.stderr[-2000:])
 
 
 def test_device_static_model_matches_oracle_trace(ctx):
