@@ -609,7 +609,7 @@ static int run_seg(bscgpu_ctx* c, const u64* keys, const u32* sa_sorted, const u
     HIP_TRY(c, ctx_sync(c));
     prof_collect(c);
     *U_out = c->hscal[0];
-    return BSC_NO_ERROR;
+    return radix_onesweep_check(c);            // the sort in front of this seg, if it used the single-read passes
 }
 
 int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64_t r, u32* I_host, int64_t* primary_out)

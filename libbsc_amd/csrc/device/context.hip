@@ -133,6 +133,8 @@ extern "C" void bscgpu_destroy(bscgpu_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) ctx_sync(c);
     if (c->tile_counts) { (void)hipFree(c->tile_counts); c->tile_counts = nullptr; }
+    if (c->os_agg) { (void)hipFree(c->os_agg); c->os_agg = nullptr; }
+    if (c->os_zero) { (void)hipFree(c->os_zero); c->os_zero = nullptr; }
     if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     for (auto& p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& e : c->event_pool) hipEventDestroy(e);
@@ -262,7 +264,7 @@ extern "C" int bscgpu_radix_sort_u64(bscgpu_ctx* c, void* keys, void* keys_alt, 
     if (rc < 0) return rc;
     HIP_TRY(c, ctx_sync(c));
     prof_collect(c);
-    return BSC_NO_ERROR;
+    return radix_onesweep_check(c);
 }
 
 // ---- C ABI: host-pointer entry points (the reference's hook shape: H2D, run, D2H, synchronous) ----

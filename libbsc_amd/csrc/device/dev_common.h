@@ -96,6 +96,15 @@ struct bscgpu_ctx {
     u64* adler_part = nullptr; // [MAX_CHUNKS][2]
     u32* tile_counts = nullptr; size_t tile_counts_cap = 0;   // [256][tiles of 8192 records]: BSC_RS_ORDER=1 experiment, allocated on first use
     u64* wc_sink = nullptr;  // [512 * 1024] write sink for predicated-off lanes of rs_scatter_wc
+    // single-read digit passes (radix_onesweep.hip), allocated on first use
+    int  num_cus = 256;           // hipDeviceAttributeMultiprocessorCount of the context's device
+    int  os_mode = 0;             // BSC_RS_ONESWEEP: 0 = off, 1 = large (key, value) sorts (default), 2 = every sort of >= 4 tiles (tests)
+    u32* os_agg = nullptr;        // [tiles][256] tile rows {launch tag, digit count}
+    u32* os_zero = nullptr;       // [8 passes] x {control block, digit totals, batch rows}: cleared per sort
+    u32  os_tiles_cap = 0;
+    u32  os_pass_stride = 0;      // words
+    u32  os_epoch = 0;            // launches so far (launch tag = epoch % 255 + 1)
+    bool os_check_pending = false;   // hscal[OS_ERR_SLOT] of the last sort has not been looked at yet
     // pinned host
     u32* hscal  = nullptr;   // 64 u32
     u64* hscal64 = nullptr;
@@ -140,6 +149,11 @@ struct RadixPass { int shift; int bits; };
 int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* vals_alt, u64 n,
                       const RadixPass* passes, int npasses, int* in_alt, u32* emit_pos = nullptr);
 
+constexpr int OS_ERR_SLOT = 1000;           // hscal / dscal word that carries the error word of the last single-read sort
+int  radix_onesweep_setup(bscgpu_ctx* c);
+bool radix_onesweep_wanted(const bscgpu_ctx* c, u64 n, int npasses, bool has_val);
+int  radix_onesweep_sort(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* vals_alt, u64 n, const RadixPass* passes, int npasses);
+int  radix_onesweep_check(bscgpu_ctx* c);   // after the next stream sync: did a pass of the last such sort give up a wait?
 int radix_engine_setup(bscgpu_ctx* c);     // per-device kernel attributes; bscgpu_create calls it with c->device current
 
 int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n, int64_t r, u32* I_host,

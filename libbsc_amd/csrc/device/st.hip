@@ -120,7 +120,7 @@ int st_device(bscgpu_ctx* c, const u8* dT_user, u8* dOut_user, int n_, int k, in
     HIP_TRY(c, ctx_sync(c));
     prof_collect(c);
     *index_out = (int)c->hscal[2];
-    return BSC_NO_ERROR;
+    return radix_onesweep_check(c);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -58,6 +58,127 @@ def _corpus(rng):
 
 
 # --------------------------------------------------------------------------------------------
+# Single-read digit passes (radix_onesweep.hip): BSC_RS_ONESWEEP=2 sends every sort of >= 4 tiles through them (the variable is
+# read when a context is created).  Oracle = numpy's stable sort.
+@pytest.fixture(scope="module")
+def os_ctx(torch_cuda):
+    import os
+    from libbsc_amd import GpuContext
+    old = os.environ.get("BSC_RS_ONESWEEP")
+    os.environ["BSC_RS_ONESWEEP"] = "2"
+    try:
+        c = GpuContext(0, max_n=(24 << 20) + 4096)
+    finally:
+        if old is None:
+            os.environ.pop("BSC_RS_ONESWEEP", None)
+        else:
+            os.environ["BSC_RS_ONESWEEP"] = old
+    yield c
+    c.close()
+
+
+def _os_keys(rng, n, kind):
+    if kind == "uniform":
+        return rng.integers(0, 2**63, n, dtype=np.int64).view(np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)
+    if kind == "skewed":            # few distinct bytes per digit, like text
+        kb = rng.integers(0, 7, (n, 8), dtype=np.uint8) * 37
+        kb[:, 3] = rng.integers(0, 256, n, dtype=np.uint8)
+        return kb.view(np.uint64).reshape(-1).copy()
+    if kind == "one-digit":         # every record in one bucket of the low passes, two buckets in the top one
+        return (rng.integers(0, 2, n, dtype=np.uint64) << np.uint64(63)) | np.uint64(0x0101010101010101)
+    # "sorted-runs": long runs of equal digits, the tile counts of a digit swing between 0 and a whole tile
+    return (np.arange(n, dtype=np.uint64) // np.uint64(5000)) * np.uint64(0x0000010000010001)
+
+
+def _os_check(torch, ctx, keys, pairs, b0, b1):
+    n = keys.size
+    vals = np.arange(n, dtype=np.uint32)
+    dk = torch.from_numpy(keys.view(np.int64)).cuda()
+    dk2 = torch.empty_like(dk)
+    dv = torch.from_numpy(vals.view(np.int32)).cuda() if pairs else None
+    dv2 = torch.empty_like(dv) if pairs else None
+    rk, rv = ctx.radix_sort(dk, dk2, dv, dv2, n, b0, b1)
+    torch.cuda.synchronize()
+    mask = np.uint64((((1 << (b1 - b0)) - 1) << b0) & 0xFFFFFFFFFFFFFFFF)
+    order = np.argsort(keys & mask, kind="stable")
+    assert np.array_equal(rk.cpu().numpy().view(np.uint64), keys[order]), f"keys mismatch n={n} bits=[{b0},{b1})"
+    if pairs:
+        assert np.array_equal(rv.cpu().numpy().view(np.uint32), vals[order]), f"vals mismatch n={n} bits=[{b0},{b1})"
+
+
+@pytest.mark.parametrize("n", [4 * 8192, 4 * 8192 + 1, 40000, 33 * 8192 + 5, 32 * 9 * 8192 + 17, 5_000_000, 20_000_003])
+@pytest.mark.parametrize("mode", ["pairs", "keys"])
+def test_single_read_passes_match_stable_sort(os_ctx, torch_cuda, n, mode):
+    rng = np.random.default_rng(n + 5)
+    for kind, ranges in (("uniform", [(0, 64), (3, 30)]), ("skewed", [(0, 64), (8, 48), (32, 58)]), ("one-digit", [(0, 64)]), ("sorted-runs", [(0, 40)])):
+        keys = _os_keys(rng, n, kind)
+        for (b0, b1) in ranges:
+            if n > 10_000_000 and (b0, b1) != ranges[0]:
+                continue
+            _os_check(torch_cuda, os_ctx, keys, mode == "pairs", b0, b1)
+
+
+def test_single_read_passes_launch_tag_wraps(os_ctx, torch_cuda):
+    """The tile rows carry a launch tag of 1..255 and are cleared when the sequence wraps: > 255 digit passes on one context,
+    alternating a small and a larger input so that rows beyond the small input keep older tags."""
+    rng = np.random.default_rng(99)
+    small = _os_keys(rng, 5 * 8192 + 11, "skewed")
+    large = _os_keys(rng, 70 * 8192 + 3, "uniform")
+    for it in range(40):                                 # 40 x 8 = 320 passes
+        _os_check(torch_cuda, os_ctx, large if it % 5 == 4 else small, True, 0, 64)
+
+
+def test_single_read_passes_under_uneven_load(os_ctx, torch_cuda):
+    """Look-back under partial residency and uneven load: other kernels occupy CUs on other streams while the digit
+    passes run, and a second context sorts at the same time.  Every word of the output is checked."""
+    import threading
+    import os
+    from libbsc_amd import GpuContext
+    torch = torch_cuda
+    stop = threading.Event()
+
+    def hog():                                          # LDS-heavy and long-running kernels on torch's own streams
+        s = torch.cuda.Stream()
+        a = torch.randn(4096, 4096, device="cuda")
+        with torch.cuda.stream(s):
+            while not stop.is_set():
+                b = a @ a
+                b = torch.sort(b.view(-1)[: 1 << 22])[0]
+                s.synchronize()
+
+    os.environ["BSC_RS_ONESWEEP"] = "2"
+    try:
+        other = GpuContext(0, max_n=(8 << 20) + 4096)
+    finally:
+        os.environ.pop("BSC_RS_ONESWEEP", None)
+    errors = []
+
+    def second():
+        try:
+            rng2 = np.random.default_rng(7)
+            k2 = _os_keys(rng2, 6_000_011, "skewed")
+            for _ in range(6):
+                _os_check(torch, other, k2, True, 0, 64)
+        except Exception as e:          # surfaced in the main thread
+            errors.append(e)
+
+    th = [threading.Thread(target=hog), threading.Thread(target=second)]
+    for t in th:
+        t.start()
+    try:
+        rng = np.random.default_rng(8)
+        keys = _os_keys(rng, 9_000_017, "uniform")
+        for rep in range(6):
+            _os_check(torch, os_ctx, keys, rep % 2 == 0, 0, 64)
+    finally:
+        stop.set()
+        for t in th:
+            t.join()
+        other.close()
+    assert not errors, errors
+
+
+# --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [0, 1, 5, 64, 4095, 4096, 4097, 100000, (1 << 20) + 123, 5_000_000])
 @pytest.mark.parametrize("mode", ["pairs", "keys"])
 def test_radix_sort_matches_stable_sort(ctx, torch_cuda, n, mode):

@@ -13,4 +13,4 @@ for rep in range(5):
     ctx.profile(True); ctx.profile_reset(); ctx.bwt_device(d, out, n, aux_rate=1 << 23); sl = ctx.scatter_launches(); ctx.profile(False)
     acc.append([m for m, rec in sl if rec == n])
 a = np.median(np.array(acc), axis=0)
-print("BSC_RS_WC=%s per pass (ms): %s  mean %.3f" % (os.environ.get("BSC_RS_WC", "0"), " ".join(f"{x:.3f}" for x in a), a.mean()))
+print("BSC_RS_ONESWEEP=%s per pass (ms): %s  mean %.3f" % (os.environ.get("BSC_RS_ONESWEEP", "default"), " ".join(f"{x:.3f}" for x in a), a.mean()))
