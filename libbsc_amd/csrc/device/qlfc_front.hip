@@ -79,20 +79,18 @@ __global__ __launch_bounds__(WG) void qf_apply_kernel(const u8* __restrict__ L, 
                                                       u32* __restrict__ first_run /*[8][256]*/)
 {
     __shared__ u32 scr[8];
-    // first run of every symbol per sub-block: minima in LDS first (a chunk of n / 1024 bytes touches at most two sub-blocks),
-    // one global atomicMin per (sub-block, symbol) the workgroup has seen — not one L2 round trip per run
-    __shared__ u32 fmin[2 * 256];
+    // first run of every symbol per sub-block: minima in LDS first, one global atomicMin per (sub-block, symbol) the workgroup
+    // has seen — not one L2 round trip per run.  All eight sub-blocks have their own row: the adaptive split (coder.cpp:83-99)
+    // cuts where the sampled run starts reach total / nblocks, so on a block that is constant except for a short noisy stretch the
+    // cuts can be as little as 32 bytes apart and one chunk can hold all of them.
+    __shared__ u32 fmin[8 * 256];
     __shared__ u32 sstart[QF_TILE];                 // the tile's runs (a tile of QF_TILE bytes has at most QF_TILE runs)
     __shared__ u8  ssym[QF_TILE];
-    for (u32 i = threadIdx.x; i < 2 * 256; i += WG) fmin[i] = 0xffffffffu;
+    __shared__ u32 scut[10];                        // cut points (a per-thread index into a kernel argument would go through scratch)
+    for (u32 i = threadIdx.x; i < 8 * 256; i += WG) fmin[i] = 0xffffffffu;
+    if (threadIdx.x < 10) scut[threadIdx.x] = (threadIdx.x <= 8 && threadIdx.x < sp.nblocks) ? sp.start[threadIdx.x < 9 ? threadIdx.x : 8] : 0xffffffffu;
     const u32 tile0 = blockIdx.x * chunk_tiles;
     u32 tile1 = tile0 + chunk_tiles; if (tile1 > num_tiles) tile1 = num_tiles;
-    u32 b_first = 0;
-    {
-        const u32 p0 = tile0 * QF_TILE;
-#pragma unroll
-        for (int q = 1; q < 8; ++q) if ((u32)q < sp.nblocks && p0 >= sp.start[q]) b_first = q;
-    }
     u32 off = segoff[blockIdx.x];
     __syncthreads();
     for (u32 tile = tile0; tile < tile1; ++tile) {
@@ -103,15 +101,19 @@ __global__ __launch_bounds__(WG) void qf_apply_kernel(const u8* __restrict__ L, 
         u32 tot;
         u32 lj = block_excl_sum(__popc(mask), scr, &tot);      // run index inside the tile
         const u32 w[4] = {bytes.x, bytes.y, bytes.z, bytes.w};
-        // sub-block of this thread's 16 bytes: the chunk's first one, or the next when a boundary has been passed
-        const u32 b_next_start = (b_first + 1 < sp.nblocks) ? sp.start[b_first + 1 < 8 ? b_first + 1 : 7] : 0xffffffffu;
+        // sub-block of this thread's first byte, from ALL the cut points; runs further right move on as they pass a cut
+        u32 b = 0;
+#pragma unroll
+        for (int q = 1; q < 8; ++q) if ((u32)q < sp.nblocks && i0 >= sp.start[q]) b = q;
+        u32 b_next_start = scut[b + 1];             // 0xffffffff behind the last sub-block
         while (mask) {
             const u32 p = __ffs(mask) - 1; mask &= mask - 1;
             const u32 c = (w[p >> 2] >> (8 * (p & 3))) & 0xffu;
             const u32 pos = i0 + p;
+            while (pos >= b_next_start) { ++b; b_next_start = scut[b + 1]; }
             ssym[lj] = (u8)c;
             sstart[lj] = pos;
-            atomicMin(&fmin[(pos >= b_next_start ? 256u : 0u) + c], off + lj);
+            atomicMin(&fmin[b * 256u + c], off + lj);
             ++lj;
         }
         __syncthreads();
@@ -120,10 +122,9 @@ __global__ __launch_bounds__(WG) void qf_apply_kernel(const u8* __restrict__ L, 
         off += tot;
         __syncthreads();
     }
-    for (u32 i = threadIdx.x; i < 2 * 256; i += WG) {
+    for (u32 i = threadIdx.x; i < 8 * 256; i += WG) {
         const u32 v = fmin[i];
-        const u32 b = b_first + (i >> 8);
-        if (v != 0xffffffffu && b < 8) atomicMin(first_run + b * 256 + (i & 255u), v);
+        if (v != 0xffffffffu) atomicMin(first_run + i, v);
     }
 }
 

@@ -47,6 +47,24 @@ constexpr int OS_CTL_WORDS = 32;
 
 struct OsPasses { int np; int shift[OS_MAXP]; u32 mask[OS_MAXP]; };
 
+// Debug builds (tools/build_variant.sh): -DOS_PHASE_TIMING=1 stamps s_memtime at the phase boundaries of the first 40 tiles of every
+// workgroup (threads 0 and 960) into the context's scratch buffer; -DOS_ABL=bits removes parts of the protocol for timing only
+// (1: no look-back loads / polls, 2: no publishing, 4: static tile order instead of tickets) — results are wrong with any bit set.
+#ifndef OS_PHASE_TIMING
+#define OS_PHASE_TIMING 0
+#endif
+#ifndef OS_ABL
+#define OS_ABL 0
+#endif
+#ifndef OS_VALS_EARLY
+#define OS_VALS_EARLY 0        // 1: the values of `cur` are requested at the top of the iteration (8 more registers live under the ranking)
+#endif
+#if OS_PHASE_TIMING
+#define OS_PH(i) do { if ((t == 0 || t == 960) && tile_no < 40u) tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + (t ? 1 : 0)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define OS_PH(i) do { } while (0)
+#endif
+
 #define OS_LOAD(p)      __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define OS_STORE(p, v)  __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define OS_ADD(p, v)    __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -138,8 +156,10 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                                                             u32 n, int shift, u32 mask, u32 ntiles,
                                                             u32* ctl, u32* err, const u32* __restrict__ totals,
                                                             u32* bagg /*[batches][256]: arrivals << 24 | sum*/,
-                                                            u32* agg /*[tiles][256]: tag | count*/, u32 tag)
+                                                            u32* agg /*[tiles][256]: tag | count*/, u32 tag, u64* tdbg)
 {
+    (void)tdbg;
+    u32 tile_no = 0; (void)tile_no;
     constexpr int WG = OS_WG, WAVES = OS_WAVES, ITEMS = OS_ITEMS, TILE = OS_TILE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* S      = reinterpret_cast<u64*>(smem);                         // [2][TILE] locally reordered keys (then values) of the two tiles in flight
@@ -167,7 +187,8 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) whist[w * 256 + i * 64 + lane] = 0;
-    if (t == 0) sclaim[0] = os_claim_finish(os_claim_issue(ctl, xcc), ctl, err, xcc, ntiles, nbatches);
+    if (OS_ABL & 4) { if (t == 0) { const u32 f = (blockIdx.x & 7u) * 32u + (blockIdx.x >> 3); sclaim[0] = f < ntiles ? f : OS_NONE; } }
+    else if (t == 0) sclaim[0] = os_claim_finish(os_claim_issue(ctl, xcc), ctl, err, xcc, ntiles, nbatches);
     __syncthreads();
     u32 cur = OS_NONE, nxt = sclaim[0];
     if (nxt == OS_NONE) return;
@@ -220,24 +241,27 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         u64* Sc = S + (size_t)cb * TILE;
         u64* Sn = S + (size_t)(cb ^ 1u) * TILE;
 
+        OS_PH(0);
         // (0) the ticket for the tile after `nxt`: drawn now, looked at in front of the third barrier
         u32 ticket = 0;
-        if (t == 0 && more) ticket = os_claim_issue(ctl, xcc);
+        if (!(OS_ABL & 4) && t == 0 && more) ticket = os_claim_issue(ctl, xcc);
 
         // (1) look-back loads for `cur`: <= 8 tile rows of its batch and <= 2 batch rows per thread, all in flight under the ranking
         const u32 cj = cv ? (cur & (u32)(OS_BATCH - 1)) : 0u, cG = cv ? (cur / (u32)OS_BATCH) : 0u;
+        if (HAS_VAL && OS_VALS_EARLY) load_vals(cur);
         u32 la[8], lb[2];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const u32 jj = grp + 4u * q;
             const u32 row = (jj < cj) ? (cur - cj + jj) : 0u;
-            la[q] = OS_LOAD(&agg[(size_t)row * 256 + dig]);
+            la[q] = (OS_ABL & 1) ? tag : OS_LOAD(&agg[(size_t)row * 256 + dig]);
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const u32 gg = gbase + grp + 4u * q;
-            lb[q] = OS_LOAD(&bagg[(size_t)(gg < cG ? gg : 0u) * 256 + dig]);
+            lb[q] = (OS_ABL & 1) ? ((u32)OS_BATCH << 24) : OS_LOAD(&bagg[(size_t)(gg < cG ? gg : 0u) * 256 + dig]);
         }
+        OS_PH(1);
 
         // (2) rank `nxt` inside its waves
         if (nv) {
@@ -247,8 +271,10 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             }
             rs_rank_wave<ITEMS>(k, shift, mask, vwh + w * 256, rk);
         }
+        OS_PH(2);
         __syncthreads();                                                                          // B1
-        if (HAS_VAL) load_vals(cur);                                    // needed behind B5: not live during the ranking
+        OS_PH(3);
+        if (HAS_VAL && !OS_VALS_EARLY) load_vals(cur);                  // needed behind B5: not live during the ranking
         if (nv) {
             u32 tot = 0;
             if (t < 256) {
@@ -263,10 +289,13 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                 for (int i = 0; i < WAVES; ++i) { const u32 ci = whist[i * 256 + t]; whist[i * 256 + t] = run; run += ci; }
                 dstart[(cb ^ 1u) * 256 + t] = ds;
                 const u32 cnt = tot - ((!ST && t == mask) ? ((u32)TILE - nxt_n) : 0u);
-                OS_STORE(&agg[(size_t)nxt * 256 + t], tag | cnt);
-                (void)OS_ADD(&bagg[(size_t)(nxt / (u32)OS_BATCH) * 256 + t], cnt | (1u << 24));
+                if (!(OS_ABL & 2)) {
+                    OS_STORE(&agg[(size_t)nxt * 256 + t], tag | cnt);
+                    (void)OS_ADD(&bagg[(size_t)(nxt / (u32)OS_BATCH) * 256 + t], cnt | (1u << 24));
+                }
             }
         }
+        OS_PH(4);
 
         // (3) sum what the look-back loads brought; poll rows that were not there yet
         if (cv) {
@@ -290,7 +319,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                     sb += x & 0xffffffu;
                 }
             }
-            for (u32 gg = gbase + 8u + grp; gg < cG; gg += 4u) {       // a workgroup that fell behind (or has just started)
+            for (u32 gg = gbase + 8u + grp; gg < cG && !(OS_ABL & 1); gg += 4u) {       // a workgroup that fell behind (or has just started)
                 sb += poll_row(bagg, gg, 0xff000000u, (u32)OS_BATCH << 24, ok) & 0xffffffu;
             }
             if (!ok) (void)OS_ADD(err, 1u);
@@ -298,8 +327,12 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             if (sb) atomicAdd(&accB[dig], sb);
             gbase = cG;
         }
-        if (t == 0) sclaim[0] = more ? os_claim_finish(ticket, ctl, err, xcc, ntiles, nbatches) : OS_NONE;
+        if (OS_ABL & 4) {                                               // static order: rounds of gridDim.x tiles, 32 consecutive tiles per XCD
+            if (t == 0) { const u32 s2 = (nxt != OS_NONE ? nxt : cur) + gridDim.x; sclaim[0] = (more && s2 < ntiles) ? s2 : OS_NONE; }
+        } else if (t == 0) sclaim[0] = more ? os_claim_finish(ticket, ctl, err, xcc, ntiles, nbatches) : OS_NONE;
+        OS_PH(5);
         __syncthreads();                                                                          // B3
+        OS_PH(6);
         const u32 nn = sclaim[0];
         if (nn == OS_NONE) more = false;
 
@@ -322,7 +355,9 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             adj[t] = r + accA[t] - dstart[cb * 256 + t];
             accA[t] = 0; accB[t] = 0;
         }
+        OS_PH(7);
         __syncthreads();                                                                          // B4
+        OS_PH(8);
 
         // (5) `cur` leaves: every digit as one contiguous run, consecutive lanes -> consecutive addresses
         u32 dd[ITEMS / 4];
@@ -339,14 +374,18 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
 #pragma unroll
             for (int j = 0; j < ITEMS / 4; ++j) dd[j] = 0;
         }
+        OS_PH(9);
         if (HAS_VAL) {
             __syncthreads();                                                                      // B5
+            OS_PH(10);
             u32* svals = reinterpret_cast<u32*>(Sc);
             if (cv) {
 #pragma unroll
                 for (int i = 0; i < ITEMS; ++i) svals[(posA[i >> 1] >> (16 * (i & 1))) & 0xffffu] = v[i];
             }
+            OS_PH(11);
             __syncthreads();                                                                      // B6
+            OS_PH(12);
             if (cv) {
 #pragma unroll
                 for (int j = 0; j < ITEMS; ++j) {
@@ -358,6 +397,11 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         }
 #pragma unroll
         for (int i = 0; i < ITEMS / 2; ++i) posA[i] = rk[2 * i] | (rk[2 * i + 1] << 16);
+        OS_PH(13);
+#if OS_PHASE_TIMING
+        if ((t == 0 || t == 960) && tile_no < 40u) tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + (t ? 1 : 0)) * 16 + 14] = ((u64)cur << 32) | nxt;
+#endif
+        ++tile_no;
         cur = nxt; nxt = nn; cb ^= 1u;
     };
 
@@ -444,15 +488,23 @@ int radix_onesweep_sort(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32*
         prof_begin(c, BSCGPU_K_RADIX_SCATTER, 2 * n * rec_bytes, n);
         if (has_val)
             hipLaunchKernelGGL(rs_onesweep_kernel<true>, dim3(grid), dim3(OS_WG), OS_LDS, c->stream,
-                               ksrc, kdst, vsrc, vdst, (u32)n, P.shift[p], P.mask[p], ntiles, ctl, c->os_zero + 1, ctl + OS_CTL_WORDS, ctl + OS_CTL_WORDS + 256, c->os_agg, tag);
+                               ksrc, kdst, vsrc, vdst, (u32)n, P.shift[p], P.mask[p], ntiles, ctl, c->os_zero + 1, ctl + OS_CTL_WORDS, ctl + OS_CTL_WORDS + 256, c->os_agg, tag, c->wc_sink);
         else
             hipLaunchKernelGGL(rs_onesweep_kernel<false>, dim3(grid), dim3(OS_WG), OS_LDS, c->stream,
-                               ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, P.shift[p], P.mask[p], ntiles, ctl, c->os_zero + 1, ctl + OS_CTL_WORDS, ctl + OS_CTL_WORDS + 256, c->os_agg, tag);
+                               ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, P.shift[p], P.mask[p], ntiles, ctl, c->os_zero + 1, ctl + OS_CTL_WORDS, ctl + OS_CTL_WORDS + 256, c->os_agg, tag, c->wc_sink);
         prof_end(c);
         HIP_TRY(c, hipGetLastError());
         u64* tk = ksrc; ksrc = kdst; kdst = tk;
         u32* tv = vsrc; vsrc = vdst; vdst = tv;
     }
+#if OS_PHASE_TIMING
+    if (n >= (1u << 24)) {      // debug builds: phase stamps of the last pass
+        static std::vector<u64> host(256 * 40 * 2 * 16);
+        if (hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(host.data(), c->wc_sink, host.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE* f = fopen("gpurun_out/os_phase_timing.bin", "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+        }
+    }
+#endif
     // the sort's error word travels to pinned memory behind the last pass; radix_onesweep_check looks at it after the caller's next sync
     HIP_TRY(c, hipMemcpyAsync(c->hscal + OS_ERR_SLOT, c->os_zero + 1, 4, hipMemcpyDeviceToHost, c->stream));
     c->os_check_pending = true;
