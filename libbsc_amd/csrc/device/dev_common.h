@@ -113,6 +113,7 @@ struct bscgpu_ctx {
     HostSlot slots[MAX_SLOTS];   // pinned landing zones for the QLFC front end; >1 when blocks are pipelined
     int      nslots = 0;
     DevCoder* dc = nullptr;
+    bool     dc_alloc_failed = false;   // the device coder's arena did not fit: this context keeps the host model (not retried per block)
     int      dc_last_fail = 0;   // why the last block left the device coder (bit mask, devcoder.hip FAIL_*), 0 = it did not
     int      dc_replays = 0;     // evaluation chunks replayed serially in the last block
     int      rs_wc_mode = 0;     // BSC_RS_WC as read at context creation (radix_engine_setup)

@@ -980,6 +980,10 @@ void devcoder_destroy(bscgpu_ctx* c)
 int devcoder_ensure(bscgpu_ctx* c)
 {
     if (c->dc) return BSC_NO_ERROR;
+    // An arena that does not fit (~220 bytes per block byte on top of the sorter's ~60) is a reason to DECLINE, not an error: the
+    // block takes the host model, as it did before the device model existed, and the allocation is not retried for every block.
+    if (c->dc_alloc_failed) return BSC_NOT_SUPPORTED;
+    if (getenv("BSC_DEVCODER_FAIL_ALLOC")) { c->dc_alloc_failed = true; return BSC_NOT_SUPPORTED; }      // tests: an arena that does not fit
     DevCoder* d = new DevCoder();
     const size_t N = ((size_t)c->max_n + 4096 + 4095) / 4096 * 4096;
     d->Mcap = N; d->Dcap = 4 * N + 65536;
@@ -1004,11 +1008,11 @@ int devcoder_ensure(bscgpu_ctx* c)
     };
     size_t total = 0;
     for (auto& cv : carve) total += dc_align(cv.bytes);
-    if (hipMalloc((void**)&d->arena, total) != hipSuccess) { (void)hipGetLastError(); delete d; return BSC_GPU_NOT_ENOUGH_MEMORY; }
+    if (hipMalloc((void**)&d->arena, total) != hipSuccess) { (void)hipGetLastError(); delete d; c->dc_alloc_failed = true; return BSC_NOT_SUPPORTED; }
     d->arena_bytes = total; d->nch_cap = NCH;
     size_t off = 0;
     for (auto& cv : carve) { *cv.p = d->arena + off; off += dc_align(cv.bytes); }
-    if (hipHostMalloc((void**)&d->hmeta, 64 * 4, hipHostMallocDefault) != hipSuccess) { hipFree(d->arena); delete d; return BSC_NOT_ENOUGH_MEMORY; }
+    if (hipHostMalloc((void**)&d->hmeta, 64 * 4, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); hipFree(d->arena); delete d; c->dc_alloc_failed = true; return BSC_NOT_SUPPORTED; }
     ModelParams mp; model_params_from_table(bschost::qlfc_static_params(), mp);
     // more than 64 KB of dynamic LDS is a per-device attribute of the function: set for every context's device
     if (hipFuncSetAttribute((const void*)dc_eval_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DC_EVAL_LDS) != hipSuccess ||

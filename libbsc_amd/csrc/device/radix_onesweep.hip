@@ -118,10 +118,16 @@ __global__ __launch_bounds__(OS_WG) void rs_hist_all_kernel(const u64* __restric
 // ---------------------------------------------------------------------------------------------
 // The common case is one returning atomic whose result is a tile; it is issued at the top of an iteration (os_claim_issue) and looked
 // at several microseconds later (os_claim_finish), so the wave does not sit in s_waitcnt vmcnt(0) behind its own streaming loads.
-__device__ __forceinline__ u32 os_claim_issue(u32* ctl, const u32 x) { return OS_ADD(ctl + 8 + x, 1u); }
+// (The address is made to look divergent — `opaque0` is a zero the compiler cannot see through —, otherwise the atomic optimiser
+// rewrites a uniform returning atomic into mbcnt / readfirstlane form and waits for it on the spot.)
+#ifndef OS_ORDER
+#define OS_ORDER 0        // 0: tile = global ticket (tiles are claimed in index order); 1: batches of 32 tiles per XCD (A/B builds)
+#endif
+__device__ __forceinline__ u32 os_claim_issue(u32* ctl, const u32 x, const u32 opaque0) { return OS_ADD(ctl + (OS_ORDER ? 8 + x : 0) + opaque0, 1u); }
 
 __device__ __forceinline__ u32 os_claim_finish(u32 wv, u32* ctl, u32* err, const u32 x, const u32 ntiles, const u32 nbatches)
 {
+    if (!OS_ORDER) return wv < ntiles ? wv : OS_NONE;
     u32* W = ctl + 8 + x;
     for (u32 guard = 0; guard < 64; ++guard) {
         const u32 b = wv >> 16, j = wv & 0xffffu;
@@ -179,6 +185,8 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     u32 xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7u;
+    u32 opaque0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
 
     {
         u32 tot;
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
 #pragma unroll
     for (int i = 0; i < 4; ++i) whist[w * 256 + i * 64 + lane] = 0;
     if (OS_ABL & 4) { if (t == 0) { const u32 f = (blockIdx.x & 7u) * 32u + (blockIdx.x >> 3); sclaim[0] = f < ntiles ? f : OS_NONE; } }
-    else if (t == 0) sclaim[0] = os_claim_finish(os_claim_issue(ctl, xcc), ctl, err, xcc, ntiles, nbatches);
+    else if (t == 0) sclaim[0] = os_claim_finish(os_claim_issue(ctl, xcc, opaque0), ctl, err, xcc, ntiles, nbatches);
     __syncthreads();
     u32 cur = OS_NONE, nxt = sclaim[0];
     if (nxt == OS_NONE) return;
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         OS_PH(0);
         // (0) the ticket for the tile after `nxt`: drawn now, looked at in front of the third barrier
         u32 ticket = 0;
-        if (!(OS_ABL & 4) && t == 0 && more) ticket = os_claim_issue(ctl, xcc);
+        if (!(OS_ABL & 4) && t == 0 && more) ticket = os_claim_issue(ctl, xcc, opaque0);
 
         // (1) look-back loads for `cur`: <= 8 tile rows of its batch and <= 2 batch rows per thread, all in flight under the ranking
         const u32 cj = cv ? (cur & (u32)(OS_BATCH - 1)) : 0u, cG = cv ? (cur / (u32)OS_BATCH) : 0u;

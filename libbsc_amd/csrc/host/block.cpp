@@ -41,9 +41,10 @@ static void  bsc_free(void* p) { if (g_free) g_free(p); else free(p); }
 // The reference keeps one cached arena behind one lock (bwt.cpp:50-52) and gets its parallelism from the CLI's OpenMP team
 // calling bsc_compress concurrently, one block per thread (bsc.cpp:184-199).  Relinked against this library those calls
 // are spread over ALL visible GPUs with no API change: every device has its own default contexts (two by default: their
-// kernels interleave), GPU-stage locks and pinned
-// slots; a call goes to the device with the fewest calls in flight (ties: round robin), so N concurrent callers on an
-// N-GPU node run one block per GPU.  BSC_GPU_DEVICE=<k> pins everything to device k; BSC_GPU_DEVICES=<n> uses the first n.
+// kernels interleave), GPU-stage locks and pinned slots.  Logical slot s lives on physical device s mod (number of devices), so
+// the first context of every GPU comes before anybody's second one, and a call goes to the slot whose GPU has the fewest calls
+// in flight (then the slot with the fewest; ties: round robin): N concurrent callers on an N-GPU node run one block per GPU, 2N
+// callers two per GPU (bscgpu_dispatch_pick / bscgpu_dispatch_device below are that rule as pure functions, unit-tested on CPU).  BSC_GPU_DEVICE=<k> pins everything to device k; BSC_GPU_DEVICES=<n> uses the first n.
 // The GPU stage of a call is serialised per device, but bsc_compress releases the lock before its host stage, so up to
 // DEFAULT_SLOTS calls overlap per device — one on the GPU, the others coding on host threads.  A device's context is only
 // re-created (for a larger block) when nobody is using it.
@@ -55,6 +56,7 @@ struct DefaultDevice {
     int64_t      cap = 0;
     int          users = 0;
     bool         slot_busy[DEFAULT_SLOTS] = {false, false, false};
+    int64_t      no_memory_for = -1;             // >= 0: creating this slot's context for a block this large failed for lack of HBM
 };
 static std::mutex   g_user_mu;                  // every DefaultDevice's ctx / cap / users / slot_busy, g_ndev, g_rr
 static std::condition_variable g_user_cv;
@@ -64,6 +66,26 @@ static int          g_dev_first = 0;
 static int          g_ctx_per_dev = 2;          // contexts per physical device: the kernels of two blocks interleave on the GPU and fill
                                                 // the SIMDs that one block's serial chains leave idle (+14 % whole-job rate; BSC_GPU_CONTEXTS)
 static unsigned     g_rr = 0;
+
+// ---- the dispatch rule, as pure functions --------------------------------------------------------------------------
+// Logical slots 0 .. nphys * ctx_per_dev - 1; slot s runs on physical device s % nphys.
+extern "C" BSCGPU_API int bscgpu_dispatch_device(int slot, int nphys) { return nphys > 0 ? slot % nphys : 0; }
+// users[s] = calls in flight on slot s, usable[s] != 0 when slot s can take this call now; start = round-robin cursor.
+// Returns the slot to use, -1 when none is usable.
+extern "C" BSCGPU_API int bscgpu_dispatch_pick(int nphys, int ctx_per_dev, const int* users, const unsigned char* usable, unsigned start)
+{
+    const int nslots = nphys * ctx_per_dev;
+    if (nslots <= 0) return -1;
+    int best = -1, best_dev_load = 0;
+    for (int k = 0; k < nslots; ++k) {
+        const int s = (int)((start + (unsigned)k) % (unsigned)nslots);
+        if (!usable[s]) continue;
+        int dev_load = 0;
+        for (int q = s % nphys; q < nslots; q += nphys) dev_load += users[q];
+        if (best < 0 || dev_load < best_dev_load || (dev_load == best_dev_load && users[s] < users[best])) { best = s; best_dev_load = dev_load; }
+    }
+    return best;
+}
 
 static int probe_devices_locked()
 {
@@ -87,24 +109,34 @@ static int default_gpu_acquire(int64_t n, bool want_slot, DefaultDevice** out, i
     const int ndev = probe_devices_locked();
     if (ndev <= 0) return LIBBSC_GPU_NOT_SUPPORTED;
     for (;;) {
-        // least-loaded device that can take the call right now; round-robin start so equal loads alternate
-        int best = -1;
-        const unsigned start = g_rr;
-        for (int k = 0; k < ndev; ++k) {
-            const int d = (int)((start + (unsigned)k) % (unsigned)ndev);
+        // the slot whose GPU is least loaded among those that can take the call right now (bscgpu_dispatch_pick)
+        const int nphys = ndev / g_ctx_per_dev;
+        int users[MAX_DEVICES]; unsigned char usable[MAX_DEVICES];
+        bool any_ctx_fits = false;
+        for (int d = 0; d < ndev; ++d) {
             DefaultDevice& D = g_dev[d];
             bool slot_free = !want_slot;
             for (int i = 0; i < DEFAULT_SLOTS && !slot_free; ++i) slot_free = !D.slot_busy[i];
-            const bool usable = (D.ctx && D.cap >= n) ? slot_free : (D.users == 0);     // an idle device can be (re)sized
-            if (usable && (best < 0 || D.users < g_dev[best].users)) best = d;
+            const bool fits = D.ctx && D.cap >= n;
+            any_ctx_fits = any_ctx_fits || fits;
+            users[d] = D.users;
+            usable[d] = D.no_memory_for >= 0 && n >= D.no_memory_for ? 0 : ((fits ? slot_free : (D.users == 0)) ? 1 : 0);   // an idle slot can be (re)sized
         }
+        const int best = bscgpu_dispatch_pick(nphys, g_ctx_per_dev, users, usable, g_rr);
         if (best >= 0) {
             DefaultDevice& D = g_dev[best];
             if (!(D.ctx && D.cap >= n)) {
                 if (D.ctx) { bscgpu_destroy(D.ctx); D.ctx = nullptr; D.cap = 0; }
                 const int64_t cap = n + n / 32 + 4096;                    // headroom like bwt.cpp:106
-                const int rc = bscgpu_create(&D.ctx, g_dev_first + best / g_ctx_per_dev, cap);
-                if (rc != LIBBSC_NO_ERROR) { D.ctx = nullptr; return rc; }
+                const int rc = bscgpu_create(&D.ctx, g_dev_first + bscgpu_dispatch_device(best, nphys), cap);
+                if (rc != LIBBSC_NO_ERROR) {
+                    D.ctx = nullptr;
+                    // No HBM for one more arena of this size: if some other context can take the block, this slot is taken out
+                    // of the draw for blocks this large and the caller queues for an existing context (large concurrent blocks
+                    // queued before there were several contexts per GPU, too); otherwise the error is the caller's.
+                    if (rc == LIBBSC_GPU_NOT_ENOUGH_MEMORY && any_ctx_fits) { D.no_memory_for = n; continue; }
+                    return rc;
+                }
                 D.cap = cap;
             }
             int s = -1;
@@ -377,16 +409,16 @@ static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
             const int pb = c->ps_toggle;
             const int r2 = devcoder_pstream(c, reinterpret_cast<const u8*>(c->vA), reinterpret_cast<const u8*>(c->vB), c->SA, m, (u32)n, J.nblocks,
                                             J.run_first, maxr, &ndec, J.poff, nullptr, pb);
-            if (r2 == LIBBSC_NO_ERROR) {
+            // (a pinned landing zone that cannot be had is a reason to take the host model, like an arena that does not fit)
+            if (r2 == LIBBSC_NO_ERROR && ctx_ensure_pstream_slot(c, *J.slot, (size_t)ndec + 64) == LIBBSC_NO_ERROR) {
                 // the stream has been synchronised behind the last kernel; the copy goes to the copy stream and is NOT waited for
                 // here: the next block's sort overlaps it, the coder tasks wait on the event
-                if (ctx_ensure_pstream_slot(c, *J.slot, (size_t)ndec + 64) != LIBBSC_NO_ERROR) return LIBBSC_NOT_ENOUGH_MEMORY;
                 if (hipMemcpyAsync(J.slot->hps, devcoder_pstream_ptr(c, pb), (size_t)ndec * 2, hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess ||
                     hipEventRecord(J.slot->copy_ev, c->copy_stream) != hipSuccess) return LIBBSC_GPU_ERROR;
                 c->ps_guard[pb] = J.slot->copy_ev; c->ps_toggle = pb ^ 1;
                 J.ps_ready = J.slot->copy_ev;
                 J.use_ps = true; J.ps = J.slot->hps; J.ndec = ndec; ok = true;
-            } else if (r2 != LIBBSC_NOT_SUPPORTED) return r2;
+            } else if (r2 != LIBBSC_NOT_SUPPORTED && r2 != LIBBSC_NO_ERROR) return r2;
         }
         if (!ok) { rc = qlfc_front_copy_runs(c, m, *J.slot); if (rc < 0) return rc; }
     }
