@@ -148,6 +148,15 @@ BSCGPU_API int  bscgpu_last_stage_ms(bscgpu_ctx* ctx, double* out6);
 
 BSCGPU_API const char* bscgpu_last_error(const bscgpu_ctx* ctx);
 
+/* ---- how the libbsc.h entry points spread concurrent callers over the GPUs of a node (pure functions, no GPU needed) -------------
+ * The host-pointer API keeps ctx_per_dev default contexts per physical device = nphys * ctx_per_dev logical slots; slot s lives
+ * on device s % nphys, so every GPU's first context comes before anybody's second one.  A call takes the usable slot whose GPU has
+ * the fewest calls in flight (then the slot with the fewest; ties in round-robin order from `start`).  The reference has one
+ * lock and one device (bwt.cpp:50-52, st.cu:56); its parallelism is the CLI's OpenMP team of concurrent bsc_compress calls
+ * (bsc.cpp:184-199), which this rule maps to one block per GPU.  Returns the slot, -1 when no slot is usable. */
+BSCGPU_API int bscgpu_dispatch_device(int slot, int nphys);
+BSCGPU_API int bscgpu_dispatch_pick(int nphys, int ctx_per_dev, const int* users, const unsigned char* usable, unsigned start);
+
 #ifdef __cplusplus
 }
 #endif

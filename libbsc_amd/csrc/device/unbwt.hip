@@ -95,8 +95,9 @@ __global__ __launch_bounds__(WG) void ub_walk_kernel(const u64* __restrict__ P, 
     if (!DECODE) { seg_len[s] = len; seg_next[s] = nxt; }
 }
 
-// Host-pointer entry: L (n bytes) -> T (n bytes), both host memory; returns BSC_NO_ERROR, a libbsc error code, or
-// LIBBSC_DATA_CORRUPT (-6) when the rows do not form one cycle through the sentinel row.
+// Host-pointer entry: L (n bytes) -> T (n bytes), both host memory; returns BSC_NO_ERROR, a libbsc error code,
+// LIBBSC_DATA_CORRUPT (-6) when the rows do not form one cycle through the sentinel row, or LIBBSC_NOT_SUPPORTED (-4) when a
+// piece of the cycle is longer than the walk kernel's step cap (T untouched: use the host walk).
 extern "C" int bscgpu_unbwt(bscgpu_ctx* c, const uint8_t* L, uint8_t* T, int64_t n64, int64_t index)
 {
     if (!c || !L || !T || n64 < 0 || index <= 0 || index > n64) return BSC_BAD_PARAMETER;
@@ -136,7 +137,11 @@ extern "C" int bscgpu_unbwt(bscgpu_ctx* c, const uint8_t* L, uint8_t* T, int64_t
     HIP_TRY(c, hipMemcpyAsync(c->hscal + 4, c->dscal + 4, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, ctx_sync(c));
     prof_collect(c);
-    if (c->hscal[4] != 0) return -6;                                   // LIBBSC_DATA_CORRUPT: a walk without end
+    // A walk longer than UB_STEP_CAP is not proof of corruption — the marked rows are a fixed hash of the row number, and a valid
+    // but adversarial block can put more than the cap between two of them —, so it is "not handled here" (the caller's host walk
+    // decides, T is still untouched); LIBBSC_DATA_CORRUPT is reserved for the chain-closure checks below.
+    if (c->hscal[4] & 2u) return BSC_NOT_SUPPORTED;
+    if (c->hscal[4] != 0) return -6;
     // order of the segments: from segment 0 (row 0 = the text's end) along the successor links; every non-empty segment must
     // be met exactly once, the lengths must add up to n and the last link must be the sentinel row
     {

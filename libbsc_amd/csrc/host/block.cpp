@@ -637,7 +637,7 @@ static void host_finalize_serial(BlockJob& J)
 
 static void host_finalize(BlockJob& J)
 {
-    if (J.use_ps && J.redo.load(std::memory_order_relaxed)) return;            // finished later by redo_on_host_model()
+    if (J.use_ps && J.redo.load(std::memory_order_relaxed)) { J.result = LIBBSC_GPU_ERROR; return; }   // finished later by redo_on_host_model(), which sets the result; an error until then
     if (J.features & LIBBSC_FEATURE_MULTITHREADING) host_finalize_parallel(J); else host_finalize_serial(J);
 }
 
@@ -847,7 +847,11 @@ static void lane_join(bscgpu_pipe* p, bscgpu_pipe::Lane& L)
     }
     L.busy = false;
     // lane_join only runs on the pipe's submitting thread (submit / wait / destroy), which owns the GPU stage
-    if (L.job->redo.load(std::memory_order_relaxed) && hipSetDevice(p->c->device) == hipSuccess) redo_on_host_model(*L.job);
+    // (a redo that cannot be run must not leave the stale result of a block whose output was never written)
+    if (L.job->redo.load(std::memory_order_relaxed)) {
+        if (hipSetDevice(p->c->device) == hipSuccess) redo_on_host_model(*L.job);
+        else L.job->result = LIBBSC_GPU_ERROR;
+    }
 }
 
 int bscgpu_pipe_create(bscgpu_ctx* c, int depth, bscgpu_pipe** out)

@@ -135,3 +135,45 @@ def test_avx2_eight_lane_range_coder_matches_scalar(tmp_path):
     r = subprocess.run([exe, "400000"], capture_output=True, text=True)
     assert r.returncode == 0 and "all equal" in r.stdout, r.stdout + r.stderr
     assert "gave up" in r.stdout            # the budget case bails out to the scalar coders
+
+
+@pytest.mark.parametrize("nphys", [1, 2, 4, 8])
+@pytest.mark.parametrize("cpd", [1, 2])
+def test_default_dispatch_spreads_callers_over_physical_devices_first(nphys, cpd):
+    """The rule behind concurrent bsc_compress calls (block.cpp default_gpu_acquire), as the pure functions it is built from:
+    N concurrent callers on an N-GPU node land on N different GPUs; the next N double up, one more per GPU; a released slot is
+    preferred again; unusable slots are skipped; nothing usable -> -1."""
+    import ctypes as C
+    from libbsc_amd import _native
+    L = _native.lib()
+    pick = L.bscgpu_dispatch_pick
+    pick.restype = C.c_int
+    pick.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_ubyte), C.c_uint]
+    dev = L.bscgpu_dispatch_device
+    dev.restype = C.c_int
+    dev.argtypes = [C.c_int, C.c_int]
+    nslots = nphys * cpd
+    users = (C.c_int * nslots)(*([0] * nslots))
+    usable = (C.c_ubyte * nslots)(*([1] * nslots))
+    rr = 0
+    per_dev = [0] * nphys
+    for caller in range(nslots):
+        s = pick(nphys, cpd, users, usable, rr)
+        assert 0 <= s < nslots and users[s] == 0, (caller, s)
+        users[s] += 1
+        rr = s + 1
+        per_dev[dev(s, nphys)] += 1
+        # after k callers no GPU has more than ceil(k / nphys) of them
+        assert max(per_dev) == -(-(caller + 1) // nphys), (caller, per_dev)
+    assert per_dev == [cpd] * nphys
+    # one more caller queues behind the least-loaded GPU; with a slot released that GPU is the one chosen
+    users[nslots - 1] -= 1
+    s = pick(nphys, cpd, users, usable, rr)
+    assert s == nslots - 1
+    # unusable slots are never chosen; all unusable -> -1
+    for i in range(nslots):
+        usable[i] = 0
+    assert pick(nphys, cpd, users, usable, 0) == -1
+    usable[0] = 1
+    assert pick(nphys, cpd, users, usable, 3) == 0
+    assert [dev(s, nphys) for s in range(nslots)] == [s % nphys for s in range(nslots)]
