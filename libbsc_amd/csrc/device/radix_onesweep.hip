@@ -191,7 +191,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             // ticket for the tile after `nxt`; look-back loads for `cur` (first 16 tile rows of its batch, first 8 batch rows): all in
             // flight while the streaming waves rank `nxt`
             u32 ticket = 0;
-            if (more) ticket = OS_ADD(ctl + opaque0, 1u);
+            if (more && lane == 0) ticket = OS_ADD(ctl + opaque0, 1u);        // ONE lane draws
             u64 a1[16], b1[8][2], a2[15];
             if (!(OS_ABL & 1)) {
 #pragma unroll
