@@ -22,12 +22,18 @@
 //                batch's row of {arrivals : 8, two 28-bit sums} words with agent-scope 64-bit atomics; a batch row is complete
 //                when arrivals == 32.  offsets(tile) = digit base + complete batch rows below its batch (a workgroup keeps a
 //                running sum: ~8 new rows per tile) + the tile rows of its own batch below it (<= 31).
-//      latency   hidden by software pipelining, not avoided: a workgroup ranks tile i+1 and publishes its counts BEFORE it writes
-//                tile i out (whose keys wait, locally reordered, in a second LDS staging buffer), so the rows a tile needs have
-//                been visible for about a tile time when it asks for them.
+//      latency   hidden by software pipelining, not avoided.  Three tiles are in flight per workgroup: tile i+2 is ranked, published and
+//                staged into an LDS buffer; tile i+1 waits in the other buffer while the scout collects its offsets — its look-back
+//                loads are issued at the top of the iteration, about half a tile time after the tile (and hence every tile claimed
+//                before it) was published, and are looked at in front of the iteration's last barrier, a whole tile time (~8 us)
+//                later; tile i is written out first thing in the iteration, at offsets that have been ready since the previous
+//                one, and leaves its buffer to tile i+2.  Under streaming load an agent-scope load takes ~3 us on this chip: with
+//                the offsets needed in the same iteration the scout sat on the critical path (0.39 ms per pass against 0.26
+//                without any look-back).
 //      the scout exists because vmcnt is an in-order counter: look-back loads issued by a streaming wave sit behind that wave's
-//                own stores of the previous tile, and using them means waiting for those stores to drain — measured 0.12 ms per
-//                pass (0.26 -> 0.38) although the rows themselves were there.  The scout's queue holds protocol traffic only.
+//                own stores of the previous tile, and using them means waiting for those stores to drain (measured: 0.12 ms per
+//                pass although the rows themselves were there).  The scout's queue holds protocol traffic only.  The two roles are
+//                separate loops behind a scalar branch (own register allocation each) that execute the same barrier sequence.
 //   Polls are bounded: a give-up poisons the sort's error word, which the host turns into LIBBSC_GPU_ERROR instead of a hang.
 // Stable: output order inside a digit = tile order, then the tile-local stable rank (rs_rank_wave), exactly as rs_scatter.
 #include "dev_common.h"
@@ -131,11 +137,10 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     u64* S      = reinterpret_cast<u64*>(smem);                         // [2][TILE] locally reordered keys (then values) of the two tiles in flight
     u32* whist  = reinterpret_cast<u32*>(smem + 2 * TILE * 8);          // [SW][256]
     u32* rbase  = whist + SW * 256;                                     // [256] first output position of every digit (prologue only)
-    u32* adj    = rbase + 256;                                          // [256] output position of staging slot q of digit d = adj[d] + q
-    u32* dstart = adj + 256;                                            // [2][256] tile-local start of every digit, per staging buffer
+    u32* adj    = rbase + 256;                                          // [2][256] per staging buffer: output position of slot q of digit d = adj[d] + q
+    u32* dstart = adj + 512;                                            // [2][256] tile-local start of every digit, per staging buffer
     u32* stot   = dstart + 512;                                         // [256] digit counts of the tile just ranked (for the scout to publish)
-    u32* spare  = stot + 256;                                           // [256]
-    u32* scr    = spare + 256;                                          // [16]
+    u32* scr    = stot + 256;                                           // [16]
     u32* sclaim = scr + 16;                                             // [1] the ticket drawn at the top of the iteration
     lds_vu32* vwh = (lds_vu32*)whist;
 
@@ -159,10 +164,12 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     }
     if (t == (u32)ST) { const u32 tk = OS_ADD(ctl + opaque0, 1u); sclaim[0] = tk < ntiles ? tk : OS_NONE; }
     __syncthreads();
-    u32 cur = OS_NONE, nxt = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);     // tile numbers are wave-uniform: scalar control flow
-    if (nxt == OS_NONE) return;
+    // Three tiles are in flight per workgroup: t0 is written out (its offsets were collected during the previous iteration), t1 waits
+    // in its staging buffer while the scout collects its offsets, t2 is ranked, published and staged into the buffer t0 leaves.
+    u32 t0 = OS_NONE, t1 = OS_NONE, t2 = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);      // tile numbers are wave-uniform: scalar control flow
+    if (t2 == OS_NONE) return;
     bool more = true;                                                   // tickets may still yield tiles
-    u32 cb = 0;                                                         // staging buffer of `cur`; `nxt` goes to cb ^ 1
+    u32 x = 0;                                                          // staging buffer of t0, and then of t2; t1 sits in x ^ 1
     __syncthreads();                                                    // everybody has read sclaim (and rbase is complete)
 
     if (scout) {
@@ -175,27 +182,27 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         for (int i = 0; i < 4; ++i) R[i] = rbase[4 * lane + i];
         // a row word that was not there yet: poll until its top byte says so (bounded; a give-up poisons the sort's error word)
         auto poll = [&](const u64* p, const u64 want, bool& ok) __attribute__((always_inline)) -> u64 {
-            u64 x = OS_LOAD(p);
+            u64 v = OS_LOAD(p);
             u32 spins = 0;
-            while ((x >> 56) != want && ok) {
+            while ((v >> 56) != want && ok) {
                 __builtin_amdgcn_s_sleep(2);
-                x = OS_LOAD(p);
+                v = OS_LOAD(p);
                 if (++spins > OS_SPIN_LIMIT || ((spins & 1023u) == 0u && OS_LOAD(err) != 0u)) ok = false;
             }
-            return x;
+            return v;
         };
-        while (cur != OS_NONE || nxt != OS_NONE) {
-            const bool cv = cur != OS_NONE, nv = nxt != OS_NONE;
-            const u32 cj = cv ? (cur & (u32)(OS_BATCH - 1)) : 0u, cG = cv ? (cur / (u32)OS_BATCH) : 0u;
+        while (t0 != OS_NONE || t1 != OS_NONE || t2 != OS_NONE) {
+            const bool v1 = t1 != OS_NONE, v2 = t2 != OS_NONE;
+            const u32 cj = v1 ? (t1 & (u32)(OS_BATCH - 1)) : 0u, cG = v1 ? (t1 / (u32)OS_BATCH) : 0u;
             OS_PH(0);
-            // ticket for the tile after `nxt`; look-back loads for `cur` (first 16 tile rows of its batch, first 8 batch rows): all in
-            // flight while the streaming waves rank `nxt`
+            // ticket for the tile after t2; every look-back load for t1 (tile rows of its batch below it, first 8 batch rows): in flight for
+            // the whole iteration, looked at in front of its last barrier
             u32 ticket = 0;
             if (more && lane == 0) ticket = OS_ADD(ctl + opaque0, 1u);        // ONE lane draws
-            u64 a1[16], b1[8][2], a2[15];
+            u64 a1[31], b1[8][2];
             if (!(OS_ABL & 1)) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) a1[q] = OS_LOAD(&agg[(size_t)(((u32)q < cj) ? (cur - cj + q) : 0u) * 64 + lane]);
+                for (int q = 0; q < 31; ++q) a1[q] = OS_LOAD(&agg[(size_t)(((u32)q < cj) ? (t1 - cj + q) : 0u) * 64 + lane]);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const u32 gg = gbase + q;
@@ -204,89 +211,73 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                 }
             }
             OS_PH(1);
-            __syncthreads();                                                                      // B1
-            OS_PH(2);
-            bool ok = true;
-            if (cv && !(OS_ABL & 1)) {
-                // batch rows: into the running sum
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const u32 gg = gbase + q;
-                    if (gg < cG) {
-                        u64 x0 = b1[q][0], x1 = b1[q][1];
-                        const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
-                        if ((x0 >> 56) != (u64)OS_BATCH) x0 = poll(p, (u64)OS_BATCH, ok);
-                        if ((x1 >> 56) != (u64)OS_BATCH) x1 = poll(p + 1, (u64)OS_BATCH, ok);
-                        R[0] += (u32)(x0 & OS_M28); R[1] += (u32)((x0 >> 28) & OS_M28);
-                        R[2] += (u32)(x1 & OS_M28); R[3] += (u32)((x1 >> 28) & OS_M28);
-                    }
-                }
-                for (u32 gg = gbase + 8u; gg < cG; ++gg) {              // a workgroup that fell behind (or has just started)
-                    const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
-                    const u64 x0 = poll(p, (u64)OS_BATCH, ok), x1 = poll(p + 1, (u64)OS_BATCH, ok);
-                    R[0] += (u32)(x0 & OS_M28); R[1] += (u32)((x0 >> 28) & OS_M28);
-                    R[2] += (u32)(x1 & OS_M28); R[3] += (u32)((x1 >> 28) & OS_M28);
-                }
-                // the tile rows 16 .. 30 of the batch, if `cur` sits that far in
-#pragma unroll
-                for (int q = 0; q < 15; ++q) a2[q] = OS_LOAD(&agg[(size_t)(((u32)q + 16u < cj) ? (cur - cj + 16u + q) : 0u) * 64 + lane]);
-            }
-            if (cv) gbase = cG;
-            if (nv) __syncthreads();                                                              // B2 (the streaming waves' digit scan)
-            if (lane == 0) sclaim[0] = (more && ticket < ntiles) ? ticket : OS_NONE;
-            OS_PH(3);
-            __syncthreads();                                                                      // B3
-            OS_PH(4);
-            const u32 nn = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);
-            if (nn == OS_NONE) more = false;
-            // publish `nxt`
-            if (nv && !(OS_ABL & 2)) {
-                const uint4 c4 = *reinterpret_cast<const uint4*>(stot + 4 * lane);
-                OS_STORE(&agg[(size_t)nxt * 64 + lane], tagw | ((u64)c4.w << 42) | ((u64)c4.z << 28) | ((u64)c4.y << 14) | (u64)c4.x);
-                u64* p = &bagg[(size_t)(nxt / (u32)OS_BATCH) * 128 + 2 * lane];
-                (void)OS_ADD(p, (1ull << 56) | ((u64)c4.y << 28) | (u64)c4.x);
-                (void)OS_ADD(p + 1, (1ull << 56) | ((u64)c4.w << 28) | (u64)c4.z);
-            }
-            // offsets of `cur`
-            if (cv) {
-                u32 sa[4] = {0, 0, 0, 0};
-                if (!(OS_ABL & 1)) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        if ((u32)q < cj) {
-                            u64 x = a1[q];
-                            if ((x >> 56) != (u64)tag8) x = poll(&agg[(size_t)(cur - cj + q) * 64 + lane], (u64)tag8, ok);
-                            sa[0] += (u32)(x & OS_M14); sa[1] += (u32)((x >> 14) & OS_M14); sa[2] += (u32)((x >> 28) & OS_M14); sa[3] += (u32)((x >> 42) & OS_M14);
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 15; ++q) {
-                        if ((u32)q + 16u < cj) {
-                            u64 x = a2[q];
-                            if ((x >> 56) != (u64)tag8) x = poll(&agg[(size_t)(cur - cj + 16u + q) * 64 + lane], (u64)tag8, ok);
-                            sa[0] += (u32)(x & OS_M14); sa[1] += (u32)((x >> 14) & OS_M14); sa[2] += (u32)((x >> 28) & OS_M14); sa[3] += (u32)((x >> 42) & OS_M14);
-                        }
-                    }
-                    if (!ok) (void)OS_ADD(err, 1u);
-                }
-                const uint4 d4 = *reinterpret_cast<const uint4*>(dstart + cb * 256 + 4 * lane);
-                uint4 o;
-                o.x = R[0] + sa[0] - d4.x; o.y = R[1] + sa[1] - d4.y; o.z = R[2] + sa[2] - d4.z; o.w = R[3] + sa[3] - d4.w;
-                *reinterpret_cast<uint4*>(adj + 4 * lane) = o;
-            }
-            OS_PH(5);
-            __syncthreads();                                                                      // B4
-            OS_PH(6);
             if (HAS_VAL) {
                 __syncthreads();                                                                  // B5
                 __syncthreads();                                                                  // B6
             }
+            __syncthreads();                                                                      // B1
+            if (v2) __syncthreads();                                                              // B2 (the streaming waves' digit scan)
+            if (lane == 0) sclaim[0] = (more && ticket < ntiles) ? ticket : OS_NONE;
+            OS_PH(2);
+            __syncthreads();                                                                      // B3
+            OS_PH(3);
+            const u32 nn = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);
+            if (nn == OS_NONE) more = false;
+            // publish t2
+            if (v2 && !(OS_ABL & 2)) {
+                const uint4 c4 = *reinterpret_cast<const uint4*>(stot + 4 * lane);
+                OS_STORE(&agg[(size_t)t2 * 64 + lane], tagw | ((u64)c4.w << 42) | ((u64)c4.z << 28) | ((u64)c4.y << 14) | (u64)c4.x);
+                u64* p = &bagg[(size_t)(t2 / (u32)OS_BATCH) * 128 + 2 * lane];
+                (void)OS_ADD(p, (1ull << 56) | ((u64)c4.y << 28) | (u64)c4.x);
+                (void)OS_ADD(p + 1, (1ull << 56) | ((u64)c4.w << 28) | (u64)c4.z);
+            }
+            // offsets of t1 (it sits in staging buffer x ^ 1)
+            if (v1) {
+                u32 sa[4] = {0, 0, 0, 0};
+                bool ok = true;
+                if (!(OS_ABL & 1)) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const u32 gg = gbase + q;
+                        if (gg < cG) {
+                            u64 y0 = b1[q][0], y1 = b1[q][1];
+                            const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
+                            if ((y0 >> 56) != (u64)OS_BATCH) y0 = poll(p, (u64)OS_BATCH, ok);
+                            if ((y1 >> 56) != (u64)OS_BATCH) y1 = poll(p + 1, (u64)OS_BATCH, ok);
+                            R[0] += (u32)(y0 & OS_M28); R[1] += (u32)((y0 >> 28) & OS_M28);
+                            R[2] += (u32)(y1 & OS_M28); R[3] += (u32)((y1 >> 28) & OS_M28);
+                        }
+                    }
+                    for (u32 gg = gbase + 8u; gg < cG; ++gg) {          // a workgroup that fell behind (or has just started)
+                        const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
+                        const u64 y0 = poll(p, (u64)OS_BATCH, ok), y1 = poll(p + 1, (u64)OS_BATCH, ok);
+                        R[0] += (u32)(y0 & OS_M28); R[1] += (u32)((y0 >> 28) & OS_M28);
+                        R[2] += (u32)(y1 & OS_M28); R[3] += (u32)((y1 >> 28) & OS_M28);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 31; ++q) {
+                        if ((u32)q < cj) {
+                            u64 y = a1[q];
+                            if ((y >> 56) != (u64)tag8) y = poll(&agg[(size_t)(t1 - cj + q) * 64 + lane], (u64)tag8, ok);
+                            sa[0] += (u32)(y & OS_M14); sa[1] += (u32)((y >> 14) & OS_M14); sa[2] += (u32)((y >> 28) & OS_M14); sa[3] += (u32)((y >> 42) & OS_M14);
+                        }
+                    }
+                    if (!ok) (void)OS_ADD(err, 1u);
+                }
+                gbase = cG;
+                const uint4 d4 = *reinterpret_cast<const uint4*>(dstart + (x ^ 1u) * 256 + 4 * lane);
+                uint4 o;
+                o.x = R[0] + sa[0] - d4.x; o.y = R[1] + sa[1] - d4.y; o.z = R[2] + sa[2] - d4.z; o.w = R[3] + sa[3] - d4.w;
+                *reinterpret_cast<uint4*>(adj + (x ^ 1u) * 256 + 4 * lane) = o;
+            }
+            OS_PH(4);
+            __syncthreads();                                                                      // B4
             OS_PH(11);
 #if OS_PHASE_TIMING
-            if (t == (u32)ST && tile_no < 40u) tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + 1) * 16 + 14] = ((u64)cur << 32) | nxt;
+            if (t == (u32)ST && tile_no < 40u) tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + 1) * 16 + 14] = ((u64)t1 << 32) | t2;
 #endif
             ++tile_no;
-            cur = nxt; nxt = nn; cb ^= 1u;
+            t0 = t1; t1 = t2; t2 = nn; x ^= 1u;
         }
         return;
     }
@@ -296,8 +287,8 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     // =============================================================================================================
     const u32 wbase = w * (64 * ITEMS) + lane;
     u64 k[ITEMS];
-    u32 v[ITEMS], rk[ITEMS] = {0, 0, 0, 0, 0, 0, 0, 0};
-    u32 posA[ITEMS / 2];                                                // staging slots of `cur`'s records, two 16-bit slots per word
+    u32 v[ITEMS] = {0, 0, 0, 0, 0, 0, 0, 0}, rk[ITEMS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u32 pos0[ITEMS / 2], pos1[ITEMS / 2];                               // staging slots of t0's / t1's records, two 16-bit slots per word
     // loads never sit behind a branch: a missing tile or a lane past the end reads record 0 (one line for the whole wave)
     // (tile = OS_NONE wraps to record numbers >= n for every lane: TILE * 0xffffffff = -TILE)
     auto load_keys = [&](const u32 tile) __attribute__((always_inline)) {
@@ -310,35 +301,72 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) { u32 e = tb + wbase + i * 64; e = e < n ? e : 0u; v[i] = __builtin_nontemporal_load(&vin[e]); }
     };
-    load_keys(nxt);
+    load_keys(t2);
 #pragma unroll
-    for (int i = 0; i < ITEMS / 2; ++i) posA[i] = 0;
+    for (int i = 0; i < ITEMS / 2; ++i) { pos0[i] = 0; pos1[i] = 0; }
 
-    // One iteration: rank `nxt` (the scout publishes it), then write out `cur` at the offsets the scout has found.
-    // FULL = both are full tiles (no guards around loads and stores: waits stay exact).
+    // One iteration: write t0 out at the offsets the scout found during the previous iteration, then rank t2 (the scout publishes it)
+    // and stage it into the buffer t0 has left.  FULL = t0 and t2 are full tiles (no guards around loads and stores: waits stay exact).
     auto iteration = [&](auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
-        const bool cv = FULL || cur != OS_NONE, nv = FULL || nxt != OS_NONE;
-        u32 cur_n = (u32)TILE, nxt_n = (u32)TILE;                      // valid records
+        const bool v0 = FULL || t0 != OS_NONE, v2 = FULL || t2 != OS_NONE;
+        u32 n0 = (u32)TILE, n2 = (u32)TILE;                            // valid records
         if (!FULL) {
-            cur_n = cv ? ((n - cur * (u32)TILE) < (u32)TILE ? (n - cur * (u32)TILE) : (u32)TILE) : 0u;
-            nxt_n = nv ? ((n - nxt * (u32)TILE) < (u32)TILE ? (n - nxt * (u32)TILE) : (u32)TILE) : 0u;
+            n0 = v0 ? ((n - t0 * (u32)TILE) < (u32)TILE ? (n - t0 * (u32)TILE) : (u32)TILE) : 0u;
+            n2 = v2 ? ((n - t2 * (u32)TILE) < (u32)TILE ? (n - t2 * (u32)TILE) : (u32)TILE) : 0u;
         }
-        u64* Sc = S + (size_t)cb * TILE;
-        u64* Sn = S + (size_t)(cb ^ 1u) * TILE;
+        u64* Sx = S + (size_t)x * TILE;
+        const u32* adjx = adj + x * 256;
         OS_PH(0);
-        if (nv) {
+        // ---- t0 leaves: every digit as one contiguous run, consecutive lanes -> consecutive addresses
+        u32 dd[ITEMS / 4];
+#pragma unroll
+        for (int j = 0; j < ITEMS / 4; ++j) dd[j] = 0;
+        if (v0) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const u32 q = j * ST + t;
+                const u64 key = Sx[q];
+                const u32 d = (u32)(key >> shift) & mask;
+                if ((j & 3) == 0) dd[j >> 2] = d; else dd[j >> 2] |= d << (8 * (j & 3));
+                if (FULL || q < n0) kout[adjx[d] + q] = key;
+            }
+        }
+        OS_PH(1);
+        if (HAS_VAL) {
+            __syncthreads();                                                                      // B5
+            OS_PH(2);
+            u32* svals = reinterpret_cast<u32*>(Sx);
+            if (v0) {
+#pragma unroll
+                for (int i = 0; i < ITEMS; ++i) svals[(pos0[i >> 1] >> (16 * (i & 1))) & 0xffffu] = v[i];
+            }
+            OS_PH(3);
+            __syncthreads();                                                                      // B6
+            OS_PH(4);
+            if (v0) {
+#pragma unroll
+                for (int j = 0; j < ITEMS; ++j) {
+                    const u32 q = j * ST + t;
+                    const u32 d = (dd[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    if (FULL || q < n0) vout[adjx[d] + q] = svals[q];
+                }
+            }
+        }
+        OS_PH(5);
+        // ---- t2: rank inside the waves
+        if (v2) {
             if (!FULL) {
 #pragma unroll
-                for (int i = 0; i < ITEMS; ++i) if (wbase + i * 64 >= nxt_n) k[i] = ~0ull;       // padding sorts last
+                for (int i = 0; i < ITEMS; ++i) if (wbase + i * 64 >= n2) k[i] = ~0ull;          // padding sorts last
             }
             rs_rank_wave<ITEMS>(k, shift, mask, vwh + w * 256, rk);
         }
-        OS_PH(1);
+        OS_PH(6);
         __syncthreads();                                                                          // B1
-        OS_PH(2);
-        if (HAS_VAL) load_vals(cur);                                    // needed behind B5: not live during the ranking
-        if (nv) {
+        OS_PH(7);
+        if (HAS_VAL) load_vals(t1);                                     // for the next iteration's write-out: not live during the ranking
+        if (v2) {
             u32 tot = 0;
             if (t < 256) {
 #pragma unroll
@@ -350,77 +378,41 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                 u32 run = ds;
 #pragma unroll
                 for (int i = 0; i < SW; ++i) { const u32 ci = whist[i * 256 + t]; whist[i * 256 + t] = run; run += ci; }
-                dstart[(cb ^ 1u) * 256 + t] = ds;
-                stot[t] = tot - ((!FULL && t == mask) ? ((u32)TILE - nxt_n) : 0u);
+                dstart[x * 256 + t] = ds;
+                stot[t] = tot - ((!FULL && t == mask) ? ((u32)TILE - n2) : 0u);
             }
         }
-        OS_PH(3);
+        OS_PH(8);
         __syncthreads();                                                                          // B3
-        OS_PH(4);
+        OS_PH(9);
         const u32 nn = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);
-        // `nxt`: tile-local reorder of the keys into its staging buffer; then the keys of the tile after it are requested
-        if (nv) {
+        // t2: tile-local reorder of the keys into the staging buffer t0 has left; then the keys of the tile after it are requested
+        if (v2) {
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 const u32 d = (u32)(k[i] >> shift) & mask;
                 const u32 pos = whist[w * 256 + d] + rk[i];
                 rk[i] = pos;
-                Sn[pos] = k[i];
+                Sx[pos] = k[i];
             }
         }
         load_keys(nn);
 #pragma unroll
         for (int i = 0; i < 4; ++i) whist[w * 256 + i * 64 + lane] = 0;           // own wave's counters, for the next ranking
-        OS_PH(5);
+        OS_PH(10);
         __syncthreads();                                                                          // B4
-        OS_PH(6);
-        // `cur` leaves: every digit as one contiguous run, consecutive lanes -> consecutive addresses
-        u32 dd[ITEMS / 4];
 #pragma unroll
-        for (int j = 0; j < ITEMS / 4; ++j) dd[j] = 0;
-        if (cv) {
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
-                const u32 q = j * ST + t;
-                const u64 key = Sc[q];
-                const u32 d = (u32)(key >> shift) & mask;
-                if ((j & 3) == 0) dd[j >> 2] = d; else dd[j >> 2] |= d << (8 * (j & 3));
-                if (FULL || q < cur_n) kout[adj[d] + q] = key;
-            }
-        }
-        OS_PH(7);
-        if (HAS_VAL) {
-            __syncthreads();                                                                      // B5
-            OS_PH(8);
-            u32* svals = reinterpret_cast<u32*>(Sc);
-            if (cv) {
-#pragma unroll
-                for (int i = 0; i < ITEMS; ++i) svals[(posA[i >> 1] >> (16 * (i & 1))) & 0xffffu] = v[i];
-            }
-            OS_PH(9);
-            __syncthreads();                                                                      // B6
-            OS_PH(10);
-            if (cv) {
-#pragma unroll
-                for (int j = 0; j < ITEMS; ++j) {
-                    const u32 q = j * ST + t;
-                    const u32 d = (dd[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                    if (FULL || q < cur_n) vout[adj[d] + q] = svals[q];
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < ITEMS / 2; ++i) posA[i] = rk[2 * i] | (rk[2 * i + 1] << 16);
+        for (int i = 0; i < ITEMS / 2; ++i) { pos0[i] = pos1[i]; pos1[i] = rk[2 * i] | (rk[2 * i + 1] << 16); }
         OS_PH(11);
 #if OS_PHASE_TIMING
-        if (t == 0 && tile_no < 40u) tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + 0) * 16 + 14] = ((u64)cur << 32) | nxt;
+        if (t == 0 && tile_no < 40u) tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + 0) * 16 + 14] = ((u64)t0 << 32) | t2;
 #endif
         ++tile_no;
-        cur = nxt; nxt = nn; cb ^= 1u;
+        t0 = t1; t1 = t2; t2 = nn; x ^= 1u;
     };
 
-    while (cur != OS_NONE || nxt != OS_NONE) {
-        const bool steady = cur != OS_NONE && nxt != OS_NONE && (u64)(cur + 1u) * TILE <= n && (u64)(nxt + 1u) * TILE <= n;
+    while (t0 != OS_NONE || t1 != OS_NONE || t2 != OS_NONE) {
+        const bool steady = t0 != OS_NONE && t2 != OS_NONE && (u64)(t0 + 1u) * TILE <= n && (u64)(t2 + 1u) * TILE <= n;
         if (steady) iteration(std::true_type());
         else iteration(std::false_type());
     }
