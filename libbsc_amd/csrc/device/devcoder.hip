@@ -37,6 +37,18 @@
 
 using namespace dcm;
 
+// Run-parallel kernels that gather (dc_ctx: the symbol-major neighbours; dc_pstream: the chain-major counter values) give every XCD
+// one contiguous eighth of the runs instead of every eighth workgroup: neighbouring runs hit neighbouring entries of a chain, so a
+// line of the gathered arrays is then fetched by ONE XCD's L2 and reused there, not by all eight (block b runs on XCD b % 8; the
+// placement only matters for speed).  The launch grid is rounded up to a multiple of 8.
+#ifndef DC_XCD_RANGES
+#define DC_XCD_RANGES 1
+#endif
+__device__ __forceinline__ u32 dc_virtual_block() {
+    if (!DC_XCD_RANGES) return blockIdx.x;
+    return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+}
+
 constexpr int DC_WCH_MAX  = 4096;      // wave-chunks of a partition job (one wavefront walks one chunk of runs)
 #ifndef DC_EV_N
 #define DC_EV_N 8192
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(WG) void dc_ctx_kernel(const u64* __restrict__ key_
     __shared__ u32 bits[DC_KIND_WORDS];
     for (u32 i = threadIdx.x; i < DC_KIND_WORDS; i += WG) bits[i] = 0;
     __syncthreads();
-    const u32 j = blockIdx.x * WG + threadIdx.x;
+    const u32 j = dc_virtual_block() * WG + threadIdx.x;
     if (j < m) {
         const u64 key = key_ch[j];
         const Item it = item_unpack(key);
@@ -870,7 +882,7 @@ __global__ __launch_bounds__(WG) void dc_pstream_kernel(DcGather G, DcSub S, con
                                                         const u32* __restrict__ meta, u16* __restrict__ out, u16* __restrict__ dbg /*[3][D] or null*/, u32 dbgD)
 {
     if (meta[DM_FAIL] != 0u) return;
-    const u32 j = blockIdx.x * WG + threadIdx.x;
+    const u32 j = dc_virtual_block() * WG + threadIdx.x;
     if (j >= G.m) return;
     const Item it = item_unpack(G.key_ch[j]);
     const int maxr = (int)S.maxr[it.sb];
@@ -1070,6 +1082,7 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     HIP_TRY(c, hipMemsetAsync(d->meta, 0, DM_COUNT * 4, c->stream));
     HIP_TRY(c, hipMemsetAsync(d->present, 0, (size_t)DC_KIND_WORDS * 4, c->stream));
     const u32 gm = (m + WG - 1) / WG;
+    const u32 gm8 = (gm + 7u) / 8u * 8u;            // kernels that use dc_virtual_block()
 
     prof_begin(c, BSCGPU_K_DC_CTX, (u64)m * 40, m);
     // avg' = (124 avg + 4 rank) >> 7 <= max(avg, rank) and rank < nsym <= 2^(max_rank + 1): with at most 32 symbols in every
@@ -1088,7 +1101,7 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     rc = radix_sort_passes(c, d->key_ch, d->key_ch_s, nullptr, nullptr, m, &top, 1, &in_alt, d->inv_ch);
     if (rc < 0) return rc;
     prof_begin(c, BSCGPU_K_DC_CTX, (u64)m * 40, m);
-    hipLaunchKernelGGL(dc_ctx_kernel, dim3(gm), dim3(WG), 0, c->stream, d->key_ch, d->key_ch_s, d->inv_ch, m, S, d->tab_rank, d->tab_run,
+    hipLaunchKernelGGL(dc_ctx_kernel, dim3(gm8), dim3(WG), 0, c->stream, d->key_ch, d->key_ch_s, d->inv_ch, m, S, d->tab_rank, d->tab_run,
                        d->key_sr, d->key_sn, d->present, d->meta);
     hipLaunchKernelGGL(dc_setup_kernel, dim3(1), dim3(WG), 0, c->stream, d->present, S, d->rounds, d->meta);
     prof_end(c);
@@ -1150,7 +1163,7 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     G.V_sp = d->V[0]; G.V_ch = d->V[1]; G.V_sr = d->V[2]; G.V_sn = d->V[3];
     prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)E[0] * 26, E[0]);
     if (c->ps_guard[psbuf & 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ps_guard[psbuf & 1], 0));     // the buffer's previous copy-out
-    hipLaunchKernelGGL(dc_pstream_kernel, dim3(gm), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, E[0]);
+    hipLaunchKernelGGL(dc_pstream_kernel, dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, E[0]);
     hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, d->doff[0], S, m, d->poff);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());

@@ -119,9 +119,14 @@ __global__ __launch_bounds__(OS_WG) void rs_hist_all_kernel(const u64* __restric
 // ---------------------------------------------------------------------------------------------
 // rs_onesweep: one digit pass, records read once and written once.
 // ---------------------------------------------------------------------------------------------
-// granule of a tile row: tag << 56 | c3 << 42 | c2 << 28 | c1 << 14 | c0 (counts of digits 4l .. 4l+3, each <= 7680)
+// granule of a tile row: four 16-bit fields {count : 14 (<= 7680), two bits of the launch tag : 2} for digits 4l .. 4l+3 — a tag byte
+//                        spread over the four fields, so that eight rows can be summed as packed 16-bit halves by plain 32-bit adds
+//                        (8 x 7680 < 2^16) after masking the tag bits off;
 // word of a batch row:   arrivals << 56 | sum_hi << 28 | sum_lo           (two words per lane: digits 4l, 4l+1 and 4l+2, 4l+3)
-constexpr u64 OS_M14 = 0x3fffull, OS_M28 = 0xfffffffull;
+constexpr u64 OS_M28 = 0xfffffffull, OS_TAGBITS = 0xC000C000C000C000ull;
+__host__ __device__ constexpr u64 os_tag_pattern(u32 tag8) {
+    return ((u64)(tag8 & 3u) << 14) | ((u64)((tag8 >> 2) & 3u) << 30) | ((u64)((tag8 >> 4) & 3u) << 46) | ((u64)((tag8 >> 6) & 3u) << 62);
+}
 
 template <bool HAS_VAL>
 __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restrict__ kin, u64* __restrict__ kout,
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     // The two roles are two separate loops behind a SCALAR branch (the wave number goes through readfirstlane), so neither role's
     // registers are live in the other's code; both execute the same sequence of workgroup barriers per iteration.
     const bool scout = (u32)__builtin_amdgcn_readfirstlane((int)w) == (u32)SW;
-    const u64 tagw = (u64)tag8 << 56;
+    const u64 tagpat = os_tag_pattern(tag8);
     u32 opaque0;
     asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));                   // a zero the compiler cannot see through: keeps the ticket atomic's
                                                                         // address "divergent", so the atomic optimiser does not rewrite it into
@@ -177,26 +182,30 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         // The scout wave.  Lane l owns digits 4l .. 4l+3.
         // =========================================================================================================
         u32 gbase = 0;                                                  // batches [0, gbase) are in R
+        u32 npolls = 0; (void)npolls;
         u32 R[4];                                                       // digit base + counts of all complete batches accounted so far
 #pragma unroll
         for (int i = 0; i < 4; ++i) R[i] = rbase[4 * lane + i];
         // a row word that was not there yet: poll until its top byte says so (bounded; a give-up poisons the sort's error word)
-        auto poll = [&](const u64* p, const u64 want, bool& ok) __attribute__((always_inline)) -> u64 {
+        auto poll = [&](const u64* p, const u64 fmask, const u64 want, bool& ok) __attribute__((always_inline)) -> u64 {
             u64 v = OS_LOAD(p);
             u32 spins = 0;
-            while ((v >> 56) != want && ok) {
+            while ((v & fmask) != want && ok) {
                 __builtin_amdgcn_s_sleep(2);
                 v = OS_LOAD(p);
                 if (++spins > OS_SPIN_LIMIT || ((spins & 1023u) == 0u && OS_LOAD(err) != 0u)) ok = false;
             }
+#if OS_PHASE_TIMING
+            ++npolls;
+#endif
             return v;
         };
         while (t0 != OS_NONE || t1 != OS_NONE || t2 != OS_NONE) {
             const bool v1 = t1 != OS_NONE, v2 = t2 != OS_NONE;
             const u32 cj = v1 ? (t1 & (u32)(OS_BATCH - 1)) : 0u, cG = v1 ? (t1 / (u32)OS_BATCH) : 0u;
             OS_PH(0);
-            // ticket for the tile after t2; every look-back load for t1 (tile rows of its batch below it, first 8 batch rows): in flight for
-            // the whole iteration, looked at in front of its last barrier
+            // ticket for the tile after t2; every look-back load for t1 (tile rows of its batch below it, first 8 batch rows): in flight
+            // from the top of the iteration; the batch rows are looked at behind barrier 1, the tile rows in front of the last barrier
             u32 ticket = 0;
             if (more && lane == 0) ticket = OS_ADD(ctl + opaque0, 1u);        // ONE lane draws
             u64 a1[31], b1[8][2];
@@ -216,6 +225,29 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                 __syncthreads();                                                                  // B6
             }
             __syncthreads();                                                                      // B1
+            bool ok = true;
+            if (v1 && !(OS_ABL & 1)) {
+                // batch rows into the running sum (they were requested a write-out and a ranking ago)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const u32 gg = gbase + q;
+                    if (gg < cG) {
+                        u64 y0 = b1[q][0], y1 = b1[q][1];
+                        const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
+                        if ((y0 >> 56) != (u64)OS_BATCH) y0 = poll(p, ~0ull << 56, (u64)OS_BATCH << 56, ok);
+                        if ((y1 >> 56) != (u64)OS_BATCH) y1 = poll(p + 1, ~0ull << 56, (u64)OS_BATCH << 56, ok);
+                        R[0] += (u32)(y0 & OS_M28); R[1] += (u32)((y0 >> 28) & OS_M28);
+                        R[2] += (u32)(y1 & OS_M28); R[3] += (u32)((y1 >> 28) & OS_M28);
+                    }
+                }
+                for (u32 gg = gbase + 8u; gg < cG; ++gg) {              // a workgroup that fell behind (or has just started)
+                    const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
+                    const u64 y0 = poll(p, ~0ull << 56, (u64)OS_BATCH << 56, ok), y1 = poll(p + 1, ~0ull << 56, (u64)OS_BATCH << 56, ok);
+                    R[0] += (u32)(y0 & OS_M28); R[1] += (u32)((y0 >> 28) & OS_M28);
+                    R[2] += (u32)(y1 & OS_M28); R[3] += (u32)((y1 >> 28) & OS_M28);
+                }
+            }
+            if (v1) gbase = cG;
             if (v2) __syncthreads();                                                              // B2 (the streaming waves' digit scan)
             if (lane == 0) sclaim[0] = (more && ticket < ntiles) ? ticket : OS_NONE;
             OS_PH(2);
@@ -226,55 +258,40 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             // publish t2
             if (v2 && !(OS_ABL & 2)) {
                 const uint4 c4 = *reinterpret_cast<const uint4*>(stot + 4 * lane);
-                OS_STORE(&agg[(size_t)t2 * 64 + lane], tagw | ((u64)c4.w << 42) | ((u64)c4.z << 28) | ((u64)c4.y << 14) | (u64)c4.x);
+                OS_STORE(&agg[(size_t)t2 * 64 + lane], tagpat | (u64)(c4.x | (c4.y << 16)) | ((u64)(c4.z | (c4.w << 16)) << 32));
                 u64* p = &bagg[(size_t)(t2 / (u32)OS_BATCH) * 128 + 2 * lane];
                 (void)OS_ADD(p, (1ull << 56) | ((u64)c4.y << 28) | (u64)c4.x);
                 (void)OS_ADD(p + 1, (1ull << 56) | ((u64)c4.w << 28) | (u64)c4.z);
             }
-            // offsets of t1 (it sits in staging buffer x ^ 1)
+            // offsets of t1 (it sits in staging buffer x ^ 1): the tile rows below it, eight at a time as packed 16-bit sums
             if (v1) {
                 u32 sa[4] = {0, 0, 0, 0};
-                bool ok = true;
                 if (!(OS_ABL & 1)) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const u32 gg = gbase + q;
-                        if (gg < cG) {
-                            u64 y0 = b1[q][0], y1 = b1[q][1];
-                            const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
-                            if ((y0 >> 56) != (u64)OS_BATCH) y0 = poll(p, (u64)OS_BATCH, ok);
-                            if ((y1 >> 56) != (u64)OS_BATCH) y1 = poll(p + 1, (u64)OS_BATCH, ok);
-                            R[0] += (u32)(y0 & OS_M28); R[1] += (u32)((y0 >> 28) & OS_M28);
-                            R[2] += (u32)(y1 & OS_M28); R[3] += (u32)((y1 >> 28) & OS_M28);
-                        }
-                    }
-                    for (u32 gg = gbase + 8u; gg < cG; ++gg) {          // a workgroup that fell behind (or has just started)
-                        const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
-                        const u64 y0 = poll(p, (u64)OS_BATCH, ok), y1 = poll(p + 1, (u64)OS_BATCH, ok);
-                        R[0] += (u32)(y0 & OS_M28); R[1] += (u32)((y0 >> 28) & OS_M28);
-                        R[2] += (u32)(y1 & OS_M28); R[3] += (u32)((y1 >> 28) & OS_M28);
-                    }
+                    for (int q0 = 0; q0 < 31; q0 += 8) {
+                        u32 plo = 0, phi = 0;
 #pragma unroll
-                    for (int q = 0; q < 31; ++q) {
-                        if ((u32)q < cj) {
-                            u64 y = a1[q];
-                            if ((y >> 56) != (u64)tag8) y = poll(&agg[(size_t)(t1 - cj + q) * 64 + lane], (u64)tag8, ok);
-                            sa[0] += (u32)(y & OS_M14); sa[1] += (u32)((y >> 14) & OS_M14); sa[2] += (u32)((y >> 28) & OS_M14); sa[3] += (u32)((y >> 42) & OS_M14);
+                        for (int q = q0; q < q0 + 8 && q < 31; ++q) {
+                            if ((u32)q < cj) {
+                                u64 y = a1[q];
+                                if ((y & OS_TAGBITS) != tagpat) y = poll(&agg[(size_t)(t1 - cj + q) * 64 + lane], OS_TAGBITS, tagpat, ok);
+                                plo += (u32)y & 0x3fff3fffu; phi += (u32)(y >> 32) & 0x3fff3fffu;
+                            }
                         }
+                        sa[0] += plo & 0xffffu; sa[1] += plo >> 16; sa[2] += phi & 0xffffu; sa[3] += phi >> 16;
                     }
-                    if (!ok) (void)OS_ADD(err, 1u);
                 }
-                gbase = cG;
                 const uint4 d4 = *reinterpret_cast<const uint4*>(dstart + (x ^ 1u) * 256 + 4 * lane);
                 uint4 o;
                 o.x = R[0] + sa[0] - d4.x; o.y = R[1] + sa[1] - d4.y; o.z = R[2] + sa[2] - d4.z; o.w = R[3] + sa[3] - d4.w;
                 *reinterpret_cast<uint4*>(adj + (x ^ 1u) * 256 + 4 * lane) = o;
             }
+            if (!ok) (void)OS_ADD(err, 1u);
             OS_PH(4);
             __syncthreads();                                                                      // B4
             OS_PH(11);
 #if OS_PHASE_TIMING
-            if (t == (u32)ST && tile_no < 40u) tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + 1) * 16 + 14] = ((u64)t1 << 32) | t2;
+            if (t == (u32)ST && tile_no < 40u) { tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + 1) * 16 + 14] = ((u64)t1 << 32) | t2; tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + 1) * 16 + 15] = npolls; }
 #endif
             ++tile_no;
             t0 = t1; t1 = t2; t2 = nn; x ^= 1u;

@@ -17,8 +17,8 @@ a = np.fromfile("gpurun_out/os_phase_timing.bin", dtype=np.uint64).reshape(256, 
 stream = [(0, 1, "key write-out (tile i)"), (1, 2, "barrier 5"), (2, 3, "value staging"), (3, 4, "barrier 6"), (4, 5, "value write-out"),
           (5, 6, "rank tile i+2 (waits its keys)"), (6, 7, "barrier 1"), (7, 8, "values of i+1 requested, digit scan (barrier 2 inside)"), (8, 9, "barrier 3"),
           (9, 10, "stage keys of i+2, request keys of i+3"), (10, 11, "barrier 4 (scout: offsets of i+1)")]
-scout = [(0, 1, "ticket + look-back loads of tile i+1 issued"), (1, 2, "barriers 5, 6, 1, 2, ticket read"), (2, 3, "barrier 3"),
-         (3, 4, "publish i+2, rows of i+1 summed (+polls), offsets"), (4, 11, "barrier 4")]
+scout = [(0, 1, "ticket + look-back loads of tile i+1 issued"), (1, 2, "barriers 5, 6, 1, batch rows summed, barrier 2, ticket read"), (2, 3, "barrier 3"),
+         (3, 4, "publish i+2, tile rows of i+1 summed (+polls), offsets"), (4, 11, "barrier 4")]
 for who, label, phases in ((0, "thread 0 (streaming wave 0)", stream), (1, "scout wave", scout)):
     st = a[:, :, who, :12].astype(np.int64)
     ok = (st[:, :, 11] > 0) & (st[:, :, 0] > 0)
@@ -32,5 +32,7 @@ for who, label, phases in ((0, "thread 0 (streaming wave 0)", stream), (1, "scou
     for i0, i1, nm in phases:
         dt = tiles[:, i1] - tiles[:, i0]
         print(f"  {nm:64s} {dt.mean():8.0f}  {100 * dt.mean() / tot:5.1f} %   (p90 {np.percentile(dt, 90):.0f})")
+np_ = a[:, :, 1, 15].astype(np.int64)
+print("scout: slow-path row reads (cumulative per workgroup over its first 40 tiles, all lanes counted once): mean %.1f max %d" % (np_.max(axis=1).mean(), np_.max()))
 cnt = ((a[:, :, 0, 14] >> 32 != 0xffffffff) & (a[:, :, 0, 11] > 0)).sum(axis=1)
 print("tiles per workgroup: min %d max %d" % (cnt.min(), cnt.max()))
