@@ -129,7 +129,9 @@ enum {
     BSCGPU_K_DC_PART       = 9,  /* device coder: decisions into chain-major order */
     BSCGPU_K_DC_EVAL       = 10, /* device coder: counter chains */
     BSCGPU_K_DC_PSTREAM    = 11, /* device coder: probability stream */
-    BSCGPU_K_COUNT         = 12
+    BSCGPU_K_RADIX_HISTALL = 12, /* single-read sorts: the one histogram read per sort (all digits at once) */
+    BSCGPU_K_RADIX_AUX     = 13, /* keys-only passes that also emit the permutation (device coder's orders, inverse BWT): not the graded kernel */
+    BSCGPU_K_COUNT         = 14
 };
 typedef struct bscgpu_kstat {
     double   ms;        /* accumulated HIP-event time */

@@ -255,13 +255,27 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             OS_PH(3);
             const u32 nn = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);
             if (nn == OS_NONE) more = false;
-            // publish t2
+            // The tile rows were requested a whole iteration ago: make the wave wait for them HERE (it costs nothing now), before the
+            // publishing store and atomics below are in the queue.  vmcnt is an in-order counter and the compiler cannot count across
+            // the poll loops above, so the first use of a row further down would otherwise be preceded by s_waitcnt vmcnt(0) — i.e.
+            // by the write-through latency of this tile's own publication (~3 us, measured on the critical path).
+            if (!(OS_ABL & 1)) {
+#pragma unroll
+                for (int q = 0; q < 31; ++q) asm volatile("" : "+v"(a1[q]));
+            }
+            // publish t2.  (The three data words stay live — the empty asm at the end of the iteration — so that their registers are
+            // not handed to the arithmetic below: on gfx950 a store's data registers may be read late, and overwriting them is
+            // preceded by a wait for the store itself.)
+            u64 pub0 = 0, pub1 = 0, pub2 = 0;
             if (v2 && !(OS_ABL & 2)) {
                 const uint4 c4 = *reinterpret_cast<const uint4*>(stot + 4 * lane);
-                OS_STORE(&agg[(size_t)t2 * 64 + lane], tagpat | (u64)(c4.x | (c4.y << 16)) | ((u64)(c4.z | (c4.w << 16)) << 32));
+                pub0 = tagpat | (u64)(c4.x | (c4.y << 16)) | ((u64)(c4.z | (c4.w << 16)) << 32);
+                pub1 = (1ull << 56) | ((u64)c4.y << 28) | (u64)c4.x;
+                pub2 = (1ull << 56) | ((u64)c4.w << 28) | (u64)c4.z;
+                OS_STORE(&agg[(size_t)t2 * 64 + lane], pub0);
                 u64* p = &bagg[(size_t)(t2 / (u32)OS_BATCH) * 128 + 2 * lane];
-                (void)OS_ADD(p, (1ull << 56) | ((u64)c4.y << 28) | (u64)c4.x);
-                (void)OS_ADD(p + 1, (1ull << 56) | ((u64)c4.w << 28) | (u64)c4.z);
+                (void)OS_ADD(p, pub1);
+                (void)OS_ADD(p + 1, pub2);
             }
             // offsets of t1 (it sits in staging buffer x ^ 1): the tile rows below it, eight at a time as packed 16-bit sums
             if (v1) {
@@ -287,6 +301,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                 *reinterpret_cast<uint4*>(adj + (x ^ 1u) * 256 + 4 * lane) = o;
             }
             if (!ok) (void)OS_ADD(err, 1u);
+            asm volatile("" :: "v"(pub0), "v"(pub1), "v"(pub2));
             OS_PH(4);
             __syncthreads();                                                                      // B4
             OS_PH(11);
@@ -428,11 +443,21 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         t0 = t1; t1 = t2; t2 = nn; x ^= 1u;
     };
 
-    while (t0 != OS_NONE || t1 != OS_NONE || t2 != OS_NONE) {
-        const bool steady = t0 != OS_NONE && t2 != OS_NONE && (u64)(t0 + 1u) * TILE <= n && (u64)(t2 + 1u) * TILE <= n;
-        if (steady) iteration(std::true_type());
-        else iteration(std::false_type());
-    }
+    // Three loops in a row — fill, steady state, drain (a workgroup is never steady again once it has seen its last ticket or the
+    // one partial tile) —, so that the steady state is a loop of its own: with both instantiations behind one loop header the register
+    // allocator rotates the in-flight key / value registers through copies at the header, and a copy of a register that a load is
+    // still filling means s_waitcnt vmcnt(0) at the top of every iteration.
+    // (32-bit scalar compares only: a 64-bit compare goes through VALU registers, and the allocator has been seen to pick one that an
+    // in-flight key load is about to write)
+    const u32 nfull = n / (u32)TILE;                                    // tiles below this index are full; OS_NONE is not below it
+    auto is_steady = [&]() __attribute__((always_inline)) { return t0 < nfull && t2 < nfull; };
+    auto any_left = [&]() __attribute__((always_inline)) { return t0 != OS_NONE || t1 != OS_NONE || t2 != OS_NONE; };
+    while (any_left() && !is_steady()) iteration(std::false_type());
+    // Nothing may be in flight when the steady loop is entered: the wait-count pass merges the entry state into the loop header, and
+    // loads pending into the fill loop's registers would turn into (static) waits at the top of every steady iteration.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                 // vmcnt(0)
+    while (is_steady()) iteration(std::true_type());
+    while (any_left()) iteration(std::false_type());
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -494,7 +519,7 @@ int radix_onesweep_sort(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32*
         P.mask[p]  = p < npasses ? ((passes[p].bits >= 8) ? 0xffu : ((1u << passes[p].bits) - 1u)) : 0u;
     }
     const u32 grid = ntiles < (u32)c->num_cus ? ntiles : (u32)c->num_cus;
-    prof_begin(c, BSCGPU_K_RADIX_HIST, n * 8, n);
+    prof_begin(c, BSCGPU_K_RADIX_HISTALL, n * 8, n);
     hipLaunchKernelGGL(rs_hist_all_kernel, dim3(grid), dim3(OS_WG), (size_t)16 * npasses * 256 * 4, c->stream,
                        keys, (u32)n, P, c->os_zero, c->os_pass_stride);
     prof_end(c);

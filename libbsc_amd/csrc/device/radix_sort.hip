@@ -747,6 +747,9 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
         HIP_TRY(c, hipFuncSetAttribute((const void*)rs_scatter_tiled_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RST_LDS));
     }
 
+    // passes that also emit the permutation serve the device coder / the inverse BWT: booked apart from the graded digit passes
+    const int kind_hist = emit_pos ? BSCGPU_K_RADIX_AUX : BSCGPU_K_RADIX_HIST, kind_scan = emit_pos ? BSCGPU_K_RADIX_AUX : BSCGPU_K_RADIX_SCAN,
+              kind_scatter = emit_pos ? BSCGPU_K_RADIX_AUX : BSCGPU_K_RADIX_SCATTER;
     for (int p = 0; p < npasses; ++p) {
         const int shift = passes[p].shift;
         const u32 mask  = (passes[p].bits >= 8) ? 0xffu : ((1u << passes[p].bits) - 1u);
@@ -772,16 +775,16 @@ int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* v
             u32* tv = vsrc; vsrc = vdst; vdst = tv;
             continue;
         }
-        prof_begin(c, BSCGPU_K_RADIX_HIST, n * 8, n);
+        prof_begin(c, kind_hist, n * 8, n);
         hipLaunchKernelGGL(rs_hist_kernel, dim3(ch.num_chunks), dim3(RS_WG), 0, c->stream,
                            ksrc, (u32)n, shift, mask, ch.chunk_tiles, ch.num_chunks, c->counts);
         prof_end(c);
 
-        prof_begin(c, BSCGPU_K_RADIX_SCAN, (u64)256 * ch.num_chunks * 8, 0);
+        prof_begin(c, kind_scan, (u64)256 * ch.num_chunks * 8, 0);
         hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(WG), 0, c->stream, c->counts, ch.num_chunks, c->rowtot);
         prof_end(c);
 
-        prof_begin(c, BSCGPU_K_RADIX_SCATTER, 2 * n * rec_bytes, n);
+        prof_begin(c, kind_scatter, 2 * n * rec_bytes + (emit_pos ? 4 * n : 0), n);
         if (use_wc) {
             const u32 grid = (ch.num_chunks + WC_SPAN - 1) / WC_SPAN;
             if (has_val)
