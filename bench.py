@@ -209,7 +209,14 @@ def main():
         ctxs[0].profile(False)
         stats_iso = ctxs[0].profile_get()
         launches_iso = ctxs[0].scatter_launches(65536)
+    # what leaves this rank's GPU over PCIe in the timed region: 16 bits per binary decision of the device model (run arrays instead
+    # for blocks on the host model: not counted) + nothing else of size (the input is resident, the sorted block never crosses);
+    # the host's DRAM sees those bytes twice (DMA write, coder read) — with 8 ranks per node this, not xGMI, is the shared resource
+    decisions = stats.get("dc_pstream", {}).get("records", 0)
+    d2h_bytes = 2.0 * decisions
     mine = {"rank": rank, "verified": verified, "gpu_stage_total_ms": round(float(stage[0] + stage[1] + stage[2]) / args.steps, 2),
+            "pcie_d2h_MBps": round(d2h_bytes / 1e6 / dt, 1), "pcie_d2h_MB_per_block": round(d2h_bytes / 1e6 / args.steps, 1),
+            "host_dram_MBps_estimate": round(2 * d2h_bytes / 1e6 / dt, 1),
             "sorter_only_MBps": round(n / 1e6 / max(stage[1] / args.steps / 1e3, 1e-9), 1),
             "cpu_seconds_per_block": round(cpu_used / args.steps, 3), "coder_threads": coder_threads,
             "effective_cpus_of_process": effective_cpus()}

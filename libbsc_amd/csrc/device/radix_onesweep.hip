@@ -204,10 +204,18 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             const bool v1 = t1 != OS_NONE, v2 = t2 != OS_NONE;
             const u32 cj = v1 ? (t1 & (u32)(OS_BATCH - 1)) : 0u, cG = v1 ? (t1 / (u32)OS_BATCH) : 0u;
             OS_PH(0);
-            // ticket for the tile after t2; every look-back load for t1 (tile rows of its batch below it, first 8 batch rows): in flight
-            // from the top of the iteration; the batch rows are looked at behind barrier 1, the tile rows in front of the last barrier
+            // Ticket for the tile after t2.  The look-back loads for t1 (tile rows of its batch below it, first 8 batch rows) are issued
+            // behind barrier 6, a quarter into the iteration: t1 and its predecessors were published late in the previous iteration,
+            // and under streaming load a published row takes ~4 us to become visible — a row that is asked for too early costs a
+            // second full round trip.  They are looked at in front of the iteration's last barrier; the scout does nothing else
+            // between the barriers, so it never holds the streaming waves up.
             u32 ticket = 0;
             if (more && lane == 0) ticket = OS_ADD(ctl + opaque0, 1u);        // ONE lane draws
+            OS_PH(1);
+            if (HAS_VAL) {
+                __syncthreads();                                                                  // B5
+                __syncthreads();                                                                  // B6
+            }
             u64 a1[31], b1[8][2];
             if (!(OS_ABL & 1)) {
 #pragma unroll
@@ -219,35 +227,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                     b1[q][0] = OS_LOAD(p); b1[q][1] = OS_LOAD(p + 1);
                 }
             }
-            OS_PH(1);
-            if (HAS_VAL) {
-                __syncthreads();                                                                  // B5
-                __syncthreads();                                                                  // B6
-            }
             __syncthreads();                                                                      // B1
-            bool ok = true;
-            if (v1 && !(OS_ABL & 1)) {
-                // batch rows into the running sum (they were requested a write-out and a ranking ago)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const u32 gg = gbase + q;
-                    if (gg < cG) {
-                        u64 y0 = b1[q][0], y1 = b1[q][1];
-                        const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
-                        if ((y0 >> 56) != (u64)OS_BATCH) y0 = poll(p, ~0ull << 56, (u64)OS_BATCH << 56, ok);
-                        if ((y1 >> 56) != (u64)OS_BATCH) y1 = poll(p + 1, ~0ull << 56, (u64)OS_BATCH << 56, ok);
-                        R[0] += (u32)(y0 & OS_M28); R[1] += (u32)((y0 >> 28) & OS_M28);
-                        R[2] += (u32)(y1 & OS_M28); R[3] += (u32)((y1 >> 28) & OS_M28);
-                    }
-                }
-                for (u32 gg = gbase + 8u; gg < cG; ++gg) {              // a workgroup that fell behind (or has just started)
-                    const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
-                    const u64 y0 = poll(p, ~0ull << 56, (u64)OS_BATCH << 56, ok), y1 = poll(p + 1, ~0ull << 56, (u64)OS_BATCH << 56, ok);
-                    R[0] += (u32)(y0 & OS_M28); R[1] += (u32)((y0 >> 28) & OS_M28);
-                    R[2] += (u32)(y1 & OS_M28); R[3] += (u32)((y1 >> 28) & OS_M28);
-                }
-            }
-            if (v1) gbase = cG;
             if (v2) __syncthreads();                                                              // B2 (the streaming waves' digit scan)
             if (lane == 0) sclaim[0] = (more && ticket < ntiles) ? ticket : OS_NONE;
             OS_PH(2);
@@ -255,13 +235,16 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             OS_PH(3);
             const u32 nn = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);
             if (nn == OS_NONE) more = false;
-            // The tile rows were requested a whole iteration ago: make the wave wait for them HERE (it costs nothing now), before the
+            bool ok = true;
+            // The rows were requested most of an iteration ago: make the wave wait for them HERE, before the
             // publishing store and atomics below are in the queue.  vmcnt is an in-order counter and the compiler cannot count across
             // the poll loops above, so the first use of a row further down would otherwise be preceded by s_waitcnt vmcnt(0) — i.e.
             // by the write-through latency of this tile's own publication (~3 us, measured on the critical path).
             if (!(OS_ABL & 1)) {
 #pragma unroll
                 for (int q = 0; q < 31; ++q) asm volatile("" : "+v"(a1[q]));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(b1[q][0]), "+v"(b1[q][1]));
             }
             // publish t2.  (The three data words stay live — the empty asm at the end of the iteration — so that their registers are
             // not handed to the arithmetic below: on gfx950 a store's data registers may be read late, and overwriting them is
@@ -277,10 +260,30 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                 (void)OS_ADD(p, pub1);
                 (void)OS_ADD(p + 1, pub2);
             }
-            // offsets of t1 (it sits in staging buffer x ^ 1): the tile rows below it, eight at a time as packed 16-bit sums
+            // offsets of t1 (it sits in staging buffer x ^ 1): batch rows into the running sum, then the tile rows below it, eight at a
+            // time as packed 16-bit sums
             if (v1) {
                 u32 sa[4] = {0, 0, 0, 0};
                 if (!(OS_ABL & 1)) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const u32 gg = gbase + q;
+                        if (gg < cG) {
+                            u64 y0 = b1[q][0], y1 = b1[q][1];
+                            const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
+                            if ((y0 >> 56) != (u64)OS_BATCH) y0 = poll(p, ~0ull << 56, (u64)OS_BATCH << 56, ok);
+                            if ((y1 >> 56) != (u64)OS_BATCH) y1 = poll(p + 1, ~0ull << 56, (u64)OS_BATCH << 56, ok);
+                            R[0] += (u32)(y0 & OS_M28); R[1] += (u32)((y0 >> 28) & OS_M28);
+                            R[2] += (u32)(y1 & OS_M28); R[3] += (u32)((y1 >> 28) & OS_M28);
+                        }
+                    }
+                    for (u32 gg = gbase + 8u; gg < cG; ++gg) {          // a workgroup that fell behind (or has just started)
+                        const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
+                        const u64 y0 = poll(p, ~0ull << 56, (u64)OS_BATCH << 56, ok), y1 = poll(p + 1, ~0ull << 56, (u64)OS_BATCH << 56, ok);
+                        R[0] += (u32)(y0 & OS_M28); R[1] += (u32)((y0 >> 28) & OS_M28);
+                        R[2] += (u32)(y1 & OS_M28); R[3] += (u32)((y1 >> 28) & OS_M28);
+                    }
+                    gbase = cG;
 #pragma unroll
                     for (int q0 = 0; q0 < 31; q0 += 8) {
                         u32 plo = 0, phi = 0;

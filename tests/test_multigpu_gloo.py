@@ -63,6 +63,79 @@ def test_gather_two_ranks_gloo():
     assert tmax == 2.0
 
 
+# ---- real compressed blocks through the concatenation stage -----------------------------------------------------------
+# What bench.py --gpus N and the file driver do with N ranks, minus the GPU: every rank compresses ITS blocks (block b belongs
+# to rank b % world; here with the CPU oracle, ragged sizes), hands them to the Concatenator round by round, and rank 0's image
+# of the gathered blocks must be the reference container of those blocks (bsc.cpp:163-178, 397-418) — byte for byte what one
+# process would have written, and unpackable by the reference's own `bsc d`.
+_BLOCK_SIZES = [20011, 31000, 8190, 26001, 17000]      # five blocks, two ranks: rank 0 gets 3, rank 1 gets 2 (padded with a skip round)
+
+
+def _block_data(b):
+    from libbsc_amd.synth import synth_text_v1
+    return synth_text_v1(70 + b, _BLOCK_SIZES[b])
+
+
+def _real_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from libbsc_amd.multigpu import Concatenator
+    from oracle.refbind import Oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = Oracle()
+    mine = assign_blocks(len(_BLOCK_SIZES), world)[rank]
+    rounds = max(len(x) for x in assign_blocks(len(_BLOCK_SIZES), world))
+    cat = Concatenator(rank, world, torch.device("cpu"), keep=True)
+    for rnd in range(rounds):
+        # a rank that has run out of blocks still takes part in the round (zero-length payload): all ranks put() equally often
+        blk = np.frombuffer(orc.compress(_block_data(mine[rnd]), 1, 1), dtype=np.uint8) if rnd < len(mine) else np.zeros(0, np.uint8)
+        cat.put(blk)
+    cat.close()
+    if rank == 0:
+        blocks = []
+        for rnd in range(rounds):
+            for r in range(world):
+                if len(cat.blocks[rnd][r]):
+                    blocks.append(cat.blocks[rnd][r].tobytes())        # round-major, rank-minor = block order b = rnd * world + r
+        q.put(blocks)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_compressed_blocks_through_concatenator_match_reference_container(tmp_path):
+    import subprocess
+    from oracle.refbind import Oracle
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_real_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    blocks = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    orc = Oracle()
+    want_blocks = [orc.compress(_block_data(b), 1, 1) for b in range(len(_BLOCK_SIZES))]
+    assert [len(b) for b in blocks] == [len(b) for b in want_blocks]
+    assert blocks == want_blocks                                           # every rank's blocks arrived whole, in block order
+    offsets = list(np.cumsum([0] + _BLOCK_SIZES[:-1]))
+    image = bsc_file_image(blocks, [int(o) for o in offsets])
+    assert image == bsc_file_image(want_blocks, [int(o) for o in offsets])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bsc = os.path.join(root, "oracle", "_ref", "bsc")
+    if os.path.exists(bsc):                                                # the reference's own decoder takes the file
+        f = tmp_path / "two_ranks.bsc"
+        f.write_bytes(image)
+        out = tmp_path / "back.bin"
+        r = subprocess.run([bsc, "d", str(f), str(out)], capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS="2"))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert out.read_bytes() == b"".join(_block_data(b).tobytes() for b in range(len(_BLOCK_SIZES)))
+
+
 def test_assign_blocks_and_file_image():
     assert assign_blocks(8, 8) == [[i] for i in range(8)]
     assert assign_blocks(5, 2) == [[0, 2, 4], [1, 3]]
