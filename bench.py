@@ -72,7 +72,9 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     ncx = max(1, args.contexts)
     if "BSCGPU_HOST_THREADS" not in os.environ:         # per pipe: this rank's CPUs are shared by its contexts
-        os.environ["BSCGPU_HOST_THREADS"] = str(max(4, min(64, effective_cpus() // max(local_world, 1) // ncx)))
+        # (half as many again as the CPU share: threads are cheap, and the short tasks of a pipe's last block should all start at once
+        # although a long task of the block before is still running)
+        os.environ["BSCGPU_HOST_THREADS"] = str(max(4, min(64, (3 * effective_cpus() // max(local_world, 1) // ncx + 1) // 2)))
     coder_threads = int(os.environ["BSCGPU_HOST_THREADS"]) * ncx
     # Range coding on the host: all eight sub-blocks of a block in SIMD lanes on one thread (0.118 CPU-s per block
     # with AVX-512VL, 0.141 with AVX2, ~0.1 s latency: four blocks in flight per context) or pairs of sub-blocks per thread
@@ -122,13 +124,19 @@ def main():
                 concat.put(blk)
         return blk
 
+    LOW_LATENCY = 0x10000                               # include/bscgpu.h
+    tail_low_latency = os.environ.get("BSC_BENCH_TAIL", "1") != "0"
+
     def run_one(k, steps, record, out):
         """`steps` blocks through pipe k: GPU stage of block i+1 overlaps the host coding of block i."""
         pipe, cx = pipes[k], ctxs[k]
         tickets, blk = [], None
         local_stage = np.zeros(6)
-        for _ in range(steps):
-            tickets.append(pipe.submit(d_in, n, args.sorter, args.coder, 3))
+        for i in range(steps):
+            # the last block of every pipe is coded as short host tasks (BSCGPU_FEATURE_LOW_LATENCY): the pipeline's drain is part of
+            # the timed region, and the coder threads are running dry by then
+            feat = 3 | (LOW_LATENCY if (tail_low_latency and i == steps - 1) else 0)
+            tickets.append(pipe.submit(d_in, n, args.sorter, args.coder, feat))
             if record:
                 local_stage += np.array(cx.last_stage_ms())
             if len(tickets) >= args.depth:

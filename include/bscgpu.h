@@ -103,6 +103,10 @@ BSCGPU_API int bscgpu_compress_device(bscgpu_ctx* ctx, const void* dInput, uint8
  * quota — clamped to 4..64; BSCGPU_HOST_THREADS overrides), so a depth of 3-4 keeps those
  * threads and the GPU busy. */
 typedef struct bscgpu_pipe bscgpu_pipe;
+/* Extra `features` bit for bscgpu_pipe_submit*: code this block's sub-blocks as several short host tasks (two interleaved scalar range
+ * coders per task, ~50 ms for a 64 MiB block) instead of one eight-lane SIMD task (~90 ms, half the CPU time).  For the LAST blocks
+ * of a job, where latency — the drain of the pipeline — counts and the coder threads are running dry anyway.  Output is identical. */
+#define BSCGPU_FEATURE_LOW_LATENCY 0x10000
 BSCGPU_API int  bscgpu_pipe_create(bscgpu_ctx* ctx, int depth, bscgpu_pipe** out);
 BSCGPU_API void bscgpu_pipe_destroy(bscgpu_pipe* pipe);
 BSCGPU_API int  bscgpu_pipe_submit(bscgpu_pipe* pipe, const void* dInput, uint8_t* output, int n,

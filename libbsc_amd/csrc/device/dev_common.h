@@ -103,6 +103,7 @@ struct bscgpu_ctx {
     u32* os_zero = nullptr;       // [8 passes] x {control block, digit totals, batch rows}: cleared per sort
     u32  os_tiles_cap = 0;
     u32  os_pass_stride = 0;      // words
+    u32  os_batch_words = 0;      // words of the batch rows inside a pass's block (the group rows follow)
     u32  os_epoch = 0;            // launches so far (launch tag = epoch % 255 + 1)
     bool os_check_pending = false;   // hscal[OS_ERR_SLOT] of the last sort has not been looked at yet
     // pinned host

@@ -37,12 +37,13 @@
 
 using namespace dcm;
 
-// Run-parallel kernels that gather (dc_ctx: the symbol-major neighbours; dc_pstream: the chain-major counter values) give every XCD
-// one contiguous eighth of the runs instead of every eighth workgroup: neighbouring runs hit neighbouring entries of a chain, so a
-// line of the gathered arrays is then fetched by ONE XCD's L2 and reused there, not by all eight (block b runs on XCD b % 8; the
-// placement only matters for speed).  The launch grid is rounded up to a multiple of 8.
+// Run-parallel kernels that gather (dc_ctx: the symbol-major neighbours; dc_pstream: the chain-major counter values) can give every
+// XCD one contiguous eighth of the runs instead of every eighth workgroup (block b runs on XCD b % 8), so that a line of the gathered
+// arrays is fetched by one XCD's L2 only.  Measured on the 64 MiB bench block (same box, round 3): dc_pstream 3.10 against 2.92 ms,
+// dc_ctx 1.44 against 1.41 ms — no gain (the lines are mostly consumed by one workgroup or its neighbour in time, and eight
+// separate streams per array cost more than the shared fetches save); kept as an A/B switch, off.
 #ifndef DC_XCD_RANGES
-#define DC_XCD_RANGES 1
+#define DC_XCD_RANGES 0
 #endif
 __device__ __forceinline__ u32 dc_virtual_block() {
     if (!DC_XCD_RANGES) return blockIdx.x;

@@ -16,12 +16,15 @@
 //                assignment of tiles to workgroups could).  Claim order = index order also means a tile's predecessors published
 //                before it did.  (Batches of 32 tiles owned by one XCD, for L2 write merging as in rs_scatter_tiled, were built and
 //                measured: the batch before a tile is then claimed AFTER it by another XCD, half of the tiles wait for it.)
-//      rows      a tile publishes ONE 512-byte row: 64 granules of 8 bytes {launch tag : 8, four 14-bit digit counts}, each
-//                written by one lane with one agent-scope store — a granule validates itself, no fence, no flag (MI355X_MICROARCH.md,
-//                hand-off table: data-tagged granules).  Tiles are grouped in batches of 32: the tile also adds its counts to the
-//                batch's row of {arrivals : 8, two 28-bit sums} words with agent-scope 64-bit atomics; a batch row is complete
-//                when arrivals == 32.  offsets(tile) = digit base + complete batch rows below its batch (a workgroup keeps a
-//                running sum: ~8 new rows per tile) + the tile rows of its own batch below it (<= 31).
+//      rows      a tile publishes ONE 512-byte row: 64 granules of 8 bytes, four 16-bit fields {digit count : 14, two bits of the launch
+//                tag : 2}, each granule written by one lane with one agent-scope store — a granule validates itself, no fence, no
+//                flag (MI355X_MICROARCH.md, hand-off table: data-tagged granules) —, and adds its counts to the row of its GROUP (8
+//                tiles) and of its BATCH (8 groups) with agent-scope 64-bit atomics on {arrivals : 8, two 28-bit sums} words; such a
+//                row is complete when arrivals == 8 / 64.  offsets(tile) = digit base + the complete batch rows below its batch (a
+//                workgroup keeps a running sum; its next tile is ~256 tiles = 4-5 batches on) + the group rows of its batch below
+//                its group (<= 7) + the tile rows of its group below it (<= 7): ~20 loads per lane.  Two levels with 32-tile batches
+//                were measured first: 8-9 new batch rows per tile, and every row beyond the eight requested in bulk cost two
+//                serial round trips of ~4 us.
 //      latency   hidden by software pipelining, not avoided.  Three tiles are in flight per workgroup: tile i+2 is ranked, published and
 //                staged into an LDS buffer; tile i+1 waits in the other buffer while the scout collects its offsets — its look-back
 //                loads are issued at the top of the iteration, about half a tile time after the tile (and hence every tile claimed
@@ -43,7 +46,8 @@
 #include <type_traits>
 
 constexpr int OS_WG = 1024, OS_WAVES = OS_WG / 64, OS_SW = OS_WAVES - 1 /* streaming waves */, OS_ST = OS_SW * 64 /* streaming threads */;
-constexpr int OS_ITEMS = 8, OS_TILE = OS_ST * OS_ITEMS /* 7680 */, OS_BATCH = 32, OS_MAXP = 8;
+constexpr int OS_ITEMS = 8, OS_TILE = OS_ST * OS_ITEMS /* 7680 */, OS_GRP = 8 /* tiles per group */, OS_GPB = 8 /* groups per batch */,
+              OS_BATCH = OS_GRP * OS_GPB /* 64 tiles */, OS_MAXP = 8;
 constexpr u32 OS_NONE = 0xffffffffu;
 constexpr u32 OS_SPIN_LIMIT = 1u << 18;
 // LDS: two key staging buffers, per-wave digit counters, five 256-entry tables, scratch
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                                                             const u32* __restrict__ vin, u32* __restrict__ vout,
                                                             u32 n, int shift, u32 mask, u32 ntiles,
                                                             u32* ctl, u32* err, const u32* __restrict__ totals,
-                                                            u64* bagg /*[batches][128]*/, u64* agg /*[tiles][64]*/, u32 tag8, u64* tdbg)
+                                                            u64* bagg /*[batches][128]*/, u64* gagg /*[groups][128]*/, u64* agg /*[tiles][64]*/, u32 tag8, u64* tdbg)
 {
     (void)tdbg;
     u32 tile_no = 0; (void)tile_no;
@@ -202,32 +206,74 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         };
         while (t0 != OS_NONE || t1 != OS_NONE || t2 != OS_NONE) {
             const bool v1 = t1 != OS_NONE, v2 = t2 != OS_NONE;
-            const u32 cj = v1 ? (t1 & (u32)(OS_BATCH - 1)) : 0u, cG = v1 ? (t1 / (u32)OS_BATCH) : 0u;
+            // t1 = tile cj of group cg of batch cG
+            const u32 cj = v1 ? (t1 & (u32)(OS_GRP - 1)) : 0u, cg = v1 ? ((t1 / (u32)OS_GRP) & (u32)(OS_GPB - 1)) : 0u, cG = v1 ? (t1 / (u32)OS_BATCH) : 0u;
+            const u32 grp0 = v1 ? (t1 / (u32)OS_GRP - cg) : 0u;        // first group of its batch
             OS_PH(0);
-            // Ticket for the tile after t2.  The look-back loads for t1 (tile rows of its batch below it, first 8 batch rows) are issued
-            // behind barrier 6, a quarter into the iteration: t1 and its predecessors were published late in the previous iteration,
-            // and under streaming load a published row takes ~4 us to become visible — a row that is asked for too early costs a
-            // second full round trip.  They are looked at in front of the iteration's last barrier; the scout does nothing else
-            // between the barriers, so it never holds the streaming waves up.
+            // Ticket for the tile after t2, and every look-back load for t1 — the tile rows of its group below it (<= 7), the group rows
+            // of its batch below its group (<= 7), the batch rows not yet in the running sum (a workgroup's next tile is ~256 tiles =
+            // 4 or 5 batches further on; 6 are requested, more are fetched one by one) —, all in flight from the top of the
+            // iteration.  Batch and group rows are summed behind barrier 1 (the scout is idle there), the tile rows, which are the
+            // freshest, in front of the iteration's last barrier.
             u32 ticket = 0;
             if (more && lane == 0) ticket = OS_ADD(ctl + opaque0, 1u);        // ONE lane draws
-            OS_PH(1);
-            if (HAS_VAL) {
-                __syncthreads();                                                                  // B5
-                __syncthreads();                                                                  // B6
-            }
-            u64 a1[31], b1[8][2];
+            u64 a1[OS_GRP - 1], g1[OS_GPB - 1][2], b1[6][2];
             if (!(OS_ABL & 1)) {
 #pragma unroll
-                for (int q = 0; q < 31; ++q) a1[q] = OS_LOAD(&agg[(size_t)(((u32)q < cj) ? (t1 - cj + q) : 0u) * 64 + lane]);
+                for (int q = 0; q < OS_GRP - 1; ++q) a1[q] = OS_LOAD(&agg[(size_t)(((u32)q < cj) ? (t1 - cj + q) : 0u) * 64 + lane]);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < OS_GPB - 1; ++q) {
+                    const u64* p = &gagg[(size_t)(((u32)q < cg) ? (grp0 + q) : 0u) * 128 + 2 * lane];
+                    g1[q][0] = OS_LOAD(p); g1[q][1] = OS_LOAD(p + 1);
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
                     const u32 gg = gbase + q;
                     const u64* p = &bagg[(size_t)(gg < cG ? gg : 0u) * 128 + 2 * lane];
                     b1[q][0] = OS_LOAD(p); b1[q][1] = OS_LOAD(p + 1);
                 }
             }
+            OS_PH(1);
+            if (HAS_VAL) {
+                __syncthreads();                                                                  // B5
+                __syncthreads();                                                                  // B6
+            }
             __syncthreads();                                                                      // B1
+            bool ok = true;
+            u32 sg[4] = {0, 0, 0, 0};                                   // counts of the complete groups of t1's batch below its group
+            auto add_row = [&](u32 (&acc)[4], const u64 y0, const u64 y1) __attribute__((always_inline)) {
+                acc[0] += (u32)(y0 & OS_M28); acc[1] += (u32)((y0 >> 28) & OS_M28);
+                acc[2] += (u32)(y1 & OS_M28); acc[3] += (u32)((y1 >> 28) & OS_M28);
+            };
+            if (v1 && !(OS_ABL & 1)) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const u32 gg = gbase + q;
+                    if (gg < cG) {
+                        u64 y0 = b1[q][0], y1 = b1[q][1];
+                        const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
+                        if ((y0 >> 56) != (u64)OS_BATCH) y0 = poll(p, ~0ull << 56, (u64)OS_BATCH << 56, ok);
+                        if ((y1 >> 56) != (u64)OS_BATCH) y1 = poll(p + 1, ~0ull << 56, (u64)OS_BATCH << 56, ok);
+                        add_row(R, y0, y1);
+                    }
+                }
+                for (u32 gg = gbase + 6u; gg < cG; ++gg) {              // a workgroup that fell behind (or has just started)
+                    const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
+                    const u64 y0 = poll(p, ~0ull << 56, (u64)OS_BATCH << 56, ok), y1 = poll(p + 1, ~0ull << 56, (u64)OS_BATCH << 56, ok);
+                    add_row(R, y0, y1);
+                }
+#pragma unroll
+                for (int q = 0; q < OS_GPB - 1; ++q) {
+                    if ((u32)q < cg) {
+                        u64 y0 = g1[q][0], y1 = g1[q][1];
+                        const u64* p = &gagg[(size_t)(grp0 + q) * 128 + 2 * lane];
+                        if ((y0 >> 56) != (u64)OS_GRP) y0 = poll(p, ~0ull << 56, (u64)OS_GRP << 56, ok);
+                        if ((y1 >> 56) != (u64)OS_GRP) y1 = poll(p + 1, ~0ull << 56, (u64)OS_GRP << 56, ok);
+                        add_row(sg, y0, y1);
+                    }
+                }
+            }
+            if (v1) gbase = cG;
             if (v2) __syncthreads();                                                              // B2 (the streaming waves' digit scan)
             if (lane == 0) sclaim[0] = (more && ticket < ntiles) ? ticket : OS_NONE;
             OS_PH(2);
@@ -235,20 +281,17 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             OS_PH(3);
             const u32 nn = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);
             if (nn == OS_NONE) more = false;
-            bool ok = true;
-            // The rows were requested most of an iteration ago: make the wave wait for them HERE, before the
+            // The tile rows were requested most of an iteration ago: make the wave wait for them HERE, before the
             // publishing store and atomics below are in the queue.  vmcnt is an in-order counter and the compiler cannot count across
             // the poll loops above, so the first use of a row further down would otherwise be preceded by s_waitcnt vmcnt(0) — i.e.
             // by the write-through latency of this tile's own publication (~3 us, measured on the critical path).
             if (!(OS_ABL & 1)) {
 #pragma unroll
-                for (int q = 0; q < 31; ++q) asm volatile("" : "+v"(a1[q]));
-#pragma unroll
-                for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(b1[q][0]), "+v"(b1[q][1]));
+                for (int q = 0; q < OS_GRP - 1; ++q) asm volatile("" : "+v"(a1[q]));
             }
-            // publish t2.  (The three data words stay live — the empty asm at the end of the iteration — so that their registers are
-            // not handed to the arithmetic below: on gfx950 a store's data registers may be read late, and overwriting them is
-            // preceded by a wait for the store itself.)
+            // publish t2: its row, and its counts into its group's and its batch's rows.  (The data words stay live — the empty asm at
+            // the end of the iteration — so that their registers are not handed to the arithmetic below: on gfx950 a store's data
+            // registers may be read late, and overwriting them is preceded by a wait for the store itself.)
             u64 pub0 = 0, pub1 = 0, pub2 = 0;
             if (v2 && !(OS_ABL & 2)) {
                 const uint4 c4 = *reinterpret_cast<const uint4*>(stot + 4 * lane);
@@ -256,51 +299,30 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                 pub1 = (1ull << 56) | ((u64)c4.y << 28) | (u64)c4.x;
                 pub2 = (1ull << 56) | ((u64)c4.w << 28) | (u64)c4.z;
                 OS_STORE(&agg[(size_t)t2 * 64 + lane], pub0);
-                u64* p = &bagg[(size_t)(t2 / (u32)OS_BATCH) * 128 + 2 * lane];
-                (void)OS_ADD(p, pub1);
-                (void)OS_ADD(p + 1, pub2);
+                u64* pg = &gagg[(size_t)(t2 / (u32)OS_GRP) * 128 + 2 * lane];
+                (void)OS_ADD(pg, pub1);
+                (void)OS_ADD(pg + 1, pub2);
+                u64* pb = &bagg[(size_t)(t2 / (u32)OS_BATCH) * 128 + 2 * lane];
+                (void)OS_ADD(pb, pub1);
+                (void)OS_ADD(pb + 1, pub2);
             }
-            // offsets of t1 (it sits in staging buffer x ^ 1): batch rows into the running sum, then the tile rows below it, eight at a
-            // time as packed 16-bit sums
+            // offsets of t1 (it sits in staging buffer x ^ 1): + the tile rows of its group below it, as packed 16-bit sums
             if (v1) {
-                u32 sa[4] = {0, 0, 0, 0};
+                u32 plo = 0, phi = 0;
                 if (!(OS_ABL & 1)) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const u32 gg = gbase + q;
-                        if (gg < cG) {
-                            u64 y0 = b1[q][0], y1 = b1[q][1];
-                            const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
-                            if ((y0 >> 56) != (u64)OS_BATCH) y0 = poll(p, ~0ull << 56, (u64)OS_BATCH << 56, ok);
-                            if ((y1 >> 56) != (u64)OS_BATCH) y1 = poll(p + 1, ~0ull << 56, (u64)OS_BATCH << 56, ok);
-                            R[0] += (u32)(y0 & OS_M28); R[1] += (u32)((y0 >> 28) & OS_M28);
-                            R[2] += (u32)(y1 & OS_M28); R[3] += (u32)((y1 >> 28) & OS_M28);
+                    for (int q = 0; q < OS_GRP - 1; ++q) {
+                        if ((u32)q < cj) {
+                            u64 y = a1[q];
+                            if ((y & OS_TAGBITS) != tagpat) y = poll(&agg[(size_t)(t1 - cj + q) * 64 + lane], OS_TAGBITS, tagpat, ok);
+                            plo += (u32)y & 0x3fff3fffu; phi += (u32)(y >> 32) & 0x3fff3fffu;     // 7 x 7680 < 2^16: no carry between the halves
                         }
-                    }
-                    for (u32 gg = gbase + 8u; gg < cG; ++gg) {          // a workgroup that fell behind (or has just started)
-                        const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
-                        const u64 y0 = poll(p, ~0ull << 56, (u64)OS_BATCH << 56, ok), y1 = poll(p + 1, ~0ull << 56, (u64)OS_BATCH << 56, ok);
-                        R[0] += (u32)(y0 & OS_M28); R[1] += (u32)((y0 >> 28) & OS_M28);
-                        R[2] += (u32)(y1 & OS_M28); R[3] += (u32)((y1 >> 28) & OS_M28);
-                    }
-                    gbase = cG;
-#pragma unroll
-                    for (int q0 = 0; q0 < 31; q0 += 8) {
-                        u32 plo = 0, phi = 0;
-#pragma unroll
-                        for (int q = q0; q < q0 + 8 && q < 31; ++q) {
-                            if ((u32)q < cj) {
-                                u64 y = a1[q];
-                                if ((y & OS_TAGBITS) != tagpat) y = poll(&agg[(size_t)(t1 - cj + q) * 64 + lane], OS_TAGBITS, tagpat, ok);
-                                plo += (u32)y & 0x3fff3fffu; phi += (u32)(y >> 32) & 0x3fff3fffu;
-                            }
-                        }
-                        sa[0] += plo & 0xffffu; sa[1] += plo >> 16; sa[2] += phi & 0xffffu; sa[3] += phi >> 16;
                     }
                 }
                 const uint4 d4 = *reinterpret_cast<const uint4*>(dstart + (x ^ 1u) * 256 + 4 * lane);
                 uint4 o;
-                o.x = R[0] + sa[0] - d4.x; o.y = R[1] + sa[1] - d4.y; o.z = R[2] + sa[2] - d4.z; o.w = R[3] + sa[3] - d4.w;
+                o.x = R[0] + sg[0] + (plo & 0xffffu) - d4.x; o.y = R[1] + sg[1] + (plo >> 16) - d4.y;
+                o.z = R[2] + sg[2] + (phi & 0xffffu) - d4.z; o.w = R[3] + sg[3] + (phi >> 16) - d4.w;
                 *reinterpret_cast<uint4*>(adj + (x ^ 1u) * 256 + 4 * lane) = o;
             }
             if (!ok) (void)OS_ADD(err, 1u);
@@ -501,8 +523,9 @@ int radix_onesweep_sort(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32*
         c->os_agg = nullptr; c->os_zero = nullptr; c->os_tiles_cap = 0;
         const u64 cap_n = (u64)c->max_n > n ? (u64)c->max_n : n;
         const u32 cap_tiles = (u32)((cap_n + OS_TILE - 1) / OS_TILE) + 1;
-        const u32 cap_batches = (cap_tiles + OS_BATCH - 1) / OS_BATCH;
-        c->os_pass_stride = OS_CTL_WORDS + 256 + cap_batches * 256;      // words: control block, digit totals, batch rows (128 x u64)
+        const u32 cap_batches = (cap_tiles + OS_BATCH - 1) / OS_BATCH, cap_groups = (cap_tiles + OS_GRP - 1) / OS_GRP;
+        c->os_batch_words = cap_batches * 256;
+        c->os_pass_stride = OS_CTL_WORDS + 256 + cap_batches * 256 + cap_groups * 256;     // words: control block, digit totals, batch rows, group rows (128 x u64 each)
         if (hipMalloc((void**)&c->os_agg, (size_t)cap_tiles * 64 * 8) != hipSuccess ||
             hipMalloc((void**)&c->os_zero, (size_t)OS_MAXP * c->os_pass_stride * 4) != hipSuccess) {
             (void)hipGetLastError();
@@ -539,10 +562,10 @@ int radix_onesweep_sort(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32*
         prof_begin(c, BSCGPU_K_RADIX_SCATTER, 2 * n * rec_bytes, n);
         if (has_val)
             hipLaunchKernelGGL(rs_onesweep_kernel<true>, dim3(grid), dim3(OS_WG), OS_LDS, c->stream,
-                               ksrc, kdst, vsrc, vdst, (u32)n, P.shift[p], P.mask[p], ntiles, ctl, c->os_zero + 1, ctl + OS_CTL_WORDS, reinterpret_cast<u64*>(ctl + OS_CTL_WORDS + 256), reinterpret_cast<u64*>(c->os_agg), tag, c->wc_sink);
+                               ksrc, kdst, vsrc, vdst, (u32)n, P.shift[p], P.mask[p], ntiles, ctl, c->os_zero + 1, ctl + OS_CTL_WORDS, reinterpret_cast<u64*>(ctl + OS_CTL_WORDS + 256), reinterpret_cast<u64*>(ctl + OS_CTL_WORDS + 256 + c->os_batch_words), reinterpret_cast<u64*>(c->os_agg), tag, c->wc_sink);
         else
             hipLaunchKernelGGL(rs_onesweep_kernel<false>, dim3(grid), dim3(OS_WG), OS_LDS, c->stream,
-                               ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, P.shift[p], P.mask[p], ntiles, ctl, c->os_zero + 1, ctl + OS_CTL_WORDS, reinterpret_cast<u64*>(ctl + OS_CTL_WORDS + 256), reinterpret_cast<u64*>(c->os_agg), tag, c->wc_sink);
+                               ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, P.shift[p], P.mask[p], ntiles, ctl, c->os_zero + 1, ctl + OS_CTL_WORDS, reinterpret_cast<u64*>(ctl + OS_CTL_WORDS + 256), reinterpret_cast<u64*>(ctl + OS_CTL_WORDS + 256 + c->os_batch_words), reinterpret_cast<u64*>(c->os_agg), tag, c->wc_sink);
         prof_end(c);
         HIP_TRY(c, hipGetLastError());
         u64* tk = ksrc; ksrc = kdst; kdst = tk;

@@ -506,6 +506,7 @@ static bool cpu_has_avx512vl() { static const bool has = __builtin_cpu_supports(
 static int ps_group(const BlockJob& J)
 {
     if (!J.use_ps || J.nblocks != 8) return 2;
+    if (J.features & BSCGPU_FEATURE_LOW_LATENCY) return 2;             // the caller asked for short tasks (tail of a job)
     const int env = ps_simd_env();
     if (env >= 0) return env == 8 ? 8 : 2;
     return (J.pipelined && cpu_has_avx512vl()) ? 8 : 2;
