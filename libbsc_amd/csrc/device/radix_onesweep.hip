@@ -50,8 +50,8 @@ constexpr int OS_ITEMS = 8, OS_TILE = OS_ST * OS_ITEMS /* 7680 */, OS_GRP = 8 /*
               OS_BATCH = OS_GRP * OS_GPB /* 64 tiles */, OS_MAXP = 8;
 constexpr u32 OS_NONE = 0xffffffffu;
 constexpr u32 OS_SPIN_LIMIT = 1u << 18;
-// LDS: two key staging buffers, per-wave digit counters, five 256-entry tables, scratch
-constexpr int OS_LDS = 2 * OS_TILE * 8 + OS_SW * 256 * 4 + 6 * 256 * 4 + 32 * 4;
+// LDS: two key staging buffers, two sets of per-wave digit tables (counts / prefixes, running counters of the ranking), six 256-entry tables, scratch
+constexpr int OS_LDS = 2 * OS_TILE * 8 + 2 * OS_SW * 256 * 4 + 6 * 256 * 4 + 32 * 4;
 static_assert(OS_LDS <= 160 * 1024, "rs_onesweep does not fit the CU's LDS");
 // per-pass control block (u32 words): [0] next ticket; word [1] of the FIRST pass's block is the error word of the whole sort
 constexpr int OS_CTL_WORDS = 32;
@@ -144,14 +144,15 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     constexpr int WAVES = OS_WAVES, SW = OS_SW, ST = OS_ST, ITEMS = OS_ITEMS, TILE = OS_TILE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* S      = reinterpret_cast<u64*>(smem);                         // [2][TILE] locally reordered keys (then values) of the two tiles in flight
-    u32* whist  = reinterpret_cast<u32*>(smem + 2 * TILE * 8);          // [SW][256]
-    u32* rbase  = whist + SW * 256;                                     // [256] first output position of every digit (prologue only)
+    u32* whist  = reinterpret_cast<u32*>(smem + 2 * TILE * 8);          // [SW][256] per wave: digit counts of the tile, then the wave's exclusive prefixes
+    u32* rcnt   = whist + SW * 256;                                     // [SW][256] per wave: running counters of the in-wave ranking (zero between tiles)
+    u32* rbase  = rcnt + SW * 256;                                     // [256] first output position of every digit (prologue only)
     u32* adj    = rbase + 256;                                          // [2][256] per staging buffer: output position of slot q of digit d = adj[d] + q
     u32* dstart = adj + 512;                                            // [2][256] tile-local start of every digit, per staging buffer
     u32* stot   = dstart + 512;                                         // [256] digit counts of the tile just ranked (for the scout to publish)
     u32* scr    = stot + 256;                                           // [16]
     u32* sclaim = scr + 16;                                             // [1] the ticket drawn at the top of the iteration
-    lds_vu32* vwh = (lds_vu32*)whist;
+    lds_vu32* vrc = (lds_vu32*)rcnt;
 
     const u32 t = threadIdx.x, w = t >> 6, lane = t & 63;
     // The two roles are two separate loops behind a SCALAR branch (the wave number goes through readfirstlane), so neither role's
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     }
     if (!scout) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) whist[w * 256 + i * 64 + lane] = 0;
+        for (int i = 0; i < 4; ++i) { whist[w * 256 + i * 64 + lane] = 0; rcnt[w * 256 + i * 64 + lane] = 0; }
     }
     if (t == (u32)ST) { const u32 tk = OS_ADD(ctl + opaque0, 1u); sclaim[0] = tk < ntiles ? tk : OS_NONE; }
     __syncthreads();
@@ -411,13 +412,16 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             }
         }
         OS_PH(5);
-        // ---- t2: rank inside the waves
+        // ---- t2: its digit counts first, so that the scout can publish it as early as possible (half an iteration earlier than behind
+        //      the ranking: a published row takes microseconds to become visible under streaming load, and the tiles that need it
+        //      ask for it at the top of their next iteration).  Per-wave tables: a wave's lanes only collide with each other.
         if (v2) {
             if (!FULL) {
 #pragma unroll
                 for (int i = 0; i < ITEMS; ++i) if (wbase + i * 64 >= n2) k[i] = ~0ull;          // padding sorts last
             }
-            rs_rank_wave<ITEMS>(k, shift, mask, vwh + w * 256, rk);
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) atomicAdd(&whist[w * 256 + ((u32)(k[i] >> shift) & mask)], 1u);
         }
         OS_PH(6);
         __syncthreads();                                                                          // B1
@@ -440,11 +444,13 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             }
         }
         OS_PH(8);
-        __syncthreads();                                                                          // B3
+        __syncthreads();                                                                          // B3: the scout publishes t2
         OS_PH(9);
         const u32 nn = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);
-        // t2: tile-local reorder of the keys into the staging buffer t0 has left; then the keys of the tile after it are requested
+        // t2: stable rank inside the wave (own running counters), tile-local reorder of the keys into the staging buffer t0 has left;
+        // then the keys of the tile after it are requested.  Wave-local from here to the barrier.
         if (v2) {
+            rs_rank_wave<ITEMS>(k, shift, mask, vrc + w * 256, rk);
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 const u32 d = (u32)(k[i] >> shift) & mask;
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         }
         load_keys(nn);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) whist[w * 256 + i * 64 + lane] = 0;           // own wave's counters, for the next ranking
+        for (int i = 0; i < 4; ++i) { whist[w * 256 + i * 64 + lane] = 0; rcnt[w * 256 + i * 64 + lane] = 0; }       // own wave's tables, for the next tile
         OS_PH(10);
         __syncthreads();                                                                          // B4
 #pragma unroll
