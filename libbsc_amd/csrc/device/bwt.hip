@@ -392,6 +392,32 @@ __global__ __launch_bounds__(WG) void bwt_round_segsort_kernel(const u32* __rest
     }
 }
 
+// The key of a refinement round on text keys: the packed codes of T[p .. p + a) (zero past the end) and, in the low 4 bits,
+// min(n - p, a) — "a proper prefix sorts first" among equal padded keys, 0 for the empty suffix.  lut: byte -> code (LDS or global).
+template <class LUT>
+__device__ __forceinline__ u64 bwt_text_round_key(const u32* __restrict__ T32, LUT lut, u64 p64, u32 n, u32 cb, u32 a)
+{
+    u64 key = 0;
+    if (p64 < n) {
+        const u32 p = (u32)p64, off = p & 3u;
+        const u32* q = T32 + (p >> 2);                  // T is 4-byte aligned at T[0] and zero padded for 32 bytes past n
+        const u32 d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+        const u32 x[4] = { __builtin_amdgcn_alignbyte(d1, d0, off), __builtin_amdgcn_alignbyte(d2, d1, off),
+                           __builtin_amdgcn_alignbyte(d3, d2, off), __builtin_amdgcn_alignbyte(d4, d3, off) };
+        const u32 left = n - p;                          // characters the suffix has
+#pragma unroll
+        for (u32 c = 0; c < 15; ++c) {
+            if (c < a) {
+                const u32 byte = (x[c >> 2] >> (8 * (c & 3))) & 0xffu;
+                const u64 code = (c < left) ? (u64)lut[byte] : 0ull;
+                key |= code << (64 - cb * (c + 1));
+            }
+        }
+        key |= (u64)(left < a ? left : a);
+    }
+    return key;
+}
+
 // ---------------------------------------------------------------------------------------------
 // A refinement round WITHOUT the inverse suffix array.  Prefix doubling orders the suffixes of a group (equal first h
 // characters) by the rank of suffix s + h, which needs ISA — a random 4-byte scatter of n entries after the first sort
@@ -409,8 +435,11 @@ __global__ __launch_bounds__(WG) void bwt_round_segsort_kernel(const u32* __rest
 __global__ __launch_bounds__(WG) void bwt_round_textsort_kernel(const u8* __restrict__ T, const u8* __restrict__ codes,
                                                                 const u32* __restrict__ csa, const u32* __restrict__ cgrp,
                                                                 u32 U, u64 h, u32 n, u32 smask, u32 cb, u32 a,
-                                                                u64* __restrict__ keys_out, u32* __restrict__ vals_out, u32* __restrict__ fallback)
+                                                                u64* __restrict__ keys_out, u32* __restrict__ vals_out, u32* __restrict__ fallback,
+                                                                const u8* __restrict__ subhead = nullptr)
 {
+    // subhead (optional): extra group boundaries inside long groups that bwt_long_* have split by the first characters of this round's
+    // key (see there): a record with subhead[k] != 0 starts a group of its own although its group rank equals its left neighbour's
     __shared__ u64 snext[RS_E];                  // first (as u32) the group ranks for the head flags, then the round keys
     __shared__ short sgs[RS_E];
     __shared__ short sge[RS_E];
@@ -433,7 +462,11 @@ __global__ __launch_bounds__(WG) void bwt_round_textsort_kernel(const u8* __rest
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const u32 i = i0 + q;
-        if (i < ext) { const bool head = (i == 0) ? (sgrp[0] != prevg) : (sgrp[i] != sgrp[i - 1]); if (head) { last_head = (int)i; hmask |= 1u << q; } }
+        if (i < ext) {
+            bool head = (i == 0) ? (sgrp[0] != prevg) : (sgrp[i] != sgrp[i - 1]);
+            if (subhead != nullptr && subhead[base + i]) head = true;
+            if (head) { last_head = (int)i; hmask |= 1u << q; }
+        }
     }
     u32 totmax;
     const u32 incl = block_incl_max((u32)(last_head + 1), scr, &totmax);
@@ -451,7 +484,7 @@ __global__ __launch_bounds__(WG) void bwt_round_textsort_kernel(const u8* __rest
     __syncthreads();
     if (t == 0 && base + ext < U) {
         const int gs = sgs[ext - 1];
-        if (gs >= 0 && (u32)gs < own && cgrp[base + ext] == sgrp[ext - 1]) atomicOr(fallback, 1u);
+        if (gs >= 0 && (u32)gs < own && cgrp[base + ext] == sgrp[ext - 1] && !(subhead != nullptr && subhead[base + ext])) atomicOr(fallback, 1u);
     }
     __syncthreads();
     // the round's keys, from the text (overwrites the group ranks in LDS)
@@ -459,26 +492,7 @@ __global__ __launch_bounds__(WG) void bwt_round_textsort_kernel(const u8* __rest
     for (u32 i = t; i < ext; i += WG) {
         const int gs = sgs[i];
         u64 key = 0;
-        if (gs >= 0 && (u32)gs < own) {
-            const u64 p64 = (u64)(csa[base + i] & smask) + h;
-            if (p64 < n) {
-                const u32 p = (u32)p64, off = p & 3u;
-                const u32* q = T32 + (p >> 2);                  // T is 4-byte aligned at T[0] and zero padded for 32 bytes past n
-                const u32 d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
-                const u32 x[4] = { __builtin_amdgcn_alignbyte(d1, d0, off), __builtin_amdgcn_alignbyte(d2, d1, off),
-                                   __builtin_amdgcn_alignbyte(d3, d2, off), __builtin_amdgcn_alignbyte(d4, d3, off) };
-                const u32 left = n - p;                          // characters the suffix has
-#pragma unroll
-                for (u32 c = 0; c < 15; ++c) {
-                    if (c < a) {
-                        const u32 byte = (x[c >> 2] >> (8 * (c & 3))) & 0xffu;
-                        const u64 code = (c < left) ? (u64)lut[byte] : 0ull;
-                        key |= code << (64 - cb * (c + 1));
-                    }
-                }
-                key |= (u64)(left < a ? left : a);
-            }
-        }
+        if (gs >= 0 && (u32)gs < own) key = bwt_text_round_key(T32, lut, (u64)(csa[base + i] & smask) + h, n, cb, a);
         snext[i] = key;
     }
     __syncthreads();
@@ -492,6 +506,96 @@ __global__ __launch_bounds__(WG) void bwt_round_textsort_kernel(const u8* __rest
         const u64 dst = base + (u32)gs + r;
         keys_out[dst] = mine;
         vals_out[dst] = csa[base + i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Groups longer than one workgroup sorts (RS_G records).  cub::DeviceSegmentedSort (libcubwt.cu:1691) takes segments of any
+// length; bwt_round_textsort_kernel does not, and used to hand the WHOLE round over to prefix doubling as soon as one such group
+// existed (w = 11 characters on the bench text: 318 long groups, BWT 6.7 -> 14.3 ms).  Now the long groups — and only they — are
+// first split by the top LG_BITS bits of this round's key (the first two characters of a text) with a counting sort per group:
+//   bwt_long_heads    every record knows where its group starts (its SA slot minus its group rank) and whether the group is long
+//                     (the record RS_G places behind the head still has the head's rank); heads of long groups draw a dense id
+//   bwt_long_count    histogram of the key's top bits per long group (global atomics: the long groups' records are few)
+//   bwt_long_scan     one workgroup per long group: exclusive scan of its 1024 counts, sub-group heads marked at bucket starts
+//   bwt_long_scatter  records of long groups move to their bucket (any order inside a bucket: they are about to be sorted by
+//                     the full key), all others are copied through
+// and the round's segmented sort runs again with the bucket starts as additional group boundaries.  Buckets are almost always short
+// enough; if one is not (a long repeat: thousands of suffixes that agree far beyond the key), or there are more than LG_MAX long
+// groups, the round is handed over to prefix doubling as before — the right tool for that shape.
+// ---------------------------------------------------------------------------------------------
+constexpr u32 LG_BITS = 10, LG_BUCKETS = 1u << LG_BITS, LG_MAX = 4096;
+struct LongTables { u32* nlong; u32* khead; u32* cnt; };        // [1], [LG_MAX], [LG_MAX][LG_BUCKETS]
+
+__device__ __forceinline__ bool bwt_group_is_long(const u32* __restrict__ cpos, const u32* __restrict__ cgrp, u32 U, u32 k, u32* kh_out)
+{
+    const u32 g = cgrp[k], kh = k - (cpos[k] - g);                                  // members of a group are contiguous, in SA order
+    *kh_out = kh;
+    return kh + (u32)RS_G < U && cgrp[kh + RS_G] == g;
+}
+
+__global__ __launch_bounds__(WG) void bwt_long_heads_kernel(const u32* __restrict__ cpos, const u32* __restrict__ cgrp, u32 U, LongTables L, u32* __restrict__ lgid)
+{
+    const u32 stride = gridDim.x * WG;
+    for (u32 k = blockIdx.x * WG + threadIdx.x; k < U; k += stride) {
+        u32 kh;
+        if (bwt_group_is_long(cpos, cgrp, U, k, &kh) && kh == k) {
+            const u32 id = atomicAdd(L.nlong, 1u);
+            lgid[k] = id;
+            if (id < LG_MAX) L.khead[id] = k;
+        }
+    }
+}
+
+__global__ __launch_bounds__(WG) void bwt_long_count_kernel(const u8* __restrict__ T, const u8* __restrict__ codes, const u32* __restrict__ csa,
+                                                            const u32* __restrict__ cpos, const u32* __restrict__ cgrp, u32 U, u64 h, u32 n, u32 smask, u32 cb, u32 a,
+                                                            LongTables L, const u32* __restrict__ lgid)
+{
+    if (*L.nlong == 0u || *L.nlong > LG_MAX) return;
+    const u32* T32 = reinterpret_cast<const u32*>(T);
+    const u32 stride = gridDim.x * WG;
+    for (u32 k = blockIdx.x * WG + threadIdx.x; k < U; k += stride) {
+        u32 kh;
+        if (!bwt_group_is_long(cpos, cgrp, U, k, &kh)) continue;
+        const u64 key = bwt_text_round_key(T32, codes, (u64)(csa[k] & smask) + h, n, cb, a);
+        atomicAdd(&L.cnt[(size_t)lgid[kh] * LG_BUCKETS + (u32)(key >> (64 - LG_BITS))], 1u);
+    }
+}
+
+__global__ __launch_bounds__(WG) void bwt_long_scan_kernel(LongTables L, u8* __restrict__ subhead)
+{
+    __shared__ u32 scr[8];
+    const u32 nl = *L.nlong;
+    if (nl > LG_MAX || blockIdx.x >= nl) return;
+    u32* row = L.cnt + (size_t)blockIdx.x * LG_BUCKETS;
+    const u32 kh = L.khead[blockIdx.x];
+    u32 c[LG_BUCKETS / WG], sum = 0;
+#pragma unroll
+    for (u32 q = 0; q < LG_BUCKETS / WG; ++q) { c[q] = row[threadIdx.x * (LG_BUCKETS / WG) + q]; sum += c[q]; }
+    u32 tot;
+    u32 run = block_excl_sum(sum, scr, &tot);
+#pragma unroll
+    for (u32 q = 0; q < LG_BUCKETS / WG; ++q) {
+        row[threadIdx.x * (LG_BUCKETS / WG) + q] = run;                           // becomes the bucket's cursor
+        if (c[q]) subhead[kh + run] = 1;
+        run += c[q];
+    }
+}
+
+__global__ __launch_bounds__(WG) void bwt_long_scatter_kernel(const u8* __restrict__ T, const u8* __restrict__ codes, const u32* __restrict__ csa,
+                                                              const u32* __restrict__ cpos, const u32* __restrict__ cgrp, u32 U, u64 h, u32 n, u32 smask, u32 cb, u32 a,
+                                                              LongTables L, const u32* __restrict__ lgid, u32* __restrict__ csa_out)
+{
+    if (*L.nlong == 0u || *L.nlong > LG_MAX) return;
+    const u32* T32 = reinterpret_cast<const u32*>(T);
+    const u32 stride = gridDim.x * WG;
+    for (u32 k = blockIdx.x * WG + threadIdx.x; k < U; k += stride) {
+        u32 kh;
+        const u32 s = csa[k];
+        if (!bwt_group_is_long(cpos, cgrp, U, k, &kh)) { csa_out[k] = s; continue; }
+        const u64 key = bwt_text_round_key(T32, codes, (u64)(s & smask) + h, n, cb, a);
+        const u32 slot = atomicAdd(&L.cnt[(size_t)lgid[kh] * LG_BUCKETS + (u32)(key >> (64 - LG_BITS))], 1u);
+        csa_out[kh + slot] = s;
     }
 }
 
@@ -700,6 +804,37 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
             HIP_TRY(c, hipMemcpyAsync(c->hscal + 2, c->dscal + 2, 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, ctx_sync(c));
             prof_collect(c);
+            static const int long_split_on = [] { const char* e = getenv("BSC_BWT_LONGSPLIT"); return e ? atoi(e) : 1; }();
+            if (c->hscal[2] != 0 && long_split_on && U > (u32)RS_G) {
+                // a group is too long for one workgroup: split the long groups by the top bits of the round's key and sort again
+                // (tables in kA, free since the first seg; group ids in ISA, unused on this path; the permuted suffixes in csa[cur ^ 1])
+                LongTables LT;
+                LT.nlong = reinterpret_cast<u32*>(c->kA); LT.khead = LT.nlong + 64; LT.cnt = LT.khead + LG_MAX;
+                if ((size_t)c->max_n * 8 >= (size_t)(64 + LG_MAX + (size_t)LG_MAX * LG_BUCKETS) * 4) {
+                    u8* subhead = c->flags;
+                    HIP_TRY(c, hipMemsetAsync(LT.nlong, 0, (size_t)(64 + LG_MAX + (size_t)LG_MAX * LG_BUCKETS) * 4, c->stream));
+                    HIP_TRY(c, hipMemsetAsync(subhead, 0, (size_t)U + 1, c->stream));
+                    HIP_TRY(c, hipMemsetAsync(c->dscal + 2, 0, 4, c->stream));
+                    u32 blocks = (U + WG - 1) / WG; if (blocks > 4096) blocks = 4096;
+                    prof_begin(c, BSCGPU_K_GATHER, (u64)U * (8 + 4 + 16 + 4) * 2, U);
+                    hipLaunchKernelGGL(bwt_long_heads_kernel, dim3(blocks), dim3(WG), 0, c->stream, c->cpos[cur], c->cgrp[cur], U, LT, c->ISA);
+                    hipLaunchKernelGGL(bwt_long_count_kernel, dim3(blocks), dim3(WG), 0, c->stream, c->dT, dcodes, c->csa[cur], c->cpos[cur], c->cgrp[cur],
+                                       U, h, n, smask, pp.cb, ta, LT, c->ISA);
+                    hipLaunchKernelGGL(bwt_long_scan_kernel, dim3(LG_MAX), dim3(WG), 0, c->stream, LT, subhead);
+                    hipLaunchKernelGGL(bwt_long_scatter_kernel, dim3(blocks), dim3(WG), 0, c->stream, c->dT, dcodes, c->csa[cur], c->cpos[cur], c->cgrp[cur],
+                                       U, h, n, smask, pp.cb, ta, LT, c->ISA, c->csa[cur ^ 1]);
+                    hipLaunchKernelGGL(bwt_round_textsort_kernel, dim3((U + RS_T - 1) / RS_T), dim3(WG), 0, c->stream,
+                                       c->dT, dcodes, c->csa[cur ^ 1], c->cgrp[cur], U, h, n, smask, pp.cb, ta, c->kB, c->vB, c->dscal + 2, subhead);
+                    prof_end(c);
+                    HIP_TRY(c, hipMemcpyAsync(c->hscal + 2, c->dscal + 2, 4, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipMemcpyAsync(c->hscal + 3, LT.nlong, 4, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, ctx_sync(c));
+                    prof_collect(c);
+                    if (c->hscal[3] > LG_MAX) c->hscal[2] = 1;                     // too many long groups for the tables: nothing was moved
+                    if (dbg) fprintf(stderr, "[bwt] text round %d: %u long group(s) split by %u key bits -> %s\n", rounds, c->hscal[3], LG_BITS,
+                                     c->hscal[2] == 0 ? "sorted" : "a bucket is still too long");
+                }
+            }
             if (c->hscal[2] == 0) {
                 u32 U2 = 0;
                 rc = run_seg<false, false>(c, c->kB, c->vB, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2, SA, c->cgrp[cur]);

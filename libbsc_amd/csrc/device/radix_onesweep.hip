@@ -50,8 +50,8 @@ constexpr int OS_ITEMS = 8, OS_TILE = OS_ST * OS_ITEMS /* 7680 */, OS_GRP = 8 /*
               OS_BATCH = OS_GRP * OS_GPB /* 64 tiles */, OS_MAXP = 8;
 constexpr u32 OS_NONE = 0xffffffffu;
 constexpr u32 OS_SPIN_LIMIT = 1u << 18;
-// LDS: two key staging buffers, two sets of per-wave digit tables (counts / prefixes, running counters of the ranking), six 256-entry tables, scratch
-constexpr int OS_LDS = 2 * OS_TILE * 8 + 2 * OS_SW * 256 * 4 + 6 * 256 * 4 + 32 * 4;
+// LDS: two key staging buffers, per-wave digit counters, five 256-entry tables, scratch
+constexpr int OS_LDS = 2 * OS_TILE * 8 + OS_SW * 256 * 4 + 6 * 256 * 4 + 32 * 4;
 static_assert(OS_LDS <= 160 * 1024, "rs_onesweep does not fit the CU's LDS");
 // per-pass control block (u32 words): [0] next ticket; word [1] of the FIRST pass's block is the error word of the whole sort
 constexpr int OS_CTL_WORDS = 32;
@@ -144,15 +144,14 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     constexpr int WAVES = OS_WAVES, SW = OS_SW, ST = OS_ST, ITEMS = OS_ITEMS, TILE = OS_TILE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* S      = reinterpret_cast<u64*>(smem);                         // [2][TILE] locally reordered keys (then values) of the two tiles in flight
-    u32* whist  = reinterpret_cast<u32*>(smem + 2 * TILE * 8);          // [SW][256] per wave: digit counts of the tile, then the wave's exclusive prefixes
-    u32* rcnt   = whist + SW * 256;                                     // [SW][256] per wave: running counters of the in-wave ranking (zero between tiles)
-    u32* rbase  = rcnt + SW * 256;                                     // [256] first output position of every digit (prologue only)
+    u32* whist  = reinterpret_cast<u32*>(smem + 2 * TILE * 8);          // [SW][256]
+    u32* rbase  = whist + SW * 256;                                     // [256] first output position of every digit (prologue only)
     u32* adj    = rbase + 256;                                          // [2][256] per staging buffer: output position of slot q of digit d = adj[d] + q
     u32* dstart = adj + 512;                                            // [2][256] tile-local start of every digit, per staging buffer
     u32* stot   = dstart + 512;                                         // [256] digit counts of the tile just ranked (for the scout to publish)
     u32* scr    = stot + 256;                                           // [16]
     u32* sclaim = scr + 16;                                             // [1] the ticket drawn at the top of the iteration
-    lds_vu32* vrc = (lds_vu32*)rcnt;
+    lds_vu32* vwh = (lds_vu32*)whist;
 
     const u32 t = threadIdx.x, w = t >> 6, lane = t & 63;
     // The two roles are two separate loops behind a SCALAR branch (the wave number goes through readfirstlane), so neither role's
@@ -170,7 +169,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     }
     if (!scout) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { whist[w * 256 + i * 64 + lane] = 0; rcnt[w * 256 + i * 64 + lane] = 0; }
+        for (int i = 0; i < 4; ++i) whist[w * 256 + i * 64 + lane] = 0;
     }
     if (t == (u32)ST) { const u32 tk = OS_ADD(ctl + opaque0, 1u); sclaim[0] = tk < ntiles ? tk : OS_NONE; }
     __syncthreads();
@@ -214,8 +213,8 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             // Ticket for the tile after t2, and every look-back load for t1 — the tile rows of its group below it (<= 7), the group rows
             // of its batch below its group (<= 7), the batch rows not yet in the running sum (a workgroup's next tile is ~256 tiles =
             // 4 or 5 batches further on; 6 are requested, more are fetched one by one) —, all in flight from the top of the
-            // iteration.  Batch and group rows are summed behind barrier 1 (the scout is idle there), the tile rows, which are the
-            // freshest, in front of the iteration's last barrier.
+            // iteration and looked at in front of its last barrier; between the barriers the scout does nothing that could hold the
+            // streaming waves up.
             u32 ticket = 0;
             if (more && lane == 0) ticket = OS_ADD(ctl + opaque0, 1u);        // ONE lane draws
             u64 a1[OS_GRP - 1], g1[OS_GPB - 1][2], b1[6][2];
@@ -240,41 +239,6 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                 __syncthreads();                                                                  // B6
             }
             __syncthreads();                                                                      // B1
-            bool ok = true;
-            u32 sg[4] = {0, 0, 0, 0};                                   // counts of the complete groups of t1's batch below its group
-            auto add_row = [&](u32 (&acc)[4], const u64 y0, const u64 y1) __attribute__((always_inline)) {
-                acc[0] += (u32)(y0 & OS_M28); acc[1] += (u32)((y0 >> 28) & OS_M28);
-                acc[2] += (u32)(y1 & OS_M28); acc[3] += (u32)((y1 >> 28) & OS_M28);
-            };
-            if (v1 && !(OS_ABL & 1)) {
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    const u32 gg = gbase + q;
-                    if (gg < cG) {
-                        u64 y0 = b1[q][0], y1 = b1[q][1];
-                        const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
-                        if ((y0 >> 56) != (u64)OS_BATCH) y0 = poll(p, ~0ull << 56, (u64)OS_BATCH << 56, ok);
-                        if ((y1 >> 56) != (u64)OS_BATCH) y1 = poll(p + 1, ~0ull << 56, (u64)OS_BATCH << 56, ok);
-                        add_row(R, y0, y1);
-                    }
-                }
-                for (u32 gg = gbase + 6u; gg < cG; ++gg) {              // a workgroup that fell behind (or has just started)
-                    const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
-                    const u64 y0 = poll(p, ~0ull << 56, (u64)OS_BATCH << 56, ok), y1 = poll(p + 1, ~0ull << 56, (u64)OS_BATCH << 56, ok);
-                    add_row(R, y0, y1);
-                }
-#pragma unroll
-                for (int q = 0; q < OS_GPB - 1; ++q) {
-                    if ((u32)q < cg) {
-                        u64 y0 = g1[q][0], y1 = g1[q][1];
-                        const u64* p = &gagg[(size_t)(grp0 + q) * 128 + 2 * lane];
-                        if ((y0 >> 56) != (u64)OS_GRP) y0 = poll(p, ~0ull << 56, (u64)OS_GRP << 56, ok);
-                        if ((y1 >> 56) != (u64)OS_GRP) y1 = poll(p + 1, ~0ull << 56, (u64)OS_GRP << 56, ok);
-                        add_row(sg, y0, y1);
-                    }
-                }
-            }
-            if (v1) gbase = cG;
             if (v2) __syncthreads();                                                              // B2 (the streaming waves' digit scan)
             if (lane == 0) sclaim[0] = (more && ticket < ntiles) ? ticket : OS_NONE;
             OS_PH(2);
@@ -282,13 +246,17 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             OS_PH(3);
             const u32 nn = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);
             if (nn == OS_NONE) more = false;
-            // The tile rows were requested most of an iteration ago: make the wave wait for them HERE, before the
-            // publishing store and atomics below are in the queue.  vmcnt is an in-order counter and the compiler cannot count across
-            // the poll loops above, so the first use of a row further down would otherwise be preceded by s_waitcnt vmcnt(0) — i.e.
-            // by the write-through latency of this tile's own publication (~3 us, measured on the critical path).
+            // The rows were requested most of an iteration ago: make the wave wait for them HERE, before the publishing store and atomics
+            // below are in the queue.  vmcnt is an in-order counter and the compiler cannot count across loops, so the first use of a
+            // row further down would otherwise be preceded by s_waitcnt vmcnt(0) — i.e. by the write-through latency of this tile's
+            // own publication (~3 us, measured on the critical path).
             if (!(OS_ABL & 1)) {
 #pragma unroll
                 for (int q = 0; q < OS_GRP - 1; ++q) asm volatile("" : "+v"(a1[q]));
+#pragma unroll
+                for (int q = 0; q < OS_GPB - 1; ++q) asm volatile("" : "+v"(g1[q][0]), "+v"(g1[q][1]));
+#pragma unroll
+                for (int q = 0; q < 6; ++q) asm volatile("" : "+v"(b1[q][0]), "+v"(b1[q][1]));
             }
             // publish t2: its row, and its counts into its group's and its batch's rows.  (The data words stay live — the empty asm at
             // the end of the iteration — so that their registers are not handed to the arithmetic below: on gfx950 a store's data
@@ -307,19 +275,57 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                 (void)OS_ADD(pb, pub1);
                 (void)OS_ADD(pb + 1, pub2);
             }
-            // offsets of t1 (it sits in staging buffer x ^ 1): + the tile rows of its group below it, as packed 16-bit sums
+            // offsets of t1 (it sits in staging buffer x ^ 1)
+            bool ok = true;
             if (v1) {
-                u32 plo = 0, phi = 0;
+                u32 sg[4] = {0, 0, 0, 0};                               // counts of the complete groups of t1's batch below its group
+                u32 plo = 0, phi = 0;                                   // counts of the tiles of its group below it, packed 16-bit halves
+                auto add_row = [&](u32 (&acc)[4], const u64 y0, const u64 y1) __attribute__((always_inline)) {
+                    acc[0] += (u32)(y0 & OS_M28); acc[1] += (u32)((y0 >> 28) & OS_M28);
+                    acc[2] += (u32)(y1 & OS_M28); acc[3] += (u32)((y1 >> 28) & OS_M28);
+                };
                 if (!(OS_ABL & 1)) {
+                    // Rows that were not there yet (published less than a visibility latency before they were asked for) are asked for
+                    // again ALL AT ONCE: one more round trip, however many they are.  Wave-uniform mask: bits 0.. tile rows, 8.. group
+                    // rows, 16.. batch rows.
+                    auto missing_rows = [&]() __attribute__((always_inline)) -> u32 {
+                        u32 m = 0;
 #pragma unroll
-                    for (int q = 0; q < OS_GRP - 1; ++q) {
-                        if ((u32)q < cj) {
-                            u64 y = a1[q];
-                            if ((y & OS_TAGBITS) != tagpat) y = poll(&agg[(size_t)(t1 - cj + q) * 64 + lane], OS_TAGBITS, tagpat, ok);
-                            plo += (u32)y & 0x3fff3fffu; phi += (u32)(y >> 32) & 0x3fff3fffu;     // 7 x 7680 < 2^16: no carry between the halves
-                        }
+                        for (int q = 0; q < OS_GRP - 1; ++q) if ((u32)q < cj && __ballot((a1[q] & OS_TAGBITS) != tagpat)) m |= 1u << q;
+#pragma unroll
+                        for (int q = 0; q < OS_GPB - 1; ++q) if ((u32)q < cg && __ballot((g1[q][0] >> 56) != (u64)OS_GRP || (g1[q][1] >> 56) != (u64)OS_GRP)) m |= 1u << (8 + q);
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) if (gbase + q < cG && __ballot((b1[q][0] >> 56) != (u64)OS_BATCH || (b1[q][1] >> 56) != (u64)OS_BATCH)) m |= 1u << (16 + q);
+                        return m;
+                    };
+                    u32 missing = missing_rows(), tries = 0;
+                    while (missing != 0u && ok) {
+                        __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+                        for (int q = 0; q < OS_GRP - 1; ++q) if (missing & (1u << q)) a1[q] = OS_LOAD(&agg[(size_t)(t1 - cj + q) * 64 + lane]);
+#pragma unroll
+                        for (int q = 0; q < OS_GPB - 1; ++q) if (missing & (1u << (8 + q))) { const u64* p = &gagg[(size_t)(grp0 + q) * 128 + 2 * lane]; g1[q][0] = OS_LOAD(p); g1[q][1] = OS_LOAD(p + 1); }
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) if (missing & (1u << (16 + q))) { const u64* p = &bagg[(size_t)(gbase + q) * 128 + 2 * lane]; b1[q][0] = OS_LOAD(p); b1[q][1] = OS_LOAD(p + 1); }
+                        missing = missing_rows();
+                        if (++tries > (OS_SPIN_LIMIT >> 4) || ((tries & 63u) == 0u && OS_LOAD(err) != 0u)) ok = false;
                     }
+#if OS_PHASE_TIMING
+                    npolls += tries;
+#endif
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) if (gbase + q < cG) add_row(R, b1[q][0], b1[q][1]);
+                    for (u32 gg = gbase + 6u; gg < cG; ++gg) {          // a workgroup that fell behind (or has just started)
+                        const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
+                        const u64 y0 = poll(p, ~0ull << 56, (u64)OS_BATCH << 56, ok), y1 = poll(p + 1, ~0ull << 56, (u64)OS_BATCH << 56, ok);
+                        add_row(R, y0, y1);
+                    }
+#pragma unroll
+                    for (int q = 0; q < OS_GPB - 1; ++q) if ((u32)q < cg) add_row(sg, g1[q][0], g1[q][1]);
+#pragma unroll
+                    for (int q = 0; q < OS_GRP - 1; ++q) if ((u32)q < cj) { plo += (u32)a1[q] & 0x3fff3fffu; phi += (u32)(a1[q] >> 32) & 0x3fff3fffu; }     // 7 x 7680 < 2^16: no carry
                 }
+                gbase = cG;
                 const uint4 d4 = *reinterpret_cast<const uint4*>(dstart + (x ^ 1u) * 256 + 4 * lane);
                 uint4 o;
                 o.x = R[0] + sg[0] + (plo & 0xffffu) - d4.x; o.y = R[1] + sg[1] + (plo >> 16) - d4.y;
@@ -412,16 +418,13 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             }
         }
         OS_PH(5);
-        // ---- t2: its digit counts first, so that the scout can publish it as early as possible (half an iteration earlier than behind
-        //      the ranking: a published row takes microseconds to become visible under streaming load, and the tiles that need it
-        //      ask for it at the top of their next iteration).  Per-wave tables: a wave's lanes only collide with each other.
+        // ---- t2: rank inside the waves
         if (v2) {
             if (!FULL) {
 #pragma unroll
                 for (int i = 0; i < ITEMS; ++i) if (wbase + i * 64 >= n2) k[i] = ~0ull;          // padding sorts last
             }
-#pragma unroll
-            for (int i = 0; i < ITEMS; ++i) atomicAdd(&whist[w * 256 + ((u32)(k[i] >> shift) & mask)], 1u);
+            rs_rank_wave<ITEMS>(k, shift, mask, vwh + w * 256, rk);
         }
         OS_PH(6);
         __syncthreads();                                                                          // B1
@@ -444,13 +447,11 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             }
         }
         OS_PH(8);
-        __syncthreads();                                                                          // B3: the scout publishes t2
+        __syncthreads();                                                                          // B3
         OS_PH(9);
         const u32 nn = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);
-        // t2: stable rank inside the wave (own running counters), tile-local reorder of the keys into the staging buffer t0 has left;
-        // then the keys of the tile after it are requested.  Wave-local from here to the barrier.
+        // t2: tile-local reorder of the keys into the staging buffer t0 has left; then the keys of the tile after it are requested
         if (v2) {
-            rs_rank_wave<ITEMS>(k, shift, mask, vrc + w * 256, rk);
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 const u32 d = (u32)(k[i] >> shift) & mask;
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         }
         load_keys(nn);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { whist[w * 256 + i * 64 + lane] = 0; rcnt[w * 256 + i * 64 + lane] = 0; }       // own wave's tables, for the next tile
+        for (int i = 0; i < 4; ++i) whist[w * 256 + i * 64 + lane] = 0;           // own wave's counters, for the next ranking
         OS_PH(10);
         __syncthreads();                                                                          // B4
 #pragma unroll
