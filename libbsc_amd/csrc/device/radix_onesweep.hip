@@ -258,6 +258,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
 #pragma unroll
                 for (int q = 0; q < 6; ++q) asm volatile("" : "+v"(b1[q][0]), "+v"(b1[q][1]));
             }
+            OS_PH(5);
             // publish t2: its row, and its counts into its group's and its batch's rows.  (The data words stay live — the empty asm at
             // the end of the iteration — so that their registers are not handed to the arithmetic below: on gfx950 a store's data
             // registers may be read late, and overwriting them is preceded by a wait for the store itself.)
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                 (void)OS_ADD(pb, pub1);
                 (void)OS_ADD(pb + 1, pub2);
             }
+            OS_PH(6);
             // offsets of t1 (it sits in staging buffer x ^ 1)
             bool ok = true;
             if (v1) {
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                         return m;
                     };
                     u32 missing = missing_rows(), tries = 0;
+                    OS_PH(7);
                     while (missing != 0u && ok) {
                         __builtin_amdgcn_s_sleep(8);
 #pragma unroll
@@ -313,6 +316,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
 #if OS_PHASE_TIMING
                     npolls += tries;
 #endif
+                    OS_PH(8);
 #pragma unroll
                     for (int q = 0; q < 6; ++q) if (gbase + q < cG) add_row(R, b1[q][0], b1[q][1]);
                     for (u32 gg = gbase + 6u; gg < cG; ++gg) {          // a workgroup that fell behind (or has just started)

@@ -326,6 +326,7 @@ struct BlockJob {
     HostSlot* slot = nullptr;        // pinned landing zones of this block (owned by the context)
     // device-side static model (devcoder.hip): the host codes from a probability stream instead of run arrays
     bool pipelined = false;        // submitted through a pipe (several blocks in flight): throughput over latency
+    int  pipe_workers = 0;         // coder threads of that pipe (0: a synchronous call, which starts its own threads)
     bool use_ps = false; const uint16_t* ps = nullptr; u32 poff[9]; u32 ndec = 0; int sorter = 0;
     hipEvent_t ps_ready = nullptr;   // the p stream's copy to the host (copy stream); coder tasks wait on it
     std::atomic<bool> redo{false};   // a sub-block did not compress: the block goes through the host model again (raw sub-blocks need the run arrays)
@@ -491,8 +492,9 @@ static void host_encode_pair(BlockJob& J, int b)
 // AVX-512VL 0.118 (one task of ~0.09 s), with AVX2 0.141 (~0.115 s).  Half the CPU time, not quite twice the latency: a pipe needs
 // three blocks in flight per context instead of two to keep the GPU busy, and then moves the same MB/s.
 //   BSC_RC_SIMD=8 / 0   eight lanes / pairs everywhere
-//   unset               eight lanes for pipelined blocks (bscgpu_pipe_*) on CPUs with AVX-512VL, pairs otherwise and for the
-//                       synchronous entry points (one block at a time: latency counts)
+//   unset               eight lanes for pipelined blocks (bscgpu_pipe_*) on CPUs with AVX-512VL, pairs otherwise; the synchronous entry
+//                       points and blocks submitted with BSCGPU_FEATURE_LOW_LATENCY (one block at a time / the tail of a job: latency
+//                       counts) take one scalar coder per task where the process has eight CPUs, else pairs
 static int ps_simd_env()
 {
     static const int mode = [] {
@@ -502,20 +504,25 @@ static int ps_simd_env()
     }();
     return mode;
 }
+static int default_coder_threads();
 static bool cpu_has_avx512vl() { static const bool has = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl"); return has; }
 static int ps_group(const BlockJob& J)
 {
     if (!J.use_ps || J.nblocks != 8) return 2;
-    if (J.features & BSCGPU_FEATURE_LOW_LATENCY) return 2;             // the caller asked for short tasks (tail of a job)
     const int env = ps_simd_env();
-    if (env >= 0) return env == 8 ? 8 : 2;
-    return (J.pipelined && cpu_has_avx512vl()) ? 8 : 2;
+    // latency first (a synchronous call, or the caller marked the tail of a job): one scalar coder per task where the process has a
+    // CPU for each of the eight (44 ms per 8 MiB sub-block on an EPYC 9575F against 52 ms for an interleaved pair), else pairs
+    const bool latency = (J.features & BSCGPU_FEATURE_LOW_LATENCY) || !J.pipelined;
+    if (env >= 0) return env == 8 ? 8 : 2;                            // BSC_RC_SIMD forces eight lanes / pairs everywhere
+    if (latency) { static const int cpus = default_coder_threads(); return (J.pipe_workers ? J.pipe_workers : cpus) >= 8 ? 1 : 2; }
+    return cpu_has_avx512vl() ? 8 : 2;
 }
 // sub-blocks b .. b + g - 1 of a device-model block, g = ps_group(J)
 static void host_encode_group(BlockJob& J, int b)
 {
     const int g = ps_group(J);
     if (g == 2) { host_encode_pair(J, b); return; }
+    if (g == 1) { host_encode_sub(J, b); return; }
     PstreamJob P[8];
     for (int k = 0; k < g; ++k) {
         const int q = b + k;
@@ -887,6 +894,7 @@ static int pipe_enqueue(bscgpu_pipe* p, bscgpu_pipe::Lane& L, int ticket)
     BlockJob& J = *L.job;
     L.ticket = ticket; L.busy = true;
     J.pipelined = p->depth >= 3;
+    J.pipe_workers = (int)p->workers.size();
     {
         std::lock_guard<std::mutex> lk(p->mu);
         if (job_uses_tasks(J)) {

@@ -15,6 +15,7 @@ from libbsc_amd.synth import synth_text_v1, synth_repeat_v1
 from oracle.refbind import Ref
 
 n = (int(sys.argv[1]) if len(sys.argv) > 1 else 64) << 20
+only = sys.argv[2] if len(sys.argv) > 2 else None          # one class only (with BSCGPU_DEBUG=1: the sorter's round-by-round trace)
 
 
 def from_files(patterns, n):
@@ -56,12 +57,14 @@ out = torch.empty(n, dtype=torch.uint8, device="cuda")
 base_ms = None
 print(f"{'class':16s} {'ms':>8s} {'x synth':>8s} {'rounds':>6s} {'GB/s':>6s}  parity   (distinct bytes)")
 for name, T in classes:
+    if only and name != only and name != "synth-text v1":
+        continue
     if T is None:
         print(f"{name:16s} (no source files in this image)"); continue
     d = torch.from_numpy(T).cuda()
     r = 1 << ((n // 8).bit_length() - 1)
     best = None
-    for rep in range(3):
+    for rep in range(1 if (only and os.environ.get("BSCGPU_DEBUG")) else 3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         idx, I = ctx.bwt_device(d, out, n, aux_rate=r)
         dt = time.perf_counter() - t0
