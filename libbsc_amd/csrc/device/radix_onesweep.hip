@@ -51,7 +51,7 @@ constexpr int OS_ITEMS = 8, OS_TILE = OS_ST * OS_ITEMS /* 7680 */, OS_GRP = 8 /*
 constexpr u32 OS_NONE = 0xffffffffu;
 constexpr u32 OS_SPIN_LIMIT = 1u << 18;
 // LDS: two key staging buffers, per-wave digit counters, five 256-entry tables, scratch
-constexpr int OS_LDS = 2 * OS_TILE * 8 + OS_SW * 256 * 4 + 6 * 256 * 4 + 32 * 4;
+constexpr int OS_LDS = 2 * OS_TILE * 8 + OS_SW * 256 * 4 + 5 * 256 * 4 + 32 * 4;
 static_assert(OS_LDS <= 160 * 1024, "rs_onesweep does not fit the CU's LDS");
 // per-pass control block (u32 words): [0] next ticket; word [1] of the FIRST pass's block is the error word of the whole sort
 constexpr int OS_CTL_WORDS = 32;
@@ -148,8 +148,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     u32* rbase  = whist + SW * 256;                                     // [256] first output position of every digit (prologue only)
     u32* adj    = rbase + 256;                                          // [2][256] per staging buffer: output position of slot q of digit d = adj[d] + q
     u32* dstart = adj + 512;                                            // [2][256] tile-local start of every digit, per staging buffer
-    u32* stot   = dstart + 512;                                         // [256] digit counts of the tile just ranked (for the scout to publish)
-    u32* scr    = stot + 256;                                           // [16]
+    u32* scr    = dstart + 512;                                         // [16]
     u32* sclaim = scr + 16;                                             // [1] the ticket drawn at the top of the iteration
     lds_vu32* vwh = (lds_vu32*)whist;
 
@@ -185,6 +184,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         // =========================================================================================================
         // The scout wave.  Lane l owns digits 4l .. 4l+3.
         // =========================================================================================================
+        __builtin_amdgcn_s_setprio(3);                                  // one wave among sixteen, and the others wait for what it computes
         u32 gbase = 0;                                                  // batches [0, gbase) are in R
         u32 npolls = 0; (void)npolls;
         u32 R[4];                                                       // digit base + counts of all complete batches accounted so far
@@ -210,13 +210,20 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             const u32 cj = v1 ? (t1 & (u32)(OS_GRP - 1)) : 0u, cg = v1 ? ((t1 / (u32)OS_GRP) & (u32)(OS_GPB - 1)) : 0u, cG = v1 ? (t1 / (u32)OS_BATCH) : 0u;
             const u32 grp0 = v1 ? (t1 / (u32)OS_GRP - cg) : 0u;        // first group of its batch
             OS_PH(0);
-            // Ticket for the tile after t2, and every look-back load for t1 — the tile rows of its group below it (<= 7), the group rows
-            // of its batch below its group (<= 7), the batch rows not yet in the running sum (a workgroup's next tile is ~256 tiles =
-            // 4 or 5 batches further on; 6 are requested, more are fetched one by one) —, all in flight from the top of the
-            // iteration and looked at in front of its last barrier; between the barriers the scout does nothing that could hold the
-            // streaming waves up.
+            // Ticket for the tile after t2.  The look-back loads for t1 — the tile rows of its group below it (<= 7), the group rows of its
+            // batch below its group (<= 7), the batch rows not yet in the running sum (a workgroup's next tile is ~256 tiles = 4 or 5
+            // batches further on; 6 are requested, more are fetched one by one) — are issued behind barrier 6 (for (key, value)
+            // passes), a quarter into the iteration: t1's predecessors were published shortly before the previous iteration's
+            // third barrier, a published row takes microseconds to become visible under streaming load, and the scout must not be
+            // late for barrier 5 (issuing ~20 loads takes ~1.5 us while fifteen waves stream through the same queue).  They are
+            // looked at in front of the iteration's last barrier; in between the scout only keeps the barriers company.
             u32 ticket = 0;
             if (more && lane == 0) ticket = OS_ADD(ctl + opaque0, 1u);        // ONE lane draws
+            OS_PH(1);
+            if (HAS_VAL) {
+                __syncthreads();                                                                  // B5
+                __syncthreads();                                                                  // B6
+            }
             u64 a1[OS_GRP - 1], g1[OS_GPB - 1][2], b1[6][2];
             if (!(OS_ABL & 1)) {
 #pragma unroll
@@ -233,24 +240,15 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                     b1[q][0] = OS_LOAD(p); b1[q][1] = OS_LOAD(p + 1);
                 }
             }
-            OS_PH(1);
-            if (HAS_VAL) {
-                __syncthreads();                                                                  // B5
-                __syncthreads();                                                                  // B6
-            }
             __syncthreads();                                                                      // B1
-            if (v2) __syncthreads();                                                              // B2 (the streaming waves' digit scan)
+            if (v2) __syncthreads();                                                              // B2 (the streaming waves' digit scan; they publish t2)
             if (lane == 0) sclaim[0] = (more && ticket < ntiles) ? ticket : OS_NONE;
             OS_PH(2);
             __syncthreads();                                                                      // B3
             OS_PH(3);
             const u32 nn = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);
             if (nn == OS_NONE) more = false;
-            // The rows were requested most of an iteration ago: make the wave wait for them HERE, before the publishing store and atomics
-            // below are in the queue.  vmcnt is an in-order counter and the compiler cannot count across loops, so the first use of a
-            // row further down would otherwise be preceded by s_waitcnt vmcnt(0) — i.e. by the write-through latency of this tile's
-            // own publication (~3 us, measured on the critical path).
-            if (!(OS_ABL & 1)) {
+            if (!(OS_ABL & 1)) {                                        // wait for the rows (exact counts for the compiler from here on)
 #pragma unroll
                 for (int q = 0; q < OS_GRP - 1; ++q) asm volatile("" : "+v"(a1[q]));
 #pragma unroll
@@ -259,23 +257,6 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                 for (int q = 0; q < 6; ++q) asm volatile("" : "+v"(b1[q][0]), "+v"(b1[q][1]));
             }
             OS_PH(5);
-            // publish t2: its row, and its counts into its group's and its batch's rows.  (The data words stay live — the empty asm at
-            // the end of the iteration — so that their registers are not handed to the arithmetic below: on gfx950 a store's data
-            // registers may be read late, and overwriting them is preceded by a wait for the store itself.)
-            u64 pub0 = 0, pub1 = 0, pub2 = 0;
-            if (v2 && !(OS_ABL & 2)) {
-                const uint4 c4 = *reinterpret_cast<const uint4*>(stot + 4 * lane);
-                pub0 = tagpat | (u64)(c4.x | (c4.y << 16)) | ((u64)(c4.z | (c4.w << 16)) << 32);
-                pub1 = (1ull << 56) | ((u64)c4.y << 28) | (u64)c4.x;
-                pub2 = (1ull << 56) | ((u64)c4.w << 28) | (u64)c4.z;
-                OS_STORE(&agg[(size_t)t2 * 64 + lane], pub0);
-                u64* pg = &gagg[(size_t)(t2 / (u32)OS_GRP) * 128 + 2 * lane];
-                (void)OS_ADD(pg, pub1);
-                (void)OS_ADD(pg + 1, pub2);
-                u64* pb = &bagg[(size_t)(t2 / (u32)OS_BATCH) * 128 + 2 * lane];
-                (void)OS_ADD(pb, pub1);
-                (void)OS_ADD(pb + 1, pub2);
-            }
             OS_PH(6);
             // offsets of t1 (it sits in staging buffer x ^ 1)
             bool ok = true;
@@ -337,7 +318,6 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                 *reinterpret_cast<uint4*>(adj + (x ^ 1u) * 256 + 4 * lane) = o;
             }
             if (!ok) (void)OS_ADD(err, 1u);
-            asm volatile("" :: "v"(pub0), "v"(pub1), "v"(pub2));
             OS_PH(4);
             __syncthreads();                                                                      // B4
             OS_PH(11);
@@ -385,6 +365,9 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         }
         u64* Sx = S + (size_t)x * TILE;
         const u32* adjx = adj + x * 256;
+        u64 pubg = 0, puba = 0;                                         // data words of this iteration's publication (kept live to its end: on
+                                                                        // gfx950 a store's data registers may be read late, and overwriting them
+                                                                        // is preceded by a wait for the store itself)
         OS_PH(0);
         // ---- t0 leaves: every digit as one contiguous run, consecutive lanes -> consecutive addresses
         u32 dd[ITEMS / 4];
@@ -447,7 +430,20 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
 #pragma unroll
                 for (int i = 0; i < SW; ++i) { const u32 ci = whist[i * 256 + t]; whist[i * 256 + t] = run; run += ci; }
                 dstart[x * 256 + t] = ds;
-                stot[t] = tot - ((!FULL && t == mask) ? ((u32)TILE - n2) : 0u);
+            }
+            // publish t2 — its row, and its counts into its group's and its batch's rows — from the four waves that hold the digit
+            // counts, here and now: earlier than any other place, and the scout's path to the iteration's last barrier stays free of
+            // memory instructions (their ISSUE alone costs ~70 ns each while fifteen waves stream through the same queue).
+            if (t < 256 && !(OS_ABL & 2)) {
+                const u32 cnt = tot - ((!FULL && t == mask) ? ((u32)TILE - n2) : 0u);
+                const u32 c1 = (u32)__shfl_down((int)cnt, 1, 64), c2 = (u32)__shfl_down((int)cnt, 2, 64), c3 = (u32)__shfl_down((int)cnt, 3, 64);
+                pubg = tagpat | (u64)(cnt | (c1 << 16)) | ((u64)(c2 | (c3 << 16)) << 32);       // digits t .. t+3 (used by lanes t % 4 == 0)
+                puba = (1ull << 56) | ((u64)c1 << 28) | (u64)cnt;                               // digits t, t+1 (lanes t % 2 == 0)
+                if ((t & 3u) == 0u) OS_STORE(&agg[(size_t)t2 * 64 + (t >> 2)], pubg);
+                if ((t & 1u) == 0u) {
+                    (void)OS_ADD(&gagg[(size_t)(t2 / (u32)OS_GRP) * 128 + (t >> 1)], puba);
+                    (void)OS_ADD(&bagg[(size_t)(t2 / (u32)OS_BATCH) * 128 + (t >> 1)], puba);
+                }
             }
         }
         OS_PH(8);
@@ -468,6 +464,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
 #pragma unroll
         for (int i = 0; i < 4; ++i) whist[w * 256 + i * 64 + lane] = 0;           // own wave's counters, for the next ranking
         OS_PH(10);
+        asm volatile("" :: "v"(pubg), "v"(puba));
         __syncthreads();                                                                          // B4
 #pragma unroll
         for (int i = 0; i < ITEMS / 2; ++i) { pos0[i] = pos1[i]; pos1[i] = rk[2 * i] | (rk[2 * i + 1] << 16); }

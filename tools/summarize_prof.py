@@ -23,11 +23,11 @@ for f in find("*kernel_trace.csv"):
     if "pmc" in f:
         continue
     rows = list(csv.DictReader(open(f)))
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "rs_scatter_kernel<true" in r["Kernel_Name"] or "rs_scatter_wc_kernel<true" in r["Kernel_Name"] or "rs_scatter_tiled_kernel<true" in r["Kernel_Name"]]
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "rs_onesweep_kernel<true" in r["Kernel_Name"] or "rs_scatter_kernel<true" in r["Kernel_Name"] or "rs_scatter_wc_kernel<true" in r["Kernel_Name"] or "rs_scatter_tiled_kernel<true" in r["Kernel_Name"]]
     if d:
         d.sort(reverse=True)
         big = [x for x in d if x > 300]
-        print(f"-- {os.path.relpath(f, root)}: rs_scatter<pairs> launches={len(d)}; launches > 300 us: {len(big)} avg {sum(big)/max(len(big),1):.1f} us")
+        print(f"-- {os.path.relpath(f, root)}: (key, value) digit-pass launches={len(d)}; launches > 300 us: {len(big)} avg {sum(big)/max(len(big),1):.1f} us")
         if big:
             print(f"   => full 64 Mi-record pass: 24 B x 67108864 / {sum(big)/len(big):.1f} us = {24*67108864/(sum(big)/len(big))/1e3:.0f} GB/s")
 # launches not overlapped by any launch of another queue: per-kernel medians (what one block costs on an otherwise idle GPU)
@@ -46,11 +46,15 @@ for f in find("*kernel_trace.csv"):
     print(f"{'kernel':66s} {'n':>4s} {'median_us':>10s} {'mean_us':>10s} {'min_us':>9s}")
     for nm, v in sorted(solo.items(), key=lambda kv: -sum(kv[1]))[:40]:
         print(f"{nm:66s} {len(v):4d} {statistics.median(v):10.1f} {sum(v)/len(v):10.1f} {min(v):9.1f}")
-    full = [x for nm, v in solo.items() if nm.startswith(("void rs_scatter_kernel<true, 1024", "void rs_scatter_wc_kernel<true", "void rs_scatter_tiled_kernel<true")) for x in v if x > 250]
+    full = [x for nm, v in solo.items() if nm.startswith(("void rs_onesweep_kernel<true", "void rs_scatter_kernel<true, 1024", "void rs_scatter_wc_kernel<true", "void rs_scatter_tiled_kernel<true")) for x in v if x > 200]
     if full:
-        print(f"   => solo full-size (key, value) digit passes (rs_scatter_tiled / rs_scatter_wc / rs_scatter 1024 x 8): {len(full)} launches, mean {sum(full)/len(full):.1f} us -> 24 B x 67108864 / mean = {24*67108864/(sum(full)/len(full))/1e3:.0f} GB/s")
+        print(f"   => solo full-size (key, value) digit passes (rs_onesweep / rs_scatter_tiled / rs_scatter_wc / rs_scatter 1024 x 8): {len(full)} launches, mean {sum(full)/len(full):.1f} us -> 24 B x 67108864 / mean = {24*67108864/(sum(full)/len(full))/1e3:.0f} GB/s")
+    ha = [x for nm, v in solo.items() if nm.startswith("rs_hist_all_kernel") for x in v if x > 100]
+    if full and ha:
+        sort_us = 8 * sum(full) / len(full) + sum(ha) / len(ha)
+        print(f"   => solo first sort = rs_hist_all ({sum(ha)/len(ha):.1f} us) + 8 digit passes = {sort_us:.1f} us for B_sort = 8 B x m + 8 x 24 B x m = {(8 + 8 * 24) * 67108864 / 1e9:.2f} GB -> {(8 + 8 * 24) * 67108864 / sort_us / 1e3:.0f} GB/s")
 print()
-print("== PMC passes (one 64 MiB BWT; counters per dispatch, summed per kernel; FETCH_SIZE/WRITE_SIZE in KiB units as reported)")
+print("== PMC passes (one whole 64 MiB block: sorter, QLFC front end, device coder; counters per dispatch, summed per kernel; FETCH_SIZE/WRITE_SIZE in KiB units as reported)")
 for tag, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     for f in find("*counter_collection.csv"):
         if tag not in f:
@@ -63,7 +67,7 @@ for tag, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
             agg[k][0] += 1
             agg[k][1] += float(r["Counter_Value"])
         print(f"-- {cname} ({os.path.relpath(f, root)})")
-        for k, (cnt, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
+        for k, (cnt, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
             print(f"{k:62s} dispatches {cnt:4d}  sum {v:16.0f}  per-dispatch {v/cnt:14.0f}")
 
 # machine-readable traffic for bench.py's roofline.traffic
@@ -74,12 +78,13 @@ def per_launch(tag, cname, kname):
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r.get("Counter_Name") == cname and kname in r["Kernel_Name"]]
         return vals
     return []
-fe = per_launch("pmc_fetch", "FETCH_SIZE", "rs_scatter_tiled_kernel<true") or per_launch("pmc_fetch", "FETCH_SIZE", "rs_scatter_wc_kernel<true") or per_launch("pmc_fetch", "FETCH_SIZE", "rs_scatter_kernel<true")
-wr = per_launch("pmc_write", "WRITE_SIZE", "rs_scatter_tiled_kernel<true") or per_launch("pmc_write", "WRITE_SIZE", "rs_scatter_wc_kernel<true") or per_launch("pmc_write", "WRITE_SIZE", "rs_scatter_kernel<true")
+fe = per_launch("pmc_fetch", "FETCH_SIZE", "rs_onesweep_kernel<true") or per_launch("pmc_fetch", "FETCH_SIZE", "rs_scatter_tiled_kernel<true") or per_launch("pmc_fetch", "FETCH_SIZE", "rs_scatter_wc_kernel<true") or per_launch("pmc_fetch", "FETCH_SIZE", "rs_scatter_kernel<true")
+wr = per_launch("pmc_write", "WRITE_SIZE", "rs_onesweep_kernel<true") or per_launch("pmc_write", "WRITE_SIZE", "rs_scatter_tiled_kernel<true") or per_launch("pmc_write", "WRITE_SIZE", "rs_scatter_wc_kernel<true") or per_launch("pmc_write", "WRITE_SIZE", "rs_scatter_kernel<true")
 if fe and wr:
     nfull = 8
     fetch_kib = sum(fe[:nfull]) / nfull; write_kib = sum(wr[:nfull]) / nfull
-    out = {"records": 67108864, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), first 8 rs_scatter launches of one 64 MiB BWT",
+    out = {"records": 67108864, "kernel": "rs_onesweep_kernel<true>" if per_launch("pmc_fetch", "FETCH_SIZE", "rs_onesweep_kernel<true") else "rs_scatter",
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), the 8 digit passes of the first sort of one 64 MiB block",
            "rs_scatter_pairs": {"fetch_size_kib_reported": fetch_kib, "write_size_kib_reported": write_kib,
                                 "traffic_bytes_per_launch": int((2 * fetch_kib + write_kib) * 1024),
                                 "algorithmic_bytes_per_launch": 24 * 67108864,
