@@ -537,21 +537,30 @@ __device__ __forceinline__ bool bwt_group_is_long(const u32* __restrict__ cpos, 
 __global__ __launch_bounds__(WG) void bwt_long_heads_kernel(const u32* __restrict__ cpos, const u32* __restrict__ cgrp, u32 U, LongTables L, u32* __restrict__ lgid)
 {
     const u32 stride = gridDim.x * WG;
-    for (u32 k = blockIdx.x * WG + threadIdx.x; k < U; k += stride) {
-        u32 kh;
-        if (bwt_group_is_long(cpos, cgrp, U, k, &kh) && kh == k) {
+    const u32 rounds = (U + stride - 1) / stride;                     // every lane takes part in the ballots
+    for (u32 it = 0; it < rounds; ++it) {
+        const u32 k = it * stride + blockIdx.x * WG + threadIdx.x;
+        u32 kh = 0;
+        const bool lng = k < U && bwt_group_is_long(cpos, cgrp, U, k, &kh);
+        if (lng && kh == k) {
             const u32 id = atomicAdd(L.nlong, 1u);
             lgid[k] = id;
             if (id < LG_MAX) L.khead[id] = k;
         }
+        const u64 m = __ballot(lng);                                  // records in long groups: one atomic per wavefront
+        if (m != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(L.nlong + 1, (u32)__popcll(m));
     }
 }
+// The split pays only while the long groups hold a small part of the round's records: their records go through global atomics
+// (counting sort per group), and on inputs with long repeats — where most unsorted suffixes sit in a few huge groups — that costs
+// far more than the hand-over to prefix doubling it tries to avoid (python sources, 64 MiB: 127 ms against 44 ms).
+__device__ __forceinline__ bool bwt_long_split_pays(const LongTables& L, u32 U) { return L.nlong[0] != 0u && L.nlong[0] <= LG_MAX && L.nlong[1] <= U / 8u; }
 
 __global__ __launch_bounds__(WG) void bwt_long_count_kernel(const u8* __restrict__ T, const u8* __restrict__ codes, const u32* __restrict__ csa,
                                                             const u32* __restrict__ cpos, const u32* __restrict__ cgrp, u32 U, u64 h, u32 n, u32 smask, u32 cb, u32 a,
                                                             LongTables L, const u32* __restrict__ lgid)
 {
-    if (*L.nlong == 0u || *L.nlong > LG_MAX) return;
+    if (!bwt_long_split_pays(L, U)) return;
     const u32* T32 = reinterpret_cast<const u32*>(T);
     const u32 stride = gridDim.x * WG;
     for (u32 k = blockIdx.x * WG + threadIdx.x; k < U; k += stride) {
@@ -562,11 +571,11 @@ __global__ __launch_bounds__(WG) void bwt_long_count_kernel(const u8* __restrict
     }
 }
 
-__global__ __launch_bounds__(WG) void bwt_long_scan_kernel(LongTables L, u8* __restrict__ subhead)
+__global__ __launch_bounds__(WG) void bwt_long_scan_kernel(LongTables L, u32 U, u8* __restrict__ subhead)
 {
     __shared__ u32 scr[8];
     const u32 nl = *L.nlong;
-    if (nl > LG_MAX || blockIdx.x >= nl) return;
+    if (!bwt_long_split_pays(L, U) || blockIdx.x >= nl) return;
     u32* row = L.cnt + (size_t)blockIdx.x * LG_BUCKETS;
     const u32 kh = L.khead[blockIdx.x];
     u32 c[LG_BUCKETS / WG], sum = 0;
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(WG) void bwt_long_scatter_kernel(const u8* __restri
                                                               const u32* __restrict__ cpos, const u32* __restrict__ cgrp, u32 U, u64 h, u32 n, u32 smask, u32 cb, u32 a,
                                                               LongTables L, const u32* __restrict__ lgid, u32* __restrict__ csa_out)
 {
-    if (*L.nlong == 0u || *L.nlong > LG_MAX) return;
+    if (!bwt_long_split_pays(L, U)) return;
     const u32* T32 = reinterpret_cast<const u32*>(T);
     const u32 stride = gridDim.x * WG;
     for (u32 k = blockIdx.x * WG + threadIdx.x; k < U; k += stride) {
@@ -816,23 +825,30 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
                     HIP_TRY(c, hipMemsetAsync(subhead, 0, (size_t)U + 1, c->stream));
                     HIP_TRY(c, hipMemsetAsync(c->dscal + 2, 0, 4, c->stream));
                     u32 blocks = (U + WG - 1) / WG; if (blocks > 4096) blocks = 4096;
-                    prof_begin(c, BSCGPU_K_GATHER, (u64)U * (8 + 4 + 16 + 4) * 2, U);
+                    prof_begin(c, BSCGPU_K_GATHER, (u64)U * 8, U);
                     hipLaunchKernelGGL(bwt_long_heads_kernel, dim3(blocks), dim3(WG), 0, c->stream, c->cpos[cur], c->cgrp[cur], U, LT, c->ISA);
-                    hipLaunchKernelGGL(bwt_long_count_kernel, dim3(blocks), dim3(WG), 0, c->stream, c->dT, dcodes, c->csa[cur], c->cpos[cur], c->cgrp[cur],
-                                       U, h, n, smask, pp.cb, ta, LT, c->ISA);
-                    hipLaunchKernelGGL(bwt_long_scan_kernel, dim3(LG_MAX), dim3(WG), 0, c->stream, LT, subhead);
-                    hipLaunchKernelGGL(bwt_long_scatter_kernel, dim3(blocks), dim3(WG), 0, c->stream, c->dT, dcodes, c->csa[cur], c->cpos[cur], c->cgrp[cur],
-                                       U, h, n, smask, pp.cb, ta, LT, c->ISA, c->csa[cur ^ 1]);
-                    hipLaunchKernelGGL(bwt_round_textsort_kernel, dim3((U + RS_T - 1) / RS_T), dim3(WG), 0, c->stream,
-                                       c->dT, dcodes, c->csa[cur ^ 1], c->cgrp[cur], U, h, n, smask, pp.cb, ta, c->kB, c->vB, c->dscal + 2, subhead);
                     prof_end(c);
-                    HIP_TRY(c, hipMemcpyAsync(c->hscal + 2, c->dscal + 2, 4, hipMemcpyDeviceToHost, c->stream));
-                    HIP_TRY(c, hipMemcpyAsync(c->hscal + 3, LT.nlong, 4, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipMemcpyAsync(c->hscal + 3, LT.nlong, 8, hipMemcpyDeviceToHost, c->stream));      // long groups, records in them
                     HIP_TRY(c, ctx_sync(c));
                     prof_collect(c);
-                    if (c->hscal[3] > LG_MAX) c->hscal[2] = 1;                     // too many long groups for the tables: nothing was moved
-                    if (dbg) fprintf(stderr, "[bwt] text round %d: %u long group(s) split by %u key bits -> %s\n", rounds, c->hscal[3], LG_BITS,
-                                     c->hscal[2] == 0 ? "sorted" : "a bucket is still too long");
+                    const bool pays = c->hscal[3] != 0 && c->hscal[3] <= LG_MAX && c->hscal[4] <= U / 8u;      // = bwt_long_split_pays on the device
+                    c->hscal[2] = 1;
+                    if (pays) {
+                        prof_begin(c, BSCGPU_K_GATHER, (u64)U * (8 + 4 + 16 + 4) * 2, U);
+                        hipLaunchKernelGGL(bwt_long_count_kernel, dim3(blocks), dim3(WG), 0, c->stream, c->dT, dcodes, c->csa[cur], c->cpos[cur], c->cgrp[cur],
+                                           U, h, n, smask, pp.cb, ta, LT, c->ISA);
+                        hipLaunchKernelGGL(bwt_long_scan_kernel, dim3(c->hscal[3]), dim3(WG), 0, c->stream, LT, U, subhead);
+                        hipLaunchKernelGGL(bwt_long_scatter_kernel, dim3(blocks), dim3(WG), 0, c->stream, c->dT, dcodes, c->csa[cur], c->cpos[cur], c->cgrp[cur],
+                                           U, h, n, smask, pp.cb, ta, LT, c->ISA, c->csa[cur ^ 1]);
+                        hipLaunchKernelGGL(bwt_round_textsort_kernel, dim3((U + RS_T - 1) / RS_T), dim3(WG), 0, c->stream,
+                                           c->dT, dcodes, c->csa[cur ^ 1], c->cgrp[cur], U, h, n, smask, pp.cb, ta, c->kB, c->vB, c->dscal + 2, subhead);
+                        prof_end(c);
+                        HIP_TRY(c, hipMemcpyAsync(c->hscal + 2, c->dscal + 2, 4, hipMemcpyDeviceToHost, c->stream));
+                        HIP_TRY(c, ctx_sync(c));
+                        prof_collect(c);
+                    }
+                    if (dbg) fprintf(stderr, "[bwt] text round %d: %u long group(s) with %u of %u records: %s\n", rounds, c->hscal[3], c->hscal[4], U,
+                                     !pays ? "not split (too many / too large)" : c->hscal[2] == 0 ? "split by the top key bits -> sorted" : "split, but a bucket is still too long");
                 }
             }
             if (c->hscal[2] == 0) {

@@ -127,7 +127,6 @@ __global__ __launch_bounds__(OS_WG) void rs_hist_all_kernel(const u64* __restric
 //                        spread over the four fields, so that eight rows can be summed as packed 16-bit halves by plain 32-bit adds
 //                        (8 x 7680 < 2^16) after masking the tag bits off;
 // word of a batch row:   arrivals << 56 | sum_hi << 28 | sum_lo           (two words per lane: digits 4l, 4l+1 and 4l+2, 4l+3)
-constexpr u64 OS_M28 = 0xfffffffull, OS_TAGBITS = 0xC000C000C000C000ull;
 __host__ __device__ constexpr u64 os_tag_pattern(u32 tag8) {
     return ((u64)(tag8 & 3u) << 14) | ((u64)((tag8 >> 2) & 3u) << 30) | ((u64)((tag8 >> 4) & 3u) << 46) | ((u64)((tag8 >> 6) & 3u) << 62);
 }
@@ -190,55 +189,51 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         u32 R[4];                                                       // digit base + counts of all complete batches accounted so far
 #pragma unroll
         for (int i = 0; i < 4; ++i) R[i] = rbase[4 * lane + i];
-        // a row word that was not there yet: poll until its top byte says so (bounded; a give-up poisons the sort's error word)
-        auto poll = [&](const u64* p, const u64 fmask, const u64 want, bool& ok) __attribute__((always_inline)) -> u64 {
-            u64 v = OS_LOAD(p);
-            u32 spins = 0;
-            while ((v & fmask) != want && ok) {
-                __builtin_amdgcn_s_sleep(2);
-                v = OS_LOAD(p);
-                if (++spins > OS_SPIN_LIMIT || ((spins & 1023u) == 0u && OS_LOAD(err) != 0u)) ok = false;
-            }
-#if OS_PHASE_TIMING
-            ++npolls;
-#endif
-            return v;
+        // Rows are read with buffer loads (scalar base, 32-bit lane offset, sc1 = agent scope like the atomics that write them): one
+        // 16-byte instruction per group / batch row, one 8-byte instruction per tile row — while fifteen waves stream through the
+        // CU's memory pipeline, ISSUING an instruction costs the scout ~70 ns, so the number of instructions is what counts.
+        typedef u32 v4u __attribute__((ext_vector_type(4)));
+        typedef u32 v2u __attribute__((ext_vector_type(2)));
+        const __amdgpu_buffer_rsrc_t ragg = __builtin_amdgcn_make_buffer_rsrc((void*)agg, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rgag = __builtin_amdgcn_make_buffer_rsrc((void*)gagg, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rbag = __builtin_amdgcn_make_buffer_rsrc((void*)bagg, 0, 0x7fffffff, 0x00020000);
+        constexpr int SC1 = 16;                                         // cache policy bit of the buffer builtins on gfx940+: sc1
+        auto ld_tile = [&](const u32 row) __attribute__((always_inline)) -> v2u { return __builtin_amdgcn_raw_buffer_load_b64(ragg, (int)(row * 512u + lane * 8u), 0, SC1); };
+        auto ld_grp  = [&](const u32 row) __attribute__((always_inline)) -> v4u { return __builtin_amdgcn_raw_buffer_load_b128(rgag, (int)(row * 1024u + lane * 16u), 0, SC1); };
+        auto ld_bat  = [&](const u32 row) __attribute__((always_inline)) -> v4u { return __builtin_amdgcn_raw_buffer_load_b128(rbag, (int)(row * 1024u + lane * 16u), 0, SC1); };
+        // {arrivals : 8, sum_hi : 28, sum_lo : 28} x 2 in 32-bit arithmetic
+        auto row_ok  = [&](const v4u y, const u32 want) __attribute__((always_inline)) -> bool { return (y.y >> 24) == want && (y.w >> 24) == want; };
+        auto add_row = [&](u32 (&acc)[4], const v4u y) __attribute__((always_inline)) {
+            acc[0] += y.x & 0xfffffffu; acc[1] += __builtin_amdgcn_alignbit(y.y, y.x, 28) & 0xfffffffu;
+            acc[2] += y.z & 0xfffffffu; acc[3] += __builtin_amdgcn_alignbit(y.w, y.z, 28) & 0xfffffffu;
         };
+        const u32 tag_lo = (u32)tagpat, tag_hi = (u32)(tagpat >> 32);
         while (t0 != OS_NONE || t1 != OS_NONE || t2 != OS_NONE) {
             const bool v1 = t1 != OS_NONE, v2 = t2 != OS_NONE;
             // t1 = tile cj of group cg of batch cG
             const u32 cj = v1 ? (t1 & (u32)(OS_GRP - 1)) : 0u, cg = v1 ? ((t1 / (u32)OS_GRP) & (u32)(OS_GPB - 1)) : 0u, cG = v1 ? (t1 / (u32)OS_BATCH) : 0u;
             const u32 grp0 = v1 ? (t1 / (u32)OS_GRP - cg) : 0u;        // first group of its batch
+            const u32 nb = (cG - gbase) < 6u ? (cG - gbase) : 6u;      // batch rows requested in bulk
             OS_PH(0);
-            // Ticket for the tile after t2.  The look-back loads for t1 — the tile rows of its group below it (<= 7), the group rows of its
-            // batch below its group (<= 7), the batch rows not yet in the running sum (a workgroup's next tile is ~256 tiles = 4 or 5
-            // batches further on; 6 are requested, more are fetched one by one) — are issued behind barrier 6 (for (key, value)
-            // passes), a quarter into the iteration: t1's predecessors were published shortly before the previous iteration's
-            // third barrier, a published row takes microseconds to become visible under streaming load, and the scout must not be
-            // late for barrier 5 (issuing ~20 loads takes ~1.5 us while fifteen waves stream through the same queue).  They are
-            // looked at in front of the iteration's last barrier; in between the scout only keeps the barriers company.
+            // Ticket for the tile after t2, and the look-back loads for t1 — only the rows that exist: the tile rows of its group below it
+            // (<= 7), the group rows of its batch below its group (<= 7), the batch rows not yet in the running sum (a workgroup's
+            // next tile is ~256 tiles = 4 or 5 batches further on; up to 6 in bulk, more one by one): ~11 instructions on average.
+            // They are looked at behind barrier 3, when they have been in flight for most of the iteration.
             u32 ticket = 0;
             if (more && lane == 0) ticket = OS_ADD(ctl + opaque0, 1u);        // ONE lane draws
+            v2u a1[OS_GRP - 1]; v4u g1[OS_GPB - 1], b1[6];
+            if (!(OS_ABL & 1)) {
+#pragma unroll
+                for (int q = 0; q < OS_GRP - 1; ++q) if ((u32)q < cj) a1[q] = ld_tile(t1 - cj + q);
+#pragma unroll
+                for (int q = 0; q < OS_GPB - 1; ++q) if ((u32)q < cg) g1[q] = ld_grp(grp0 + q);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) if ((u32)q < nb) b1[q] = ld_bat(gbase + q);
+            }
             OS_PH(1);
             if (HAS_VAL) {
                 __syncthreads();                                                                  // B5
                 __syncthreads();                                                                  // B6
-            }
-            u64 a1[OS_GRP - 1], g1[OS_GPB - 1][2], b1[6][2];
-            if (!(OS_ABL & 1)) {
-#pragma unroll
-                for (int q = 0; q < OS_GRP - 1; ++q) a1[q] = OS_LOAD(&agg[(size_t)(((u32)q < cj) ? (t1 - cj + q) : 0u) * 64 + lane]);
-#pragma unroll
-                for (int q = 0; q < OS_GPB - 1; ++q) {
-                    const u64* p = &gagg[(size_t)(((u32)q < cg) ? (grp0 + q) : 0u) * 128 + 2 * lane];
-                    g1[q][0] = OS_LOAD(p); g1[q][1] = OS_LOAD(p + 1);
-                }
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    const u32 gg = gbase + q;
-                    const u64* p = &bagg[(size_t)(gg < cG ? gg : 0u) * 128 + 2 * lane];
-                    b1[q][0] = OS_LOAD(p); b1[q][1] = OS_LOAD(p + 1);
-                }
             }
             __syncthreads();                                                                      // B1
             if (v2) __syncthreads();                                                              // B2 (the streaming waves' digit scan; they publish t2)
@@ -248,25 +243,11 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             OS_PH(3);
             const u32 nn = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);
             if (nn == OS_NONE) more = false;
-            if (!(OS_ABL & 1)) {                                        // wait for the rows (exact counts for the compiler from here on)
-#pragma unroll
-                for (int q = 0; q < OS_GRP - 1; ++q) asm volatile("" : "+v"(a1[q]));
-#pragma unroll
-                for (int q = 0; q < OS_GPB - 1; ++q) asm volatile("" : "+v"(g1[q][0]), "+v"(g1[q][1]));
-#pragma unroll
-                for (int q = 0; q < 6; ++q) asm volatile("" : "+v"(b1[q][0]), "+v"(b1[q][1]));
-            }
-            OS_PH(5);
-            OS_PH(6);
             // offsets of t1 (it sits in staging buffer x ^ 1)
             bool ok = true;
             if (v1) {
                 u32 sg[4] = {0, 0, 0, 0};                               // counts of the complete groups of t1's batch below its group
                 u32 plo = 0, phi = 0;                                   // counts of the tiles of its group below it, packed 16-bit halves
-                auto add_row = [&](u32 (&acc)[4], const u64 y0, const u64 y1) __attribute__((always_inline)) {
-                    acc[0] += (u32)(y0 & OS_M28); acc[1] += (u32)((y0 >> 28) & OS_M28);
-                    acc[2] += (u32)(y1 & OS_M28); acc[3] += (u32)((y1 >> 28) & OS_M28);
-                };
                 if (!(OS_ABL & 1)) {
                     // Rows that were not there yet (published less than a visibility latency before they were asked for) are asked for
                     // again ALL AT ONCE: one more round trip, however many they are.  Wave-uniform mask: bits 0.. tile rows, 8.. group
@@ -274,11 +255,11 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                     auto missing_rows = [&]() __attribute__((always_inline)) -> u32 {
                         u32 m = 0;
 #pragma unroll
-                        for (int q = 0; q < OS_GRP - 1; ++q) if ((u32)q < cj && __ballot((a1[q] & OS_TAGBITS) != tagpat)) m |= 1u << q;
+                        for (int q = 0; q < OS_GRP - 1; ++q) if ((u32)q < cj && __ballot((a1[q].x & 0xC000C000u) != tag_lo || (a1[q].y & 0xC000C000u) != tag_hi)) m |= 1u << q;
 #pragma unroll
-                        for (int q = 0; q < OS_GPB - 1; ++q) if ((u32)q < cg && __ballot((g1[q][0] >> 56) != (u64)OS_GRP || (g1[q][1] >> 56) != (u64)OS_GRP)) m |= 1u << (8 + q);
+                        for (int q = 0; q < OS_GPB - 1; ++q) if ((u32)q < cg && __ballot(!row_ok(g1[q], (u32)OS_GRP))) m |= 1u << (8 + q);
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) if (gbase + q < cG && __ballot((b1[q][0] >> 56) != (u64)OS_BATCH || (b1[q][1] >> 56) != (u64)OS_BATCH)) m |= 1u << (16 + q);
+                        for (int q = 0; q < 6; ++q) if ((u32)q < nb && __ballot(!row_ok(b1[q], (u32)OS_BATCH))) m |= 1u << (16 + q);
                         return m;
                     };
                     u32 missing = missing_rows(), tries = 0;
@@ -286,11 +267,11 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                     while (missing != 0u && ok) {
                         __builtin_amdgcn_s_sleep(8);
 #pragma unroll
-                        for (int q = 0; q < OS_GRP - 1; ++q) if (missing & (1u << q)) a1[q] = OS_LOAD(&agg[(size_t)(t1 - cj + q) * 64 + lane]);
+                        for (int q = 0; q < OS_GRP - 1; ++q) if (missing & (1u << q)) a1[q] = ld_tile(t1 - cj + q);
 #pragma unroll
-                        for (int q = 0; q < OS_GPB - 1; ++q) if (missing & (1u << (8 + q))) { const u64* p = &gagg[(size_t)(grp0 + q) * 128 + 2 * lane]; g1[q][0] = OS_LOAD(p); g1[q][1] = OS_LOAD(p + 1); }
+                        for (int q = 0; q < OS_GPB - 1; ++q) if (missing & (1u << (8 + q))) g1[q] = ld_grp(grp0 + q);
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) if (missing & (1u << (16 + q))) { const u64* p = &bagg[(size_t)(gbase + q) * 128 + 2 * lane]; b1[q][0] = OS_LOAD(p); b1[q][1] = OS_LOAD(p + 1); }
+                        for (int q = 0; q < 6; ++q) if (missing & (1u << (16 + q))) b1[q] = ld_bat(gbase + q);
                         missing = missing_rows();
                         if (++tries > (OS_SPIN_LIMIT >> 4) || ((tries & 63u) == 0u && OS_LOAD(err) != 0u)) ok = false;
                     }
@@ -299,16 +280,21 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
 #endif
                     OS_PH(8);
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) if (gbase + q < cG) add_row(R, b1[q][0], b1[q][1]);
+                    for (int q = 0; q < 6; ++q) if ((u32)q < nb) add_row(R, b1[q]);
                     for (u32 gg = gbase + 6u; gg < cG; ++gg) {          // a workgroup that fell behind (or has just started)
-                        const u64* p = &bagg[(size_t)gg * 128 + 2 * lane];
-                        const u64 y0 = poll(p, ~0ull << 56, (u64)OS_BATCH << 56, ok), y1 = poll(p + 1, ~0ull << 56, (u64)OS_BATCH << 56, ok);
-                        add_row(R, y0, y1);
+                        v4u y = ld_bat(gg);
+                        u32 spins = 0;
+                        while (__ballot(!row_ok(y, (u32)OS_BATCH)) && ok) {
+                            __builtin_amdgcn_s_sleep(8);
+                            y = ld_bat(gg);
+                            if (++spins > (OS_SPIN_LIMIT >> 4) || ((spins & 63u) == 0u && OS_LOAD(err) != 0u)) ok = false;
+                        }
+                        add_row(R, y);
                     }
 #pragma unroll
-                    for (int q = 0; q < OS_GPB - 1; ++q) if ((u32)q < cg) add_row(sg, g1[q][0], g1[q][1]);
+                    for (int q = 0; q < OS_GPB - 1; ++q) if ((u32)q < cg) add_row(sg, g1[q]);
 #pragma unroll
-                    for (int q = 0; q < OS_GRP - 1; ++q) if ((u32)q < cj) { plo += (u32)a1[q] & 0x3fff3fffu; phi += (u32)(a1[q] >> 32) & 0x3fff3fffu; }     // 7 x 7680 < 2^16: no carry
+                    for (int q = 0; q < OS_GRP - 1; ++q) if ((u32)q < cj) { plo += a1[q].x & 0x3fff3fffu; phi += a1[q].y & 0x3fff3fffu; }     // 7 x 7680 < 2^16: no carry
                 }
                 gbase = cG;
                 const uint4 d4 = *reinterpret_cast<const uint4*>(dstart + (x ^ 1u) * 256 + 4 * lane);

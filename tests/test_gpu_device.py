@@ -270,19 +270,21 @@ def test_bwt_device_resident_16m(ctx, ref, torch_cuda):
 def test_bwt_long_groups_are_split_not_handed_over(torch_cuda):
     """Groups longer than one workgroup sorts (1024 records): the reference's cub::DeviceSegmentedSort takes any segment length
     (libcubwt.cu:1691); here the long groups are split by the top bits of the round's key and the segmented sort runs again.  A child
-    process with shorter first-sort keys (BSC_BWT_W=9: thousands of long groups on text) and the debug log on: the 16 MiB text block
-    and the 64 MiB golden block must come out bit-exact, and the log must show long groups being split and sorted."""
+    process with shorter first-sort keys (BSC_BWT_W=11: hundreds of long groups on the 64 MiB text block) and the debug log on: the
+    16 MiB text block, the edge corpus and the 64 MiB golden block must come out bit-exact, and the log must show long groups being
+    split and sorted.  (A split that would not pay — most records in long groups, as with long repeats — is declined and the round is
+    handed over to prefix doubling as before: the deep-LCP golden block and the periodic inputs of the corpus take that way.)"""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BSC_BWT_W="9", BSCGPU_DEBUG="1")
+    env = dict(os.environ, BSC_BWT_W="11", BSCGPU_DEBUG="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_device.py"), os.path.join(root, "tests", "test_gpu_compress.py"),
                         "-q", "-x", "-s", "-k", "bwt_device_resident_16m or full_size_64m_block_golden or bwt_matches_reference"],
                        capture_output=True, text=True, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     log = r.stdout + r.stderr
-    assert "long group(s) split" in log and "-> sorted" in log, log[-3000:]
+    assert "split by the top key bits -> sorted" in log, log[-3000:]
 
 
 @pytest.mark.parametrize("k", [3, 4, 5, 6, 7, 8])

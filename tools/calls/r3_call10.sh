@@ -9,3 +9,8 @@ timeout 1200 python tools/os_ab.py default:BSC_RS_ONESWEEP=0 default $V/libbsc_o
 echo "== phase stamps"; BSC_LIB_OVERRIDE=$V/libbsc_os_ph.so BSC_RS_ONESWEEP=1 timeout 300 python tools/os_phase_timing.py 2>&1 | tail -28
 } > gpurun_out/r3_call10.txt 2>&1
 cat gpurun_out/r3_call10.txt
+{
+echo "== tests: bwt (long-group split)"; timeout 900 python -m pytest tests/test_gpu_device.py tests/test_gpu_compress.py -x -q -k "bwt or full_size_64m" 2>&1 | tail -4
+echo "== bwt input classes"; timeout 600 python tools/bwt_inputs.py 2>&1 | tail -7
+} >> gpurun_out/r3_call10.txt 2>&1
+tail -14 gpurun_out/r3_call10.txt
