@@ -45,7 +45,11 @@
 #include <cstdlib>
 #include <type_traits>
 
-constexpr int OS_WG = 1024, OS_WAVES = OS_WG / 64, OS_SW = OS_WAVES - 1 /* streaming waves */, OS_ST = OS_SW * 64 /* streaming threads */;
+#ifndef OS_SW_N
+#define OS_SW_N 15              // streaming waves per workgroup (A/B builds: fewer waves = smaller tiles)
+#endif
+constexpr int HA_WG = 1024;     // rs_hist_all
+constexpr int OS_SW = OS_SW_N /* streaming waves */, OS_WAVES = OS_SW + 1, OS_WG = OS_WAVES * 64, OS_ST = OS_SW * 64 /* streaming threads */;
 constexpr int OS_ITEMS = 8, OS_TILE = OS_ST * OS_ITEMS /* 7680 */, OS_GRP = 8 /* tiles per group */, OS_GPB = 8 /* groups per batch */,
               OS_BATCH = OS_GRP * OS_GPB /* 64 tiles */, OS_MAXP = 8;
 constexpr u32 OS_NONE = 0xffffffffu;
@@ -81,14 +85,14 @@ struct OsPasses { int np; int shift[OS_MAXP]; u32 mask[OS_MAXP]; };
 // rs_hist_all: totals[p][d] += number of keys whose digit p equals d, for every pass of the sort, in one read of the keys.
 // 16 replicas of the np x 256 counters per workgroup (selected by lane and wave bits: text digits are skewed).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(OS_WG) void rs_hist_all_kernel(const u64* __restrict__ keys, u32 n, OsPasses P,
+__global__ __launch_bounds__(HA_WG) void rs_hist_all_kernel(const u64* __restrict__ keys, u32 n, OsPasses P,
                                                            u32* __restrict__ zero_base, u32 pass_stride_words)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32* h = reinterpret_cast<u32*>(smem);                     // [16][np][256]
     const u32 t = threadIdx.x, w = t >> 6;
     const u32 np = (u32)P.np;
-    for (u32 i = t; i < 16u * np * 256u; i += OS_WG) h[i] = 0;
+    for (u32 i = t; i < 16u * np * 256u; i += HA_WG) h[i] = 0;
     __syncthreads();
     u32* hr = h + (((t & 3u) | ((w & 3u) << 2)) * np) * 256u;
     auto count = [&](const u64 key) __attribute__((always_inline)) {
@@ -96,23 +100,23 @@ __global__ __launch_bounds__(OS_WG) void rs_hist_all_kernel(const u64* __restric
         for (int p = 0; p < OS_MAXP; ++p)
             if ((u32)p < np) atomicAdd(&hr[p * 256 + ((u32)(key >> P.shift[p]) & P.mask[p])], 1u);
     };
-    constexpr u64 HA_TILE = (u64)OS_WG * 8;                    // 8 keys per thread and round
+    constexpr u64 HA_TILE = (u64)HA_WG * 8;                    // 8 keys per thread and round
     const u64 stride = (u64)gridDim.x * HA_TILE;
     for (u64 base = (u64)blockIdx.x * HA_TILE; base < n; base += stride) {
         const u64 i = base + 2 * t;
         if (base + HA_TILE <= n) {
             ulonglong2 a, b, c, d;
             a.x = __builtin_nontemporal_load(keys + i);             a.y = __builtin_nontemporal_load(keys + i + 1);
-            b.x = __builtin_nontemporal_load(keys + i + 2 * OS_WG); b.y = __builtin_nontemporal_load(keys + i + 2 * OS_WG + 1);
-            c.x = __builtin_nontemporal_load(keys + i + 4 * OS_WG); c.y = __builtin_nontemporal_load(keys + i + 4 * OS_WG + 1);
-            d.x = __builtin_nontemporal_load(keys + i + 6 * OS_WG); d.y = __builtin_nontemporal_load(keys + i + 6 * OS_WG + 1);
+            b.x = __builtin_nontemporal_load(keys + i + 2 * HA_WG); b.y = __builtin_nontemporal_load(keys + i + 2 * HA_WG + 1);
+            c.x = __builtin_nontemporal_load(keys + i + 4 * HA_WG); c.y = __builtin_nontemporal_load(keys + i + 4 * HA_WG + 1);
+            d.x = __builtin_nontemporal_load(keys + i + 6 * HA_WG); d.y = __builtin_nontemporal_load(keys + i + 6 * HA_WG + 1);
             count(a.x); count(a.y); count(b.x); count(b.y); count(c.x); count(c.y); count(d.x); count(d.y);
         } else {
-            for (u64 e = base + t; e < n; e += OS_WG) count(keys[e]);
+            for (u64 e = base + t; e < n; e += HA_WG) count(keys[e]);
         }
     }
     __syncthreads();
-    for (u32 i = t; i < np * 256u; i += OS_WG) {
+    for (u32 i = t; i < np * 256u; i += HA_WG) {
         u32 sum = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum += h[(u32)r * np * 256u + i];
@@ -540,7 +544,7 @@ int radix_onesweep_sort(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32*
     }
     const u32 grid = ntiles < (u32)c->num_cus ? ntiles : (u32)c->num_cus;
     prof_begin(c, BSCGPU_K_RADIX_HISTALL, n * 8, n);
-    hipLaunchKernelGGL(rs_hist_all_kernel, dim3(grid), dim3(OS_WG), (size_t)16 * npasses * 256 * 4, c->stream,
+    hipLaunchKernelGGL(rs_hist_all_kernel, dim3(grid), dim3(HA_WG), (size_t)16 * npasses * 256 * 4, c->stream,
                        keys, (u32)n, P, c->os_zero, c->os_pass_stride);
     prof_end(c);
 
