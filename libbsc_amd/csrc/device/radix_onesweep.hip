@@ -7,9 +7,9 @@
 //   rs_hist_all      one streaming read of the keys, the global 256-bin histogram of every digit of the sort (<= 8).
 //   rs_onesweep      persistent workgroups (one per CU, 16 waves).  FIFTEEN waves stream 7680-record tiles (the tile loop of
 //                    rs_scatter_tiled: wave-striped loads, ballot-match ranking, tile-local reorder through LDS, every digit
-//                    leaves as one run); the SIXTEENTH wave — the scout — moves no records: it draws the tickets, publishes the
-//                    tile's digit counts and collects the counts of all earlier tiles, i.e. the tile's output offsets, which a
-//                    three-kernel pass gets from rs_hist + rs_scan.
+//                    leaves as one run) and publish each tile's digit counts right after the digit scan; the SIXTEENTH wave —
+//                    the scout — moves no records: it draws the tickets and collects the counts of all earlier tiles, i.e. the
+//                    tile's output offsets, which a three-kernel pass gets from rs_hist + rs_scan.
 //      order     tile = ticket (one returning atomic per tile): tiles are claimed in index order by workgroups that are RUNNING,
 //                so every tile a wait can depend on has an owner that is executing and does not itself wait for a later tile —
 //                the pass cannot deadlock under partial residency (several contexts share a GPU in bench.py; a static
@@ -31,8 +31,10 @@
 //                before it) was published, and are looked at in front of the iteration's last barrier, a whole tile time (~8 us)
 //                later; tile i is written out first thing in the iteration, at offsets that have been ready since the previous
 //                one, and leaves its buffer to tile i+2.  Under streaming load an agent-scope load takes ~3 us on this chip: with
-//                the offsets needed in the same iteration the scout sat on the critical path (0.39 ms per pass against 0.26
-//                without any look-back).
+//                the offsets needed in the same iteration the scout sat on the critical path (0.39 ms per pass).  Rows that are
+//                still missing when the scout looks are asked for again ALL AT ONCE (one round trip per retry, not one per row).
+//                Four tiles in flight (11 streaming waves x 5632-record tiles, three staging buffers) took the scout off the
+//                critical path entirely and were slower: smaller tiles write shorter runs (DESIGN.md 3.1 has the numbers).
 //      the scout exists because vmcnt is an in-order counter: look-back loads issued by a streaming wave sit behind that wave's
 //                own stores of the previous tile, and using them means waiting for those stores to drain (measured: 0.12 ms per
 //                pass although the rows themselves were there).  The scout's queue holds protocol traffic only.  The two roles are
@@ -45,18 +47,13 @@
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef OS_SW_N
-#define OS_SW_N 11              // streaming waves per workgroup: 5632-record tiles, three staging buffers fit the LDS (15 waves: two)
-#endif
-constexpr int HA_WG = 1024;     // rs_hist_all
-constexpr int OS_SW = OS_SW_N /* streaming waves */, OS_WAVES = OS_SW + 1, OS_WG = OS_WAVES * 64, OS_ST = OS_SW * 64 /* streaming threads */;
+constexpr int OS_WG = 1024, OS_WAVES = OS_WG / 64, OS_SW = OS_WAVES - 1 /* streaming waves */, OS_ST = OS_SW * 64 /* streaming threads */;
 constexpr int OS_ITEMS = 8, OS_TILE = OS_ST * OS_ITEMS /* 7680 */, OS_GRP = 8 /* tiles per group */, OS_GPB = 8 /* groups per batch */,
               OS_BATCH = OS_GRP * OS_GPB /* 64 tiles */, OS_MAXP = 8;
 constexpr u32 OS_NONE = 0xffffffffu;
 constexpr u32 OS_SPIN_LIMIT = 1u << 18;
 // LDS: two key staging buffers, per-wave digit counters, five 256-entry tables, scratch
-constexpr int OS_NBUF = 3;       // staging buffers = tiles that can wait for their offsets + 1
-constexpr int OS_LDS = OS_NBUF * OS_TILE * 8 + OS_SW * 256 * 4 + (1 + 2 * OS_NBUF) * 256 * 4 + 32 * 4;
+constexpr int OS_LDS = 2 * OS_TILE * 8 + OS_SW * 256 * 4 + 5 * 256 * 4 + 32 * 4;
 static_assert(OS_LDS <= 160 * 1024, "rs_onesweep does not fit the CU's LDS");
 // per-pass control block (u32 words): [0] next ticket; word [1] of the FIRST pass's block is the error word of the whole sort
 constexpr int OS_CTL_WORDS = 32;
@@ -86,14 +83,14 @@ struct OsPasses { int np; int shift[OS_MAXP]; u32 mask[OS_MAXP]; };
 // rs_hist_all: totals[p][d] += number of keys whose digit p equals d, for every pass of the sort, in one read of the keys.
 // 16 replicas of the np x 256 counters per workgroup (selected by lane and wave bits: text digits are skewed).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(HA_WG) void rs_hist_all_kernel(const u64* __restrict__ keys, u32 n, OsPasses P,
+__global__ __launch_bounds__(OS_WG) void rs_hist_all_kernel(const u64* __restrict__ keys, u32 n, OsPasses P,
                                                            u32* __restrict__ zero_base, u32 pass_stride_words)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32* h = reinterpret_cast<u32*>(smem);                     // [16][np][256]
     const u32 t = threadIdx.x, w = t >> 6;
     const u32 np = (u32)P.np;
-    for (u32 i = t; i < 16u * np * 256u; i += HA_WG) h[i] = 0;
+    for (u32 i = t; i < 16u * np * 256u; i += OS_WG) h[i] = 0;
     __syncthreads();
     u32* hr = h + (((t & 3u) | ((w & 3u) << 2)) * np) * 256u;
     auto count = [&](const u64 key) __attribute__((always_inline)) {
@@ -101,23 +98,23 @@ __global__ __launch_bounds__(HA_WG) void rs_hist_all_kernel(const u64* __restric
         for (int p = 0; p < OS_MAXP; ++p)
             if ((u32)p < np) atomicAdd(&hr[p * 256 + ((u32)(key >> P.shift[p]) & P.mask[p])], 1u);
     };
-    constexpr u64 HA_TILE = (u64)HA_WG * 8;                    // 8 keys per thread and round
+    constexpr u64 HA_TILE = (u64)OS_WG * 8;                    // 8 keys per thread and round
     const u64 stride = (u64)gridDim.x * HA_TILE;
     for (u64 base = (u64)blockIdx.x * HA_TILE; base < n; base += stride) {
         const u64 i = base + 2 * t;
         if (base + HA_TILE <= n) {
             ulonglong2 a, b, c, d;
             a.x = __builtin_nontemporal_load(keys + i);             a.y = __builtin_nontemporal_load(keys + i + 1);
-            b.x = __builtin_nontemporal_load(keys + i + 2 * HA_WG); b.y = __builtin_nontemporal_load(keys + i + 2 * HA_WG + 1);
-            c.x = __builtin_nontemporal_load(keys + i + 4 * HA_WG); c.y = __builtin_nontemporal_load(keys + i + 4 * HA_WG + 1);
-            d.x = __builtin_nontemporal_load(keys + i + 6 * HA_WG); d.y = __builtin_nontemporal_load(keys + i + 6 * HA_WG + 1);
+            b.x = __builtin_nontemporal_load(keys + i + 2 * OS_WG); b.y = __builtin_nontemporal_load(keys + i + 2 * OS_WG + 1);
+            c.x = __builtin_nontemporal_load(keys + i + 4 * OS_WG); c.y = __builtin_nontemporal_load(keys + i + 4 * OS_WG + 1);
+            d.x = __builtin_nontemporal_load(keys + i + 6 * OS_WG); d.y = __builtin_nontemporal_load(keys + i + 6 * OS_WG + 1);
             count(a.x); count(a.y); count(b.x); count(b.y); count(c.x); count(c.y); count(d.x); count(d.y);
         } else {
-            for (u64 e = base + t; e < n; e += HA_WG) count(keys[e]);
+            for (u64 e = base + t; e < n; e += OS_WG) count(keys[e]);
         }
     }
     __syncthreads();
-    for (u32 i = t; i < np * 256u; i += HA_WG) {
+    for (u32 i = t; i < np * 256u; i += OS_WG) {
         u32 sum = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum += h[(u32)r * np * 256u + i];
@@ -145,14 +142,14 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
 {
     (void)tdbg;
     u32 tile_no = 0; (void)tile_no;
-    constexpr int WAVES = OS_WAVES, SW = OS_SW, ST = OS_ST, ITEMS = OS_ITEMS, TILE = OS_TILE, NBUF = OS_NBUF;
+    constexpr int WAVES = OS_WAVES, SW = OS_SW, ST = OS_ST, ITEMS = OS_ITEMS, TILE = OS_TILE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* S      = reinterpret_cast<u64*>(smem);                         // [NBUF][TILE] locally reordered keys (then values) of the tiles that wait
-    u32* whist  = reinterpret_cast<u32*>(smem + NBUF * TILE * 8);       // [SW][256]
+    u64* S      = reinterpret_cast<u64*>(smem);                         // [2][TILE] locally reordered keys (then values) of the two tiles in flight
+    u32* whist  = reinterpret_cast<u32*>(smem + 2 * TILE * 8);          // [SW][256]
     u32* rbase  = whist + SW * 256;                                     // [256] first output position of every digit (prologue only)
-    u32* adj    = rbase + 256;                                          // [NBUF][256] per staging buffer: output position of slot q of digit d = adj[d] + q
-    u32* dstart = adj + NBUF * 256;                                     // [NBUF][256] tile-local start of every digit, per staging buffer
-    u32* scr    = dstart + NBUF * 256;                                  // [16]
+    u32* adj    = rbase + 256;                                          // [2][256] per staging buffer: output position of slot q of digit d = adj[d] + q
+    u32* dstart = adj + 512;                                            // [2][256] tile-local start of every digit, per staging buffer
+    u32* scr    = dstart + 512;                                         // [16]
     u32* sclaim = scr + 16;                                             // [1] the ticket drawn at the top of the iteration
     lds_vu32* vwh = (lds_vu32*)whist;
 
@@ -176,28 +173,25 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     }
     if (t == (u32)ST) { const u32 tk = OS_ADD(ctl + opaque0, 1u); sclaim[0] = tk < ntiles ? tk : OS_NONE; }
     __syncthreads();
-    // FOUR tiles are in flight per workgroup: t0 is written out first thing in the iteration; t1 and t2 wait in their staging
-    // buffers — the scout finishes t1's offsets during this iteration (from rows it asked for in the previous one) and asks for
-    // t2's rows; t3 is ranked, published and staged into the buffer t0 has left.  A tile is published two full iterations
-    // (~14 us) before its offsets are needed.
-    u32 t0 = OS_NONE, t1 = OS_NONE, t2 = OS_NONE, t3 = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);     // wave-uniform: scalar control flow
-    if (t3 == OS_NONE) return;
+    // Three tiles are in flight per workgroup: t0 is written out (its offsets were collected during the previous iteration), t1 waits
+    // in its staging buffer while the scout collects its offsets, t2 is ranked, published and staged into the buffer t0 leaves.
+    u32 t0 = OS_NONE, t1 = OS_NONE, t2 = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);      // tile numbers are wave-uniform: scalar control flow
+    if (t2 == OS_NONE) return;
     bool more = true;                                                   // tickets may still yield tiles
-    u32 x = 0;                                                          // staging buffer of t0, and then of t3; t1 sits in x + 1, t2 in x + 2 (mod NBUF)
-    auto nextbuf = [](const u32 b) __attribute__((always_inline)) { return b + 1u == (u32)NBUF ? 0u : b + 1u; };
+    u32 x = 0;                                                          // staging buffer of t0, and then of t2; t1 sits in x ^ 1
     __syncthreads();                                                    // everybody has read sclaim (and rbase is complete)
 
     if (scout) {
         // =========================================================================================================
         // The scout wave.  Lane l owns digits 4l .. 4l+3.
         // =========================================================================================================
-        __builtin_amdgcn_s_setprio(3);                                  // one wave among many, and the others wait for what it computes
+        u32 gbase = 0;                                                  // batches [0, gbase) are in R
         u32 npolls = 0; (void)npolls;
         u32 R[4];                                                       // digit base + counts of all complete batches accounted so far
 #pragma unroll
         for (int i = 0; i < 4; ++i) R[i] = rbase[4 * lane + i];
         // Rows are read with buffer loads (scalar base, 32-bit lane offset, sc1 = agent scope like the atomics that write them): one
-        // 16-byte instruction per group / batch row, one 8-byte instruction per tile row — while the other waves stream through the
+        // 16-byte instruction per group / batch row, one 8-byte instruction per tile row — while fifteen waves stream through the
         // CU's memory pipeline, ISSUING an instruction costs the scout ~70 ns, so the number of instructions is what counts.
         typedef u32 v4u __attribute__((ext_vector_type(4)));
         typedef u32 v2u __attribute__((ext_vector_type(2)));
@@ -215,27 +209,45 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             acc[2] += y.z & 0xfffffffu; acc[3] += __builtin_amdgcn_alignbit(y.w, y.z, 28) & 0xfffffffu;
         };
         const u32 tag_lo = (u32)tagpat, tag_hi = (u32)(tagpat >> 32);
-        // Two sets of row registers alternate: an iteration finishes the tile whose rows it asked for in the previous iteration
-        // (set P ^ 1) and asks for the rows of the tile published in the previous iteration (set P).
-        struct RowSet { v2u a[OS_GRP - 1]; v4u g[OS_GPB - 1], b[6]; u32 tile, cj, cg, grp0, nb, gb, cG; };
-        RowSet rs0, rs1;
-        rs0.tile = rs1.tile = OS_NONE; rs0.cj = rs0.cg = rs0.grp0 = rs0.nb = rs0.gb = rs0.cG = 0; rs1.cj = rs1.cg = rs1.grp0 = rs1.nb = rs1.gb = rs1.cG = 0;
-        u32 gissued = 0;                                                // batches [0, gissued) are covered by rows already asked for (or in R)
-
-        auto scout_iteration = [&](RowSet& ask, RowSet& fin) __attribute__((always_inline)) {
-            const bool v3 = t3 != OS_NONE;
+        while (t0 != OS_NONE || t1 != OS_NONE || t2 != OS_NONE) {
+            const bool v1 = t1 != OS_NONE, v2 = t2 != OS_NONE;
+            // t1 = tile cj of group cg of batch cG
+            const u32 cj = v1 ? (t1 & (u32)(OS_GRP - 1)) : 0u, cg = v1 ? ((t1 / (u32)OS_GRP) & (u32)(OS_GPB - 1)) : 0u, cG = v1 ? (t1 / (u32)OS_BATCH) : 0u;
+            const u32 grp0 = v1 ? (t1 / (u32)OS_GRP - cg) : 0u;        // first group of its batch
+            const u32 nb = (cG - gbase) < 6u ? (cG - gbase) : 6u;      // batch rows requested in bulk
             OS_PH(0);
+            // Ticket for the tile after t2, and the look-back loads for t1 — only the rows that exist: the tile rows of its group below it
+            // (<= 7), the group rows of its batch below its group (<= 7), the batch rows not yet in the running sum (a workgroup's
+            // next tile is ~256 tiles = 4 or 5 batches further on; up to 6 in bulk, more one by one): ~11 instructions on average.
+            // They are looked at behind barrier 3, when they have been in flight for most of the iteration.
             u32 ticket = 0;
-            if (more && lane == 0) ticket = OS_ADD(ctl + opaque0, 1u);        // ONE lane draws: the ticket for the tile after t3
+            if (more && lane == 0) ticket = OS_ADD(ctl + opaque0, 1u);        // ONE lane draws
+            v2u a1[OS_GRP - 1]; v4u g1[OS_GPB - 1], b1[6];
+            if (!(OS_ABL & 1)) {
+#pragma unroll
+                for (int q = 0; q < OS_GRP - 1; ++q) if ((u32)q < cj) a1[q] = ld_tile(t1 - cj + q);
+#pragma unroll
+                for (int q = 0; q < OS_GPB - 1; ++q) if ((u32)q < cg) g1[q] = ld_grp(grp0 + q);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) if ((u32)q < nb) b1[q] = ld_bat(gbase + q);
+            }
             OS_PH(1);
             if (HAS_VAL) {
                 __syncthreads();                                                                  // B5
                 __syncthreads();                                                                  // B6
             }
-            // ---- the window in which the streaming waves rank: finish t1 (rows asked for one iteration ago), then ask for t2's rows
+            __syncthreads();                                                                      // B1
+            if (v2) __syncthreads();                                                              // B2 (the streaming waves' digit scan; they publish t2)
+            if (lane == 0) sclaim[0] = (more && ticket < ntiles) ? ticket : OS_NONE;
+            OS_PH(2);
+            __syncthreads();                                                                      // B3
+            OS_PH(3);
+            const u32 nn = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);
+            if (nn == OS_NONE) more = false;
+            // offsets of t1 (it sits in staging buffer x ^ 1)
             bool ok = true;
-            if (fin.tile != OS_NONE) {                                  // fin.tile == t1
-                u32 sg[4] = {0, 0, 0, 0};                               // counts of the complete groups of its batch below its group
+            if (v1) {
+                u32 sg[4] = {0, 0, 0, 0};                               // counts of the complete groups of t1's batch below its group
                 u32 plo = 0, phi = 0;                                   // counts of the tiles of its group below it, packed 16-bit halves
                 if (!(OS_ABL & 1)) {
                     // Rows that were not there yet (published less than a visibility latency before they were asked for) are asked for
@@ -244,11 +256,11 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                     auto missing_rows = [&]() __attribute__((always_inline)) -> u32 {
                         u32 m = 0;
 #pragma unroll
-                        for (int q = 0; q < OS_GRP - 1; ++q) if ((u32)q < fin.cj && __ballot((fin.a[q].x & 0xC000C000u) != tag_lo || (fin.a[q].y & 0xC000C000u) != tag_hi)) m |= 1u << q;
+                        for (int q = 0; q < OS_GRP - 1; ++q) if ((u32)q < cj && __ballot((a1[q].x & 0xC000C000u) != tag_lo || (a1[q].y & 0xC000C000u) != tag_hi)) m |= 1u << q;
 #pragma unroll
-                        for (int q = 0; q < OS_GPB - 1; ++q) if ((u32)q < fin.cg && __ballot(!row_ok(fin.g[q], (u32)OS_GRP))) m |= 1u << (8 + q);
+                        for (int q = 0; q < OS_GPB - 1; ++q) if ((u32)q < cg && __ballot(!row_ok(g1[q], (u32)OS_GRP))) m |= 1u << (8 + q);
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) if ((u32)q < fin.nb && __ballot(!row_ok(fin.b[q], (u32)OS_BATCH))) m |= 1u << (16 + q);
+                        for (int q = 0; q < 6; ++q) if ((u32)q < nb && __ballot(!row_ok(b1[q], (u32)OS_BATCH))) m |= 1u << (16 + q);
                         return m;
                     };
                     u32 missing = missing_rows(), tries = 0;
@@ -256,11 +268,11 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                     while (missing != 0u && ok) {
                         __builtin_amdgcn_s_sleep(8);
 #pragma unroll
-                        for (int q = 0; q < OS_GRP - 1; ++q) if (missing & (1u << q)) fin.a[q] = ld_tile(fin.tile - fin.cj + q);
+                        for (int q = 0; q < OS_GRP - 1; ++q) if (missing & (1u << q)) a1[q] = ld_tile(t1 - cj + q);
 #pragma unroll
-                        for (int q = 0; q < OS_GPB - 1; ++q) if (missing & (1u << (8 + q))) fin.g[q] = ld_grp(fin.grp0 + q);
+                        for (int q = 0; q < OS_GPB - 1; ++q) if (missing & (1u << (8 + q))) g1[q] = ld_grp(grp0 + q);
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) if (missing & (1u << (16 + q))) fin.b[q] = ld_bat(fin.gb + q);
+                        for (int q = 0; q < 6; ++q) if (missing & (1u << (16 + q))) b1[q] = ld_bat(gbase + q);
                         missing = missing_rows();
                         if (++tries > (OS_SPIN_LIMIT >> 4) || ((tries & 63u) == 0u && OS_LOAD(err) != 0u)) ok = false;
                     }
@@ -269,8 +281,8 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
 #endif
                     OS_PH(8);
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) if ((u32)q < fin.nb) add_row(R, fin.b[q]);
-                    for (u32 gg = fin.gb + 6u; gg < fin.cG; ++gg) {     // a workgroup that fell behind (or has just started)
+                    for (int q = 0; q < 6; ++q) if ((u32)q < nb) add_row(R, b1[q]);
+                    for (u32 gg = gbase + 6u; gg < cG; ++gg) {          // a workgroup that fell behind (or has just started)
                         v4u y = ld_bat(gg);
                         u32 spins = 0;
                         while (__ballot(!row_ok(y, (u32)OS_BATCH)) && ok) {
@@ -281,68 +293,37 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                         add_row(R, y);
                     }
 #pragma unroll
-                    for (int q = 0; q < OS_GPB - 1; ++q) if ((u32)q < fin.cg) add_row(sg, fin.g[q]);
+                    for (int q = 0; q < OS_GPB - 1; ++q) if ((u32)q < cg) add_row(sg, g1[q]);
 #pragma unroll
-                    for (int q = 0; q < OS_GRP - 1; ++q) if ((u32)q < fin.cj) { plo += fin.a[q].x & 0x3fff3fffu; phi += fin.a[q].y & 0x3fff3fffu; }     // 7 tiles < 2^16: no carry
+                    for (int q = 0; q < OS_GRP - 1; ++q) if ((u32)q < cj) { plo += a1[q].x & 0x3fff3fffu; phi += a1[q].y & 0x3fff3fffu; }     // 7 x 7680 < 2^16: no carry
                 }
-                const u32 xb = nextbuf(x);                              // t1's staging buffer
-                const uint4 d4 = *reinterpret_cast<const uint4*>(dstart + xb * 256 + 4 * lane);
+                gbase = cG;
+                const uint4 d4 = *reinterpret_cast<const uint4*>(dstart + (x ^ 1u) * 256 + 4 * lane);
                 uint4 o;
                 o.x = R[0] + sg[0] + (plo & 0xffffu) - d4.x; o.y = R[1] + sg[1] + (plo >> 16) - d4.y;
                 o.z = R[2] + sg[2] + (phi & 0xffffu) - d4.z; o.w = R[3] + sg[3] + (phi >> 16) - d4.w;
-                *reinterpret_cast<uint4*>(adj + xb * 256 + 4 * lane) = o;
+                *reinterpret_cast<uint4*>(adj + (x ^ 1u) * 256 + 4 * lane) = o;
             }
             if (!ok) (void)OS_ADD(err, 1u);
             OS_PH(4);
-            // the rows t2 needs: it was published during the previous iteration, every tile below it earlier than that
-            ask.tile = t2;
-            if (t2 != OS_NONE) {
-                ask.cj = t2 & (u32)(OS_GRP - 1); ask.cg = (t2 / (u32)OS_GRP) & (u32)(OS_GPB - 1); ask.cG = t2 / (u32)OS_BATCH;
-                ask.grp0 = t2 / (u32)OS_GRP - ask.cg; ask.gb = gissued;
-                ask.nb = (ask.cG - gissued) < 6u ? (ask.cG - gissued) : 6u;
-                gissued = ask.cG;
-                if (!(OS_ABL & 1)) {
-#pragma unroll
-                    for (int q = 0; q < OS_GRP - 1; ++q) if ((u32)q < ask.cj) ask.a[q] = ld_tile(t2 - ask.cj + q);
-#pragma unroll
-                    for (int q = 0; q < OS_GPB - 1; ++q) if ((u32)q < ask.cg) ask.g[q] = ld_grp(ask.grp0 + q);
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) if ((u32)q < ask.nb) ask.b[q] = ld_bat(ask.gb + q);
-                }
-            }
-            OS_PH(5);
-            __syncthreads();                                                                      // B1
-            if (v3) __syncthreads();                                                              // B2 (the streaming waves' digit scan; they publish t3)
-            if (lane == 0) sclaim[0] = (more && ticket < ntiles) ? ticket : OS_NONE;
-            OS_PH(2);
-            __syncthreads();                                                                      // B3
-            OS_PH(3);
-            const u32 nn = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);
-            if (nn == OS_NONE) more = false;
             __syncthreads();                                                                      // B4
             OS_PH(11);
 #if OS_PHASE_TIMING
-            if (t == (u32)ST && tile_no < 40u) { tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + 1) * 16 + 14] = ((u64)t1 << 32) | t3; tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + 1) * 16 + 15] = npolls; }
+            if (t == (u32)ST && tile_no < 40u) { tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + 1) * 16 + 14] = ((u64)t1 << 32) | t2; tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + 1) * 16 + 15] = npolls; }
 #endif
             ++tile_no;
-            t0 = t1; t1 = t2; t2 = t3; t3 = nn; x = nextbuf(x);
-        };
-        auto any_left_s = [&]() __attribute__((always_inline)) { return t0 != OS_NONE || t1 != OS_NONE || t2 != OS_NONE || t3 != OS_NONE; };
-        while (any_left_s()) {
-            scout_iteration(rs0, rs1);
-            if (!any_left_s()) break;
-            scout_iteration(rs1, rs0);
+            t0 = t1; t1 = t2; t2 = nn; x ^= 1u;
         }
         return;
     }
 
     // =============================================================================================================
-    // The streaming waves.
+    // The fifteen streaming waves.
     // =============================================================================================================
     const u32 wbase = w * (64 * ITEMS) + lane;
     u64 k[ITEMS];
     u32 v[ITEMS] = {0, 0, 0, 0, 0, 0, 0, 0}, rk[ITEMS] = {0, 0, 0, 0, 0, 0, 0, 0};
-    u32 pos0[ITEMS / 2], pos1[ITEMS / 2], pos2[ITEMS / 2];             // staging slots of t0's / t1's / t2's records, two 16-bit slots per word
+    u32 pos0[ITEMS / 2], pos1[ITEMS / 2];                               // staging slots of t0's / t1's records, two 16-bit slots per word
     // loads never sit behind a branch: a missing tile or a lane past the end reads record 0 (one line for the whole wave)
     // (tile = OS_NONE wraps to record numbers >= n for every lane: TILE * 0xffffffff = -TILE)
     auto load_keys = [&](const u32 tile) __attribute__((always_inline)) {
@@ -355,19 +336,19 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) { u32 e = tb + wbase + i * 64; e = e < n ? e : 0u; v[i] = __builtin_nontemporal_load(&vin[e]); }
     };
-    load_keys(t3);
+    load_keys(t2);
 #pragma unroll
-    for (int i = 0; i < ITEMS / 2; ++i) { pos0[i] = 0; pos1[i] = 0; pos2[i] = 0; }
+    for (int i = 0; i < ITEMS / 2; ++i) { pos0[i] = 0; pos1[i] = 0; }
 
-    // One iteration: write t0 out at the offsets the scout finished during the previous iteration, then rank t3, publish it and stage
-    // it into the buffer t0 has left.  FULL = t0 and t3 are full tiles (no guards around loads and stores: waits stay exact).
+    // One iteration: write t0 out at the offsets the scout found during the previous iteration, then rank t2 and publish it
+    // and stage it into the buffer t0 has left.  FULL = t0 and t2 are full tiles (no guards around loads and stores: waits stay exact).
     auto iteration = [&](auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
-        const bool v0 = FULL || t0 != OS_NONE, v3 = FULL || t3 != OS_NONE;
-        u32 n0 = (u32)TILE, n3 = (u32)TILE;                            // valid records
+        const bool v0 = FULL || t0 != OS_NONE, v2 = FULL || t2 != OS_NONE;
+        u32 n0 = (u32)TILE, n2 = (u32)TILE;                            // valid records
         if (!FULL) {
             n0 = v0 ? ((n - t0 * (u32)TILE) < (u32)TILE ? (n - t0 * (u32)TILE) : (u32)TILE) : 0u;
-            n3 = v3 ? ((n - t3 * (u32)TILE) < (u32)TILE ? (n - t3 * (u32)TILE) : (u32)TILE) : 0u;
+            n2 = v2 ? ((n - t2 * (u32)TILE) < (u32)TILE ? (n - t2 * (u32)TILE) : (u32)TILE) : 0u;
         }
         u64* Sx = S + (size_t)x * TILE;
         const u32* adjx = adj + x * 256;
@@ -411,11 +392,11 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             }
         }
         OS_PH(5);
-        // ---- t3: rank inside the waves
-        if (v3) {
+        // ---- t2: rank inside the waves
+        if (v2) {
             if (!FULL) {
 #pragma unroll
-                for (int i = 0; i < ITEMS; ++i) if (wbase + i * 64 >= n3) k[i] = ~0ull;          // padding sorts last
+                for (int i = 0; i < ITEMS; ++i) if (wbase + i * 64 >= n2) k[i] = ~0ull;          // padding sorts last
             }
             rs_rank_wave<ITEMS>(k, shift, mask, vwh + w * 256, rk);
         }
@@ -423,7 +404,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         __syncthreads();                                                                          // B1
         OS_PH(7);
         if (HAS_VAL) load_vals(t1);                                     // for the next iteration's write-out: not live during the ranking
-        if (v3) {
+        if (v2) {
             u32 tot = 0;
             if (t < 256) {
 #pragma unroll
@@ -437,18 +418,18 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                 for (int i = 0; i < SW; ++i) { const u32 ci = whist[i * 256 + t]; whist[i * 256 + t] = run; run += ci; }
                 dstart[x * 256 + t] = ds;
             }
-            // publish t3 — its row, and its counts into its group's and its batch's rows — from the four waves that hold the digit
-            // counts, here and now: earlier than any other place, and the scout stays free of these memory instructions (their
-            // ISSUE alone costs ~70 ns each while the other waves stream through the same queue).
+            // publish t2 — its row, and its counts into its group's and its batch's rows — from the four waves that hold the digit
+            // counts, here and now: earlier than any other place, and the scout's path to the iteration's last barrier stays free of
+            // memory instructions (their ISSUE alone costs ~70 ns each while fifteen waves stream through the same queue).
             if (t < 256 && !(OS_ABL & 2)) {
-                const u32 cnt = tot - ((!FULL && t == mask) ? ((u32)TILE - n3) : 0u);
+                const u32 cnt = tot - ((!FULL && t == mask) ? ((u32)TILE - n2) : 0u);
                 const u32 c1 = (u32)__shfl_down((int)cnt, 1, 64), c2 = (u32)__shfl_down((int)cnt, 2, 64), c3 = (u32)__shfl_down((int)cnt, 3, 64);
                 pubg = tagpat | (u64)(cnt | (c1 << 16)) | ((u64)(c2 | (c3 << 16)) << 32);       // digits t .. t+3 (used by lanes t % 4 == 0)
                 puba = (1ull << 56) | ((u64)c1 << 28) | (u64)cnt;                               // digits t, t+1 (lanes t % 2 == 0)
-                if ((t & 3u) == 0u) OS_STORE(&agg[(size_t)t3 * 64 + (t >> 2)], pubg);
+                if ((t & 3u) == 0u) OS_STORE(&agg[(size_t)t2 * 64 + (t >> 2)], pubg);
                 if ((t & 1u) == 0u) {
-                    (void)OS_ADD(&gagg[(size_t)(t3 / (u32)OS_GRP) * 128 + (t >> 1)], puba);
-                    (void)OS_ADD(&bagg[(size_t)(t3 / (u32)OS_BATCH) * 128 + (t >> 1)], puba);
+                    (void)OS_ADD(&gagg[(size_t)(t2 / (u32)OS_GRP) * 128 + (t >> 1)], puba);
+                    (void)OS_ADD(&bagg[(size_t)(t2 / (u32)OS_BATCH) * 128 + (t >> 1)], puba);
                 }
             }
         }
@@ -456,8 +437,8 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         __syncthreads();                                                                          // B3
         OS_PH(9);
         const u32 nn = (u32)__builtin_amdgcn_readfirstlane((int)sclaim[0]);
-        // t3: tile-local reorder of the keys into the staging buffer t0 has left; then the keys of the tile after it are requested
-        if (v3) {
+        // t2: tile-local reorder of the keys into the staging buffer t0 has left; then the keys of the tile after it are requested
+        if (v2) {
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 const u32 d = (u32)(k[i] >> shift) & mask;
@@ -473,13 +454,13 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         asm volatile("" :: "v"(pubg), "v"(puba));
         __syncthreads();                                                                          // B4
 #pragma unroll
-        for (int i = 0; i < ITEMS / 2; ++i) { pos0[i] = pos1[i]; pos1[i] = pos2[i]; pos2[i] = rk[2 * i] | (rk[2 * i + 1] << 16); }
+        for (int i = 0; i < ITEMS / 2; ++i) { pos0[i] = pos1[i]; pos1[i] = rk[2 * i] | (rk[2 * i + 1] << 16); }
         OS_PH(11);
 #if OS_PHASE_TIMING
-        if (t == 0 && tile_no < 40u) tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + 0) * 16 + 14] = ((u64)t0 << 32) | t3;
+        if (t == 0 && tile_no < 40u) tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + 0) * 16 + 14] = ((u64)t0 << 32) | t2;
 #endif
         ++tile_no;
-        t0 = t1; t1 = t2; t2 = t3; t3 = nn; x = nextbuf(x);
+        t0 = t1; t1 = t2; t2 = nn; x ^= 1u;
     };
 
     // Three loops in a row — fill, steady state, drain (a workgroup is never steady again once it has seen its last ticket or the
@@ -489,8 +470,8 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     // (32-bit scalar compares only: a 64-bit compare goes through VALU registers, and the allocator has been seen to pick one that an
     // in-flight key load is about to write)
     const u32 nfull = n / (u32)TILE;                                    // tiles below this index are full; OS_NONE is not below it
-    auto is_steady = [&]() __attribute__((always_inline)) { return t0 < nfull && t3 < nfull; };
-    auto any_left = [&]() __attribute__((always_inline)) { return t0 != OS_NONE || t1 != OS_NONE || t2 != OS_NONE || t3 != OS_NONE; };
+    auto is_steady = [&]() __attribute__((always_inline)) { return t0 < nfull && t2 < nfull; };
+    auto any_left = [&]() __attribute__((always_inline)) { return t0 != OS_NONE || t1 != OS_NONE || t2 != OS_NONE; };
     while (any_left() && !is_steady()) iteration(std::false_type());
     // Nothing may be in flight when the steady loop is entered: the wait-count pass merges the entry state into the loop header, and
     // loads pending into the fill loop's registers would turn into (static) waits at the top of every steady iteration.
@@ -560,7 +541,7 @@ int radix_onesweep_sort(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32*
     }
     const u32 grid = ntiles < (u32)c->num_cus ? ntiles : (u32)c->num_cus;
     prof_begin(c, BSCGPU_K_RADIX_HISTALL, n * 8, n);
-    hipLaunchKernelGGL(rs_hist_all_kernel, dim3(grid), dim3(HA_WG), (size_t)16 * npasses * 256 * 4, c->stream,
+    hipLaunchKernelGGL(rs_hist_all_kernel, dim3(grid), dim3(OS_WG), (size_t)16 * npasses * 256 * 4, c->stream,
                        keys, (u32)n, P, c->os_zero, c->os_pass_stride);
     prof_end(c);
 

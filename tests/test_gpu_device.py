@@ -106,7 +106,7 @@ def _os_check(torch, ctx, keys, pairs, b0, b1):
         assert np.array_equal(rv.cpu().numpy().view(np.uint32), vals[order]), f"vals mismatch n={n} bits=[{b0},{b1})"
 
 
-@pytest.mark.parametrize("n", [4 * 5632, 4 * 5632 + 1, 40000, 65 * 5632 + 5, 64 * 5632, 64 * 9 * 5632 + 17, 5_000_000, 20_000_003])
+@pytest.mark.parametrize("n", [4 * 7680, 4 * 7680 + 1, 40000, 65 * 7680 + 5, 64 * 7680, 64 * 9 * 7680 + 17, 5_000_000, 20_000_003])
 @pytest.mark.parametrize("mode", ["pairs", "keys"])
 def test_single_read_passes_match_stable_sort(os_ctx, torch_cuda, n, mode):
     rng = np.random.default_rng(n + 5)
@@ -122,8 +122,8 @@ def test_single_read_passes_launch_tag_wraps(os_ctx, torch_cuda):
     """The tile rows carry a launch tag of 1..255 and are cleared when the sequence wraps: > 255 digit passes on one context,
     alternating a small and a larger input so that rows beyond the small input keep older tags."""
     rng = np.random.default_rng(99)
-    small = _os_keys(rng, 5 * 5632 + 11, "skewed")
-    large = _os_keys(rng, 70 * 5632 + 3, "uniform")
+    small = _os_keys(rng, 5 * 7680 + 11, "skewed")
+    large = _os_keys(rng, 70 * 7680 + 3, "uniform")
     for it in range(40):                                 # 40 x 8 = 320 passes
         _os_check(torch_cuda, os_ctx, large if it % 5 == 4 else small, True, 0, 64)
 

@@ -15,10 +15,11 @@ if os.path.exists("gpurun_out/os_phase_timing.bin"): os.remove("gpurun_out/os_ph
 ctx.bwt_device(d, out, n, aux_rate=1 << 23)
 a = np.fromfile("gpurun_out/os_phase_timing.bin", dtype=np.uint64).reshape(256, 40, 2, 16)
 stream = [(0, 1, "key write-out (tile i)"), (1, 2, "barrier 5"), (2, 3, "value staging"), (3, 4, "barrier 6"), (4, 5, "value write-out"),
-          (5, 6, "rank tile i+3 (waits its keys)"), (6, 7, "barrier 1"), (7, 8, "values of i+1 requested, digit scan, publication of i+3 (barrier 2 inside)"), (8, 9, "barrier 3"),
-          (9, 10, "stage keys of i+3, request keys of i+4"), (10, 11, "barrier 4")]
-scout = [(0, 1, "ticket"), (1, 7, "barriers 5, 6; which rows of tile i+1 are missing"), (7, 8, "re-requests (all missing rows at once)"), (8, 4, "sums, offsets of tile i+1"),
-         (4, 5, "rows of tile i+2 requested"), (5, 2, "barriers 1, 2, ticket read"), (2, 3, "barrier 3"), (3, 11, "barrier 4")]
+          (5, 6, "rank tile i+2 (waits its keys)"), (6, 7, "barrier 1"), (7, 8, "values of i+1 requested, digit scan (barrier 2 inside)"), (8, 9, "barrier 3"),
+          (9, 10, "stage keys of i+2, request keys of i+3"), (10, 11, "barrier 4 (scout: offsets of i+1)")]
+scout = [(0, 1, "ticket + look-back loads of tile i+1 issued"), (1, 2, "barriers 5, 6, 1, 2, ticket read"), (2, 3, "barrier 3"),
+         (3, 7, "wait for the rows, which are missing"), (7, 8, "re-requests (all missing rows at once)"),
+         (8, 4, "sums, offsets"), (4, 11, "barrier 4")]
 for who, label, phases in ((0, "thread 0 (streaming wave 0)", stream), (1, "scout wave", scout)):
     st = a[:, :, who, :12].astype(np.int64)
     ok = (st[:, :, 11] > 0) & (st[:, :, 0] > 0)
