@@ -71,25 +71,28 @@ def main():
     # "all of them", which is right for one rank per box
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     ncx = max(1, args.contexts)
-    if "BSCGPU_HOST_THREADS" not in os.environ:         # per pipe: this rank's CPUs are shared by its contexts
-        # (half as many again as the CPU share: threads are cheap, and the short tasks of a pipe's last block should all start at once
-        # although a long task of the block before is still running)
-        os.environ["BSCGPU_HOST_THREADS"] = str(max(4, min(64, (3 * effective_cpus() // max(local_world, 1) // ncx + 1) // 2)))
-    coder_threads = int(os.environ["BSCGPU_HOST_THREADS"]) * ncx
+    cpus_rank = max(1, effective_cpus() // max(local_world, 1))
+    if "BSCGPU_HOST_THREADS" not in os.environ:         # ONE coder pool per process, shared by this rank's contexts
+        # (half as many threads again as the CPU share: threads are cheap, a task spends part of its life waiting for its block's
+        # copy from the GPU, and the pool counts idle CPUs against BSCGPU_HOST_CPUS, not against its threads)
+        os.environ["BSCGPU_HOST_THREADS"] = str(max(4, min(96, (3 * cpus_rank + 1) // 2)))
+        os.environ.setdefault("BSCGPU_HOST_CPUS", str(cpus_rank))
+    coder_threads = int(os.environ["BSCGPU_HOST_THREADS"])
     # Range coding on the host: all eight sub-blocks of a block in SIMD lanes on one thread (0.118 CPU-s per block
-    # with AVX-512VL, 0.141 with AVX2, ~0.1 s latency: four blocks in flight per context) or pairs of sub-blocks per thread
-    # (0.228 CPU-s per block, 0.05 s latency: two blocks in flight).  Same MB/s on this box either way once the GPU is the
-    # limit; the lanes leave half of the CPUs idle, so they are the default where the CPU has AVX-512VL, and in any case when this
-    # rank's share of the CPUs could not feed its GPU with pairs (~64 blocks/s x 0.228 s = 15 CPUs).  BSC_RC_SIMD overrides.
-    cpus_rank = effective_cpus() // max(local_world, 1)
+    # with AVX-512VL, 0.141 with AVX2, ~0.09 s latency) or pairs of sub-blocks per task (0.228 CPU-s per block, 0.05 s latency).
+    # The library picks per block (block.cpp: ps_group): pairs while at least four CPUs of the pool's budget are idle, eight lanes
+    # when the coder threads are busy; without AVX-512VL it takes pairs, and then a rank whose share of the CPUs could not feed its
+    # GPU with pairs (~68 blocks/s x 0.228 s = 15 CPUs) is given the AVX2 lanes here.  BSC_RC_SIMD=8 / 0 forces one of the two.
     try:
         has_avx512vl = "avx512vl" in open("/proc/cpuinfo").read()
     except OSError:
         has_avx512vl = False
     if "BSC_RC_SIMD" not in os.environ:
-        os.environ["BSC_RC_SIMD"] = "8" if (os.environ.get("BSC_RC_X8") == "1" or (args.coder == 1 and (has_avx512vl or cpus_rank < 14))) else "0"
-    rc_simd = int(os.environ["BSC_RC_SIMD"])
-    rc_x8 = rc_simd == 8
+        if os.environ.get("BSC_RC_X8") == "1" or (args.coder == 1 and not has_avx512vl and cpus_rank < 14):
+            os.environ["BSC_RC_SIMD"] = "8"
+    rc_simd = int(os.environ.get("BSC_RC_SIMD", "-1"))
+    rc_adaptive = rc_simd < 0 and has_avx512vl and os.environ.get("BSC_RC_ADAPTIVE", "1") != "0"
+    rc_x8 = rc_simd == 8 or (rc_simd < 0 and has_avx512vl)
     if args.depth <= 0:                                 # blocks in flight per context
         args.depth = max(2, min(4, 8 // ncx))
         if rc_x8: args.depth = max(2, min(4, 16 // ncx))      # one longer task per block: 16 blocks in flight per GPU
@@ -125,7 +128,7 @@ def main():
         return blk
 
     LOW_LATENCY = 0x10000                               # include/bscgpu.h
-    tail_low_latency = os.environ.get("BSC_BENCH_TAIL", "1") != "0"
+    tail_low_latency = os.environ.get("BSC_BENCH_TAIL", "0") != "0"     # off: the pool itself codes a block as short tasks while CPUs are idle
 
     def run_one(k, steps, record, out):
         """`steps` blocks through pipe k: GPU stage of block i+1 overlaps the host coding of block i."""
@@ -133,8 +136,7 @@ def main():
         tickets, blk = [], None
         local_stage = np.zeros(6)
         for i in range(steps):
-            # the last block of every pipe is coded as short host tasks (BSCGPU_FEATURE_LOW_LATENCY): the pipeline's drain is part of
-            # the timed region, and the coder threads are running dry by then
+            # (BSC_BENCH_TAIL=1: the last block of every pipe is explicitly marked BSCGPU_FEATURE_LOW_LATENCY — eight scalar tasks)
             feat = 3 | (LOW_LATENCY if (tail_low_latency and i == steps - 1) else 0)
             tickets.append(pipe.submit(d_in, n, args.sorter, args.coder, feat))
             if record:
@@ -177,6 +179,8 @@ def main():
         cx.profile(True)
         cx.profile_reset()
     sync()
+    from libbsc_amd.gpu import coder_pool_stats
+    coder_pool_stats(reset=True)
     cpu0 = time.process_time()
     t0 = time.perf_counter()
     blk = run(args.steps, record=True)
@@ -185,6 +189,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     cpu_used = time.process_time() - cpu0               # all threads of this rank
+    pool_modes = coder_pool_stats()                     # how the timed blocks were coded (block.cpp: ps_group)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -299,6 +304,15 @@ def main():
                                         "note": f"per-launch durations while {ncx} contexts share the GPU (launches overlap; sum of durations > wall time)"}
         per_kernel = {k: {"ms_per_block": round(v["ms"] / iso_blocks, 3), "GBps": round(v["bytes"] / 1e6 / v["ms"], 1) if v["ms"] > 0 else None}
                       for k, v in stats_iso.items() if v["launches"]}
+        simd = "AVX-512VL" if has_avx512vl else "AVX2"
+        if rc_adaptive:
+            coder_desc = (f"per block either all eight sub-blocks in the SIMD lanes of one task ({simd}; {pool_modes['eight_lane_task']} of this rank's {args.steps} timed blocks) "
+                          f"or four tasks of two interleaved scalar coders, taken while >= 4 CPUs of the pool's budget were idle ({pool_modes['pair_tasks']} blocks)"
+                          + (f", or eight scalar tasks for blocks marked low-latency ({pool_modes['scalar_tasks']})" if pool_modes['scalar_tasks'] else ""))
+        elif rc_x8:
+            coder_desc = f"all eight sub-blocks of a block in the SIMD lanes of one task, {simd}"
+        else:
+            coder_desc = "two sub-blocks per task, interleaved scalar coders"
         out = {
             "metric": "MB/s compress (BWT+QLFC) on 64 MiB blocks", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
@@ -306,10 +320,9 @@ def main():
             "config": {"workload": f"{world} x {n >> 20} MiB synth-text-v1 block(s) per step (seed {'2' if world == 1 else '10..'+str(9+world)}), "
                                    f"bsc_compress(lzp off, sorter={args.sorter}, coder={args.coder}); input resident in HBM; "
                                    "Adler-32 + sorter + QLFC run/rank front end" + (" + the static coder's whole adaptive model on the GPU, 16 bits per binary decision over PCIe, "
-                                   "range coding on host threads (" + ("all eight sub-blocks of a block in the SIMD lanes of one task, " + ("AVX-512VL" if has_avx512vl else "AVX2")
-                                                                       if rc_x8 else "two sub-blocks per task, interleaved scalar coders") + ")" if args.coder == 1 else
+                                   "range coding on host threads (" + coder_desc + ")" if args.coder == 1 else
                                    "; adaptive model and range coding on host threads (one task per sub-block)") +
-                                   f"; {ncx} GPU context(s) x {args.depth} = {ncx * args.depth} block(s) in flight per GPU feeding {coder_threads} coder threads; "
+                                   f"; {ncx} GPU context(s) x {args.depth} = {ncx * args.depth} block(s) in flight per GPU feeding one pool of {coder_threads} coder threads; "
                                    "output checked against the reference's (see verified)",
                        "block_bytes": n, "blocks_per_step": world, "sorter": "BWT" if args.sorter == 1 else f"ST{args.sorter}",
                        "coder": {1: "QLFC static (-e1)", 2: "QLFC adaptive (-e2)", 3: "QLFC fast (-e0)"}[args.coder],
@@ -326,7 +339,7 @@ def main():
             "kernels": per_kernel,
             "kernels_note": "HIP-event time per kernel class and block, from the region named in roofline.measured_on",
             "host": {"cpus": os.cpu_count(), "effective_cpus": effective_cpus(), "coder_threads_per_gpu": coder_threads,
-                     "range_coder": ("8 sub-blocks per thread in SIMD lanes (" + ("AVX-512VL" if has_avx512vl else "AVX2") + ")") if rc_x8 else "2 sub-blocks per thread, interleaved",
+                     "range_coder": coder_desc, "blocks_by_coder_task_shape_rank0": pool_modes, "cpu_budget_of_pool": int(os.environ.get("BSCGPU_HOST_CPUS", cpus_rank)),
                      "cpu_seconds_per_block_rank0": round(cpu_used / args.steps, 3),
                      "cpu_busy_fraction_of_effective": round(cpu_used / (dt * max(effective_cpus() / max(local_world, 1), 1)), 3)},
         }

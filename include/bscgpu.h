@@ -98,16 +98,21 @@ BSCGPU_API int bscgpu_compress_device(bscgpu_ctx* ctx, const void* dInput, uint8
  * (QLFC modelling + range coding, one task per sub-block; container) to the pipe's coder threads, so block i+1 sorts
  * while blocks i, i-1, ... are coded.
  * dInput and output must stay valid until wait() returns for that ticket.  wait() returns what
- * bscgpu_compress_device would have returned.  One submitting thread per pipe.  The host work is queued as
- * per-sub-block tasks for a pool of coder threads per pipe (default: the CPUs the process may use — affinity and cgroup
- * quota — clamped to 4..64; BSCGPU_HOST_THREADS overrides), so a depth of 3-4 keeps those
- * threads and the GPU busy. */
+ * bscgpu_compress_device would have returned.  One submitting thread per pipe.  The host work is queued as tasks for the
+ * process's pool of coder threads, shared by all pipes (default: the CPUs the process may use — affinity and cgroup quota —
+ * clamped to 4..64; BSCGPU_HOST_THREADS overrides the thread count, BSCGPU_HOST_CPUS the CPU budget idle CPUs are counted
+ * against), so a depth of 3-4 keeps those threads and the GPU busy.  A device-model block is one eight-lane SIMD task (half the
+ * CPU time, ~90 ms) when the pool is busy and four tasks of two interleaved sub-blocks (~50 ms) while at least four CPUs of
+ * the budget are idle (BSC_RC_ADAPTIVE=0: always the former; BSC_RC_SIMD=8 / 0 forces one of the two). */
 typedef struct bscgpu_pipe bscgpu_pipe;
 /* Extra `features` bit for bscgpu_pipe_submit*: code this block's sub-blocks as several short host tasks (two interleaved scalar range
  * coders per task, ~50 ms for a 64 MiB block) instead of one eight-lane SIMD task (~90 ms, half the CPU time).  For the LAST blocks
  * of a job, where latency — the drain of the pipeline — counts and the coder threads are running dry anyway.  Output is identical. */
 #define BSCGPU_FEATURE_LOW_LATENCY 0x10000
 BSCGPU_API int  bscgpu_pipe_create(bscgpu_ctx* ctx, int depth, bscgpu_pipe** out);
+/* How the pool has coded the pipes' blocks so far: out[0] blocks as eight scalar tasks, [1] as four pair tasks, [2] as one eight-lane
+ * task, [3] blocks on the host model (one task per sub-block).  reset != 0 clears the counts.  (bench.py reports them.) */
+BSCGPU_API void bscgpu_coder_pool_stats(uint64_t out[4], int reset);
 BSCGPU_API void bscgpu_pipe_destroy(bscgpu_pipe* pipe);
 BSCGPU_API int  bscgpu_pipe_submit(bscgpu_pipe* pipe, const void* dInput, uint8_t* output, int n,
                                    int blockSorter, int coder, int features);       /* ticket >= 0 or error */

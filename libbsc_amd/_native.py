@@ -68,6 +68,8 @@ def lib():
     L.bscgpu_pipe_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.bscgpu_pipe_destroy.argtypes = [vp]
     L.bscgpu_pipe_destroy.restype = None
+    L.bscgpu_coder_pool_stats.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    L.bscgpu_coder_pool_stats.restype = None
     L.bscgpu_pipe_submit.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.bscgpu_pipe_wait.argtypes = [vp, C.c_int]
     L.bscgpu_pipe_submit_host.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]

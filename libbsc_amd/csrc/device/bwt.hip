@@ -25,6 +25,7 @@
 //      test (libcubwt does the same, libcubwt.cu:1383).
 //   6. bwt_find / bwt_emit: primary and aux indexes from a scan of SA, L from SA (predecessor codes) or SA/T.
 #include "dev_common.h"
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -193,6 +194,12 @@ __global__ __launch_bounds__(WG) void seg_reduce_kernel(const u64* __restrict__ 
     if (t == 0) { segsum[blockIdx.x] = tot; segsum[MAX_CHUNKS + blockIdx.x] = mx; }
 }
 
+// Geometry of the segmented sorts of the refinement rounds (bwt_round_segsort_kernel / bwt_round_textsort_kernel below): a workgroup owns
+// the groups whose head lies in its tile of RS_T records and sees RS_G records past the tile, so a group of up to RS_G + 1 records always
+// fits; seg_apply counts the groups that do not (see there).
+constexpr int RS_T = 2048, RS_G = 1024, RS_E = RS_T + RS_G;       // 24 KB of LDS per workgroup: 6 workgroups per CU hide the ISA gather
+constexpr int DS_NLONG = 5, DS_EXCESS = 6;                        // dscal slots: groups of > RS_G records in the new unsorted set, their records past the first RS_G
+
 // seg phase B: one workgroup scans the <= 1024 chunk summaries.
 //   segoff[c]            = exclusive sum of unsorted counts
 //   segoff[MAX_CHUNKS+c] = max(last head + 1) over chunks < c
@@ -222,23 +229,30 @@ __global__ __launch_bounds__(WG) void seg_scan_kernel(const u32* __restrict__ se
         carrymax = (carrymax > totmax) ? carrymax : totmax;
         __syncthreads();
     }
-    if (threadIdx.x == 0) dscal[0] = carry;
+    if (threadIdx.x == 0) { dscal[0] = carry; dscal[DS_NLONG] = 0; dscal[DS_EXCESS] = 0; }       // (seg_apply, the next launch, adds to the two counters)
 }
 
 // seg phase C: ranks (position of the group head), SA / ISA write-back, compaction of unsorted records.
 // WRITE_ISA = false (rounds on text keys): nobody reads ISA, the random 4-byte scatter is skipped.
+// Also counts, for free, what the next round's segmented sort cannot take: an unsorted record knows its SA slot and its group's rank (the
+// slot of the group's head), and members of a group are contiguous in SA — the record RS_G places behind its head proves a group of more
+// than RS_G records (one such record per long group: dscal[DS_NLONG]), every record at or beyond that distance is counted in
+// dscal[DS_EXCESS].  The host reads both with the size of the unsorted set and never launches a segmented sort that would give up.
 template <bool INITIAL, bool WRITE_ISA>
 __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ flags, const u32* sa_sorted,
                                                        const u32* __restrict__ cpos_in, u32 m, u32 smask,
                                                        u32 chunk_tiles, u32 num_tiles, const u32* __restrict__ segoff,
                                                        u32* SA, u32* __restrict__ ISA,
                                                        u32* __restrict__ cpos_out, u32* __restrict__ csa_out,
-                                                       u32* __restrict__ cgrp_out)
+                                                       u32* __restrict__ cgrp_out, u32* __restrict__ dscal)
 {
     __shared__ u32 scr[8];
     __shared__ u32 sprev[WG];
     __shared__ u32 cstage[3 * SEG_TILE];            // SA slot, suffix, group rank of the tile's unsorted records
+    __shared__ u32 slong[2];
     const u32 t = threadIdx.x;
+    if (t < 2) slong[t] = 0;
+    u32 n_long = 0, n_excess = 0;
     const u32 tile0 = blockIdx.x * chunk_tiles;
     u32 tile1 = tile0 + chunk_tiles; if (tile1 > num_tiles) tile1 = num_tiles;
     u32 off   = segoff[blockIdx.x];                 // next compacted slot
@@ -276,7 +290,11 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
                 const u32 rank = run - 1;
                 if (!INITIAL || SA != sa_sorted) SA[pos[q]] = s[q];          // the first seg may run in place: SA = the sort's value array
                 if (WRITE_ISA) ISA[s[q] & smask] = rank;   // SA / csa keep the predecessor code in their high bits
-                if (f[q] & 2u) { cstage[kslot] = pos[q]; cstage[SEG_TILE + kslot] = s[q]; cstage[2 * SEG_TILE + kslot] = rank; ++kslot; }
+                if (f[q] & 2u) {
+                    cstage[kslot] = pos[q]; cstage[SEG_TILE + kslot] = s[q]; cstage[2 * SEG_TILE + kslot] = rank; ++kslot;
+                    const u32 dist = pos[q] - rank;
+                    n_long += (u32)(dist == (u32)RS_G); n_excess += (u32)(dist >= (u32)RS_G);
+                }
             }
         }
         __syncthreads();
@@ -290,6 +308,9 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
         off += totcnt;
         __syncthreads();
     }
+    if (n_excess) { atomicAdd(&slong[1], n_excess); if (n_long) atomicAdd(&slong[0], n_long); }
+    __syncthreads();
+    if (t == 0 && slong[1]) { atomicAdd(&dscal[DS_EXCESS], slong[1]); if (slong[0]) atomicAdd(&dscal[DS_NLONG], slong[0]); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -319,7 +340,6 @@ __global__ __launch_bounds__(WG) void bwt_gather_kernel(const u32* __restrict__ 
 // <= 1024, three quarters in groups of <= 8; sum of squares ~ 23 comparisons per record).  Output = the same (key, value)
 // arrays the radix path produced.  A group longer than RS_G raises `fallback` and the round is redone by the radix engine.
 // ---------------------------------------------------------------------------------------------
-constexpr int RS_T = 2048, RS_G = 1024, RS_E = RS_T + RS_G;       // 24 KB of LDS per workgroup: 6 workgroups per CU hide the ISA gather
 
 __global__ __launch_bounds__(WG) void bwt_round_segsort_kernel(const u32* __restrict__ csa, const u32* __restrict__ cgrp, const u32* __restrict__ ISA,
                                                                u32 U, u64 h, u64 n, int lo_bits, u32 smask,
@@ -536,25 +556,22 @@ __device__ __forceinline__ bool bwt_group_is_long(const u32* __restrict__ cpos, 
 
 __global__ __launch_bounds__(WG) void bwt_long_heads_kernel(const u32* __restrict__ cpos, const u32* __restrict__ cgrp, u32 U, LongTables L, u32* __restrict__ lgid)
 {
+    // heads of long groups draw a dense id (one atomic per long group; how many long groups and records there are the host already knows
+    // from seg_apply — a count per wavefront here was 285 K atomics on one address, 3.3 ms on a block with 18 M such records)
     const u32 stride = gridDim.x * WG;
-    const u32 rounds = (U + stride - 1) / stride;                     // every lane takes part in the ballots
-    for (u32 it = 0; it < rounds; ++it) {
-        const u32 k = it * stride + blockIdx.x * WG + threadIdx.x;
+    for (u32 k = blockIdx.x * WG + threadIdx.x; k < U; k += stride) {
         u32 kh = 0;
-        const bool lng = k < U && bwt_group_is_long(cpos, cgrp, U, k, &kh);
-        if (lng && kh == k) {
+        if (bwt_group_is_long(cpos, cgrp, U, k, &kh) && kh == k) {
             const u32 id = atomicAdd(L.nlong, 1u);
             lgid[k] = id;
             if (id < LG_MAX) L.khead[id] = k;
         }
-        const u64 m = __ballot(lng);                                  // records in long groups: one atomic per wavefront
-        if (m != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(L.nlong + 1, (u32)__popcll(m));
     }
 }
 // The split pays only while the long groups hold a small part of the round's records: their records go through global atomics
 // (counting sort per group), and on inputs with long repeats — where most unsorted suffixes sit in a few huge groups — that costs
 // far more than the hand-over to prefix doubling it tries to avoid (python sources, 64 MiB: 127 ms against 44 ms).
-__device__ __forceinline__ bool bwt_long_split_pays(const LongTables& L, u32 U) { return L.nlong[0] != 0u && L.nlong[0] <= LG_MAX && L.nlong[1] <= U / 8u; }
+__device__ __forceinline__ bool bwt_long_split_pays(const LongTables& L, u32 U) { (void)U; return L.nlong[0] != 0u && L.nlong[0] <= LG_MAX; }     // (the host decides; this only guards the tables)
 
 __global__ __launch_bounds__(WG) void bwt_long_count_kernel(const u8* __restrict__ T, const u8* __restrict__ codes, const u32* __restrict__ csa,
                                                             const u32* __restrict__ cpos, const u32* __restrict__ cgrp, u32 U, u64 h, u32 n, u32 smask, u32 cb, u32 a,
@@ -715,10 +732,10 @@ static int run_seg(bscgpu_ctx* c, const u64* keys, const u32* sa_sorted, const u
     prof_begin(c, BSCGPU_K_SEG, (u64)m * (1 + 4 + (INITIAL ? 0 : 4) + 4 + 4), m);
     hipLaunchKernelGGL((seg_apply_kernel<INITIAL, WRITE_ISA>), dim3(ch.num_chunks), dim3(WG), 0, c->stream,
                        c->flags, sa_sorted, cpos_in, m, smask, ch.chunk_tiles, ch.num_tiles, c->segoff,
-                       SA, c->ISA, cpos_out, csa_out, cgrp_out);
+                       SA, c->ISA, cpos_out, csa_out, cgrp_out, c->dscal);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->hscal, c->dscal, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->hscal, c->dscal, (DS_EXCESS + 1) * 4, hipMemcpyDeviceToHost, c->stream));   // U, (slots of other kernels), long groups, excess
     HIP_TRY(c, ctx_sync(c));
     prof_collect(c);
     *U_out = c->hscal[0];
@@ -801,64 +818,70 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
     int rounds = 0, text_rounds = 0;
     const bool dbg = getenv("BSCGPU_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[bwt] n=%u initial unsorted=%u\n", n, U);
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_round = dbg ? now_ms() : 0.0;                       // debug trace only: wall time of a round (every round ends in a sync)
+    auto lap = [&] { const double t = now_ms(), d = t - t_round; t_round = t; return d; };
     while (U > 0) {
         if (++rounds > 60) return ctx_fail(c, BSC_GPU_ERROR, "prefix doubling did not converge", hipSuccess);
+        // what the seg that produced this unsorted set counted (seg_apply): groups no segmented sort of this round can take
+        const u32 n_long = c->hscal[DS_NLONG], n_long_rec = c->hscal[DS_EXCESS] + c->hscal[DS_NLONG] * (u32)RS_G;
         if (!isa_valid) {
             // a round on text keys; it hands over to doubling when a group does not fit a workgroup or the round did not pay
-            HIP_TRY(c, hipMemsetAsync(c->dscal + 2, 0, 4, c->stream));
-            prof_begin(c, BSCGPU_K_GATHER, (u64)U * (4 + 4 + 16 + 8 + 4), U);
-            hipLaunchKernelGGL(bwt_round_textsort_kernel, dim3((U + RS_T - 1) / RS_T), dim3(WG), 0, c->stream,
-                               c->dT, dcodes, c->csa[cur], c->cgrp[cur], U, h, n, smask, pp.cb, ta, c->kB, c->vB, c->dscal + 2);
-            prof_end(c);
-            HIP_TRY(c, hipMemcpyAsync(c->hscal + 2, c->dscal + 2, 4, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, ctx_sync(c));
-            prof_collect(c);
             static const int long_split_on = [] { const char* e = getenv("BSC_BWT_LONGSPLIT"); return e ? atoi(e) : 1; }();
-            if (c->hscal[2] != 0 && long_split_on && U > (u32)RS_G) {
-                // a group is too long for one workgroup: split the long groups by the top bits of the round's key and sort again
+            bool round_done = false;
+            if (n_long == 0) {
+                HIP_TRY(c, hipMemsetAsync(c->dscal + 2, 0, 4, c->stream));
+                prof_begin(c, BSCGPU_K_GATHER, (u64)U * (4 + 4 + 16 + 8 + 4), U);
+                hipLaunchKernelGGL(bwt_round_textsort_kernel, dim3((U + RS_T - 1) / RS_T), dim3(WG), 0, c->stream,
+                                   c->dT, dcodes, c->csa[cur], c->cgrp[cur], U, h, n, smask, pp.cb, ta, c->kB, c->vB, c->dscal + 2);
+                prof_end(c);
+                HIP_TRY(c, hipMemcpyAsync(c->hscal + 2, c->dscal + 2, 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, ctx_sync(c));
+                prof_collect(c);
+                round_done = c->hscal[2] == 0;
+            } else {
+                // Groups too long for one workgroup.  While they hold a small part of the round's records they — and only they — are
+                // split by the top bits of this round's key and the segmented sort runs with the bucket starts as extra boundaries;
+                // otherwise (long repeats: most unsorted suffixes sit in a few huge groups, and their records would all go through
+                // global atomics — python sources, 64 MiB: 127 ms against 44 ms) the round is handed over to prefix doubling at once,
+                // without first running a sort that gives up (9.5 ms on that block).
                 // (tables in kA, free since the first seg; group ids in ISA, unused on this path; the permuted suffixes in csa[cur ^ 1])
                 LongTables LT;
                 LT.nlong = reinterpret_cast<u32*>(c->kA); LT.khead = LT.nlong + 64; LT.cnt = LT.khead + LG_MAX;
-                if ((size_t)c->max_n * 8 >= (size_t)(64 + LG_MAX + (size_t)LG_MAX * LG_BUCKETS) * 4) {
+                const bool fits = (size_t)c->max_n * 8 >= (size_t)(64 + LG_MAX + (size_t)LG_MAX * LG_BUCKETS) * 4;
+                const bool pays = long_split_on && fits && n_long <= LG_MAX && n_long_rec <= U / 8u;
+                if (pays) {
                     u8* subhead = c->flags;
                     HIP_TRY(c, hipMemsetAsync(LT.nlong, 0, (size_t)(64 + LG_MAX + (size_t)LG_MAX * LG_BUCKETS) * 4, c->stream));
                     HIP_TRY(c, hipMemsetAsync(subhead, 0, (size_t)U + 1, c->stream));
                     HIP_TRY(c, hipMemsetAsync(c->dscal + 2, 0, 4, c->stream));
                     u32 blocks = (U + WG - 1) / WG; if (blocks > 4096) blocks = 4096;
-                    prof_begin(c, BSCGPU_K_GATHER, (u64)U * 8, U);
+                    prof_begin(c, BSCGPU_K_GATHER, (u64)U * (8 + (8 + 4 + 16 + 4) * 2), U);
                     hipLaunchKernelGGL(bwt_long_heads_kernel, dim3(blocks), dim3(WG), 0, c->stream, c->cpos[cur], c->cgrp[cur], U, LT, c->ISA);
+                    hipLaunchKernelGGL(bwt_long_count_kernel, dim3(blocks), dim3(WG), 0, c->stream, c->dT, dcodes, c->csa[cur], c->cpos[cur], c->cgrp[cur],
+                                       U, h, n, smask, pp.cb, ta, LT, c->ISA);
+                    hipLaunchKernelGGL(bwt_long_scan_kernel, dim3(n_long), dim3(WG), 0, c->stream, LT, U, subhead);
+                    hipLaunchKernelGGL(bwt_long_scatter_kernel, dim3(blocks), dim3(WG), 0, c->stream, c->dT, dcodes, c->csa[cur], c->cpos[cur], c->cgrp[cur],
+                                       U, h, n, smask, pp.cb, ta, LT, c->ISA, c->csa[cur ^ 1]);
+                    hipLaunchKernelGGL(bwt_round_textsort_kernel, dim3((U + RS_T - 1) / RS_T), dim3(WG), 0, c->stream,
+                                       c->dT, dcodes, c->csa[cur ^ 1], c->cgrp[cur], U, h, n, smask, pp.cb, ta, c->kB, c->vB, c->dscal + 2, subhead);
                     prof_end(c);
-                    HIP_TRY(c, hipMemcpyAsync(c->hscal + 3, LT.nlong, 8, hipMemcpyDeviceToHost, c->stream));      // long groups, records in them
+                    HIP_TRY(c, hipMemcpyAsync(c->hscal + 2, c->dscal + 2, 4, hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(c, ctx_sync(c));
                     prof_collect(c);
-                    const bool pays = c->hscal[3] != 0 && c->hscal[3] <= LG_MAX && c->hscal[4] <= U / 8u;      // = bwt_long_split_pays on the device
-                    c->hscal[2] = 1;
-                    if (pays) {
-                        prof_begin(c, BSCGPU_K_GATHER, (u64)U * (8 + 4 + 16 + 4) * 2, U);
-                        hipLaunchKernelGGL(bwt_long_count_kernel, dim3(blocks), dim3(WG), 0, c->stream, c->dT, dcodes, c->csa[cur], c->cpos[cur], c->cgrp[cur],
-                                           U, h, n, smask, pp.cb, ta, LT, c->ISA);
-                        hipLaunchKernelGGL(bwt_long_scan_kernel, dim3(c->hscal[3]), dim3(WG), 0, c->stream, LT, U, subhead);
-                        hipLaunchKernelGGL(bwt_long_scatter_kernel, dim3(blocks), dim3(WG), 0, c->stream, c->dT, dcodes, c->csa[cur], c->cpos[cur], c->cgrp[cur],
-                                           U, h, n, smask, pp.cb, ta, LT, c->ISA, c->csa[cur ^ 1]);
-                        hipLaunchKernelGGL(bwt_round_textsort_kernel, dim3((U + RS_T - 1) / RS_T), dim3(WG), 0, c->stream,
-                                           c->dT, dcodes, c->csa[cur ^ 1], c->cgrp[cur], U, h, n, smask, pp.cb, ta, c->kB, c->vB, c->dscal + 2, subhead);
-                        prof_end(c);
-                        HIP_TRY(c, hipMemcpyAsync(c->hscal + 2, c->dscal + 2, 4, hipMemcpyDeviceToHost, c->stream));
-                        HIP_TRY(c, ctx_sync(c));
-                        prof_collect(c);
-                    }
-                    if (dbg) fprintf(stderr, "[bwt] text round %d: %u long group(s) with %u of %u records: %s\n", rounds, c->hscal[3], c->hscal[4], U,
-                                     !pays ? "not split (too many / too large)" : c->hscal[2] == 0 ? "split by the top key bits -> sorted" : "split, but a bucket is still too long");
+                    round_done = c->hscal[2] == 0;
                 }
+                if (dbg) fprintf(stderr, "[bwt] text round %d: %u long group(s) with %u of %u records: %s\n", rounds, n_long, n_long_rec, U,
+                                 !pays ? "not split (too many / too large)" : round_done ? "split by the top key bits -> sorted" : "split, but a bucket is still too long");
             }
-            if (c->hscal[2] == 0) {
+            if (round_done) {
                 u32 U2 = 0;
                 rc = run_seg<false, false>(c, c->kB, c->vB, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2, SA, c->cgrp[cur]);
                 if (rc < 0) return rc;
                 cur ^= 1;
                 ++text_rounds;
                 h += ta;
-                if (dbg) fprintf(stderr, "[bwt] text round %d depth %llu U %u -> %u\n", rounds, (unsigned long long)h, U, U2);
+                if (dbg) fprintf(stderr, "[bwt] text round %d depth %llu U %u -> %u  (%.2f ms)\n", rounds, (unsigned long long)h, U, U2, lap());
                 const bool pays = U2 < 65536u || U2 <= U / 4;
                 U = U2;
                 if (U == 0 || (pays && text_rounds < 8)) continue;
@@ -873,12 +896,12 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
             hipLaunchKernelGGL(bwt_isa_fix_kernel, dim3(fb), dim3(WG), 0, c->stream, c->csa[cur], c->cgrp[cur], U, smask, c->ISA);
             prof_end(c);
             isa_valid = true;
-            if (c->hscal[2] == 0) continue;          // the round itself was done; the next one doubles
+            if (round_done) continue;                // the round itself was done; the next one doubles
         }
         // segmented sort of the grouped records (falls back to the radix engine when a group is too long for one workgroup)
         static const int segsort_on = [] { const char* e = getenv("BSC_BWT_SEGSORT"); return e ? atoi(e) : 1; }();
         bool sorted = false;
-        if (segsort_on) {
+        if (segsort_on && c->hscal[DS_NLONG] == 0) {        // (with a group of > RS_G records the kernel would only find out and give up)
             HIP_TRY(c, hipMemsetAsync(c->dscal + 2, 0, 4, c->stream));
             prof_begin(c, BSCGPU_K_GATHER, (u64)U * (4 + 4 + 4 + 8 + 4), U);
             hipLaunchKernelGGL(bwt_round_segsort_kernel, dim3((U + RS_T - 1) / RS_T), dim3(WG), 0, c->stream,
@@ -915,7 +938,7 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
         rc = run_seg<false, true>(c, ks, vs, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2, SA);
         if (rc < 0) return rc;
         cur ^= 1;
-        if (dbg) fprintf(stderr, "[bwt] round %d h=%llu U %u -> %u (passes %d)\n", rounds, (unsigned long long)h, U, U2, np);
+        if (dbg) fprintf(stderr, "[bwt] round %d h=%llu U %u -> %u (passes %d)  (%.2f ms)\n", rounds, (unsigned long long)h, U, U2, np, lap());
         U = U2;
         h <<= 1;
     }

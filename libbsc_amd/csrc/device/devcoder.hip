@@ -165,14 +165,19 @@ __global__ __launch_bounds__(WG) void dc_ctx_kernel(const u64* __restrict__ key_
         // symbol-major neighbours: the previous runs of this symbol in this sub-block, nearest first (loaded once)
         const u32 q = inv_ch[j];
         const u64 chain_id = key >> 53;                               // X and sub-block
-        constexpr int NP = 5;
+        // (all NP loads are issued at once — the index does not depend on what the nearer neighbours turn out to be — and NP is large
+        // enough that the bracket below almost always closes: with five, a few per cent of the runs — one lane in most wavefronts —
+        // took the serial look-back further down, and the kernel spent 89 % of its wave cycles waiting)
+        constexpr int NP = 9;
+        u64 pk[NP];
+#pragma unroll
+        for (int t = 1; t <= NP; ++t) pk[t - 1] = key_ch_s[q >= (u32)t ? q - (u32)t : 0u];
         u32 prun[NP], prank0 = 0; int np = 0; bool at_start = false;
 #pragma unroll
         for (int t = 1; t <= NP; ++t) {
             bool have = false;
-            if (!at_start && q >= (u32)t) {
-                const u64 pk = key_ch_s[q - t];
-                if ((pk >> 53) == chain_id) { const Item pi = item_unpack(pk); prun[t - 1] = pi.run; if (t == 1) prank0 = pi.rank; have = true; np = t; }
+            if (!at_start && q >= (u32)t && (pk[t - 1] >> 53) == chain_id) {
+                const Item pi = item_unpack(pk[t - 1]); prun[t - 1] = pi.run; if (t == 1) prank0 = pi.rank; have = true; np = t;
             }
             if (!have) { at_start = true; prun[t - 1] = 1; }
         }
@@ -879,32 +884,52 @@ struct DcGather {
 // (global memory takes dword-aligned multi-dword accesses) instead of four dword loads
 struct __attribute__((packed, aligned(4))) DcU4 { u32 a, b, c, d; };
 
+// The entries of a run are 2 bytes each and 1..~20 per run: written straight from the lanes, every store instruction of a wavefront
+// touches ~13 lines with 2 bytes per lane, and the same lines again in the next iteration (PMC: WRITE_SIZE 2.66 GB for 0.37 GB of
+// entries, and the read-modify-write traffic behind it).  The entries of a wavefront's 64 runs are contiguous in the stream, so
+// they are collected in LDS and leave as whole 128-byte pieces (DC_PS_STAGE entries per wavefront; a wavefront with more — 64 runs of
+// > 28 decisions on average — stores directly).
+#ifndef DC_PS_STAGE_N
+#define DC_PS_STAGE_N 1792
+#endif
+constexpr u32 DC_PS_STAGE = DC_PS_STAGE_N;
+typedef __attribute__((address_space(3))) volatile u16 dc_lds_vu16;
+
 __global__ __launch_bounds__(WG) void dc_pstream_kernel(DcGather G, DcSub S, const ModelParams* __restrict__ mp,
                                                         const u32* __restrict__ meta, u16* __restrict__ out, u16* __restrict__ dbg /*[3][D] or null*/, u32 dbgD)
 {
+    __shared__ u16 stage[WAVES][DC_PS_STAGE];
     if (meta[DM_FAIL] != 0u) return;
     const u32 j = dc_virtual_block() * WG + threadIdx.x;
-    if (j >= G.m) return;
-    const Item it = item_unpack(G.key_ch[j]);
+    const u32 lane = threadIdx.x & 63u;
+    const bool valid = j < G.m;                                       // (whole wavefronts past the end still take part in the shuffles below)
+    const Item it = item_unpack(valid ? G.key_ch[j] : 0ull);
     const int maxr = (int)S.maxr[it.sb];
-    const int n_rank = count_rank_side(it, maxr), n_run = count_run_side(it), nd = n_rank + n_run;
-    const u32 b_sp = G.doff_sp[j];
+    const int n_rank = valid ? count_rank_side(it, maxr) : 0, n_run = valid ? count_run_side(it) : 0, nd = n_rank + n_run;
+    const u32 b_sp = valid ? G.doff_sp[j] : 0u;
+    const u32 incl = wave_incl_sum((u32)nd);
+    const u32 loc = incl - (u32)nd;                                   // this run's first entry inside the wavefront's piece of the stream
+    const u32 wtotal = (u32)__shfl((int)incl, 63, 64);
+    const u32 wbase = (u32)__shfl((int)b_sp, 0, 64);                  // lane 0 is valid whenever any lane is
+    const bool staged = wtotal <= DC_PS_STAGE;                        // wave-uniform
+    dc_lds_vu16* sg = (dc_lds_vu16*)&stage[threadIdx.x >> 6][0];
     const u32* p_sp = G.pos_sp + b_sp;
-    const u32* p_ch = G.pos_ch + G.doff_ch[G.inv_ch[j]];
-    const u32* p_sr = G.pos_sr + G.doff_sr[G.inv_sr[j]];
-    const u32* p_sn = G.pos_sn + G.doff_sn[G.inv_sn[j]];
+    const u32* p_ch = G.pos_ch + (valid ? G.doff_ch[G.inv_ch[j]] : 0u);
+    const u32* p_sr = G.pos_sr + (valid ? G.doff_sr[G.inv_sr[j]] : 0u);
+    const u32* p_sn = G.pos_sn + (valid ? G.doff_sn[G.inv_sn[j]] : 0u);
     u16* o = out + b_sp;
     auto emit = [&](int k, u32 q_sp, u32 q_ch, u32 q_st, bool run_side, int tau, u32 bit) {
         const int v_sp = G.V_sp[q_sp];
         const int v_ch = G.V_ch[q_ch];
         const int v_st = run_side ? G.V_sn[q_st] : G.V_sr[q_st];
         const int p = blend(v_ch, v_st, v_sp, mp->lr[tau_class(tau)]);
-        o[k] = (u16)((u32)p | (bit << 12) | (k == 0 ? (u32)PS_RUN : 0u));
+        const u16 e = (u16)((u32)p | (bit << 12) | (k == 0 ? (u32)PS_RUN : 0u));
+        if (staged) sg[loc + (u32)k] = e; else o[k] = e;
         if (dbg) { dbg[b_sp + k] = (u16)v_st; dbg[(size_t)dbgD + b_sp + k] = (u16)v_ch; dbg[2 * (size_t)dbgD + b_sp + k] = (u16)v_sp; }
     };
     // first 8 decisions: positions by wide loads (the arrays have slack behind their last entry), static register indices
     u32 qsp[8], qch[8];
-    {
+    if (valid) {
         const DcU4 a0 = *reinterpret_cast<const DcU4*>(p_sp), a1 = *reinterpret_cast<const DcU4*>(p_sp + 4);
         const DcU4 c0 = *reinterpret_cast<const DcU4*>(p_ch), c1 = *reinterpret_cast<const DcU4*>(p_ch + 4);
         qsp[0] = a0.a; qsp[1] = a0.b; qsp[2] = a0.c; qsp[3] = a0.d; qsp[4] = a1.a; qsp[5] = a1.b; qsp[6] = a1.c; qsp[7] = a1.d;
@@ -923,6 +948,17 @@ __global__ __launch_bounds__(WG) void dc_pstream_kernel(DcGather G, DcSub S, con
         u32 bit; bool rs;
         const int tau = nth_decision(it, maxr, n_rank, k, &bit, &rs);
         emit(k, p_sp[k], p_ch[k], rs ? p_sn[k - n_rank] : p_sr[k], rs, tau, bit);
+    }
+    if (staged) {
+        // the wavefront's piece [wbase, wbase + wtotal) of the stream: 4-byte stores from the first even entry on, the odd ends singly
+        __builtin_amdgcn_wave_barrier();
+        u16* ow = out + wbase;
+        const u32 head = wbase & 1u;                                  // 1: the piece starts on an odd entry
+        if (head && lane == 0 && wtotal > 0) ow[0] = sg[0];
+        const u32 body = (wtotal - (head < wtotal ? head : wtotal)) >> 1;     // whole 4-byte words after the head
+        u32* ow32 = reinterpret_cast<u32*>(ow + head);
+        for (u32 t = lane; t < body; t += 64) ow32[t] = (u32)sg[head + 2 * t] | ((u32)sg[head + 2 * t + 1] << 16);
+        if (lane == 0 && wtotal > head && ((wtotal - head) & 1u)) ow[wtotal - 1] = sg[wtotal - 1];
     }
 }
 

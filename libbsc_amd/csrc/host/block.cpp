@@ -326,7 +326,9 @@ struct BlockJob {
     HostSlot* slot = nullptr;        // pinned landing zones of this block (owned by the context)
     // device-side static model (devcoder.hip): the host codes from a probability stream instead of run arrays
     bool pipelined = false;        // submitted through a pipe (several blocks in flight): throughput over latency
-    int  pipe_workers = 0;         // coder threads of that pipe (0: a synchronous call, which starts its own threads)
+    int  pipe_workers = 0;         // coder threads of the process-wide pool (0: a synchronous call, which starts its own threads)
+    int  pool_free = -1;           // CPUs of the pool's budget with nothing to do when the block was queued (-1: not a pipe's block)
+    int  ps_g = 2;                 // device-model sub-blocks per coder task (ps_group), fixed when the block's host work starts
     bool use_ps = false; const uint16_t* ps = nullptr; u32 poff[9]; u32 ndec = 0; int sorter = 0;
     hipEvent_t ps_ready = nullptr;   // the p stream's copy to the host (copy stream); coder tasks wait on it
     std::atomic<bool> redo{false};   // a sub-block did not compress: the block goes through the host model again (raw sub-blocks need the run arrays)
@@ -515,12 +517,19 @@ static int ps_group(const BlockJob& J)
     const bool latency = (J.features & BSCGPU_FEATURE_LOW_LATENCY) || !J.pipelined;
     if (env >= 0) return env == 8 ? 8 : 2;                            // BSC_RC_SIMD forces eight lanes / pairs everywhere
     if (latency) { static const int cpus = default_coder_threads(); return (J.pipe_workers ? J.pipe_workers : cpus) >= 8 ? 1 : 2; }
-    return cpu_has_avx512vl() ? 8 : 2;
+    if (!cpu_has_avx512vl()) return 2;
+    // A pipe's block: the eight-lane task costs half the CPU time of four pair tasks (0.118 against 0.228 CPU-s per 64 MiB block) but
+    // takes 90 instead of 52 ms.  While the pool has four CPUs with nothing to do the pairs cost nothing and the block is out 40 ms
+    // earlier (a short job is mostly pipeline fill and drain: 20 blocks at 14.7 ms); when the coder threads are busy — many GPUs
+    // per host, a small quota — every block is one eight-lane task and the pool's throughput is what counts.  BSC_RC_ADAPTIVE=0:
+    // eight lanes always.
+    static const int adaptive = [] { const char* e = getenv("BSC_RC_ADAPTIVE"); return e ? atoi(e) : 1; }();
+    return (adaptive && J.pool_free >= 4) ? 2 : 8;
 }
 // sub-blocks b .. b + g - 1 of a device-model block, g = ps_group(J)
 static void host_encode_group(BlockJob& J, int b)
 {
-    const int g = ps_group(J);
+    const int g = J.ps_g;
     if (g == 2) { host_encode_pair(J, b); return; }
     if (g == 1) { host_encode_sub(J, b); return; }
     PstreamJob P[8];
@@ -655,7 +664,7 @@ static void host_stage(BlockJob& J)
     if (J.stored_small) return;
     host_prepare(J);
     if (job_uses_tasks(J)) {
-        if (J.use_ps) { const int g = ps_group(J); run_tasks(J.nblocks / g, [&J, g](int t) { host_encode_group(J, g * t); }); }
+        if (J.use_ps) { const int g = J.ps_g = ps_group(J); run_tasks(J.nblocks / g, [&J, g](int t) { host_encode_group(J, g * t); }); }
         else run_tasks(J.nblocks, [&J](int b) { host_encode_sub(J, b); });
         host_finalize(J);
         return;
@@ -809,19 +818,18 @@ static int default_coder_threads()
 }
 
 // ---- pipe: several blocks in flight -------------------------------------------------------------------------
-// submit() runs the GPU stage on the calling thread and queues the block's host work as per-sub-block tasks; a fixed
-// pool of worker threads (16 by default = the per-GPU host budget) drains the FIFO queue, so the coder threads stay
-// busy across block boundaries; the worker that finishes a block's last sub-block frames it.
-struct bscgpu_pipe {
-    bscgpu_ctx* c = nullptr;
-    int depth = 1;
-    int next_ticket = 0;
-    struct Lane { std::unique_ptr<BlockJob> job; int ticket = -1; bool busy = false; };
-    Lane lanes[MAX_SLOTS];
+// submit() runs the GPU stage on the calling thread and queues the block's host work as tasks for the coder pool: ONE pool per
+// process (the CPUs it may use: affinity and cgroup quota, default_coder_threads(); BSCGPU_HOST_THREADS overrides the number of
+// threads, BSCGPU_HOST_CPUS the CPU budget the idle test below counts against — a multi-rank driver gives each rank its share),
+// shared by every pipe — several contexts per GPU, as bench.py runs them, draw on the same threads, so a block whose own pipe
+// is momentarily quiet is coded by whoever is free, and the pool knows how busy the process's CPUs are (ps_group).  FIFO; the
+// worker that finishes a block's last task frames it.
+struct CoderPool {
     struct Task { BlockJob* job; int sub; };          // sub = -1: whole host stage of the block as one task; else first sub-block of the task
     std::mutex mu; std::condition_variable cv_work, cv_done;
     std::deque<Task> queue;
     std::vector<std::thread> workers;
+    int active = 0, budget = 0, users = 0;
     bool stop = false;
 
     void worker_loop()
@@ -833,6 +841,7 @@ struct bscgpu_pipe {
                 cv_work.wait(lk, [&] { return stop || !queue.empty(); });
                 if (queue.empty()) return;
                 t = queue.front(); queue.pop_front();
+                ++active;
             }
             BlockJob& J = *t.job;
             bool finished = false;
@@ -841,17 +850,64 @@ struct bscgpu_pipe {
                 if (J.use_ps) host_encode_group(J, t.sub); else host_encode_sub(J, t.sub);
                 if (J.remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) { host_finalize(J); finished = true; }
             }
-            if (finished) { { std::lock_guard<std::mutex> lk(mu); J.done = true; } cv_done.notify_all(); }
+            { std::lock_guard<std::mutex> lk(mu); --active; if (finished) J.done = true; }
+            if (finished) cv_done.notify_all();
         }
     }
+    // CPUs of the budget that have neither a task nor one waiting for them (caller holds mu)
+    int free_cpus() const { const int f = budget - active - (int)queue.size(); return f < 0 ? 0 : f; }
+};
+static std::mutex g_pool_mu;
+static CoderPool* g_pool = nullptr;
+static std::atomic<uint64_t> g_pool_mode[4];          // blocks queued as: 8 scalar tasks, 4 pair tasks, one eight-lane task, host-model tasks
+
+void bscgpu_coder_pool_stats(uint64_t out[4], int reset)
+{
+    for (int i = 0; i < 4; ++i) { out[i] = g_pool_mode[i].load(std::memory_order_relaxed); if (reset) g_pool_mode[i].store(0, std::memory_order_relaxed); }
+}
+
+static CoderPool* pool_acquire()
+{
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    if (!g_pool) {
+        CoderPool* P = new CoderPool;
+        int nworkers = default_coder_threads();
+        if (const char* e = getenv("BSCGPU_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) nworkers = v; }
+        P->budget = nworkers < default_coder_threads() ? nworkers : default_coder_threads();
+        if (const char* e = getenv("BSCGPU_HOST_CPUS")) { int v = atoi(e); if (v >= 1 && v <= 256) P->budget = v; }
+        for (int i = 0; i < nworkers; ++i) P->workers.emplace_back([P] { P->worker_loop(); });
+        g_pool = P;
+    }
+    ++g_pool->users;
+    return g_pool;
+}
+static void pool_release(CoderPool* P)                 // the last pipe takes the threads with it
+{
+    std::unique_lock<std::mutex> g(g_pool_mu);
+    if (--P->users > 0) return;
+    g_pool = nullptr;
+    g.unlock();
+    { std::lock_guard<std::mutex> lk(P->mu); P->stop = true; }
+    P->cv_work.notify_all();
+    for (auto& t : P->workers) t.join();
+    delete P;
+}
+
+struct bscgpu_pipe {
+    bscgpu_ctx* c = nullptr;
+    int depth = 1;
+    int next_ticket = 0;
+    struct Lane { std::unique_ptr<BlockJob> job; int ticket = -1; bool busy = false; };
+    Lane lanes[MAX_SLOTS];
+    CoderPool* pool = nullptr;
 };
 
 static void lane_join(bscgpu_pipe* p, bscgpu_pipe::Lane& L)
 {
     if (!L.busy) return;
     {
-        std::unique_lock<std::mutex> lk(p->mu);
-        p->cv_done.wait(lk, [&] { return L.job->done; });
+        std::unique_lock<std::mutex> lk(p->pool->mu);
+        p->pool->cv_done.wait(lk, [&] { return L.job->done; });
     }
     L.busy = false;
     // lane_join only runs on the pipe's submitting thread (submit / wait / destroy), which owns the GPU stage
@@ -870,10 +926,8 @@ int bscgpu_pipe_create(bscgpu_ctx* c, int depth, bscgpu_pipe** out)
     if (rc < 0) return rc;
     bscgpu_pipe* p = new bscgpu_pipe;
     p->c = c; p->depth = depth;
-    int nworkers = default_coder_threads();             // the CPUs this process may use (affinity and cgroup quota)
-    if (const char* e = getenv("BSCGPU_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) nworkers = v; }
     for (int i = 0; i < depth; ++i) p->lanes[i].job.reset(new BlockJob);
-    for (int i = 0; i < nworkers; ++i) p->workers.emplace_back([p] { p->worker_loop(); });
+    p->pool = pool_acquire();
     *out = p;
     return LIBBSC_NO_ERROR;
 }
@@ -882,9 +936,7 @@ void bscgpu_pipe_destroy(bscgpu_pipe* p)
 {
     if (!p) return;
     for (int i = 0; i < p->depth; ++i) lane_join(p, p->lanes[i]);
-    { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
-    p->cv_work.notify_all();
-    for (auto& t : p->workers) t.join();
+    pool_release(p->pool);
     delete p;
 }
 
@@ -894,24 +946,29 @@ static int pipe_enqueue(bscgpu_pipe* p, bscgpu_pipe::Lane& L, int ticket)
     BlockJob& J = *L.job;
     L.ticket = ticket; L.busy = true;
     J.pipelined = p->depth >= 3;
-    J.pipe_workers = (int)p->workers.size();
+    CoderPool* P = p->pool;
+    J.pipe_workers = (int)P->workers.size();
     {
-        std::lock_guard<std::mutex> lk(p->mu);
+        std::lock_guard<std::mutex> lk(P->mu);
+        J.pool_free = P->free_cpus();
         if (job_uses_tasks(J)) {
             host_prepare(J);
-            if (J.use_ps) {                                      // device model: 2 (interleaved scalar) or 8 (AVX2 lanes) sub-blocks per task
-                const int g = ps_group(J);
+            if (J.use_ps) {                                      // device model: 1 (scalar), 2 (interleaved scalar) or 8 (SIMD lanes) sub-blocks per task
+                const int g = J.ps_g = ps_group(J);
+                g_pool_mode[g == 1 ? 0 : g == 2 ? 1 : 2].fetch_add(1, std::memory_order_relaxed);
                 J.remaining.store(J.nblocks / g, std::memory_order_release);
-                for (int b = 0; b < J.nblocks; b += g) p->queue.push_back({&J, b});
+                for (int b = 0; b < J.nblocks; b += g) P->queue.push_back({&J, b});
             } else {
+                g_pool_mode[3].fetch_add(1, std::memory_order_relaxed);
                 J.remaining.store(J.nblocks, std::memory_order_release);
-                for (int b = 0; b < J.nblocks; ++b) p->queue.push_back({&J, b});
+                for (int b = 0; b < J.nblocks; ++b) P->queue.push_back({&J, b});
             }
         } else {
-            p->queue.push_back({&J, -1});
+            g_pool_mode[3].fetch_add(1, std::memory_order_relaxed);
+            P->queue.push_back({&J, -1});
         }
     }
-    p->cv_work.notify_all();
+    P->cv_work.notify_all();
     p->next_ticket = ticket + 1;
     return ticket;
 }

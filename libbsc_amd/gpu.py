@@ -165,6 +165,13 @@ class GpuContext:
         return list(out)
 
 
+def coder_pool_stats(reset=False):
+    """how the process's coder pool has coded the pipes' blocks: {scalar x8 tasks, pairs x4 tasks, eight_lanes x1 task, host_model}"""
+    out = (C.c_uint64 * 4)()
+    N.lib().bscgpu_coder_pool_stats(out, 1 if reset else 0)
+    return {"scalar_tasks": int(out[0]), "pair_tasks": int(out[1]), "eight_lane_task": int(out[2]), "host_model": int(out[3])}
+
+
 class Pipe:
     """Several blocks in flight on one GPU (bscgpu_pipe_*): submit() runs the GPU stage, the host coder of that
     block runs on worker threads while the next block is sorted."""
