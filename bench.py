@@ -130,21 +130,31 @@ def main():
     LOW_LATENCY = 0x10000                               # include/bscgpu.h
     tail_low_latency = os.environ.get("BSC_BENCH_TAIL", "0") != "0"     # off: the pool itself codes a block as short tasks while CPUs are idle
 
+    trace = [] if os.environ.get("BSC_BENCH_TRACE") else None      # (pipe, block, what, seconds since the run started): where a short run's time goes
+    t_run0 = [0.0]
+
     def run_one(k, steps, record, out):
         """`steps` blocks through pipe k: GPU stage of block i+1 overlaps the host coding of block i."""
         pipe, cx = pipes[k], ctxs[k]
         tickets, blk = [], None
         local_stage = np.zeros(6)
+        done = 0
         for i in range(steps):
             # (BSC_BENCH_TAIL=1: the last block of every pipe is explicitly marked BSCGPU_FEATURE_LOW_LATENCY — eight scalar tasks)
             feat = 3 | (LOW_LATENCY if (tail_low_latency and i == steps - 1) else 0)
+            if trace is not None and record: trace.append((k, i, "submit", time.perf_counter() - t_run0[0]))
             tickets.append(pipe.submit(d_in, n, args.sorter, args.coder, feat))
+            if trace is not None and record: trace.append((k, i, "gpu stage done", time.perf_counter() - t_run0[0]))
             if record:
                 local_stage += np.array(cx.last_stage_ms())
             if len(tickets) >= args.depth:
                 blk = finish(pipe, tickets.pop(0))
+                if trace is not None and record: trace.append((k, done, "coded", time.perf_counter() - t_run0[0]))
+                done += 1
         while tickets:
             blk = finish(pipe, tickets.pop(0))
+            if trace is not None and record: trace.append((k, done, "coded", time.perf_counter() - t_run0[0]))
+            done += 1
         out[k] = blk
         if record:
             with stage_lock:
@@ -183,12 +193,17 @@ def main():
     coder_pool_stats(reset=True)
     cpu0 = time.process_time()
     t0 = time.perf_counter()
+    t_run0[0] = t0
     blk = run(args.steps, record=True)
     if concat is not None:
         concat.close()                                  # every block of the timed region has reached rank 0's host memory
     sync()
     dt = time.perf_counter() - t0
     cpu_used = time.process_time() - cpu0               # all threads of this rank
+    if trace is not None and rank == 0:
+        for k, i, what, t in sorted(trace, key=lambda x: x[3]):
+            print(f"[trace] {t * 1e3:8.1f} ms  pipe {k} block {i}: {what}", file=sys.stderr)
+        print(f"[trace] {dt * 1e3:8.1f} ms  end of the timed region", file=sys.stderr)
     pool_modes = coder_pool_stats()                     # how the timed blocks were coded (block.cpp: ps_group)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)

@@ -166,8 +166,9 @@ __global__ __launch_bounds__(WG) void dc_ctx_kernel(const u64* __restrict__ key_
         const u32 q = inv_ch[j];
         const u64 chain_id = key >> 53;                               // X and sub-block
         // (all NP loads are issued at once — the index does not depend on what the nearer neighbours turn out to be — and NP is large
-        // enough that the bracket below almost always closes: with five, a few per cent of the runs — one lane in most wavefronts —
-        // took the serial look-back further down, and the kernel spent 89 % of its wave cycles waiting)
+        // enough that the bracket below almost always closes: on the bench block 1.9 % of the runs — a lane in 38 % of the wavefronts —
+        // stay open after five predecessors (a symbol whose recent runs all have length 2 or 3 has two fixed points, 1 and 2), 0.015 %
+        // after nine)
         constexpr int NP = 9;
         u64 pk[NP];
 #pragma unroll
@@ -222,7 +223,12 @@ __global__ __launch_bounds__(WG) void dc_ctx_kernel(const u64* __restrict__ key_
         mark(DC_KIND_RUN + (it.run < 64u ? it.run : 64u + (u32)bsr(it.run)));
     }
     __syncthreads();
-    for (u32 i = threadIdx.x; i < DC_KIND_WORDS; i += WG) if (bits[i]) atomicOr(&present[i], bits[i]);
+    // Bits are only ever set during the launch, so a plain look first is safe (a stale zero costs one atomic, a one is a one): without it
+    // every workgroup — 110 K of them — sent ~20 atomics to the same few dozen words, and those serialise at ~11 ns apiece.
+    for (u32 i = threadIdx.x; i < DC_KIND_WORDS; i += WG) {
+        const u32 mine = bits[i];
+        if (mine) { const u32 need = mine & ~__builtin_nontemporal_load(&present[i]); if (need) atomicOr(&present[i], need); }
+    }
 }
 
 // 1d. the canonical rounds that occur (and how many decision types: diagnostics).  One workgroup.
@@ -610,8 +616,17 @@ __device__ __forceinline__ void dc_walk(const DcEvalJob& J, const ModelParams* _
         }
         u32 lim = k1 < rowend ? k1 : rowend;
         // 8 events per 16-byte load while aligned and inside the row
+        // (four loads are kept in flight: a lane walks 8 events in ~0.1 us and a load takes ~0.6; the one replay of the bench block — a
+        // serial walk of 8192 events by a single lane while the GPU waits — was 0.39 ms with a load per 8 events waited for in turn)
+        uint4 qb[4];
+        if ((k & 7u) == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (k + 8u * (u32)i + 8u <= lim) qb[i] = *reinterpret_cast<const uint4*>(J.events + k + 8u * (u32)i);
+        }
         while ((k & 7u) == 0 && k + 8 <= lim) {
-            const uint4 q = *reinterpret_cast<const uint4*>(J.events + k);
+            const uint4 q = qb[0];
+            qb[0] = qb[1]; qb[1] = qb[2]; qb[2] = qb[3];
+            if (k + 40u <= lim) qb[3] = *reinterpret_cast<const uint4*>(J.events + k + 32u);
             const u32 wds[4] = {q.x, q.y, q.z, q.w};
             u32 outw[4];
 #pragma unroll
