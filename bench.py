@@ -128,7 +128,9 @@ def main():
         return blk
 
     LOW_LATENCY = 0x10000                               # include/bscgpu.h
-    tail_low_latency = os.environ.get("BSC_BENCH_TAIL", "0") != "0"     # off: the pool itself codes a block as short tasks while CPUs are idle
+    # the last block of every pipe is marked BSCGPU_FEATURE_LOW_LATENCY (short host tasks whatever the pool's load): the pipeline's drain
+    # is part of the timed region, and only the caller knows where a job ends
+    tail_low_latency = os.environ.get("BSC_BENCH_TAIL", "1") != "0"
 
     trace = [] if os.environ.get("BSC_BENCH_TRACE") else None      # (pipe, block, what, seconds since the run started): where a short run's time goes
     t_run0 = [0.0]
@@ -140,7 +142,6 @@ def main():
         local_stage = np.zeros(6)
         done = 0
         for i in range(steps):
-            # (BSC_BENCH_TAIL=1: the last block of every pipe is explicitly marked BSCGPU_FEATURE_LOW_LATENCY — eight scalar tasks)
             feat = 3 | (LOW_LATENCY if (tail_low_latency and i == steps - 1) else 0)
             if trace is not None and record: trace.append((k, i, "submit", time.perf_counter() - t_run0[0]))
             tickets.append(pipe.submit(d_in, n, args.sorter, args.coder, feat))
@@ -322,8 +323,9 @@ def main():
         simd = "AVX-512VL" if has_avx512vl else "AVX2"
         if rc_adaptive:
             coder_desc = (f"per block either all eight sub-blocks in the SIMD lanes of one task ({simd}; {pool_modes['eight_lane_task']} of this rank's {args.steps} timed blocks) "
-                          f"or four tasks of two interleaved scalar coders, taken while >= 4 CPUs of the pool's budget were idle ({pool_modes['pair_tasks']} blocks)"
-                          + (f", or eight scalar tasks for blocks marked low-latency ({pool_modes['scalar_tasks']})" if pool_modes['scalar_tasks'] else ""))
+                          f"or four tasks of two interleaved scalar coders — blocks queued while >= 4 CPUs of the pool's budget were idle"
+                          + (f", and the last block of each of the {ncx} pipes, marked low-latency" if tail_low_latency else "") + f" ({pool_modes['pair_tasks']} blocks)"
+                          + (f", or eight scalar tasks, a low-latency block that found >= 12 CPUs idle ({pool_modes['scalar_tasks']})" if pool_modes['scalar_tasks'] else ""))
         elif rc_x8:
             coder_desc = f"all eight sub-blocks of a block in the SIMD lanes of one task, {simd}"
         else:

@@ -507,6 +507,7 @@ static int ps_simd_env()
     return mode;
 }
 static int default_coder_threads();
+static std::atomic<int> g_sync_callers{0};            // synchronous host stages running right now (bsc_compress / bscgpu_compress_device callers)
 static bool cpu_has_avx512vl() { static const bool has = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl"); return has; }
 static int ps_group(const BlockJob& J)
 {
@@ -516,7 +517,15 @@ static int ps_group(const BlockJob& J)
     // CPU for each of the eight (44 ms per 8 MiB sub-block on an EPYC 9575F against 52 ms for an interleaved pair), else pairs
     const bool latency = (J.features & BSCGPU_FEATURE_LOW_LATENCY) || !J.pipelined;
     if (env >= 0) return env == 8 ? 8 : 2;                            // BSC_RC_SIMD forces eight lanes / pairs everywhere
-    if (latency) { static const int cpus = default_coder_threads(); return (J.pipe_workers ? J.pipe_workers : cpus) >= 8 ? 1 : 2; }
+    if (latency) {
+        // (a pipe's block marked low-latency: pairs — the blocks around it are still being coded, eight more tasks would queue behind them)
+        if (J.pool_free >= 0) return J.pool_free >= 12 ? 1 : 2;
+        // a synchronous call starts its own threads: eight only if this call's share of the CPUs has room for them (the reference CLI
+        // calls bsc_compress from an OpenMP team: four callers x eight threads on 16 CPUs took twice as long as four x four)
+        static const int cpus = default_coder_threads();
+        const int callers = g_sync_callers.load(std::memory_order_relaxed);
+        return cpus / (callers > 1 ? callers : 1) >= 8 ? 1 : 2;
+    }
     if (!cpu_has_avx512vl()) return 2;
     // A pipe's block: the eight-lane task costs half the CPU time of four pair tasks (0.118 against 0.228 CPU-s per 64 MiB block) but
     // takes 90 instead of 52 ms.  While the pool has four CPUs with nothing to do the pairs cost nothing and the block is out 40 ms
@@ -664,6 +673,7 @@ static void host_stage(BlockJob& J)
     if (J.stored_small) return;
     host_prepare(J);
     if (job_uses_tasks(J)) {
+        struct Caller { Caller() { g_sync_callers.fetch_add(1, std::memory_order_relaxed); } ~Caller() { g_sync_callers.fetch_sub(1, std::memory_order_relaxed); } } caller;
         if (J.use_ps) { const int g = J.ps_g = ps_group(J); run_tasks(J.nblocks / g, [&J, g](int t) { host_encode_group(J, g * t); }); }
         else run_tasks(J.nblocks, [&J](int b) { host_encode_sub(J, b); });
         host_finalize(J);
