@@ -226,7 +226,45 @@ __global__ __launch_bounds__(WG) void qf_rank_kernel(const u8* __restrict__ sym,
         for (int b = 8; b >= 1; --b) if ((u32)b <= rb.nblocks && j < rb.first[b]) re = rb.first[b];
         return re;
     };
-    {   // every lane: at most QF_SHORT runs ahead, inside the tile
+    // Tiles that lie inside one sub-block, sets of one word: binary lifting instead of a walk.  win[k][p] = the symbols at tile
+    // positions (p, p + 2^k] (cut at the tile's end), built level by level (one OR per lane and level); a lane then takes the windows
+    // 128, 64, .. 1 that do not contain its symbol, greedily — eight uniform steps whatever the distance, where the walk below is as
+    // slow as the wavefront's slowest lane (up to QF_SHORT serial LDS reads; 30 % of the kernel's wave cycles were executing, half of
+    // that scalar loop control).  A lane whose symbol does not come back inside the tile goes on from the tile's end as before.
+    const u32 tile_end = (base + WG < m) ? base + WG : m;
+    const bool lifted = DENSE && WG == 256 && sub_end(base) >= tile_end;       // workgroup-uniform
+    if (lifted) {
+        __shared__ u64 win[8][WG];
+        const u32 j = base + t;
+        win[0][t] = (j + 1 < tile_end) ? (1ull << scode[t + 1]) : 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            const u32 h = 1u << (k - 1);
+            win[k][t] = win[k - 1][t] | ((t + h < (u32)WG) ? win[k - 1][t + h] : 0ull);
+            __syncthreads();
+        }
+        if (j < m) {
+            const u32 re = sub_end(j);
+            if (j + 1 == re) rank[j] = 1;
+            else {
+                const u32 c = scode[t];
+                u64 set = 0; u32 p = t;
+#pragma unroll
+                for (int k = 7; k >= 0; --k) {
+                    const u64 w = (p < (u32)WG) ? win[k][p] : 0ull;
+                    if (!((w >> c) & 1ull)) { set |= w; p += 1u << k; }
+                }
+                // p = last tile position known to be free of c (possibly past the end): the symbol comes back at p + 1, or not in this tile
+                const bool found = base + p + 1 < tile_end;
+                if (found || tile_end == re) rank[j] = (u8)__popcll(set);
+                else {
+                    const u32 slot = atomicAdd(&qn, 1u);
+                    qt[slot] = (u8)t; qi[slot] = (u16)WG; qset[slot * W] = set;             // goes on at the tile's end
+                }
+            }
+        }
+    } else {   // every lane: at most QF_SHORT runs ahead, inside the tile
         const u32 j = base + t;
         if (j < m) {
             const u32 re = sub_end(j);
