@@ -414,16 +414,25 @@ __global__ __launch_bounds__(WG) void bwt_round_segsort_kernel(const u32* __rest
 
 // The key of a refinement round on text keys: the packed codes of T[p .. p + a) (zero past the end) and, in the low 4 bits,
 // min(n - p, a) — "a proper prefix sorts first" among equal padded keys, 0 for the empty suffix.  lut: byte -> code (LDS or global).
+// (two halves so that a caller can have the loads of several records in flight before it packs the first key)
+struct TextWin { u32 d[5]; };
+__device__ __forceinline__ TextWin bwt_text_window(const u32* __restrict__ T32, u64 p64, u32 n)
+{
+    TextWin w;
+    const u32 p = p64 < n ? (u32)p64 : 0u;                // (past the end: any valid address, the key is 0 anyway)
+    const u32* q = T32 + (p >> 2);                         // T is 4-byte aligned at T[0] and zero padded for 32 bytes past n
+#pragma unroll
+    for (int i = 0; i < 5; ++i) w.d[i] = q[i];
+    return w;
+}
 template <class LUT>
-__device__ __forceinline__ u64 bwt_text_round_key(const u32* __restrict__ T32, LUT lut, u64 p64, u32 n, u32 cb, u32 a)
+__device__ __forceinline__ u64 bwt_text_key_of(const TextWin& w, LUT lut, u64 p64, u32 n, u32 cb, u32 a)
 {
     u64 key = 0;
     if (p64 < n) {
         const u32 p = (u32)p64, off = p & 3u;
-        const u32* q = T32 + (p >> 2);                  // T is 4-byte aligned at T[0] and zero padded for 32 bytes past n
-        const u32 d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
-        const u32 x[4] = { __builtin_amdgcn_alignbyte(d1, d0, off), __builtin_amdgcn_alignbyte(d2, d1, off),
-                           __builtin_amdgcn_alignbyte(d3, d2, off), __builtin_amdgcn_alignbyte(d4, d3, off) };
+        const u32 x[4] = { __builtin_amdgcn_alignbyte(w.d[1], w.d[0], off), __builtin_amdgcn_alignbyte(w.d[2], w.d[1], off),
+                           __builtin_amdgcn_alignbyte(w.d[3], w.d[2], off), __builtin_amdgcn_alignbyte(w.d[4], w.d[3], off) };
         const u32 left = n - p;                          // characters the suffix has
 #pragma unroll
         for (u32 c = 0; c < 15; ++c) {
@@ -436,6 +445,13 @@ __device__ __forceinline__ u64 bwt_text_round_key(const u32* __restrict__ T32, L
         key |= (u64)(left < a ? left : a);
     }
     return key;
+}
+template <class LUT>
+__device__ __forceinline__ u64 bwt_text_round_key(const u32* __restrict__ T32, LUT lut, u64 p64, u32 n, u32 cb, u32 a)
+{
+    if (p64 >= n) return 0;
+    const TextWin w = bwt_text_window(T32, p64, n);
+    return bwt_text_key_of(w, lut, p64, n, cb, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -509,11 +525,25 @@ __global__ __launch_bounds__(WG) void bwt_round_textsort_kernel(const u8* __rest
     __syncthreads();
     // the round's keys, from the text (overwrites the group ranks in LDS)
     const u32* T32 = reinterpret_cast<const u32*>(T);
-    for (u32 i = t; i < ext; i += WG) {
-        const int gs = sgs[i];
-        u64 key = 0;
-        if (gs >= 0 && (u32)gs < own) key = bwt_text_round_key(T32, lut, (u64)(csa[base + i] & smask) + h, n, cb, a);
-        snext[i] = key;
+    // (four records at a time: their suffix numbers first, then the 20 bytes of text of each — 20 loads in flight per lane — then the keys;
+    // one record after the other, each behind the test of its group, left the kernel waiting for memory 75 % of its wave cycles)
+#pragma unroll
+    for (int q0 = 0; q0 < RS_E / WG; q0 += 4) {
+        u64 pp[4]; bool ok[4]; TextWin w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 i = t + (u32)(q0 + q) * WG;
+            const int gs = (i < ext) ? (int)sgs[i] : -1;
+            ok[q] = gs >= 0 && (u32)gs < own;
+            pp[q] = ok[q] ? (u64)(csa[base + i] & smask) + h : (u64)n;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = bwt_text_window(T32, pp[q], n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 i = t + (u32)(q0 + q) * WG;
+            if (i < ext) snext[i] = ok[q] ? bwt_text_key_of(w[q], lut, pp[q], n, cb, a) : 0ull;
+        }
     }
     __syncthreads();
     for (u32 i = t; i < ext; i += WG) {

@@ -48,7 +48,10 @@
 #include <type_traits>
 
 constexpr int OS_WG = 1024, OS_WAVES = OS_WG / 64, OS_SW = OS_WAVES - 1 /* streaming waves */, OS_ST = OS_SW * 64 /* streaming threads */;
-constexpr int OS_ITEMS = 8, OS_TILE = OS_ST * OS_ITEMS /* 7680 */, OS_GRP = 8 /* tiles per group */, OS_GPB = 8 /* groups per batch */,
+#ifndef OS_ITEMS_N
+#define OS_ITEMS_N 8
+#endif
+constexpr int OS_ITEMS = OS_ITEMS_N, OS_TILE = OS_ST * OS_ITEMS /* 7680 */, OS_GRP = 8 /* tiles per group */, OS_GPB = 8 /* groups per batch */,
               OS_BATCH = OS_GRP * OS_GPB /* 64 tiles */, OS_MAXP = 8;
 constexpr u32 OS_NONE = 0xffffffffu;
 constexpr u32 OS_SPIN_LIMIT = 1u << 18;
@@ -77,6 +80,9 @@ struct OsPasses { int np; int shift[OS_MAXP]; u32 mask[OS_MAXP]; };
 
 #define OS_LOAD(p)      __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define OS_STORE(p, v)  __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#ifndef OS_STATIC_ORDER
+#define OS_STATIC_ORDER 0
+#endif
 #define OS_ADD(p, v)    __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
 // ---------------------------------------------------------------------------------------------
@@ -171,7 +177,15 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
 #pragma unroll
         for (int i = 0; i < 4; ++i) whist[w * 256 + i * 64 + lane] = 0;
     }
+#if OS_STATIC_ORDER
+    // EXPERIMENT (timing only, needs all workgroups resident): no tickets — workgroup b takes tiles k * 256 + map(b), an XCD (b % 8) working on
+    // OS_STATIC_ORDER consecutive tiles at a time: what an XCD-aware claim order would be worth to the write pattern.
+    const u32 os_map = ((blockIdx.x >> 3) / (u32)OS_STATIC_ORDER) * (8u * (u32)OS_STATIC_ORDER) + (blockIdx.x & 7u) * (u32)OS_STATIC_ORDER + ((blockIdx.x >> 3) % (u32)OS_STATIC_ORDER);
+    u32 os_round = 1;
+    if (t == (u32)ST) { const u32 tk = os_map + opaque0; sclaim[0] = tk < ntiles ? tk : OS_NONE; }
+#else
     if (t == (u32)ST) { const u32 tk = OS_ADD(ctl + opaque0, 1u); sclaim[0] = tk < ntiles ? tk : OS_NONE; }
+#endif
     __syncthreads();
     // Three tiles are in flight per workgroup: t0 is written out (its offsets were collected during the previous iteration), t1 waits
     // in its staging buffer while the scout collects its offsets, t2 is ranked, published and staged into the buffer t0 leaves.
@@ -221,7 +235,12 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
             // next tile is ~256 tiles = 4 or 5 batches further on; up to 6 in bulk, more one by one): ~11 instructions on average.
             // They are looked at behind barrier 3, when they have been in flight for most of the iteration.
             u32 ticket = 0;
+#if OS_STATIC_ORDER
+            if (more && lane == 0) ticket = os_round * gridDim.x + os_map;
+            ++os_round;
+#else
             if (more && lane == 0) ticket = OS_ADD(ctl + opaque0, 1u);        // ONE lane draws
+#endif
             v2u a1[OS_GRP - 1]; v4u g1[OS_GPB - 1], b1[6];
             if (!(OS_ABL & 1)) {
 #pragma unroll
@@ -322,8 +341,11 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     // =============================================================================================================
     const u32 wbase = w * (64 * ITEMS) + lane;
     u64 k[ITEMS];
-    u32 v[ITEMS] = {0, 0, 0, 0, 0, 0, 0, 0}, rk[ITEMS] = {0, 0, 0, 0, 0, 0, 0, 0};
-    u32 pos0[ITEMS / 2], pos1[ITEMS / 2];                               // staging slots of t0's / t1's records, two 16-bit slots per word
+    u32 v[ITEMS], rk[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) { v[i] = 0; rk[i] = 0; }
+    constexpr int HP = (ITEMS + 1) / 2;
+    u32 pos0[HP], pos1[HP];                               // staging slots of t0's / t1's records, two 16-bit slots per word
     // loads never sit behind a branch: a missing tile or a lane past the end reads record 0 (one line for the whole wave)
     // (tile = OS_NONE wraps to record numbers >= n for every lane: TILE * 0xffffffff = -TILE)
     auto load_keys = [&](const u32 tile) __attribute__((always_inline)) {
@@ -338,7 +360,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     };
     load_keys(t2);
 #pragma unroll
-    for (int i = 0; i < ITEMS / 2; ++i) { pos0[i] = 0; pos1[i] = 0; }
+    for (int i = 0; i < HP; ++i) { pos0[i] = 0; pos1[i] = 0; }
 
     // One iteration: write t0 out at the offsets the scout found during the previous iteration, then rank t2 and publish it
     // and stage it into the buffer t0 has left.  FULL = t0 and t2 are full tiles (no guards around loads and stores: waits stay exact).
@@ -454,7 +476,7 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
         asm volatile("" :: "v"(pubg), "v"(puba));
         __syncthreads();                                                                          // B4
 #pragma unroll
-        for (int i = 0; i < ITEMS / 2; ++i) { pos0[i] = pos1[i]; pos1[i] = rk[2 * i] | (rk[2 * i + 1] << 16); }
+        for (int i = 0; i < HP; ++i) { pos0[i] = pos1[i]; pos1[i] = rk[2 * i] | ((2 * i + 1 < ITEMS ? rk[(2 * i + 1 < ITEMS) ? 2 * i + 1 : 0] : 0u) << 16); }
         OS_PH(11);
 #if OS_PHASE_TIMING
         if (t == 0 && tile_no < 40u) tdbg[(((size_t)blockIdx.x * 40 + tile_no) * 2 + 0) * 16 + 14] = ((u64)t0 << 32) | t2;

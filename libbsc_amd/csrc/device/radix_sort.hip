@@ -395,7 +395,10 @@ __global__ __launch_bounds__(RSB_WG) void rs_scatter_tiled_kernel(const u64* __r
     auto fetch_offset = [&](const u32 tile) __attribute__((always_inline)) -> u32 {          // every thread loads (no branch around a load)
         return offsets[(size_t)(t & 255u) * num_tiles + (tile < num_tiles ? tile : num_tiles - 1)];
     };
-    const u32 first = (blockIdx.x & 7u) * 32u + (blockIdx.x >> 3);
+#ifndef RST_XCD_RUN
+#define RST_XCD_RUN 32          // consecutive tiles an XCD works on at a time (A/B builds: 8, 1 = plain round robin)
+#endif
+    const u32 first = ((blockIdx.x >> 3) / (u32)RST_XCD_RUN) * (8u * (u32)RST_XCD_RUN) + (blockIdx.x & 7u) * (u32)RST_XCD_RUN + ((blockIdx.x >> 3) % (u32)RST_XCD_RUN);
     u32 off_next = fetch_offset(first);
     prefetch_keys(first);
     if (HAS_VAL) prefetch_vals(first);
