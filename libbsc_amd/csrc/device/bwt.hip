@@ -525,25 +525,13 @@ __global__ __launch_bounds__(WG) void bwt_round_textsort_kernel(const u8* __rest
     __syncthreads();
     // the round's keys, from the text (overwrites the group ranks in LDS)
     const u32* T32 = reinterpret_cast<const u32*>(T);
-    // (four records at a time: their suffix numbers first, then the 20 bytes of text of each — 20 loads in flight per lane — then the keys;
-    // one record after the other, each behind the test of its group, left the kernel waiting for memory 75 % of its wave cycles)
-#pragma unroll
-    for (int q0 = 0; q0 < RS_E / WG; q0 += 4) {
-        u64 pp[4]; bool ok[4]; TextWin w[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const u32 i = t + (u32)(q0 + q) * WG;
-            const int gs = (i < ext) ? (int)sgs[i] : -1;
-            ok[q] = gs >= 0 && (u32)gs < own;
-            pp[q] = ok[q] ? (u64)(csa[base + i] & smask) + h : (u64)n;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = bwt_text_window(T32, pp[q], n);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const u32 i = t + (u32)(q0 + q) * WG;
-            if (i < ext) snext[i] = ok[q] ? bwt_text_key_of(w[q], lut, pp[q], n, cb, a) : 0ull;
-        }
+    // (issuing the text loads of four records at a time — 20 loads in flight per lane — was measured: 1.02 ms against 1.00, no gain; the
+    // kernel waits on the gathers' sector traffic, 2 GB for 28 M records, not on their latency)
+    for (u32 i = t; i < ext; i += WG) {
+        const int gs = sgs[i];
+        u64 key = 0;
+        if (gs >= 0 && (u32)gs < own) key = bwt_text_round_key(T32, lut, (u64)(csa[base + i] & smask) + h, n, cb, a);
+        snext[i] = key;
     }
     __syncthreads();
     for (u32 i = t; i < ext; i += WG) {

@@ -594,69 +594,6 @@ __device__ __forceinline__ u32 dc_find_row(P rowstart, u32 k)
     return lo;
 }
 
-// Walk events [k0, k1) of one chunk.  MODE 0: two-sided bracket, returns (lo, hi).  MODE 1: exact from `start`, optionally
-// writing the value each event sees.
-template <bool WRITE>
-__device__ __forceinline__ void dc_walk(const DcEvalJob& J, const ModelParams* __restrict__ mp, u32 k0, u32 k1, int& lo, int& hi, bool bracket,
-                                        u16* __restrict__ Vout)
-{
-    u32 row = dc_find_row(J.rowstart, k0);
-    u32 rowend = J.rowstart[row + 1];
-    while (rowend <= k0 && row < (u32)DC_ROWS - 1) { ++row; rowend = J.rowstart[row + 1]; }     // k0 inside an empty-row run: move to its row
-    int cls = tau_class((int)row);
-    Rates R = mp->rates[cls][J.fam];
-    u32 prev = (k0 > J.rowstart[row]) ? ((u32)J.events[k0 - 1] & DC_SIGMASK) : 0xffffu;
-    if (bracket) { lo = mp->vmin[cls][J.fam]; hi = mp->vmax[cls][J.fam]; }
-    u32 k = k0;
-    while (k < k1) {
-        if (k == rowend) {
-            row = dc_find_row(J.rowstart, k); rowend = J.rowstart[row + 1];                 // the next non-empty row (empty ones in between: most types never occur)
-            cls = tau_class((int)row); R = mp->rates[cls][J.fam];
-            prev = 0xffffu;
-        }
-        u32 lim = k1 < rowend ? k1 : rowend;
-        // 8 events per 16-byte load while aligned and inside the row
-        // (four loads are kept in flight: a lane walks 8 events in ~0.1 us and a load takes ~0.6; the one replay of the bench block — a
-        // serial walk of 8192 events by a single lane while the GPU waits — was 0.39 ms with a load per 8 events waited for in turn)
-        uint4 qb[4];
-        if ((k & 7u) == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) if (k + 8u * (u32)i + 8u <= lim) qb[i] = *reinterpret_cast<const uint4*>(J.events + k + 8u * (u32)i);
-        }
-        while ((k & 7u) == 0 && k + 8 <= lim) {
-            const uint4 q = qb[0];
-            qb[0] = qb[1]; qb[1] = qb[2]; qb[2] = qb[3];
-            if (k + 40u <= lim) qb[3] = *reinterpret_cast<const uint4*>(J.events + k + 32u);
-            const u32 wds[4] = {q.x, q.y, q.z, q.w};
-            u32 outw[4];
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const u32 e = (wds[x >> 1] >> (16 * (x & 1))) & 0xffffu;
-                const u32 sig = e & DC_SIGMASK;
-                if (sig != prev) { lo = 2048; hi = 2048; prev = sig; }
-                const u32 b = (e >> 11) & 1u;
-                if (WRITE) { if (x & 1) outw[x >> 1] |= (u32)lo << 16; else outw[x >> 1] = (u32)lo; }
-                lo = step(lo, b, R);
-                if (!WRITE) hi = step(hi, b, R);
-            }
-            if (WRITE) *reinterpret_cast<uint4*>(Vout + k) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
-            k += 8;
-        }
-        if (k < lim && ((k & 7u) != 0 || k + 8 > lim)) {
-            const u32 stop = ((k & 7u) != 0) ? (((k | 7u) + 1u) < lim ? ((k | 7u) + 1u) : lim) : lim;
-            for (; k < stop; ++k) {
-                const u32 e = J.events[k];
-                const u32 sig = e & DC_SIGMASK;
-                if (sig != prev) { lo = 2048; hi = 2048; prev = sig; }
-                const u32 b = (e >> 11) & 1u;
-                if (WRITE) Vout[k] = (u16)lo;
-                lo = step(lo, b, R);
-                if (!WRITE) hi = step(hi, b, R);
-            }
-        }
-    }
-}
-
 // Phases a and c as one wavefront per 64 chunks: the lanes own one chunk each (a serial chain), but memory is touched as
 // full lines — for every batch of 64 events per lane the wavefront loads the 64 lanes' 128-byte pieces cooperatively
 // (8 x 16 B per lane, eight rows per instruction), transposes them through LDS, and (phase c) writes the values back the same
@@ -880,9 +817,28 @@ __global__ __launch_bounds__(WG) void dc_eval_b_kernel(DcEvalAll A, const ModelP
         if (depth > 64) { atomicOr(&meta[DM_FAIL], (u32)FAIL_REPLAY); Sv[c] = 2048; return; }
     }
     atomicAdd(&meta[DM_REPLAYS], depth);
-    int lo = start, hi = start;
-    dc_walk<false>(J, mp, j * EV, c * EV, lo, hi, false, nullptr);          // exact walk (lo == hi throughout), no output
-    Sv[c] = (u16)lo;
+    // Exact walk over chunks j .. c - 1.  None of them coalesced, so none contains a chain boundary (a boundary resets both ends of the
+    // bracket to 2048 and they stay equal from there on): one chain, one row, one set of rates — a bare loop, eight events per 16-byte
+    // load with four loads in flight (EV is a multiple of 8 and chunks start 16-byte aligned).  The GPU waits for this one lane:
+    // 0.37 ms per replayed chunk with the general walk (row look-ups and signature tests per event), 0.32 ms like this (~80 cycles per
+    // event: a lone wavefront issues the five dependent operations of a step ~8 cycles apart).  With several contexts on the GPU the
+    // other blocks' kernels fill the machine meanwhile.
+    const Rates R = mp->rates[tau_class((int)dc_find_row(J.rowstart, j * EV))][J.fam];
+    int v = start;
+    const uint4* ev = reinterpret_cast<const uint4*>(J.events + (size_t)j * EV);
+    const u32 nq = (c - j) * (EV / 8u);
+    uint4 qb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qb[i] = ev[(u32)i < nq ? (u32)i : 0u];
+    for (u32 i = 0; i < nq; ++i) {
+        const uint4 q = qb[0];
+        qb[0] = qb[1]; qb[1] = qb[2]; qb[2] = qb[3];
+        qb[3] = ev[i + 4u < nq ? i + 4u : i];
+        const u32 wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int x = 0; x < 8; ++x) v = step(v, (wds[x >> 1] >> (16 * (x & 1) + 11)) & 1u, R);
+    }
+    Sv[c] = (u16)v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

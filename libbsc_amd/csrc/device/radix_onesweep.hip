@@ -379,9 +379,9 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                                                                         // is preceded by a wait for the store itself)
         OS_PH(0);
         // ---- t0 leaves: every digit as one contiguous run, consecutive lanes -> consecutive addresses
-        u32 dd[ITEMS / 4];
+        u32 dd[(ITEMS + 3) / 4];
 #pragma unroll
-        for (int j = 0; j < ITEMS / 4; ++j) dd[j] = 0;
+        for (int j = 0; j < (ITEMS + 3) / 4; ++j) dd[j] = 0;
         if (v0) {
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
