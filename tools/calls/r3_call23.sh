@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 3, GPU call 23: final build — full GPU suite, smoke, the driver's bench command, default bench (also 6 contexts x 3), rocprofv3 evidence
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+export TMPDIR=/tmp
+O=gpurun_out/r3_final; mkdir -p $O
+{
+echo "== full GPU suite"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+echo "== bench, the driver's command"; timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_20.json 2> $O/bench_20.err; cut -c1-200 $O/bench_20.json
+echo "== bench, defaults"; timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-200 $O/bench_default.json
+echo "== bench, 6 contexts x 3"; timeout 900 python bench.py --contexts 6 --depth 3 --no-cpu-baseline 2>/dev/null | cut -c1-200
+echo "== bench, 3 contexts x 4"; timeout 900 python bench.py --contexts 3 --depth 4 --no-cpu-baseline 2>/dev/null | cut -c1-200
+echo "== profile_round"; timeout 900 bash tools/profile_round.sh r03 > $O/profile_round.log 2>&1; tail -2 $O/profile_round.log | cut -c1-300
+} > gpurun_out/r3_call23.txt 2>&1
+cat gpurun_out/r3_call23.txt | cut -c1-260
