@@ -42,8 +42,9 @@ def main():
     ap.add_argument("--sorter", type=int, default=1)
     ap.add_argument("--coder", type=int, default=1)
     ap.add_argument("--depth", type=int, default=0, help="blocks in flight per GPU (0 = from the coder pool size); their sub-blocks feed the pool of coder threads")
-    ap.add_argument("--contexts", type=int, default=4, help="GPU contexts (own stream, arena and pipe each) driven concurrently on every GPU: "
-                    "kernels of two blocks interleave on the device, which fills the SIMDs that one block's serial chains leave idle")
+    ap.add_argument("--contexts", type=int, default=6, help="GPU contexts (own stream, arena and pipe each) driven concurrently on every GPU: "
+                    "kernels of different blocks interleave on the device, which fills what one block's latency-bound kernels leave idle "
+                    "(one box, 320 / 20 steps: 3 x 4 4834, 4 x 4 4882 / 3655, 6 x 3 5054 / 3903, 5 x 3 - / 3640, 8 x 2 - / 3513 MB/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -95,7 +96,7 @@ def main():
     rc_x8 = rc_simd == 8 or (rc_simd < 0 and has_avx512vl)
     if args.depth <= 0:                                 # blocks in flight per context
         args.depth = max(2, min(4, 8 // ncx))
-        if rc_x8: args.depth = max(2, min(4, 16 // ncx))      # one longer task per block: 16 blocks in flight per GPU
+        if rc_x8: args.depth = max(2, min(4, 18 // ncx))      # one longer task per block: 16-18 blocks in flight per GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm_dev = dev if backend == "nccl" else torch.device("cpu")

@@ -13,6 +13,9 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 ref = Ref()
 MAXN = int(sys.argv[3]) if len(sys.argv) > 3 else (12 << 20)
+VERBOSE = bool(__import__("os").environ.get("FUZZ_VERBOSE"))       # one line per case BEFORE it runs (a crash then names its case)
+def say(*a):
+    if VERBOSE: print("case", *a, flush=True)
 EDGES = [1 << 12, 1 << 16, 1 << 18, 1 << 20, 1 << 21, 1 << 22, (1 << 22) + (1 << 21), 1 << 23, 4096 * 1024, 8192 * 512, 8192 * 1024, 16384 * 256]
 
 def draw_n():
@@ -39,11 +42,13 @@ while time.time() - t0 < budget:
     what = int(rng.integers(0, 3))
     try:
         if what == 0:
+            say(cases, n, "bwt")
             L, idx, aux = api.bsc_bwt_encode(T, aux=(n >= 16))
             wL, widx, waux = ref.bwt_encode(T, aux=(n >= 16))
             ok = np.array_equal(L, wL) and idx == widx and list(aux) == list(waux)
         elif what == 1:
             k = int(rng.integers(3, 9))
+            say(cases, n, "st", k)
             L, idx = api.bsc_st_encode(T, k)
             if k <= 6:
                 wL, widx = ref.st_encode(T, k)
@@ -55,6 +60,7 @@ while time.time() - t0 < budget:
         else:
             sorter = int(rng.choice([1, 1, 1, 3, 4, 5, 6, 7, 8])); coder = int(rng.integers(1, 4)); feat = int(rng.choice([0, 1, 3]))
             lz = (0, 0) if rng.integers(0, 3) else (int(rng.integers(10, 20)), int(rng.choice([4, 6, 8, 12, 16, 32, 128])))
+            say(cases, n, "compress", sorter, coder, feat, lz)
             got = api.bsc_compress(T, sorter, coder, lzp_hash=lz[0], lzp_min=lz[1], features=feat)
             if sorter <= 6:
                 want = ref.compress(T, sorter, coder, lzp_hash=lz[0], lzp_min=lz[1], features=feat)
