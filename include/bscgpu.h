@@ -113,6 +113,10 @@ BSCGPU_API int  bscgpu_pipe_create(bscgpu_ctx* ctx, int depth, bscgpu_pipe** out
 /* How the pool has coded the pipes' blocks so far: out[0] blocks as eight scalar tasks, [1] as four pair tasks, [2] as one eight-lane
  * task, [3] blocks on the host model (one task per sub-block).  reset != 0 clears the counts.  (bench.py reports them.) */
 BSCGPU_API void bscgpu_coder_pool_stats(uint64_t out[4], int reset);
+/* The rule behind those shapes as a pure function (unit-tested on CPU): sub-blocks per coder task — 8 (one SIMD task), 2 or 1 — from
+ * forced (-1 none, 8 or 0: BSC_RC_SIMD), low_latency (synchronous call or BSCGPU_FEATURE_LOW_LATENCY), pool_free (idle CPUs of the
+ * pool's budget; -1: a synchronous call), sync_cpus (CPUs / synchronous callers running), wide_simd (AVX-512VL), adaptive. */
+BSCGPU_API int bscgpu_coder_task_shape(int forced, int low_latency, int pool_free, int sync_cpus, int wide_simd, int adaptive);
 BSCGPU_API void bscgpu_pipe_destroy(bscgpu_pipe* pipe);
 BSCGPU_API int  bscgpu_pipe_submit(bscgpu_pipe* pipe, const void* dInput, uint8_t* output, int n,
                                    int blockSorter, int coder, int features);       /* ticket >= 0 or error */

@@ -489,14 +489,13 @@ static void host_encode_pair(BlockJob& J, int b)
     J.sub_res[b + 1] = r1 < 0 ? J.size[b + 1] : r1;
 }
 
-// All eight sub-blocks of a device-model block in the lanes of one SIMD range-coder loop (qlfc_encode_static_pstream_x8): one
-// task instead of four.  EPYC 9575F, CPU-seconds per 64 MiB block with framing: pairs 0.228 (4 x 0.052 s), eight lanes with
-// AVX-512VL 0.118 (one task of ~0.09 s), with AVX2 0.141 (~0.115 s).  Half the CPU time, not quite twice the latency: a pipe needs
-// three blocks in flight per context instead of two to keep the GPU busy, and then moves the same MB/s.
-//   BSC_RC_SIMD=8 / 0   eight lanes / pairs everywhere
-//   unset               eight lanes for pipelined blocks (bscgpu_pipe_*) on CPUs with AVX-512VL, pairs otherwise; the synchronous entry
-//                       points and blocks submitted with BSCGPU_FEATURE_LOW_LATENCY (one block at a time / the tail of a job: latency
-//                       counts) take one scalar coder per task where the process has eight CPUs, else pairs
+// How the eight sub-blocks of a device-model block are coded on the host (EPYC 9575F, per 64 MiB block with framing):
+//   8  all eight in the lanes of one SIMD range-coder loop (qlfc_encode_static_pstream_x8): one task, 0.118 CPU-s with AVX-512VL
+//      (0.141 with AVX2), ~90 ms
+//   2  four tasks of two interleaved scalar coders: 0.228 CPU-s, ~52 ms
+//   1  eight tasks of one scalar coder: 0.35 CPU-s, ~44 ms
+// bscgpu_coder_task_shape is the rule (a pure function, unit-tested on CPU); ps_group feeds it.  BSC_RC_SIMD=8 / 0 forces eight lanes /
+// pairs everywhere, BSC_RC_ADAPTIVE=0 turns the idle test off (eight lanes for every block that is not marked low-latency).
 static int ps_simd_env()
 {
     static const int mode = [] {
@@ -509,31 +508,35 @@ static int ps_simd_env()
 static int default_coder_threads();
 static std::atomic<int> g_sync_callers{0};            // synchronous host stages running right now (bsc_compress / bscgpu_compress_device callers)
 static bool cpu_has_avx512vl() { static const bool has = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl"); return has; }
+// forced: -1 none, 8 / 0 (BSC_RC_SIMD); low_latency: a synchronous call, or the caller marked the block (BSCGPU_FEATURE_LOW_LATENCY);
+// pool_free: CPUs of the coder pool's budget with nothing to do when the block is queued, -1 for a synchronous call (which starts
+// its own threads: sync_cpus = CPUs / synchronous callers running); wide_simd: AVX-512VL; adaptive: BSC_RC_ADAPTIVE.
+extern "C" BSCGPU_API int bscgpu_coder_task_shape(int forced, int low_latency, int pool_free, int sync_cpus, int wide_simd, int adaptive)
+{
+    if (forced >= 0) return forced == 8 ? 8 : 2;
+    if (low_latency) {
+        // a pipe's block marked low-latency: pairs — the blocks around it are still being coded, eight more tasks would queue behind
+        // them — unless the pool is nearly idle
+        if (pool_free >= 0) return pool_free >= 12 ? 1 : 2;
+        // a synchronous call: eight threads only if its share of the CPUs has room for them (the reference CLI calls bsc_compress from
+        // an OpenMP team: four callers x eight threads on 16 CPUs took 1.29 s for 8 x 64 MiB, sized by share 1.15 s)
+        return sync_cpus >= 8 ? 1 : 2;
+    }
+    if (!wide_simd) return 2;
+    // A pipe's block: the eight-lane task costs half the CPU time of four pair tasks but takes 90 instead of 52 ms.  While the pool has
+    // four CPUs with nothing to do the pairs cost nothing and the block is out 40 ms earlier (a short job is mostly pipeline fill and
+    // drain); when the coder threads are busy — many GPUs per host, a small quota — every block is one eight-lane task and the pool's
+    // throughput is what counts.
+    return (adaptive && pool_free >= 4) ? 2 : 8;
+}
 static int ps_group(const BlockJob& J)
 {
     if (!J.use_ps || J.nblocks != 8) return 2;
-    const int env = ps_simd_env();
-    // latency first (a synchronous call, or the caller marked the tail of a job): one scalar coder per task where the process has a
-    // CPU for each of the eight (44 ms per 8 MiB sub-block on an EPYC 9575F against 52 ms for an interleaved pair), else pairs
-    const bool latency = (J.features & BSCGPU_FEATURE_LOW_LATENCY) || !J.pipelined;
-    if (env >= 0) return env == 8 ? 8 : 2;                            // BSC_RC_SIMD forces eight lanes / pairs everywhere
-    if (latency) {
-        // (a pipe's block marked low-latency: pairs — the blocks around it are still being coded, eight more tasks would queue behind them)
-        if (J.pool_free >= 0) return J.pool_free >= 12 ? 1 : 2;
-        // a synchronous call starts its own threads: eight only if this call's share of the CPUs has room for them (the reference CLI
-        // calls bsc_compress from an OpenMP team: four callers x eight threads on 16 CPUs took twice as long as four x four)
-        static const int cpus = default_coder_threads();
-        const int callers = g_sync_callers.load(std::memory_order_relaxed);
-        return cpus / (callers > 1 ? callers : 1) >= 8 ? 1 : 2;
-    }
-    if (!cpu_has_avx512vl()) return 2;
-    // A pipe's block: the eight-lane task costs half the CPU time of four pair tasks (0.118 against 0.228 CPU-s per 64 MiB block) but
-    // takes 90 instead of 52 ms.  While the pool has four CPUs with nothing to do the pairs cost nothing and the block is out 40 ms
-    // earlier (a short job is mostly pipeline fill and drain: 20 blocks at 14.7 ms); when the coder threads are busy — many GPUs
-    // per host, a small quota — every block is one eight-lane task and the pool's throughput is what counts.  BSC_RC_ADAPTIVE=0:
-    // eight lanes always.
     static const int adaptive = [] { const char* e = getenv("BSC_RC_ADAPTIVE"); return e ? atoi(e) : 1; }();
-    return (adaptive && J.pool_free >= 4) ? 2 : 8;
+    static const int cpus = default_coder_threads();
+    const int callers = g_sync_callers.load(std::memory_order_relaxed);
+    return bscgpu_coder_task_shape(ps_simd_env(), ((J.features & BSCGPU_FEATURE_LOW_LATENCY) || !J.pipelined) ? 1 : 0, J.pool_free,
+                                   cpus / (callers > 1 ? callers : 1), cpu_has_avx512vl() ? 1 : 0, adaptive);
 }
 // sub-blocks b .. b + g - 1 of a device-model block, g = ps_group(J)
 static void host_encode_group(BlockJob& J, int b)

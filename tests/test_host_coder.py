@@ -177,3 +177,25 @@ def test_default_dispatch_spreads_callers_over_physical_devices_first(nphys, cpd
     usable[0] = 1
     assert pick(nphys, cpd, users, usable, 3) == 0
     assert [dev(s, nphys) for s in range(nslots)] == [s % nphys for s in range(nslots)]
+
+
+def test_coder_task_shape_rule():
+    """How the host codes the eight sub-blocks of a device-model block (block.cpp: ps_group), as the pure function it is built on:
+    one eight-lane SIMD task when the pool is busy, four pair tasks while >= 4 CPUs of its budget are idle, short tasks for blocks
+    marked low-latency and for synchronous calls (sized by the caller's share of the CPUs), BSC_RC_SIMD overrides everything."""
+    import ctypes as C
+    from libbsc_amd import _native
+    f = _native.lib().bscgpu_coder_task_shape
+    f.restype = C.c_int
+    f.argtypes = [C.c_int] * 6
+    shape = lambda forced=-1, low=0, free=-1, sync=16, wide=1, adaptive=1: f(forced, low, free, sync, wide, adaptive)
+    # a pipe's block on a CPU with AVX-512VL: by the pool's idle CPUs
+    assert [shape(free=k) for k in (0, 3, 4, 16)] == [8, 8, 2, 2]
+    assert shape(free=16, adaptive=0) == 8                      # BSC_RC_ADAPTIVE=0
+    assert shape(free=0, wide=0) == 2 and shape(free=16, wide=0) == 2      # no AVX-512VL: pairs (bench.py forces the AVX2 lanes where the CPU share is small)
+    # marked low-latency in a pipe: never the eight-lane task; eight scalar tasks only on a nearly idle pool
+    assert [shape(low=1, free=k) for k in (0, 4, 11, 12, 24)] == [2, 2, 2, 1, 1]
+    # synchronous calls: by the share of the CPUs per caller
+    assert [shape(low=1, sync=c) for c in (2, 4, 7, 8, 16)] == [2, 2, 2, 1, 1]
+    # forced
+    assert shape(forced=8, low=1, free=24) == 8 and shape(forced=0, free=0) == 2
