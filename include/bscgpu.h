@@ -166,7 +166,8 @@ BSCGPU_API const char* bscgpu_last_error(const bscgpu_ctx* ctx);
 /* ---- how the libbsc.h entry points spread concurrent callers over the GPUs of a node (pure functions, no GPU needed) -------------
  * The host-pointer API keeps ctx_per_dev default contexts per physical device = nphys * ctx_per_dev logical slots; slot s lives
  * on device s % nphys, so every GPU's first context comes before anybody's second one.  A call takes the usable slot whose GPU has
- * the fewest calls in flight (then the slot with the fewest; ties in round-robin order from `start`).  The reference has one
+ * the fewest calls in flight (then the slot with the fewest, then a slot marked usable = 2 — its context exists and is large
+ * enough — before one that would have to be created; remaining ties in round-robin order from `start`).  The reference has one
  * lock and one device (bwt.cpp:50-52, st.cu:56); its parallelism is the CLI's OpenMP team of concurrent bsc_compress calls
  * (bsc.cpp:184-199), which this rule maps to one block per GPU.  Returns the slot, -1 when no slot is usable. */
 BSCGPU_API int bscgpu_dispatch_device(int slot, int nphys);

@@ -70,7 +70,9 @@ static unsigned     g_rr = 0;
 // ---- the dispatch rule, as pure functions --------------------------------------------------------------------------
 // Logical slots 0 .. nphys * ctx_per_dev - 1; slot s runs on physical device s % nphys.
 extern "C" BSCGPU_API int bscgpu_dispatch_device(int slot, int nphys) { return nphys > 0 ? slot % nphys : 0; }
-// users[s] = calls in flight on slot s, usable[s] != 0 when slot s can take this call now; start = round-robin cursor.
+// users[s] = calls in flight on slot s; usable[s] != 0 when slot s can take this call now, 2 when its context already exists and is
+// large enough (preferred among equally loaded slots: a lone caller then stays on one context instead of alternating between two and
+// paying for two arenas, two sets of pinned buffers and every resize twice); start = round-robin cursor.
 // Returns the slot to use, -1 when none is usable.
 extern "C" BSCGPU_API int bscgpu_dispatch_pick(int nphys, int ctx_per_dev, const int* users, const unsigned char* usable, unsigned start)
 {
@@ -82,7 +84,8 @@ extern "C" BSCGPU_API int bscgpu_dispatch_pick(int nphys, int ctx_per_dev, const
         if (!usable[s]) continue;
         int dev_load = 0;
         for (int q = s % nphys; q < nslots; q += nphys) dev_load += users[q];
-        if (best < 0 || dev_load < best_dev_load || (dev_load == best_dev_load && users[s] < users[best])) { best = s; best_dev_load = dev_load; }
+        if (best < 0 || dev_load < best_dev_load ||
+            (dev_load == best_dev_load && (users[s] < users[best] || (users[s] == users[best] && usable[s] > usable[best])))) { best = s; best_dev_load = dev_load; }
     }
     return best;
 }
@@ -120,7 +123,7 @@ static int default_gpu_acquire(int64_t n, bool want_slot, DefaultDevice** out, i
             const bool fits = D.ctx && D.cap >= n;
             any_ctx_fits = any_ctx_fits || fits;
             users[d] = D.users;
-            usable[d] = D.no_memory_for >= 0 && n >= D.no_memory_for ? 0 : ((fits ? slot_free : (D.users == 0)) ? 1 : 0);   // an idle slot can be (re)sized
+            usable[d] = D.no_memory_for >= 0 && n >= D.no_memory_for ? 0 : (fits ? (slot_free ? 2 : 0) : (D.users == 0 ? 1 : 0));   // an idle slot can be (re)sized
         }
         const int best = bscgpu_dispatch_pick(nphys, g_ctx_per_dev, users, usable, g_rr);
         if (best >= 0) {

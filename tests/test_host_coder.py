@@ -170,6 +170,16 @@ def test_default_dispatch_spreads_callers_over_physical_devices_first(nphys, cpd
     users[nslots - 1] -= 1
     s = pick(nphys, cpd, users, usable, rr)
     assert s == nslots - 1
+    # among equally loaded slots one whose context already exists and fits (usable = 2) is preferred: a lone caller stays put
+    for i in range(nslots):
+        users[i] = 0
+    usable[nslots - 1] = 2
+    for start in range(nslots):
+        assert pick(nphys, cpd, users, usable, start) == nslots - 1
+    users[nslots - 1] = 1                                    # ... but never over an idle GPU / an idle slot
+    if nslots > 1:
+        assert pick(nphys, cpd, users, usable, 0) != nslots - 1
+    users[nslots - 1] = 0
     # unusable slots are never chosen; all unusable -> -1
     for i in range(nslots):
         usable[i] = 0
