@@ -57,6 +57,10 @@ constexpr u32 OS_NONE = 0xffffffffu;
 constexpr u32 OS_SPIN_LIMIT = 1u << 18;
 // LDS: two key staging buffers, per-wave digit counters, five 256-entry tables, scratch
 constexpr int OS_LDS = 2 * OS_TILE * 8 + OS_SW * 256 * 4 + 5 * 256 * 4 + 32 * 4;
+static_assert(OS_TILE < (1 << 14), "a tile row stores 14-bit digit counts");
+static_assert((OS_GRP - 1) * OS_TILE < (1 << 16), "the tile rows of a group are summed as packed 16-bit halves");
+static_assert(OS_BATCH * OS_TILE < (1 << 28), "group / batch rows carry 28-bit sums");
+static_assert(OS_LDS <= 160 * 1024, "one workgroup per CU: the staging buffers must fit the CU's LDS");
 static_assert(OS_LDS <= 160 * 1024, "rs_onesweep does not fit the CU's LDS");
 // per-pass control block (u32 words): [0] next ticket; word [1] of the FIRST pass's block is the error word of the whole sort
 constexpr int OS_CTL_WORDS = 32;
