@@ -67,6 +67,9 @@ extern "C" int bscgpu_device_count(void)
     return n;
 }
 
+#ifndef ARENA_ALIGN
+#define ARENA_ALIGN 256          // alignment of every buffer carved from the arena
+#endif
 extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
 {
     if (!out || max_n < 0 || max_n >= 0x7fffffffll) return BSC_BAD_PARAMETER;
@@ -108,12 +111,12 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
         {(void**)&c->wc_sink, (size_t)512 * 1024 * 8, 0},
     };
     size_t total = 0;
-    for (auto& cv : carve) total += align_up(cv.bytes, 256);
+    for (auto& cv : carve) total += align_up(cv.bytes, ARENA_ALIGN);
     hipError_t e = hipMalloc((void**)&c->arena, total);
     if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return BSC_GPU_NOT_ENOUGH_MEMORY; }
     c->arena_bytes = total;
     size_t off = 0;
-    for (auto& cv : carve) { *cv.p = c->arena + off + cv.lead; off += align_up(cv.bytes, 256); }
+    for (auto& cv : carve) { *cv.p = c->arena + off + cv.lead; off += align_up(cv.bytes, ARENA_ALIGN); }
     if (hipMemsetAsync(c->arena, 0, total, c->stream) != hipSuccess) { bscgpu_destroy(c); return BSC_GPU_ERROR; }
 
     bool ok = hipHostMalloc((void**)&c->hscal, 1024 * 4, hipHostMallocDefault) == hipSuccess
