@@ -73,36 +73,49 @@ struct PackParams { u32 cb; u32 w; u32 tc; u32 low_shift; u32 pred_shift; };   /
 __global__ __launch_bounds__(WG) void bwt_pack_kernel(const u8* __restrict__ T, u32 n, PackParams pp,
                                                       const u8* __restrict__ codes, u64* __restrict__ keys, u32* __restrict__ vals)
 {
+    // A thread builds the keys of four consecutive suffixes (their windows share all but three characters); written from there the
+    // stores of a wavefront have a 32-byte lane pitch — every line of the output is touched by four instructions.  The workgroup's
+    // 1024 records therefore go through LDS and leave lane-contiguous (the few tail suffixes, whose slots are elsewhere, directly).
     __shared__ u8 lut[256];
+    __shared__ u64 skey[4 * WG];
+    __shared__ u32 sval[4 * WG];
     lut[threadIdx.x] = codes[threadIdx.x];
     __syncthreads();
-    const u32 i0 = 4u * (blockIdx.x * WG + threadIdx.x);
-    if (i0 >= n) return;
-    // characters i0 .. i0 + w + 2 (<= 19 bytes; T is 16-B aligned at T[0] and zero padded for 32 bytes past n)
-    const u32* T32 = reinterpret_cast<const u32*>(T + i0);
-    u32 wds[5];
+    const u32 b0 = 4u * blockIdx.x * WG;                                 // first suffix of the workgroup
+    const u32 i0 = b0 + 4u * threadIdx.x;
+    if (i0 < n) {
+        // characters i0 .. i0 + w + 2 (<= 19 bytes; T is 16-B aligned at T[0] and zero padded for 32 bytes past n)
+        const u32* T32 = reinterpret_cast<const u32*>(T + i0);
+        u32 wds[5];
 #pragma unroll
-    for (int x = 0; x < 5; ++x) wds[x] = T32[x];
-    u32 pcode = (pp.pred_shift && i0 > 0) ? (u32)lut[T[i0 - 1]] : 0u;        // code of the character in front of suffix i0
-    u64 cd[19];                                     // codes of characters i0 .. i0+18 (0 past the end)
+        for (int x = 0; x < 5; ++x) wds[x] = T32[x];
+        u32 pcode = (pp.pred_shift && i0 > 0) ? (u32)lut[T[i0 - 1]] : 0u;        // code of the character in front of suffix i0
+        u64 cd[19];                                     // codes of characters i0 .. i0+18 (0 past the end)
 #pragma unroll
-    for (u32 t = 0; t < 19; ++t) {
-        const u32 c = (wds[t >> 2] >> (8 * (t & 3))) & 0xffu;
-        cd[t] = (i0 + t < n) ? (u64)lut[c] : 0ull;
-    }
-#pragma unroll
-    for (u32 j = 0; j < 4; ++j) {
-        const u32 i = i0 + j;
-        if (i < n) {
-            u64 key = 0;
-#pragma unroll
-            for (u32 t = 0; t < 16; ++t) if (t < pp.w) key |= cd[j + t] << (64 - pp.cb * (t + 1));
-            const bool tail = (u64)i + pp.w > (u64)n;
-            const u32 slot = tail ? (n - 1 - i) : (i + pp.tc);
-            keys[slot] = key;
-            vals[slot] = pp.pred_shift ? (i | (pcode << pp.pred_shift)) : i;
-            pcode = (u32)cd[j];                                                 // this suffix's first character precedes the next one
+        for (u32 t = 0; t < 19; ++t) {
+            const u32 c = (wds[t >> 2] >> (8 * (t & 3))) & 0xffu;
+            cd[t] = (i0 + t < n) ? (u64)lut[c] : 0ull;
         }
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+            const u32 i = i0 + j;
+            if (i < n) {
+                u64 key = 0;
+#pragma unroll
+                for (u32 t = 0; t < 16; ++t) if (t < pp.w) key |= cd[j + t] << (64 - pp.cb * (t + 1));
+                const u32 val = pp.pred_shift ? (i | (pcode << pp.pred_shift)) : i;
+                const bool tail = (u64)i + pp.w > (u64)n;
+                if (tail) { keys[n - 1 - i] = key; vals[n - 1 - i] = val; }
+                else { skey[4u * threadIdx.x + j] = key; sval[4u * threadIdx.x + j] = val; }
+                pcode = (u32)cd[j];                                                 // this suffix's first character precedes the next one
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+        const u32 li = k * WG + threadIdx.x, i = b0 + li;
+        if (i < n && (u64)i + pp.w <= (u64)n) { keys[i + pp.tc] = skey[li]; vals[i + pp.tc] = sval[li]; }
     }
 }
 
