@@ -158,17 +158,23 @@ __global__ __launch_bounds__(WG) void seg_reduce_kernel(const u64* __restrict__ 
         }
         k[0] = (j > 0) ? keys[j - 1] : 0;
         k[SEG_ITEMS + 1] = (j + SEG_ITEMS < m) ? keys[j + SEG_ITEMS] : 0;
-        if (INITIAL) {
+        if (INITIAL || grp != nullptr) {
+            // suffix numbers (first seg) / group ranks (text rounds) j-1 .. j+8: the thread's own eight as two 16-byte loads (ten
+            // 4-byte loads at a 32-byte lane pitch put every line through the address path eight times)
+            const u32* src = INITIAL ? sa : grp;
+            const u32 msk = INITIAL ? smask : 0xffffffffu;
+            if (full && SEG_ITEMS == 8) {
+                const uint4 a = *reinterpret_cast<const uint4*>(src + j), b = *reinterpret_cast<const uint4*>(src + j + 4);
+                s[1] = a.x & msk; s[2] = a.y & msk; s[3] = a.z & msk; s[4] = a.w & msk;
+                s[5] = b.x & msk; s[6] = b.y & msk; s[7] = b.z & msk; s[8] = b.w & msk;
+                s[0] = (j > 0) ? (src[j - 1] & msk) : 0;
+                s[9] = (j + 8 < m) ? (src[j + 8] & msk) : 0;
+            } else {
 #pragma unroll
-            for (int q = 0; q < SEG_ITEMS + 2; ++q) {
-                const long long x = (long long)j - 1 + q;
-                s[q] = (x >= 0 && x < (long long)m) ? (sa[x] & smask) : 0;
-            }
-        } else if (grp != nullptr) {
-#pragma unroll
-            for (int q = 0; q < SEG_ITEMS + 2; ++q) {
-                const long long x = (long long)j - 1 + q;
-                s[q] = (x >= 0 && x < (long long)m) ? grp[x] : 0;
+                for (int q = 0; q < SEG_ITEMS + 2; ++q) {
+                    const long long x = (long long)j - 1 + q;
+                    s[q] = (x >= 0 && x < (long long)m) ? (src[x] & msk) : 0;
+                }
             }
         }
         u32 h[SEG_ITEMS + 1];
