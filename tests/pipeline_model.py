@@ -49,6 +49,14 @@ def seg(keys, sa, cpos_in, m, n, initial):
     return pos, rank.astype(np.uint32), uns
 
 
+def seg_long_counts(pos, rank, uns, limit=1024):
+    """What seg_apply counts for free (bwt.hip, DS_NLONG / DS_EXCESS): an unsorted record knows its SA slot (pos) and the slot of its
+    group's head (rank), and members of a group are contiguous in SA — the record `limit` places behind its head proves a group of more
+    than `limit` records (one such record per long group), every record at or beyond that distance counts as excess."""
+    d = pos[uns].astype(np.int64) - rank[uns].astype(np.int64)
+    return int(np.count_nonzero(d == limit)), int(np.count_nonzero(d >= limit))
+
+
 def bit_length(x):
     return int(x).bit_length()
 

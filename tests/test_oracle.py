@@ -74,3 +74,29 @@ def test_oracle_matches_golden_fixtures(orc):
         if e["n"] <= g["oracle_max_n"]:
             blk = orc.compress(T, e["sorter"], e["coder"])
             assert len(blk) == e["size"] and hashlib.md5(blk).hexdigest() == e["md5"], e
+
+
+def test_long_group_counting_rule():
+    """bwt.hip: seg_apply tells the host how many groups the next round's segmented sort cannot take (> 1024 records) and how many
+    records lie beyond the first 1024 of such groups, from (SA slot - group rank) alone.  The numpy model of that rule against the
+    group sizes counted directly, on keys with long runs of equal values (first seg and a later round's compacted set)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from pipeline_model import seg, seg_long_counts
+    rng = np.random.default_rng(12)
+    for limit, m, kinds in ((1024, 200_000, 40), (64, 50_000, 300), (8, 5_000, 200)):
+        keys = np.sort(rng.integers(0, kinds, m).astype(np.uint64) ** 3)           # sorted keys: groups of very different sizes
+        sa = rng.permutation(m).astype(np.uint32)
+        pos, rank, uns = seg(keys, sa, None, m, m + 100, True)                       # (n > m + 8: no tail suffixes among them)
+        n_long, n_excess = seg_long_counts(pos, rank, uns, limit)
+        _, sizes = np.unique(rank[uns], return_counts=True)
+        assert n_long == int(np.count_nonzero(sizes > limit))
+        assert n_excess == int(np.sum(np.maximum(sizes - limit, 0)))
+        # a later round: the compacted set keeps SA slots (cpos) and is re-grouped by a finer key
+        cpos = pos[uns].astype(np.uint32)
+        finer = (rank[uns].astype(np.uint64) << np.uint64(20)) | rng.integers(0, 3, cpos.size).astype(np.uint64)
+        order = np.argsort(finer, kind="stable")
+        pos2, rank2, uns2 = seg(finer[order], sa[:cpos.size], cpos, cpos.size, m + 100, False)
+        n_long2, n_excess2 = seg_long_counts(pos2, rank2, uns2, limit)
+        _, sizes2 = np.unique(rank2[uns2], return_counts=True)
+        assert n_long2 == int(np.count_nonzero(sizes2 > limit)) and n_excess2 == int(np.sum(np.maximum(sizes2 - limit, 0)))
