@@ -282,16 +282,36 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
         const u32 j = tile * SEG_TILE + t * SEG_ITEMS;
         u32 f[SEG_ITEMS], pos[SEG_ITEMS], s[SEG_ITEMS];
         u32 lmax = 0, lcnt = 0;
+        if (SEG_ITEMS == 8 && j + SEG_ITEMS <= m) {
+            // a thread's eight records: flags as one 8-byte load, suffixes (and SA slots) as two 16-byte loads each — not 8 + 8 (+ 8) narrow ones
+            const u64 fw = *reinterpret_cast<const u64*>(flags + j);
+            const uint4 s0 = *reinterpret_cast<const uint4*>(sa_sorted + j), s1 = *reinterpret_cast<const uint4*>(sa_sorted + j + 4);
+            s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
+            if (INITIAL) {
 #pragma unroll
-        for (int q = 0; q < SEG_ITEMS; ++q) {
-            const u32 x = j + q;
-            if (x < m) {
-                f[q]   = flags[x];
-                pos[q] = INITIAL ? x : cpos_in[x];
-                s[q]   = sa_sorted[x];
+                for (int q = 0; q < 8; ++q) pos[q] = j + q;
+            } else {
+                const uint4 p0 = *reinterpret_cast<const uint4*>(cpos_in + j), p1 = *reinterpret_cast<const uint4*>(cpos_in + j + 4);
+                pos[0] = p0.x; pos[1] = p0.y; pos[2] = p0.z; pos[3] = p0.w; pos[4] = p1.x; pos[5] = p1.y; pos[6] = p1.z; pos[7] = p1.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                f[q] = (u32)(fw >> (8 * q)) & 0xffu;
                 if (f[q] & 1u) lmax = pos[q] + 1;
                 lcnt += (f[q] >> 1) & 1u;
-            } else { f[q] = 0; pos[q] = 0; s[q] = 0; }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < SEG_ITEMS; ++q) {
+                const u32 x = j + q;
+                if (x < m) {
+                    f[q]   = flags[x];
+                    pos[q] = INITIAL ? x : cpos_in[x];
+                    s[q]   = sa_sorted[x];
+                    if (f[q] & 1u) lmax = pos[q] + 1;
+                    lcnt += (f[q] >> 1) & 1u;
+                } else { f[q] = 0; pos[q] = 0; s[q] = 0; }
+            }
         }
         u32 totmax, totcnt;
         const u32 imax = block_incl_max(lmax, scr, &totmax);
