@@ -107,15 +107,15 @@ def main():
     seed = (3 if (args.sorter in (5, 6) and n == (128 << 20)) else 2) if world == 1 else 10 + rank
     host_in = api.synth_text_v1(seed, n)
     d_in = torch.from_numpy(host_in).to(dev)
-    ctxs = [GpuContext(local, max_n=n + 4096) for _ in range(ncx)]
-    ctx = ctxs[0]
+    ctxs = []
 
     # rank 0 receives world - 1 compressed blocks per round into one staging tensor; the others stage one block
     gather_buf = torch.empty((n + 64) * (max(world - 1, 1) if rank == 0 else 1), dtype=torch.uint8, device=comm_dev)
 
     from libbsc_amd.multigpu import Concatenator
     import threading
-    pipes = [cx.pipe(args.depth, reuse_outputs=True) for cx in ctxs]        # compressed blocks land in recycled host buffers
+    pipes = []                                                              # compressed blocks land in recycled host buffers
+    thread_errors = []
     stage = np.zeros(6)
     stage_lock = threading.Lock()
 
@@ -165,12 +165,19 @@ def main():
     def run(steps, record=False):
         out = [None] * ncx
         share = [steps // ncx + (1 if k < steps % ncx else 0) for k in range(ncx)]
+        def guarded(k):
+            try:
+                run_one(k, share[k], record, out)
+            except BaseException as e:                                      # a thread's exception must fail the run, not shorten it
+                thread_errors.append(e)
         if ncx == 1:
-            run_one(0, steps, record, out)
+            guarded(0)
         else:
-            ths = [threading.Thread(target=run_one, args=(k, share[k], record, out)) for k in range(ncx)]
+            ths = [threading.Thread(target=guarded, args=(k,)) for k in range(ncx)]
             for t in ths: t.start()
             for t in ths: t.join()
+        if thread_errors:
+            raise thread_errors[0]
         return next(b for b in reversed(out) if b is not None)
 
     def sync():
@@ -182,7 +189,24 @@ def main():
         concat = Concatenator(rank, world, comm_dev, staging=gather_buf)
     # setup, untimed: every pipeline slot is used once, so that its pinned landing zones (allocated on first use) and the
     # contexts' device arenas exist before the warm-up steps — otherwise those allocations land in the timed region
-    run(ncx * args.depth)
+    # (six contexts want ~19 GB of HBM and ~2.7 GB of pinned host memory each at 64 MiB blocks: a box that cannot give that gets fewer
+    # contexts instead of a crash, and the JSON line says how many ran)
+    for cand in [ncx] + [k for k in (4, 2, 1) if k < ncx]:
+        try:
+            ncx = cand
+            ctxs = [GpuContext(local, max_n=n + 4096) for _ in range(ncx)]
+            pipes = [cx.pipe(args.depth, reuse_outputs=True) for cx in ctxs]
+            run(ncx * args.depth)
+            break
+        except Exception as e:
+            print(f"[bench] rank {rank}: {cand} context(s) x {args.depth} could not be set up ({e!r})" + ("; trying fewer" if cand > 1 else ""), file=sys.stderr)
+            del thread_errors[:]
+            for p in pipes: p.close()
+            for cx in ctxs: cx.close()
+            pipes, ctxs = [], []
+            if cand == 1:
+                raise
+    ctx = ctxs[0]
     blk = run(args.warmup)
     if concat is not None:
         concat.close()
