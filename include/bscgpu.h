@@ -95,7 +95,7 @@ BSCGPU_API int bscgpu_compress_device(bscgpu_ctx* ctx, const void* dInput, uint8
 
 /* Pipelined variant: up to `depth` (<= 8) blocks in flight on one GPU.  submit() runs the GPU stage of a block
  * (Adler-32, sort transform, QLFC front end, D2H of the run arrays) on the calling thread and hands the host stage
- * (QLFC modelling + range coding, one task per sub-block; container) to the pipe's coder threads, so block i+1 sorts
+ * (QLFC modelling + range coding, one task per sub-block; container) to the process's coder threads, so block i+1 sorts
  * while blocks i, i-1, ... are coded.
  * dInput and output must stay valid until wait() returns for that ticket.  wait() returns what
  * bscgpu_compress_device would have returned.  One submitting thread per pipe.  The host work is queued as tasks for the
