@@ -2,6 +2,8 @@
 
     python -m libbsc_amd.build            # incremental
     python -m libbsc_amd.build --force
+    python -m libbsc_amd.build --asan     # second library with AddressSanitizer + UBSan on every line of HOST code
+                                          # (device code unchanged): libbsc_amd/lib/asan/libbsc_mi355x.so, see asan_env()
 
 Output: libbsc_amd/lib/libbsc_mi355x.so (git-ignored; travels to the GPU box with gpurun).
 hipcc cross-compiles for gfx950 without a GPU present.
@@ -17,6 +19,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libbsc_mi355x.so")
+ASAN_OBJ = os.path.join(HERE, "lib", "obj_asan")
+ASAN_LIB = os.path.join(HERE, "lib", "asan", "libbsc_mi355x.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 ARCH = "gfx950"
@@ -24,6 +28,32 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-result"]
 DEVFLAGS = [f"--offload-arch={ARCH}"]
+# Sanitizer build (SURVEY.md:248): the host side of every translation unit — the C++ files and the launch / arena / pipeline
+# code inside the .hip files — is instrumented; kernels are compiled as always (-fno-gpu-sanitize).  The runtime is the shared
+# one so that an uninstrumented python can host it (LD_PRELOAD, asan_env()).
+SANFLAGS = ["-fsanitize=address,undefined", "-fno-sanitize=alignment,vptr,function", "-fno-sanitize-recover=undefined",
+            "-fno-gpu-sanitize", "-shared-libasan", "-fno-omit-frame-pointer", "-g", "-DBSC_SANITIZE=1"]
+
+
+def asan_runtime():
+    r = subprocess.run([HIPCC, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    p = r.stdout.strip()
+    if not os.path.isabs(p):
+        import glob
+        hits = glob.glob(os.path.join(ROCM, "lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+        p = hits[0] if hits else p
+    return p
+
+
+def asan_env(extra_options=""):
+    """Environment for running an uninstrumented host (python, the reference CLI) on the sanitizer build."""
+    env = dict(os.environ)
+    env["LD_PRELOAD"] = asan_runtime() + (":" + env["LD_PRELOAD"] if env.get("LD_PRELOAD") else "")
+    # leaks: python itself never frees everything; the HSA runtime maps memory ASan has not seen (protect_shadow_gap)
+    env["ASAN_OPTIONS"] = "detect_leaks=0:protect_shadow_gap=0:abort_on_error=1:halt_on_error=1:detect_stack_use_after_return=0" + (":" + extra_options if extra_options else "")
+    env["UBSAN_OPTIONS"] = "print_stacktrace=1:halt_on_error=1"
+    env["BSC_LIB_OVERRIDE"] = ASAN_LIB
+    return env
 
 
 def _sources():
@@ -38,7 +68,7 @@ def _sources():
     return out
 
 
-def _deps_hash(src):
+def _deps_hash(src, asan=False):
     """hash of the source plus every header under csrc/ and include/ (coarse but safe)."""
     h = hashlib.sha1()
     files = [src]
@@ -50,12 +80,12 @@ def _deps_hash(src):
     for f in sorted(set(files)):
         with open(f, "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
-    h.update(" ".join(_command(src, "OBJ")).encode())       # the full per-source command line: host-only flags included
+    h.update(" ".join(_command(src, "OBJ", asan)).encode())       # the full per-source command line: host-only flags included
     return h.hexdigest()
 
 
-def _command(src, obj):
-    cmd = [HIPCC] + COMMON
+def _command(src, obj, asan=False):
+    cmd = [HIPCC] + COMMON + (SANFLAGS if asan else [])
     if src.endswith(".hip"):
         cmd += DEVFLAGS
     else:
@@ -66,14 +96,14 @@ def _command(src, obj):
     return cmd + ["-c", src, "-o", obj]
 
 
-def _compile(src, force):
+def _compile(src, force, asan=False):
     name = os.path.splitext(os.path.basename(src))[0]
-    obj = os.path.join(OBJ, name + ".o")
+    obj = os.path.join(ASAN_OBJ if asan else OBJ, name + ".o")
     stamp = obj + ".sha1"
-    want = _deps_hash(src)
+    want = _deps_hash(src, asan)
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
         return obj, False
-    cmd = _command(src, obj)
+    cmd = _command(src, obj, asan)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("compile failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
@@ -82,15 +112,19 @@ def _compile(src, force):
     return obj, True
 
 
-def build(force=False, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, verbose=True, asan=False):
+    LIB = ASAN_LIB if asan else globals()["LIB"]
+    os.makedirs(ASAN_OBJ if asan else OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        res = list(ex.map(lambda s: _compile(s, force), srcs))
+        res = list(ex.map(lambda s: _compile(s, force, asan), srcs))
     objs = [o for o, _ in res]
     changed = any(c for _, c in res)
     if changed or force or not os.path.exists(LIB):
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-Wl,-Bsymbolic"]
+        if asan:
+            cmd += ["-fsanitize=address,undefined", "-shared-libasan", "-fno-gpu-sanitize"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
@@ -102,4 +136,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, asan="--asan" in sys.argv)

@@ -711,7 +711,7 @@ static int decode_model1(const uint8_t* in, const uint8_t* in_end, uint8_t* out,
             }
             rank_hist[c] = (uint8_t)bsr32((unsigned)rank);
         }
-        if (rank > 255) return DATA_CORRUPT;
+        if (rank < 1 || rank > 255) return DATA_CORRUPT;      // 0 only from a damaged stream (escape code): it would index the state tables at -1
         requeue(mtf, rank, (uint8_t)c);
 
         avg_rank = (avg_rank * 124 + rank * 4) >> 7;
