@@ -263,6 +263,25 @@ def main():
         ctxs[0].profile(False)
         stats_iso = ctxs[0].profile_get()
         launches_iso = ctxs[0].scatter_launches(65536)
+    # ---- pattern ceiling of the digit pass: the same blocks once more through the same context with the three-kernel passes
+    # (BSCGPU_OPT_RS_ONESWEEP = 0): their scatter kernel moves the same records into the same 256 runs per tile with the same ranking
+    # code, but every offset is known before it starts (rs_hist + rs_scan) — no tickets, no look-back, no scout wave.  What it reaches
+    # on THIS box is the denominator `frac` lacks besides the spec sheet: the boxes of the pool differ by ~15 % for this access pattern.
+    launches_ceiling = []
+    if rank == 0 and args.sorter == 1 and os.environ.get("BSC_RS_ONESWEEP", "1") != "0":
+        try:
+            prev = ctxs[0].option_set(ctxs[0].OPT_RS_ONESWEEP, 0)
+            ctxs[0].profile(True)
+            ctxs[0].profile_reset()
+            concat = None
+            run_one(0, max(2, min(4, args.steps)), False, [None] * ncx)
+            torch.cuda.synchronize()
+            ctxs[0].profile(False)
+            launches_ceiling = ctxs[0].scatter_launches(65536)
+            ctxs[0].option_set(ctxs[0].OPT_RS_ONESWEEP, prev)
+        except Exception as e:                            # reporting only
+            print(f"[bench] pattern-ceiling leg failed: {e!r}", file=sys.stderr)
+    free_b, total_b = torch.cuda.mem_get_info(local)
     # what leaves this rank's GPU over PCIe in the timed region: 16 bits per binary decision of the device model (run arrays instead
     # for blocks on the host model: not counted) + nothing else of size (the input is resident, the sorted block never crosses);
     # the host's DRAM sees those bytes twice (DMA write, coder read) — with 8 ranks per node this, not xGMI, is the shared resource
@@ -327,7 +346,7 @@ def main():
             "sort_note": "whole sort: every radix kernel of the sorter (histogram read(s), scans, digit passes) over SURVEY 8d's B_sort = m*8 + P*2*m*(8+4)",
             "measured_on": ("the timed region (one context per GPU: launches do not overlap)" if ncx == 1 else
                             f"{iso_blocks} more blocks of the same workload through ONE context right after the timed region (HIP events on its stream); in the timed "
-                            f"region {ncx} contexts run side by side, so a launch's duration there measures sharing of the chip, see timed_region"),
+                            f"region {ncx} contexts run side by side, so a launch's duration there would measure sharing of the chip"),
             "traffic": traffic, "traffic_note": "bytes per full-size launch = 2 x FETCH_SIZE + WRITE_SIZE from profiles/pmc_traffic.json "
                                                 "(rocprofv3 PMC passes; algorithmic bytes per full-size launch = %d)" % (2 * rec_bytes * n),
             "launches": len(full), "avg_launch_ms": round(tot_ms / max(len(full), 1), 4),
@@ -339,10 +358,19 @@ def main():
             roofline["other_radix_passes"] = {"what": "keys-only passes over the block's runs that also emit the permutation (device coder), histogram + scan + scatter, "
                                                       "20 B per record; not the graded kernel", "GBps": round(aux["bytes"] / 1e6 / max(aux["ms"], 1e-9), 1),
                                               "ms_per_block": round(aux["ms"] / iso_blocks, 3)}
-        if ncx > 1:
-            _, t_ms, _, t_ach = scatter_rate(launches_timed)
-            roofline["timed_region"] = {"achieved": round(t_ach, 1), "frac": round(t_ach / HBM_PEAK_GBPS, 4), "sort_frac": round(sort_rate(stats, launches_timed) / HBM_PEAK_GBPS, 4),
-                                        "note": f"per-launch durations while {ncx} contexts share the GPU (launches overlap; sum of durations > wall time)"}
+        if launches_ceiling:
+            cfull, c_ms, _, c_ach = scatter_rate(launches_ceiling)
+            if cfull:
+                roofline["pattern_ceiling"] = {
+                    "achieved": round(c_ach, 1), "frac_of_peak": round(c_ach / HBM_PEAK_GBPS, 4), "avg_launch_ms": round(c_ms / len(cfull), 4), "launches": len(cfull),
+                    "frac_of_ceiling": round(achieved / c_ach, 4),
+                    "what": "rs_scatter_tiled_kernel<true> on the same blocks in the same run and context: the same records into the same 256 runs per tile with the "
+                            "same ranking code, all offsets precomputed by rs_hist + rs_scan (whose 8 B per record and pass are NOT charged here) - "
+                            "the scatter pattern without any cross-workgroup protocol; frac_of_ceiling = graded kernel / this"}
+        # share of a block's GPU time that is digit passes (the kernel's own rate, not the contended in-region durations: with several
+        # contexts per GPU launches of different blocks overlap, and the sum of their durations exceeds the wall time)
+        roofline["digit_pass_ms_per_block"] = round(tot_ms / iso_blocks, 3)
+        roofline["digit_pass_share_of_step"] = round(tot_ms / iso_blocks / (dt / args.steps * 1e3), 3)
         per_kernel = {k: {"ms_per_block": round(v["ms"] / iso_blocks, 3), "GBps": round(v["bytes"] / 1e6 / v["ms"], 1) if v["ms"] > 0 else None}
                       for k, v in stats_iso.items() if v["launches"]}
         simd = "AVX-512VL" if has_avx512vl else "AVX2"
@@ -378,6 +406,8 @@ def main():
                                   "gpu_stage_total": round((stage[0] + stage[1] + stage[2]) / args.steps, 2),
                                   "doubling_rounds": stage[5] / args.steps, "blocks_in_flight_per_context": args.depth, "contexts_per_gpu": ncx, "blocks_in_flight_per_gpu": ncx * args.depth},
             "sorter_only_MBps": round(n / 1e6 / max(stage[1] / args.steps / 1e3, 1e-9), 1),
+            "hbm_bytes_in_use": int(total_b - free_b),
+            "hbm_note": f"device memory in use on this GPU at the end of the run (hipMemGetInfo): {ncx} context arena(s), device-coder arenas, look-back tables, the resident input",
             "kernels": per_kernel,
             "kernels_note": "HIP-event time per kernel class and block, from the region named in roofline.measured_on",
             "host": {"cpus": os.cpu_count(), "effective_cpus": effective_cpus(), "coder_threads_per_gpu": coder_threads,

@@ -126,6 +126,42 @@ BSCGPU_API int  bscgpu_pipe_submit_host(bscgpu_pipe* pipe, const uint8_t* input,
                                         int lzpHashSize, int lzpMinLen, int blockSorter, int coder, int features);
 BSCGPU_API int  bscgpu_pipe_wait(bscgpu_pipe* pipe, int ticket);
 
+/* ---- multi-GPU job: every GPU of a node from one process, C/C++ callers ----------------------------------------------------
+ * The reference parallelises over blocks with the CLI's OpenMP team (bsc.cpp:182-199: next block under critical(input),
+ * bsc_compress, write under critical(output)) and knows one GPU behind one lock (bwt.cpp:50-52).  A job is that loop for N GPUs:
+ * `contexts_per_device` pipes per device (their kernels interleave on the GPU), `depth` blocks in flight per pipe, one worker thread
+ * per pipe pulling the next block from ONE queue (blocks are independent, so block b -> whichever GPU is free next: on equal GPUs one
+ * block per GPU per round, with load balancing for free), host coding on the process-wide coder pool.  The caller adds blocks in
+ * order and collects them in order: bscgpu_job_wait(b) returns what bsc_compress would have returned for block b, and the bytes
+ * are in that block's output buffer — the ordered host gather of the multi-GPU run (inside one process nothing has to travel
+ * between GPUs; the RCCL concatenation belongs to the one-process-per-GPU layout, libbsc_amd/multigpu.py).
+ *   devices / ndevices   device ordinals; ndevices = 0: every visible device
+ *   input / output       host buffers, n and n + 28 bytes, valid until the block has been waited for
+ * add() returns the block's number (0, 1, 2, ... in call order) or a negative code; it never blocks on the GPU.  One thread adds
+ * and waits; destroy() finishes what is queued, then frees every context.  */
+typedef struct bscgpu_job bscgpu_job;
+BSCGPU_API int  bscgpu_job_create(bscgpu_job** job, const int* devices, int ndevices, int contexts_per_device, int depth, int64_t max_block_bytes);
+BSCGPU_API int  bscgpu_job_add(bscgpu_job* job, const uint8_t* input, uint8_t* output, int n, int lzpHashSize, int lzpMinLen,
+                               int blockSorter, int coder, int features);
+BSCGPU_API int  bscgpu_job_wait(bscgpu_job* job, int block);
+/* which worker (= pipe; return value) on which device took the block — known once a worker has claimed it */
+BSCGPU_API int  bscgpu_job_block_worker(bscgpu_job* job, int block, int* device);
+BSCGPU_API void bscgpu_job_destroy(bscgpu_job* job);
+/* The executor behind a job's pipes as a table of functions (default: bscgpu_create / bscgpu_pipe_* of this library).  Tests drive
+ * the scheduler with a CPU stand-in (tests/test_job_driver.py); semantics of every entry = the bscgpu_* function it stands for. */
+typedef struct bscgpu_job_backend {
+    void* user;
+    int  (*ctx_create)(void* user, void** ctx, int device, int64_t max_n);
+    void (*ctx_destroy)(void* user, void* ctx);
+    int  (*pipe_create)(void* user, void* ctx, int depth, void** pipe);
+    void (*pipe_destroy)(void* user, void* pipe);
+    int  (*pipe_submit_host)(void* user, void* pipe, const uint8_t* input, uint8_t* output, int n, int lzpHashSize, int lzpMinLen,
+                             int blockSorter, int coder, int features);          /* ticket >= 0 or error */
+    int  (*pipe_wait)(void* user, void* pipe, int ticket);
+} bscgpu_job_backend;
+BSCGPU_API int  bscgpu_job_create_ex(bscgpu_job** job, const int* devices, int ndevices, int contexts_per_device, int depth,
+                                     int64_t max_block_bytes, const bscgpu_job_backend* backend /* NULL = this library */);
+
 /* ---- profiling --------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on the context's stream (the stream
  * the kernels run on) and accumulated per kernel class. */
@@ -162,6 +198,17 @@ BSCGPU_API int  bscgpu_profile_scatter_launches(bscgpu_ctx* ctx, double* ms, uin
 BSCGPU_API int  bscgpu_last_stage_ms(bscgpu_ctx* ctx, double* out6);
 
 BSCGPU_API const char* bscgpu_last_error(const bscgpu_ctx* ctx);
+
+/* ---- measurement / test knobs of one context ------------------------------------------------
+ * BSCGPU_OPT_RS_ONESWEEP   which large (key, value) sorts take the single-read digit passes: 0 none (three-kernel passes: histogram,
+ *                          scan and a scatter whose offsets are all known before it starts — what bench.py times as the digit pass's
+ *                          `pattern_ceiling`), 1 the default, 2 every sort of >= 4 tiles (tests).  Results are identical.
+ * BSCGPU_CNT_OS_RETRIES    (get only) transforms this context has redone through the three-kernel passes because a single-read pass
+ *                          gave up a wait (bounded polls; the block still comes out right).
+ * set returns the previous value or a negative libbsc error code; get the value or a negative error code. */
+enum { BSCGPU_OPT_RS_ONESWEEP = 1, BSCGPU_CNT_OS_RETRIES = 2 };
+BSCGPU_API int bscgpu_option_set(bscgpu_ctx* ctx, int key, int value);
+BSCGPU_API int bscgpu_option_get(bscgpu_ctx* ctx, int key);
 
 /* ---- how the libbsc.h entry points spread concurrent callers over the GPUs of a node (pure functions, no GPU needed) -------------
  * The host-pointer API keeps ctx_per_dev default contexts per physical device = nphys * ctx_per_dev logical slots; slot s lives

@@ -30,10 +30,13 @@ def lib():
     # torch bundles its own libamdhip64.so.7; load it FIRST so that our DT_NEEDED "libamdhip64.so.7" binds to
     # the same runtime instead of pulling a second HIP runtime (/opt/rocm) into the process, which leaves
     # whichever loads second without a usable device.
-    try:
-        import torch  # noqa: F401
-    except Exception:  # pragma: no cover - pure-C deployments have no torch; /opt/rocm's runtime is used
-        pass
+    # BSC_NO_TORCH=1 (sanitizer runs, tools/asan_run.py): ROCm's ASan runtime intercepts the HSA allocation calls and dlopen()s
+    # libhsa-runtime64.so itself; with torch's private copy of the runtime in the process that is a second, uninitialised HSA.
+    if not os.environ.get("BSC_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - pure-C deployments have no torch; /opt/rocm's runtime is used
+            pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"native library {LIB_PATH} is missing — build it with `python -m libbsc_amd.build` "
@@ -64,6 +67,8 @@ def lib():
     L.bscgpu_profile_scatter_launches.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
     L.bscgpu_last_stage_ms.argtypes = [vp, C.POINTER(C.c_double)]
     L.bscgpu_last_error.argtypes = [vp]
+    L.bscgpu_option_set.argtypes = [vp, C.c_int, C.c_int]
+    L.bscgpu_option_get.argtypes = [vp, C.c_int]
     L.bscgpu_last_error.restype = C.c_char_p
     L.bscgpu_pipe_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.bscgpu_pipe_destroy.argtypes = [vp]

@@ -2,8 +2,8 @@
 
     python -m libbsc_amd.build            # incremental
     python -m libbsc_amd.build --force
-    python -m libbsc_amd.build --asan     # second library with AddressSanitizer + UBSan on every line of HOST code
-                                          # (device code unchanged): libbsc_amd/lib/asan/libbsc_mi355x.so, see asan_env()
+    python -m libbsc_amd.build --asan     # second library with AddressSanitizer + UBSan on the C++ host side (csrc/host/*.cpp,
+                                          # device code unchanged): libbsc_amd/lib/asan/libbsc_mi355x.so, see asan_env()
 
 Output: libbsc_amd/lib/libbsc_mi355x.so (git-ignored; travels to the GPU box with gpurun).
 hipcc cross-compiles for gfx950 without a GPU present.
@@ -28,21 +28,23 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-result"]
 DEVFLAGS = [f"--offload-arch={ARCH}"]
-# Sanitizer build (SURVEY.md:248): the host side of every translation unit — the C++ files and the launch / arena / pipeline
-# code inside the .hip files — is instrumented; kernels are compiled as always (-fno-gpu-sanitize).  The runtime is the shared
-# one so that an uninstrumented python can host it (LD_PRELOAD, asan_env()).
-SANFLAGS = ["-fsanitize=address,undefined", "-fno-sanitize=alignment,vptr,function", "-fno-sanitize-recover=undefined",
-            "-fno-gpu-sanitize", "-shared-libasan", "-fno-omit-frame-pointer", "-g", "-DBSC_SANITIZE=1"]
+# Sanitizer build (SURVEY.md:248): the C++ translation units under csrc/host/ — container, pipeline, coder pool, the three coders and
+# decoders, LZP, framing — are compiled by g++ with AddressSanitizer + UBSan and run on GCC's runtime; the .hip files (kernels and
+# their launch code) are compiled as always.  Why not hipcc's own -fsanitize=address for everything: ROCm's ASan runtime intercepts
+# hsa_amd_memory_pool_allocate to manage device memory itself, and on this image every HIP allocation then dies with "allocator is
+# trying to allocate 0x400000 bytes" (with torch's HSA copy in the process and without; profiles/r04/asan.txt).  GCC's runtime knows
+# nothing about HSA and leaves the GPU alone.  The runtime is preloaded so that an uninstrumented python can host the library.
+GXX = shutil.which("g++") or "g++"
+SANFLAGS = ["-fsanitize=address,undefined", "-fno-sanitize=alignment,vptr", "-fno-sanitize-recover=undefined",
+            "-fno-omit-frame-pointer", "-g", "-DBSC_SANITIZE=1"]
 
 
 def asan_runtime():
-    r = subprocess.run([HIPCC, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
-    p = r.stdout.strip()
-    if not os.path.isabs(p):
-        import glob
-        hits = glob.glob(os.path.join(ROCM, "lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
-        p = hits[0] if hits else p
-    return p
+    out = []
+    for name in ("libasan.so", "libubsan.so"):
+        r = subprocess.run([GXX, "-print-file-name=" + name], capture_output=True, text=True)
+        out.append(os.path.realpath(r.stdout.strip()))
+    return ":".join(out)
 
 
 def asan_env(extra_options=""):
@@ -85,7 +87,10 @@ def _deps_hash(src, asan=False):
 
 
 def _command(src, obj, asan=False):
-    cmd = [HIPCC] + COMMON + (SANFLAGS if asan else [])
+    if asan and not src.endswith(".hip"):
+        return [GXX] + COMMON + SANFLAGS + ["-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROCM, "include"), "-march=x86-64-v3",
+                                           "-Wno-unknown-pragmas", "-Wno-attributes", "-c", src, "-o", obj]
+    cmd = [HIPCC] + COMMON + (["-g"] if asan else [])
     if src.endswith(".hip"):
         cmd += DEVFLAGS
     else:
@@ -123,8 +128,7 @@ def build(force=False, verbose=True, asan=False):
     changed = any(c for _, c in res)
     if changed or force or not os.path.exists(LIB):
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-Wl,-Bsymbolic"]
-        if asan:
-            cmd += ["-fsanitize=address,undefined", "-shared-libasan", "-fno-gpu-sanitize"]
+
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)

@@ -799,7 +799,25 @@ static int run_seg(bscgpu_ctx* c, const u64* keys, const u32* sa_sorted, const u
     return radix_onesweep_check(c);            // the sort in front of this seg, if it used the single-read passes
 }
 
+static int bwt_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64_t r, u32* I_host, int64_t* primary_out, bool reuse_text);
+
+// A single-read digit pass that gave up a wait (radix_onesweep.hip: bounded polls; pre-emption, a debugger, a hogged CU) fails the
+// sort, not the block: the transform is redone once with the three-kernel passes, which have no cross-workgroup protocol at all.
+// Every sort is checked (run_seg) before anything is written to the caller's buffer, and the private copy of the text is still there.
 int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64_t r, u32* I_host, int64_t* primary_out)
+{
+    c->os_gave_up = false;
+    int rc = bwt_device_once(c, dT_user, dL_user, n64, r, I_host, primary_out, false);
+    if (rc == BSC_GPU_ERROR && c->os_gave_up) {
+        const int mode = c->os_mode;
+        c->os_mode = 0; c->os_gave_up = false; ++c->os_retries;
+        rc = bwt_device_once(c, dT_user, dL_user, n64, r, I_host, primary_out, true);
+        c->os_mode = mode;
+    }
+    return rc;
+}
+
+static int bwt_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64_t r, u32* I_host, int64_t* primary_out, bool reuse_text)
 {
     if (n64 < 0 || n64 > c->max_n || n64 >= 0x7fffffffll) return BSC_BAD_PARAMETER;
     if (n64 == 0) { *primary_out = 0; return BSC_NO_ERROR; }
@@ -807,7 +825,7 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
     int rc;
 
     // private, padded copy of the text (emit may overwrite the user's buffer when dL aliases dT)
-    HIP_TRY(c, hipMemcpyAsync(c->dT, dT_user, n, hipMemcpyDeviceToDevice, c->stream));
+    if (!reuse_text) HIP_TRY(c, hipMemcpyAsync(c->dT, dT_user, n, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->dT + n, 0, 32, c->stream));
 
     // alphabet: byte histogram -> dense order-preserving codes
@@ -902,14 +920,21 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
                 // otherwise (long repeats: most unsorted suffixes sit in a few huge groups, and their records would all go through
                 // global atomics — python sources, 64 MiB: 127 ms against 44 ms) the round is handed over to prefix doubling at once,
                 // without first running a sort that gives up (9.5 ms on that block).
-                // (tables in kA, free since the first seg; group ids in ISA, unused on this path; the permuted suffixes in csa[cur ^ 1])
+                // (tables in an allocation of their own, made when a block first needs them — 16.8 MB per context; round 3 carved them
+                // out of kA on the strength of a comment.  Group ids go to ISA, which does not exist yet on this path — isa_valid is
+                // false, it is built at the hand-over —, sub-group heads to flags, which only the seg kernels behind the round rewrite;
+                // the permuted suffixes to csa[cur ^ 1], the half the next seg writes.)
+                constexpr size_t LT_BYTES = (size_t)(64 + LG_MAX + (size_t)LG_MAX * LG_BUCKETS) * 4;
+                bool fits = n_long <= LG_MAX && n_long_rec <= U / 8u && long_split_on;
+                if (fits && !c->long_tables) {
+                    if (hipMalloc((void**)&c->long_tables, LT_BYTES) != hipSuccess) { (void)hipGetLastError(); c->long_tables = nullptr; fits = false; }
+                }
                 LongTables LT;
-                LT.nlong = reinterpret_cast<u32*>(c->kA); LT.khead = LT.nlong + 64; LT.cnt = LT.khead + LG_MAX;
-                const bool fits = (size_t)c->max_n * 8 >= (size_t)(64 + LG_MAX + (size_t)LG_MAX * LG_BUCKETS) * 4;
-                const bool pays = long_split_on && fits && n_long <= LG_MAX && n_long_rec <= U / 8u;
+                LT.nlong = c->long_tables; LT.khead = LT.nlong + 64; LT.cnt = LT.khead + LG_MAX;
+                const bool pays = fits;
                 if (pays) {
                     u8* subhead = c->flags;
-                    HIP_TRY(c, hipMemsetAsync(LT.nlong, 0, (size_t)(64 + LG_MAX + (size_t)LG_MAX * LG_BUCKETS) * 4, c->stream));
+                    HIP_TRY(c, hipMemsetAsync(LT.nlong, 0, LT_BYTES, c->stream));
                     HIP_TRY(c, hipMemsetAsync(subhead, 0, (size_t)U + 1, c->stream));
                     HIP_TRY(c, hipMemsetAsync(c->dscal + 2, 0, 4, c->stream));
                     u32 blocks = (U + WG - 1) / WG; if (blocks > 4096) blocks = 4096;

@@ -138,6 +138,7 @@ extern "C" void bscgpu_destroy(bscgpu_ctx* c)
     if (c->tile_counts) { (void)hipFree(c->tile_counts); c->tile_counts = nullptr; }
     if (c->os_agg) { (void)hipFree(c->os_agg); c->os_agg = nullptr; }
     if (c->os_zero) { (void)hipFree(c->os_zero); c->os_zero = nullptr; }
+    if (c->long_tables) { (void)hipFree(c->long_tables); c->long_tables = nullptr; }
     if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     for (auto& p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& e : c->event_pool) hipEventDestroy(e);
@@ -218,6 +219,19 @@ extern "C" int bscgpu_profile_scatter_launches(bscgpu_ctx* c, double* ms, uint64
     int from = cnt > max ? cnt - max : 0;
     for (int i = from; i < cnt; ++i) { ms[i - from] = c->scatter_log[i].ms; records[i - from] = c->scatter_log[i].records; }
     return cnt - from;
+}
+extern "C" int bscgpu_option_set(bscgpu_ctx* c, int key, int value)
+{
+    if (!c) return BSC_BAD_PARAMETER;
+    if (key == BSCGPU_OPT_RS_ONESWEEP && value >= 0 && value <= 2 && (value == 0 || c->os_available)) { const int old = c->os_mode; c->os_mode = value; return old; }
+    return BSC_BAD_PARAMETER;
+}
+extern "C" int bscgpu_option_get(bscgpu_ctx* c, int key)
+{
+    if (!c) return BSC_BAD_PARAMETER;
+    if (key == BSCGPU_OPT_RS_ONESWEEP) return c->os_mode;
+    if (key == BSCGPU_CNT_OS_RETRIES) return c->os_retries;
+    return BSC_BAD_PARAMETER;
 }
 extern "C" int bscgpu_last_stage_ms(bscgpu_ctx* c, double* out6)
 {

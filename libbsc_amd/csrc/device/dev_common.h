@@ -91,10 +91,11 @@ struct bscgpu_ctx {
     u32* rowtot = nullptr;   // [256]
     u32* segsum = nullptr;   // [2][MAX_CHUNKS] per-chunk (unsorted count, last head+1)
     u32* segoff = nullptr;   // [2][MAX_CHUNKS] scanned
-    u32* dscal  = nullptr;   // small device scalars (64 u32)
+    u32* dscal  = nullptr;   // small device scalars (1024 u32, mirrored slot by slot in hscal)
     u64* dscal64 = nullptr;  // small device u64 scalars (16)
     u64* adler_part = nullptr; // [MAX_CHUNKS][2]
     u32* tile_counts = nullptr; size_t tile_counts_cap = 0;   // [256][tiles of 8192 records]: BSC_RS_ORDER=1 experiment, allocated on first use
+    u32* long_tables = nullptr;   // BWT text rounds: counting-sort tables of the long-group split (bwt.hip LongTables), allocated on first use
     u64* wc_sink = nullptr;  // [512 * 1024] write sink for predicated-off lanes of rs_scatter_wc
     // single-read digit passes (radix_onesweep.hip), allocated on first use
     int  num_cus = 256;           // hipDeviceAttributeMultiprocessorCount of the context's device
@@ -105,9 +106,12 @@ struct bscgpu_ctx {
     u32  os_pass_stride = 0;      // words
     u32  os_batch_words = 0;      // words of the batch rows inside a pass's block (the group rows follow)
     u32  os_epoch = 0;            // launches so far (launch tag = epoch % 255 + 1)
-    bool os_check_pending = false;   // hscal[OS_ERR_SLOT] of the last sort has not been looked at yet
+    bool os_check_pending = false;   // hscal[OS_ERR_SLOT] has not been looked at since the last single-read sort
+    bool os_available = true;        // the single-read kernels could be set up on this device (radix_onesweep_setup)
+    int  os_retries = 0;             // transforms redone through the three-kernel passes after a give-up (bscgpu_debug_counter)
+    bool os_gave_up = false;         // radix_onesweep_check found a give-up: the caller may redo its sorts through the three-kernel passes
     // pinned host
-    u32* hscal  = nullptr;   // 64 u32
+    u32* hscal  = nullptr;   // 1024 u32 (slot map: the users' comments; OS_ERR_SLOT = 1000)
     u64* hscal64 = nullptr;
     u64* hadler = nullptr;
     u64* hsplit = nullptr;   // pinned: split-flag words (max_n / 256 + 64 bytes)
@@ -151,7 +155,7 @@ struct RadixPass { int shift; int bits; };
 int radix_sort_passes(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* vals_alt, u64 n,
                       const RadixPass* passes, int npasses, int* in_alt, u32* emit_pos = nullptr);
 
-constexpr int OS_ERR_SLOT = 1000;           // hscal / dscal word that carries the error word of the last single-read sort
+constexpr int OS_ERR_SLOT = 1000;           // hscal / dscal word: sticky error word of the single-read digit passes (cleared by radix_onesweep_check only)
 int  radix_onesweep_setup(bscgpu_ctx* c);
 bool radix_onesweep_wanted(const bscgpu_ctx* c, u64 n, int npasses, bool has_val);
 int  radix_onesweep_sort(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* vals_alt, u64 n, const RadixPass* passes, int npasses);

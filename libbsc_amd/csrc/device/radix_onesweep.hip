@@ -39,13 +39,18 @@
 //                own stores of the previous tile, and using them means waiting for those stores to drain (measured: 0.12 ms per
 //                pass although the rows themselves were there).  The scout's queue holds protocol traffic only.  The two roles are
 //                separate loops behind a scalar branch (own register allocation each) that execute the same barrier sequence.
-//   Polls are bounded: a give-up poisons the sort's error word, which the host turns into LIBBSC_GPU_ERROR instead of a hang.
+//   Polls are bounded.  A scout that gives up (a predecessor's row did not arrive within ~16 K polls: wave pre-emption, a debugger, a
+//   hogged CU) raises the context's STICKY error word and points its tile's stores at the tile's own place in the output (in bounds,
+//   wrong order) instead of at offsets built from incomplete sums, which could lie up to 7 x 7680 records beyond the true ones — past
+//   the output buffers.  Workgroups that see the word raised stop claiming tiles, later passes of the sort return at once, and the
+//   host redoes the whole sort through the three-kernel passes (bwt_device / st_device; radix_onesweep_check).
 // Stable: output order inside a digit = tile order, then the tile-local stable rank (rs_rank_wave), exactly as rs_scatter.
 #include "dev_common.h"
 #include "radix_dev.h"
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <atomic>
 
 constexpr int OS_WG = 1024, OS_WAVES = OS_WG / 64, OS_SW = OS_WAVES - 1 /* streaming waves */, OS_ST = OS_SW * 64 /* streaming threads */;
 #ifndef OS_ITEMS_N
@@ -62,7 +67,7 @@ static_assert((OS_GRP - 1) * OS_TILE < (1 << 16), "the tile rows of a group are 
 static_assert(OS_BATCH * OS_TILE < (1 << 28), "group / batch rows carry 28-bit sums");
 static_assert(OS_LDS <= 160 * 1024, "one workgroup per CU: the staging buffers must fit the CU's LDS");
 static_assert(OS_LDS <= 160 * 1024, "rs_onesweep does not fit the CU's LDS");
-// per-pass control block (u32 words): [0] next ticket; word [1] of the FIRST pass's block is the error word of the whole sort
+// per-pass control block (u32 words): [0] next ticket (the error word lives in the context's scalar area, dscal[OS_ERR_SLOT])
 constexpr int OS_CTL_WORDS = 32;
 
 struct OsPasses { int np; int shift[OS_MAXP]; u32 mask[OS_MAXP]; };
@@ -188,7 +193,9 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
     u32 os_round = 1;
     if (t == (u32)ST) { const u32 tk = os_map + opaque0; sclaim[0] = tk < ntiles ? tk : OS_NONE; }
 #else
-    if (t == (u32)ST) { const u32 tk = OS_ADD(ctl + opaque0, 1u); sclaim[0] = tk < ntiles ? tk : OS_NONE; }
+    // (a launch that finds the error word raised — by an earlier pass of this sort, or by a workgroup of this launch — claims nothing:
+    // its input is already unusable; the decision is taken by ONE lane, so it is uniform over the workgroup's barriers)
+    if (t == (u32)ST) { const u32 e0 = OS_LOAD(err); const u32 tk = OS_ADD(ctl + opaque0, 1u); sclaim[0] = (tk < ntiles && e0 == 0u) ? tk : OS_NONE; }
 #endif
     __syncthreads();
     // Three tiles are in flight per workgroup: t0 is written out (its offsets were collected during the previous iteration), t1 waits
@@ -325,6 +332,9 @@ __global__ __launch_bounds__(OS_WG) void rs_onesweep_kernel(const u64* __restric
                 uint4 o;
                 o.x = R[0] + sg[0] + (plo & 0xffffu) - d4.x; o.y = R[1] + sg[1] + (plo >> 16) - d4.y;
                 o.z = R[2] + sg[2] + (phi & 0xffffu) - d4.z; o.w = R[3] + sg[3] + (phi >> 16) - d4.w;
+                // gave up: the sums are incomplete (a stale row may even have been added).  The tile is written over its own TILE
+                // slots of the output — slot q of any digit goes to t1 * TILE + q — so no store can leave the buffers.
+                if (!ok) { const u32 home = t1 * (u32)TILE; o.x = home; o.y = home; o.z = home; o.w = home; }
                 *reinterpret_cast<uint4*>(adj + (x ^ 1u) * 256 + 4 * lane) = o;
             }
             if (!ok) (void)OS_ADD(err, 1u);
@@ -521,6 +531,7 @@ int radix_onesweep_setup(bscgpu_ctx* c)
         hipFuncSetAttribute((const void*)rs_hist_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * OS_MAXP * 256 * 4) != hipSuccess) {
         (void)hipGetLastError();
         c->os_mode = 0;                        // the three-kernel pass serves every sort
+        c->os_available = false;
     }
     return BSC_NO_ERROR;
 }
@@ -574,7 +585,13 @@ int radix_onesweep_sort(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32*
     u64 *ksrc = keys, *kdst = keys_alt;
     u32 *vsrc = vals, *vdst = vals_alt;
     const u64 rec_bytes = 8 + (has_val ? 4 : 0);
+    // BSC_RS_FAULT_DEV=<k> (tests): the k-th single-read sort of the process finds the error word raised after its first pass, as if a
+    // scout of that pass had given up: the later passes must return at once and the caller's check must fail the sort.
+    static const int fault_dev_at = [] { const char* e = getenv("BSC_RS_FAULT_DEV"); return e ? atoi(e) : 0; }();
+    static std::atomic<int> sorts{0};
+    const bool inject = fault_dev_at > 0 && sorts.fetch_add(1) + 1 == fault_dev_at;
     for (int p = 0; p < npasses; ++p) {
+        if (inject && p == 1) HIP_TRY(c, hipMemsetAsync(c->dscal + OS_ERR_SLOT, 1, 4, c->stream));
         // launch tag: 1..255 in the top byte of every tile row; the rows are cleared when the sequence wraps
         if (c->os_epoch % 255u == 0u) HIP_TRY(c, hipMemsetAsync(c->os_agg, 0, (size_t)c->os_tiles_cap * 64 * 8, c->stream));
         const u32 tag = (c->os_epoch % 255u) + 1u;
@@ -583,10 +600,10 @@ int radix_onesweep_sort(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32*
         prof_begin(c, BSCGPU_K_RADIX_SCATTER, 2 * n * rec_bytes, n);
         if (has_val)
             hipLaunchKernelGGL(rs_onesweep_kernel<true>, dim3(grid), dim3(OS_WG), OS_LDS, c->stream,
-                               ksrc, kdst, vsrc, vdst, (u32)n, P.shift[p], P.mask[p], ntiles, ctl, c->os_zero + 1, ctl + OS_CTL_WORDS, reinterpret_cast<u64*>(ctl + OS_CTL_WORDS + 256), reinterpret_cast<u64*>(ctl + OS_CTL_WORDS + 256 + c->os_batch_words), reinterpret_cast<u64*>(c->os_agg), tag, c->wc_sink);
+                               ksrc, kdst, vsrc, vdst, (u32)n, P.shift[p], P.mask[p], ntiles, ctl, c->dscal + OS_ERR_SLOT, ctl + OS_CTL_WORDS, reinterpret_cast<u64*>(ctl + OS_CTL_WORDS + 256), reinterpret_cast<u64*>(ctl + OS_CTL_WORDS + 256 + c->os_batch_words), reinterpret_cast<u64*>(c->os_agg), tag, c->wc_sink);
         else
             hipLaunchKernelGGL(rs_onesweep_kernel<false>, dim3(grid), dim3(OS_WG), OS_LDS, c->stream,
-                               ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, P.shift[p], P.mask[p], ntiles, ctl, c->os_zero + 1, ctl + OS_CTL_WORDS, reinterpret_cast<u64*>(ctl + OS_CTL_WORDS + 256), reinterpret_cast<u64*>(ctl + OS_CTL_WORDS + 256 + c->os_batch_words), reinterpret_cast<u64*>(c->os_agg), tag, c->wc_sink);
+                               ksrc, kdst, (const u32*)nullptr, (u32*)nullptr, (u32)n, P.shift[p], P.mask[p], ntiles, ctl, c->dscal + OS_ERR_SLOT, ctl + OS_CTL_WORDS, reinterpret_cast<u64*>(ctl + OS_CTL_WORDS + 256), reinterpret_cast<u64*>(ctl + OS_CTL_WORDS + 256 + c->os_batch_words), reinterpret_cast<u64*>(c->os_agg), tag, c->wc_sink);
         prof_end(c);
         HIP_TRY(c, hipGetLastError());
         u64* tk = ksrc; ksrc = kdst; kdst = tk;
@@ -600,19 +617,30 @@ int radix_onesweep_sort(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32*
         }
     }
 #endif
-    // the sort's error word travels to pinned memory behind the last pass; radix_onesweep_check looks at it after the caller's next sync
-    HIP_TRY(c, hipMemcpyAsync(c->hscal + OS_ERR_SLOT, c->os_zero + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    // The error word is the context's, not the sort's: it is only ever cleared by radix_onesweep_check, so a give-up of ANY sort since the
+    // last check is still there when the check comes (several sorts in front of one sync lose nothing).  It travels to pinned memory
+    // behind the last pass; radix_onesweep_check looks at it after the caller's next sync.
+    HIP_TRY(c, hipMemcpyAsync(c->hscal + OS_ERR_SLOT, c->dscal + OS_ERR_SLOT, 4, hipMemcpyDeviceToHost, c->stream));
     c->os_check_pending = true;
     (void)nbatches;
     return BSC_NO_ERROR;
 }
 
-// After the stream has been synchronised: did any pass of the last sort give up a wait?  (Cannot happen by construction;
-// a non-zero word means corrupted tables, and the sort's output must not be used.)
+// After the stream has been synchronised: did any single-read pass since the last check give up a wait?  Then the output of every
+// sort since then is unusable (in bounds, but not sorted): the word is cleared, c->os_gave_up tells the caller that a retry through
+// the three-kernel passes is in order (bwt_device / st_device do that once), and the call fails with BSC_GPU_ERROR otherwise.
+// BSC_RS_FAULT=<k> (tests): the k-th check of the process reports a give-up that did not happen.
 int radix_onesweep_check(bscgpu_ctx* c)
 {
     if (!c->os_check_pending) return BSC_NO_ERROR;
     c->os_check_pending = false;
-    if (c->hscal[OS_ERR_SLOT] != 0) return ctx_fail(c, BSC_GPU_ERROR, "digit pass gave up waiting for a predecessor tile", hipSuccess);
+    static const int fault_at = [] { const char* e = getenv("BSC_RS_FAULT"); return e ? atoi(e) : 0; }();
+    static std::atomic<int> checks{0};
+    const bool injected = fault_at > 0 && checks.fetch_add(1) + 1 == fault_at;
+    if (c->hscal[OS_ERR_SLOT] != 0 || injected) {
+        c->os_gave_up = true;
+        (void)hipMemsetAsync(c->dscal + OS_ERR_SLOT, 0, 4, c->stream);
+        return ctx_fail(c, BSC_GPU_ERROR, "digit pass gave up waiting for a predecessor tile", hipSuccess);
+    }
     return BSC_NO_ERROR;
 }

@@ -74,7 +74,24 @@ __global__ __launch_bounds__(WG) void st_post_kernel(const u64* __restrict__ key
     else for (u32 q = 0; j0 + q < n; ++q) out[j0 + q] = (u8)(word >> (8 * q));
 }
 
+static int st_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dOut_user, int n_, int k, int* index_out, bool reuse_text);
+
+// as bwt_device: a single-read pass that gave up fails the sort, and the transform is redone once with the three-kernel passes from
+// the private copy of the text (the caller's buffer may already hold the failed attempt's bytes when it is also the output)
 int st_device(bscgpu_ctx* c, const u8* dT_user, u8* dOut_user, int n_, int k, int* index_out)
+{
+    c->os_gave_up = false;
+    int rc = st_device_once(c, dT_user, dOut_user, n_, k, index_out, false);
+    if (rc == BSC_GPU_ERROR && c->os_gave_up) {
+        const int mode = c->os_mode;
+        c->os_mode = 0; c->os_gave_up = false; ++c->os_retries;
+        rc = st_device_once(c, dT_user, dOut_user, n_, k, index_out, true);
+        c->os_mode = mode;
+    }
+    return rc;
+}
+
+static int st_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dOut_user, int n_, int k, int* index_out, bool reuse_text)
 {
     if (n_ < 0 || n_ > c->max_n) return BSC_BAD_PARAMETER;
     if (k < 3 || k > 8) return BSC_BAD_PARAMETER;
@@ -85,7 +102,7 @@ int st_device(bscgpu_ctx* c, const u8* dT_user, u8* dOut_user, int n_, int k, in
         *index_out = 0;
         return BSC_NO_ERROR;
     }
-    HIP_TRY(c, hipMemcpyAsync(c->dT, dT_user, n, hipMemcpyDeviceToDevice, c->stream));
+    if (!reuse_text) HIP_TRY(c, hipMemcpyAsync(c->dT, dT_user, n, hipMemcpyDeviceToDevice, c->stream));
     hipLaunchKernelGGL(st_pad_kernel, dim3(1), dim3(64), 0, c->stream, c->dT, n);
     HIP_TRY(c, hipMemsetAsync(c->dscal + 2, 0xff, 4, c->stream));
 

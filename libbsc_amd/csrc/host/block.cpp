@@ -129,7 +129,11 @@ static int default_gpu_acquire(int64_t n, bool want_slot, DefaultDevice** out, i
         if (best >= 0) {
             DefaultDevice& D = g_dev[best];
             if (!(D.ctx && D.cap >= n)) {
-                if (D.ctx) { bscgpu_destroy(D.ctx); D.ctx = nullptr; D.cap = 0; }
+                if (D.ctx) {
+                    bscgpu_destroy(D.ctx); D.ctx = nullptr; D.cap = 0;
+                    // HBM came back on this physical device: slots that had been taken out of the draw for lack of it are in again
+                    for (int q = best % nphys; q < ndev; q += nphys) g_dev[q].no_memory_for = -1;
+                }
                 const int64_t cap = n + n / 32 + 4096;                    // headroom like bwt.cpp:106
                 const int rc = bscgpu_create(&D.ctx, g_dev_first + bscgpu_dispatch_device(best, nphys), cap);
                 if (rc != LIBBSC_NO_ERROR) {
@@ -141,6 +145,7 @@ static int default_gpu_acquire(int64_t n, bool want_slot, DefaultDevice** out, i
                     return rc;
                 }
                 D.cap = cap;
+                if (D.no_memory_for >= 0 && cap >= D.no_memory_for) D.no_memory_for = -1;     // it fits after all
             }
             int s = -1;
             if (want_slot) { for (int i = 0; i < DEFAULT_SLOTS; ++i) if (!D.slot_busy[i]) { s = i; break; } D.slot_busy[s] = true; }
@@ -148,6 +153,16 @@ static int default_gpu_acquire(int64_t n, bool want_slot, DefaultDevice** out, i
             g_rr = (unsigned)best + 1u;
             *out = &D; if (slot_out) *slot_out = s;
             return LIBBSC_NO_ERROR;
+        }
+        // Nothing usable right now.  Somebody in flight will release a slot: wait.  Nobody in flight: nothing can change by itself — the
+        // slots are all marked "no memory for this size" by an earlier failure — so the marks are dropped and creation is tried again
+        // (the HBM may be free again: other processes, destroyed pipes); a second failure is the caller's error.
+        bool in_flight = false, marked = false;
+        for (int d = 0; d < ndev; ++d) { in_flight = in_flight || g_dev[d].users > 0; marked = marked || g_dev[d].no_memory_for >= 0; }
+        if (!in_flight) {
+            if (!marked) return LIBBSC_GPU_NOT_ENOUGH_MEMORY;
+            for (int d = 0; d < ndev; ++d) g_dev[d].no_memory_for = -1;
+            continue;
         }
         g_user_cv.wait(lk);
     }

@@ -1,0 +1,198 @@
+// job.cpp — multi-GPU block driver in C++ behind a C ABI: N devices x contexts x blocks in flight, one queue of blocks, results
+// collected in block order.
+//
+// Role: the reference's own block parallelism is the CLI's OpenMP team — every thread reads the next block under `critical(input)`,
+// calls bsc_compress and writes under `critical(output)` (bsc.cpp:182-199, :218-221, :397-400); it knows one GPU and one lock
+// (bwt.cpp:50-52).  Here the same shape is spread over every GPU of a node from ONE process: blocks are independent (own header,
+// own Adler-32s, own model state), so block b simply goes to whichever pipe is free next — a work queue, which on equal GPUs is the
+// north star's "one block per GPU" with load balancing for free — and the caller collects the compressed blocks in index order
+// (bscgpu_job_wait), which is the `critical(output)` half.  Inside one process there is nothing to exchange between GPUs: a block's
+// compressed bytes are produced by host threads of this process in host memory.  (The one-process-per-GPU layout that bench.py's
+// contract prescribes does have an exchange step — variable-size blocks to rank 0 — and that one runs over RCCL: libbsc_amd/multigpu.py.)
+//
+// One worker thread per pipe = per (device, context): it owns its bscgpu context, submits blocks with bscgpu_pipe_submit_host
+// (LZP on the host, one H2D copy, GPU stage) keeping `depth` of them in flight, and publishes each result as its ticket completes.
+// The host coding of all pipes runs on the process-wide coder pool (block.cpp).  The executor behind a pipe is a table of function
+// pointers: the default is the bscgpu_* entry points; tests drive the scheduler with a CPU stand-in (tests/test_job_driver.py), and
+// an embedder can put its own transport there.
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../../include/libbsc.h"
+#include "../../../include/bscgpu.h"
+
+namespace {
+
+struct Block {
+    const uint8_t* input; uint8_t* output; int n, lzpHashSize, lzpMinLen, sorter, coder, features;
+    int result = 0; int worker = -1; bool done = false;
+};
+
+struct Job;
+struct Worker {
+    Job* job = nullptr; int id = 0, device = 0;
+    void* ctx = nullptr; void* pipe = nullptr;
+    std::thread th;
+    int setup_rc = 0; bool ready = false;
+    uint64_t blocks = 0;
+};
+
+struct Job {
+    bscgpu_job_backend be;
+    int depth = 2;
+    int64_t max_block = 0;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done, cv_ready;
+    std::deque<Block> blocks;          // by block number (a deque: references stay valid while blocks are appended)
+    size_t next = 0;                    // first block nobody has taken yet
+    bool closing = false;
+    std::vector<Worker> workers;
+
+    void run(Worker& w);
+};
+
+void Job::run(Worker& w)
+{
+    // the worker owns its context and pipe: created here so that context creation (arena, pinned buffers) runs in parallel over devices
+    int rc = be.ctx_create(be.user, &w.ctx, w.device, max_block);
+    if (rc == LIBBSC_NO_ERROR) rc = be.pipe_create(be.user, w.ctx, depth, &w.pipe);
+    { std::lock_guard<std::mutex> lk(mu); w.setup_rc = rc; w.ready = true; }
+    cv_ready.notify_all();
+    if (rc != LIBBSC_NO_ERROR) return;
+
+    std::deque<std::pair<int, size_t>> inflight;      // (ticket, block number), oldest first
+    auto retire = [&] {
+        const auto [ticket, b] = inflight.front(); inflight.pop_front();
+        const int res = be.pipe_wait(be.user, w.pipe, ticket);
+        { std::lock_guard<std::mutex> lk(mu); blocks[b].result = res; blocks[b].done = true; }
+        cv_done.notify_all();
+    };
+    for (;;) {
+        size_t b = 0; bool have = false;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            // with blocks of its own in flight a worker never sleeps on the queue: their results must reach the collector
+            if (inflight.empty()) cv_work.wait(lk, [&] { return closing || next < blocks.size(); });
+            if (next < blocks.size()) { b = next++; blocks[b].worker = w.id; have = true; ++w.blocks; }
+            else if (inflight.empty()) break;             // closing and nothing left
+        }
+        if (have) {
+            if ((int)inflight.size() == depth) retire();
+            Block& B = blocks[b];                         // (stable: a deque never moves its elements on push_back)
+            const int ticket = be.pipe_submit_host(be.user, w.pipe, B.input, B.output, B.n, B.lzpHashSize, B.lzpMinLen, B.sorter, B.coder, B.features);
+            if (ticket < 0) {
+                { std::lock_guard<std::mutex> lk(mu); B.result = ticket; B.done = true; }
+                cv_done.notify_all();
+            } else inflight.emplace_back(ticket, b);
+        } else retire();                                  // queue empty: drain the oldest, then look again
+    }
+    be.pipe_destroy(be.user, w.pipe); w.pipe = nullptr;
+    be.ctx_destroy(be.user, w.ctx); w.ctx = nullptr;
+}
+
+// ---- the default executor: this library's own contexts and pipes ---------------------------------------------------------------
+int d_ctx_create(void*, void** ctx, int device, int64_t max_n) { bscgpu_ctx* c = nullptr; const int rc = bscgpu_create(&c, device, max_n); *ctx = c; return rc; }
+void d_ctx_destroy(void*, void* ctx) { bscgpu_destroy((bscgpu_ctx*)ctx); }
+int d_pipe_create(void*, void* ctx, int depth, void** pipe) { bscgpu_pipe* p = nullptr; const int rc = bscgpu_pipe_create((bscgpu_ctx*)ctx, depth, &p); *pipe = p; return rc; }
+void d_pipe_destroy(void*, void* pipe) { bscgpu_pipe_destroy((bscgpu_pipe*)pipe); }
+int d_submit(void*, void* pipe, const uint8_t* in, uint8_t* out, int n, int lh, int lm, int sorter, int coder, int features)
+{ return bscgpu_pipe_submit_host((bscgpu_pipe*)pipe, in, out, n, lh, lm, sorter, coder, features); }
+int d_wait(void*, void* pipe, int ticket) { return bscgpu_pipe_wait((bscgpu_pipe*)pipe, ticket); }
+
+}  // namespace
+
+struct bscgpu_job { Job j; };
+
+extern "C" {
+
+int bscgpu_job_create_ex(bscgpu_job** out, const int* devices, int ndevices, int contexts_per_device, int depth, int64_t max_block_bytes,
+                         const bscgpu_job_backend* backend)
+{
+    if (!out || ndevices < 0 || contexts_per_device < 1 || contexts_per_device > 8 || depth < 1 || depth > 8 || max_block_bytes < 0) return LIBBSC_BAD_PARAMETER;
+    *out = nullptr;
+    std::vector<int> devs;
+    if (ndevices == 0) {                                   // every visible device (the default executor's view)
+        const int n = backend ? 0 : bscgpu_device_count();
+        if (n <= 0) return backend ? LIBBSC_BAD_PARAMETER : LIBBSC_GPU_NOT_SUPPORTED;
+        for (int d = 0; d < n; ++d) devs.push_back(d);
+    } else {
+        if (!devices) return LIBBSC_BAD_PARAMETER;
+        devs.assign(devices, devices + ndevices);
+    }
+    bscgpu_job* J = new bscgpu_job;
+    Job& j = J->j;
+    if (backend) j.be = *backend;
+    else j.be = bscgpu_job_backend{nullptr, d_ctx_create, d_ctx_destroy, d_pipe_create, d_pipe_destroy, d_submit, d_wait};
+    j.depth = depth; j.max_block = max_block_bytes;
+    // worker w: context w / ndev of device w % ndev — the first context of every device comes before anybody's second
+    j.workers.resize(devs.size() * (size_t)contexts_per_device);
+    for (size_t w = 0; w < j.workers.size(); ++w) { j.workers[w].job = &j; j.workers[w].id = (int)w; j.workers[w].device = devs[w % devs.size()]; }
+    for (auto& w : j.workers) w.th = std::thread([&j, &w] { j.run(w); });
+    // all contexts up before the first block: a device that cannot be set up fails the job here, not in the middle of it
+    int rc = LIBBSC_NO_ERROR;
+    {
+        std::unique_lock<std::mutex> lk(j.mu);
+        j.cv_ready.wait(lk, [&] { for (auto& w : j.workers) if (!w.ready) return false; return true; });
+        for (auto& w : j.workers) if (w.setup_rc != LIBBSC_NO_ERROR && rc == LIBBSC_NO_ERROR) rc = w.setup_rc;
+    }
+    if (rc != LIBBSC_NO_ERROR) { bscgpu_job_destroy(J); return rc; }
+    *out = J;
+    return LIBBSC_NO_ERROR;
+}
+
+int bscgpu_job_create(bscgpu_job** out, const int* devices, int ndevices, int contexts_per_device, int depth, int64_t max_block_bytes)
+{ return bscgpu_job_create_ex(out, devices, ndevices, contexts_per_device, depth, max_block_bytes, nullptr); }
+
+int bscgpu_job_add(bscgpu_job* J, const uint8_t* input, uint8_t* output, int n, int lzpHashSize, int lzpMinLen, int blockSorter, int coder, int features)
+{
+    if (!J || !input || !output || n < 0 || (int64_t)n > J->j.max_block) return LIBBSC_BAD_PARAMETER;
+    Job& j = J->j;
+    int number;
+    {
+        std::lock_guard<std::mutex> lk(j.mu);
+        if (j.closing) return LIBBSC_BAD_PARAMETER;
+        number = (int)j.blocks.size();
+        j.blocks.push_back(Block{input, output, n, lzpHashSize, lzpMinLen, blockSorter, coder, features});
+    }
+    j.cv_work.notify_one();
+    return number;
+}
+
+int bscgpu_job_wait(bscgpu_job* J, int block)
+{
+    if (!J || block < 0) return LIBBSC_BAD_PARAMETER;
+    Job& j = J->j;
+    std::unique_lock<std::mutex> lk(j.mu);
+    if ((size_t)block >= j.blocks.size()) return LIBBSC_BAD_PARAMETER;
+    j.cv_done.wait(lk, [&] { return j.blocks[(size_t)block].done; });
+    return j.blocks[(size_t)block].result;
+}
+
+int bscgpu_job_block_worker(bscgpu_job* J, int block, int* device)
+{
+    if (!J || block < 0) return LIBBSC_BAD_PARAMETER;
+    Job& j = J->j;
+    std::lock_guard<std::mutex> lk(j.mu);
+    if ((size_t)block >= j.blocks.size() || j.blocks[(size_t)block].worker < 0) return LIBBSC_BAD_PARAMETER;
+    const int w = j.blocks[(size_t)block].worker;
+    if (device) *device = j.workers[(size_t)w].device;
+    return w;
+}
+
+void bscgpu_job_destroy(bscgpu_job* J)
+{
+    if (!J) return;
+    Job& j = J->j;
+    { std::lock_guard<std::mutex> lk(j.mu); j.closing = true; }
+    j.cv_work.notify_all();
+    for (auto& w : j.workers) if (w.th.joinable()) w.th.join();     // queued blocks are still processed: destroy = finish, then tear down
+    delete J;
+}
+
+}  // extern "C"

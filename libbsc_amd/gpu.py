@@ -140,6 +140,15 @@ class GpuContext:
     def pipe(self, depth=2, reuse_outputs=False):
         return Pipe(self, depth, reuse_outputs)
 
+    # ---- measurement / test knobs (include/bscgpu.h: BSCGPU_OPT_*, BSCGPU_CNT_*) ---------------------------------
+    OPT_RS_ONESWEEP, CNT_OS_RETRIES = 1, 2
+
+    def option_set(self, key, value):
+        return self._check(self.L.bscgpu_option_set(self.h, key, value))
+
+    def option_get(self, key):
+        return self._check(self.L.bscgpu_option_get(self.h, key))
+
     # ---- profiling ---------------------------------------------------------------------------
     def profile(self, on=True):
         self.L.bscgpu_profile_enable(self.h, 1 if on else 0)

@@ -178,6 +178,50 @@ def test_single_read_passes_under_uneven_load(os_ctx, torch_cuda):
     assert not errors, errors
 
 
+def test_single_read_pass_give_up_is_retried_not_fatal(torch_cuda):
+    """A scout wave that exhausts its bounded poll (pre-emption, a debugger, a hogged CU) must cost a retry, not the block and never a
+    store outside the buffers: the sticky error word fails the sort, the transform is redone once through the three-kernel passes
+    (bwt_device / st_device) and the context counts it.  The give-up is injected (BSC_RS_FAULT=<k>: the k-th check of the process
+    reports one that did not happen; BSC_RS_FAULT_DEV=<k>: the k-th single-read sort finds the device word raised after its first pass, so
+    its later passes take the early exit and its output is garbage), in child processes because the knobs are read once; BWT and ST8
+    (key + value passes)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from libbsc_amd import GpuContext, api
+from oracle.refbind import Ref
+ref = Ref()
+ctx = GpuContext(0, max_n=(9 << 20) + 4096)
+T = api.synth_text_v1(5, 9 << 20)
+before = ctx.option_get(ctx.CNT_OS_RETRIES)
+L, idx, _ = ctx.bwt(T)                                   # the first check of the process is the one behind the first sort: injected
+wL, widx, _ = ref.bwt_encode(T, aux=False)
+assert idx == widx and np.array_equal(L, wL), "BWT after a retried sort differs"
+assert ctx.option_get(ctx.CNT_OS_RETRIES) == before + 1, ctx.option_get(ctx.CNT_OS_RETRIES)
+L2, idx2, _ = ctx.bwt(T)                                 # and nothing sticks: the next transform runs the single-read passes again
+assert idx2 == widx and np.array_equal(L2, wL) and ctx.option_get(ctx.CNT_OS_RETRIES) == before + 1
+print("retried ok")
+""" % root
+    for knob in ("BSC_RS_FAULT", "BSC_RS_FAULT_DEV"):
+        env = dict(os.environ, BSC_RS_ONESWEEP="2")
+        env[knob] = "1"
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root)
+        assert r.returncode == 0 and "retried ok" in r.stdout, knob + r.stdout[-2000:] + r.stderr[-2000:]
+    code_st = code.replace("L, idx, _ = ctx.bwt(T)", "out, idx = ctx.st_encode(T, 8); L = out").replace(
+        "wL, widx, _ = ref.bwt_encode(T, aux=False)", "wL, widx = ctx.st_encode(T, 8)").replace(
+        "L2, idx2, _ = ctx.bwt(T)", "L2, idx2 = ctx.st_encode(T, 8)")
+    # ST8: the injected run is compared with an uninjected run of the same context (the reference's CPU build has no ST8 encoder)
+    env = dict(os.environ, BSC_RS_FAULT_DEV="1", BSC_RS_ONESWEEP="2")
+    r = subprocess.run([sys.executable, "-c", code_st], capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0 and "retried ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [0, 1, 5, 64, 4095, 4096, 4097, 100000, (1 << 20) + 123, 5_000_000])
 @pytest.mark.parametrize("mode", ["pairs", "keys"])
@@ -285,6 +329,44 @@ def test_bwt_long_groups_are_split_not_handed_over(torch_cuda):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     log = r.stdout + r.stderr
     assert "split by the top key bits -> sorted" in log, log[-3000:]
+
+
+def test_bwt_long_groups_with_default_keys(torch_cuda):
+    """Long groups with the DEFAULT first-sort keys (12 characters of text): a 13-character phrase planted 3000 times, each time followed
+    by different text — the suffixes at the phrase and at its first few characters agree on more than the key, so several groups of
+    ~3000 records (> 1024, what one workgroup sorts) survive the first sort among otherwise ordinary text; the round's key then starts
+    inside the phrase and its second character differs, so the split by the top key bits succeeds.  The same with a 40-character phrase:
+    the split's buckets are still too long and the round hands over to prefix doubling.  Child process with the debug log on: both
+    outcomes must appear in the log, and both blocks must equal libsais's output."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from libbsc_amd import GpuContext, api
+from oracle.refbind import Ref
+ref = Ref()
+n = 6 << 20
+ctx = GpuContext(0, max_n=n + 4096)
+rng = np.random.default_rng(4)
+for plen in (13, 40):
+    T = api.synth_text_v1(31, n).copy()
+    phrase = np.frombuffer(b"qzjxvkwpyfgmbqzjxvkwpyfgmbqzjxvkwpyfgmbhh"[:plen], np.uint8)
+    for p in rng.choice((n - 64) // 64, 3000, replace=False) * 64:
+        T[p:p + plen] = phrase
+    L, idx, _ = ctx.bwt(T)
+    wL, widx, _ = ref.bwt_encode(T, aux=False)
+    assert idx == widx and np.array_equal(L, wL), plen
+    print("planted phrase of", plen, "ok", flush=True)
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, BSCGPU_DEBUG="1"), cwd=root)
+    log = r.stdout + r.stderr
+    assert r.returncode == 0 and "planted phrase of 40 ok" in log, log[-3000:]
+    assert "split by the top key bits -> sorted" in log, log[-3000:]
+    assert "handing over" in log or "not split" in log or "still too long" in log, log[-3000:]
 
 
 @pytest.mark.parametrize("k", [3, 4, 5, 6, 7, 8])

@@ -1,0 +1,154 @@
+"""The C multi-GPU job driver (include/bscgpu.h: bscgpu_job_*, csrc/host/job.cpp) on CPU: its scheduler — one queue of blocks, one worker
+per (device, context) pipe, `depth` blocks in flight per pipe, results collected in block order — runs here against a stand-in
+executor (bscgpu_job_backend: python callbacks instead of bscgpu_create / bscgpu_pipe_*), so ordering, depth limits, load balance over
+unequal devices, error propagation and teardown are checked without a GPU.  The stand-in "compresses" with bsc_store."""
+import ctypes as C
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from libbsc_amd import _native as N
+
+vp, ci = C.c_void_p, C.c_int
+CTX_CREATE = C.CFUNCTYPE(ci, vp, C.POINTER(vp), ci, C.c_int64)
+CTX_DESTROY = C.CFUNCTYPE(None, vp, vp)
+PIPE_CREATE = C.CFUNCTYPE(ci, vp, vp, ci, C.POINTER(vp))
+PIPE_DESTROY = C.CFUNCTYPE(None, vp, vp)
+SUBMIT = C.CFUNCTYPE(ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci)
+WAIT = C.CFUNCTYPE(ci, vp, vp, ci)
+
+
+class Backend(C.Structure):
+    _fields_ = [("user", vp), ("ctx_create", CTX_CREATE), ("ctx_destroy", CTX_DESTROY), ("pipe_create", PIPE_CREATE),
+                ("pipe_destroy", PIPE_DESTROY), ("pipe_submit_host", SUBMIT), ("pipe_wait", WAIT)]
+
+
+class FakeNode:
+    """devices whose pipes take `ms[device]` milliseconds per block; records everything the driver does"""
+
+    def __init__(self, ms, fail_device=None, fail_sorter=99):
+        self.L = N.lib()
+        self.L.bsc_store.argtypes = [vp, vp, ci, ci]
+        self.ms, self.fail_device, self.fail_sorter = ms, fail_device, fail_sorter
+        self.lock = threading.Lock()
+        self.ctx = {}          # ctx id -> device
+        self.pipes = {}        # pipe id -> dict(device, depth, tickets {ticket: (in, out, n)}, next, max_inflight, blocks)
+        self.destroyed = []
+        self.ids = 0
+        self.cb = Backend(None, CTX_CREATE(self.ctx_create), CTX_DESTROY(self.ctx_destroy), PIPE_CREATE(self.pipe_create),
+                          PIPE_DESTROY(self.pipe_destroy), SUBMIT(self.submit), WAIT(self.wait))
+
+    def ctx_create(self, user, out, device, max_n):
+        if device == self.fail_device:
+            return -9
+        with self.lock:
+            self.ids += 1
+            self.ctx[self.ids] = device
+            out[0] = self.ids
+        return 0
+
+    def ctx_destroy(self, user, ctx):
+        with self.lock:
+            self.destroyed.append(("ctx", ctx))
+
+    def pipe_create(self, user, ctx, depth, out):
+        with self.lock:
+            self.ids += 1
+            self.pipes[self.ids] = dict(device=self.ctx[ctx], depth=depth, tickets={}, next=0, max_inflight=0, blocks=0)
+            out[0] = self.ids
+        return 0
+
+    def pipe_destroy(self, user, pipe):
+        with self.lock:
+            assert not self.pipes[pipe]["tickets"], "pipe destroyed with blocks in flight"
+            self.destroyed.append(("pipe", pipe))
+
+    def submit(self, user, pipe, inp, out, n, lh, lm, sorter, coder, features):
+        if sorter == self.fail_sorter:
+            return -1
+        with self.lock:
+            p = self.pipes[pipe]
+            t = p["next"]; p["next"] += 1
+            p["tickets"][t] = (inp, out, n)
+            p["max_inflight"] = max(p["max_inflight"], len(p["tickets"]))
+            p["blocks"] += 1
+        return t
+
+    def wait(self, user, pipe, ticket):
+        with self.lock:
+            p = self.pipes[pipe]
+            inp, out, n = p["tickets"][ticket]
+        time.sleep(self.ms[p["device"]] / 1e3)
+        r = self.L.bsc_store(inp, out, n, 0)
+        with self.lock:
+            del p["tickets"][ticket]
+        return r
+
+
+def _job(node, devices, cpd, depth, max_block=1 << 20):
+    L = N.lib()
+    L.bscgpu_job_create_ex.argtypes = [C.POINTER(vp), C.POINTER(ci), ci, ci, ci, C.c_int64, C.POINTER(Backend)]
+    L.bscgpu_job_add.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci]
+    L.bscgpu_job_wait.argtypes = [vp, ci]
+    L.bscgpu_job_block_worker.argtypes = [vp, ci, C.POINTER(ci)]
+    L.bscgpu_job_destroy.argtypes = [vp]
+    L.bscgpu_job_destroy.restype = None
+    h = vp()
+    devs = (ci * len(devices))(*devices)
+    rc = L.bscgpu_job_create_ex(C.byref(h), devs, len(devices), cpd, depth, max_block, C.byref(node.cb))
+    return L, h, rc
+
+
+def test_job_collects_blocks_in_order_over_unequal_devices():
+    node = FakeNode({0: 2.0, 1: 2.0, 2: 12.0, 3: 2.0})           # device 2 is six times slower
+    L, h, rc = _job(node, [0, 1, 2, 3], 2, 3)
+    assert rc == 0 and len(node.pipes) == 8
+    rng = np.random.default_rng(1)
+    ins = [rng.integers(0, 256, int(rng.integers(1, 5000)), dtype=np.uint8) for _ in range(120)]
+    outs = [np.zeros(a.size + 28, np.uint8) for a in ins]
+    for b, (a, o) in enumerate(zip(ins, outs)):
+        assert L.bscgpu_job_add(h, N.np_ptr(a), N.np_ptr(o), a.size, 0, 0, 1, 1, 3) == b      # numbers follow the order of the calls
+    per_dev = {}
+    for b, (a, o) in enumerate(zip(ins, outs)):                 # collected in block order, whatever order they finished in
+        assert L.bscgpu_job_wait(h, b) == a.size + 28
+        assert o[28:].tobytes() == a.tobytes() and int.from_bytes(o[4:8].tobytes(), "little") == a.size
+        dev = ci(-1)
+        w = L.bscgpu_job_block_worker(h, b, C.byref(dev))
+        assert 0 <= w < 8 and dev.value == [0, 1, 2, 3][w % 4]   # worker w lives on device w % ndev: first contexts before second ones
+        per_dev[dev.value] = per_dev.get(dev.value, 0) + 1
+    assert all(p["max_inflight"] <= 3 for p in node.pipes.values())
+    assert max(p["max_inflight"] for p in node.pipes.values()) == 3          # and the depth is used
+    assert set(per_dev) == {0, 1, 2, 3} and per_dev[2] < min(per_dev[0], per_dev[1], per_dev[3])     # the queue balances: the slow GPU takes fewer
+    assert L.bscgpu_job_wait(h, 120) == -1 and L.bscgpu_job_wait(h, -1) == -1
+    L.bscgpu_job_destroy(h)
+    assert len([d for d in node.destroyed if d[0] == "pipe"]) == 8 and len([d for d in node.destroyed if d[0] == "ctx"]) == 8
+
+
+def test_job_destroy_finishes_queued_blocks_and_errors_reach_the_caller():
+    node = FakeNode({0: 3.0, 1: 3.0}, fail_sorter=7)
+    L, h, rc = _job(node, [0, 1], 1, 2)
+    assert rc == 0
+    ins = [np.full(100 + i, i, np.uint8) for i in range(30)]
+    outs = [np.zeros(a.size + 28, np.uint8) for a in ins]
+    for b, (a, o) in enumerate(zip(ins, outs)):
+        L.bscgpu_job_add(h, N.np_ptr(a), N.np_ptr(o), a.size, 0, 0, 7 if b == 11 else 1, 1, 3)
+    assert L.bscgpu_job_wait(h, 11) == -1                        # the executor's error code is the block's result; the job goes on
+    assert L.bscgpu_job_wait(h, 12) == ins[12].size + 28
+    assert L.bscgpu_job_add(h, N.np_ptr(ins[0]), N.np_ptr(outs[0]), (1 << 20) + 1, 0, 0, 1, 1, 3) == -1     # larger than the job's contexts
+    L.bscgpu_job_destroy(h)                                      # nothing waited for beyond 12: destroy = finish, then tear down
+    for b, (a, o) in enumerate(zip(ins, outs)):
+        if b != 11:
+            assert o[28:].tobytes() == a.tobytes(), b
+    assert sum(p["blocks"] for p in node.pipes.values()) == 29
+
+
+def test_job_creation_fails_as_a_whole_when_a_device_cannot_be_set_up():
+    node = FakeNode({0: 1.0, 1: 1.0, 2: 1.0}, fail_device=1)
+    L, h, rc = _job(node, [0, 1, 2], 1, 2)
+    assert rc == -9 and not h.value
+    assert len([d for d in node.destroyed if d[0] == "ctx"]) == 2            # what had been created is released again
+    node2 = FakeNode({0: 1.0})
+    assert _job(node2, [], 1, 2)[2] == -1                                    # "every visible device" is the default executor's notion
+    assert _job(node2, [0], 0, 2)[2] == -1 and _job(node2, [0], 1, 9)[2] == -1
