@@ -136,16 +136,58 @@ def main():
     trace = [] if os.environ.get("BSC_BENCH_TRACE") else None      # (pipe, block, what, seconds since the run started): where a short run's time goes
     t_run0 = [0.0]
 
+    host_leg = [False]              # the boundary leg after the timed region: blocks enter through bscgpu_pipe_submit_host (pageable host memory)
+
+    # How the blocks of a run reach the contexts.  Steady state wants all contexts busy (kernels of different blocks interleave on the
+    # GPU: +14 %), but the END of a job does not: six contexts that each hold one of the last six blocks finish their GPU stages in one
+    # burst at the very end, and ~1.4 CPU-s of range coding are then left for 16 CPUs (round 3: 94 ms of drain behind 265 ms of GPU
+    # work at the driver's 20 steps).  So the blocks come from ONE queue, and context k only takes a block while more than k blocks are
+    # left: the last block goes to context 0 alone, the last two to contexts 0 and 1, ... — the tail's GPU stages finish one after
+    # the other, and their coding overlaps the GPU work still to come.  BSC_BENCH_QUEUE=0: the static split of rounds 1-3.
+    # The START of a job is tapered the same way: context k draws its first block once k GPU stages of the run have finished.  With all
+    # contexts starting at once their first six GPU stages interleave and end together after ~6 x 13 ms, and the coder threads have
+    # nothing to do until then (round 3's timeline: first block coded at 144 ms of 340); staggered, the first block reaches them after
+    # one GPU stage, and the stages keep ending one at a time.
+    use_queue = os.environ.get("BSC_BENCH_QUEUE", "1") != "0"
+    queue_lock = threading.Condition()
+    queue_state = {"next": 0, "total": 0, "stages_done": 0}
+
+    def take_block(k, i_static, steps_static):
+        """-> (take it?, is one of the job's last blocks?)"""
+        if queue_state["total"] == 0:                     # static split: pipe k's own share
+            return i_static < steps_static, i_static == steps_static - 1
+        with queue_lock:
+            if i_static == 0:                             # this context's first block of the run
+                queue_lock.wait_for(lambda: queue_state["stages_done"] >= k or queue_state["next"] >= queue_state["total"])
+            left = queue_state["total"] - queue_state["next"]
+            if left <= k:
+                return False, False
+            queue_state["next"] += 1
+            return True, left <= ncx
+
+    def stage_finished():
+        if queue_state["total"]:
+            with queue_lock:
+                queue_state["stages_done"] += 1
+                queue_lock.notify_all()
+
     def run_one(k, steps, record, out):
-        """`steps` blocks through pipe k: GPU stage of block i+1 overlaps the host coding of block i."""
+        """blocks through pipe k (`steps` of them with the static split, else from the queue): GPU stage of block i+1 overlaps the host
+        coding of block i."""
         pipe, cx = pipes[k], ctxs[k]
         tickets, blk = [], None
         local_stage = np.zeros(6)
         done = 0
-        for i in range(steps):
-            feat = 3 | (LOW_LATENCY if (tail_low_latency and i == steps - 1) else 0)
+        i = -1
+        while True:
+            i += 1
+            take, last = take_block(k, i, steps)
+            if not take:
+                break
+            feat = 3 | (LOW_LATENCY if (tail_low_latency and last) else 0)
             if trace is not None and record: trace.append((k, i, "submit", time.perf_counter() - t_run0[0]))
-            tickets.append(pipe.submit(d_in, n, args.sorter, args.coder, feat))
+            tickets.append(pipe.submit_host(host_in, args.sorter, args.coder, 0, 0, feat) if host_leg[0] else pipe.submit(d_in, n, args.sorter, args.coder, feat))
+            stage_finished()
             if trace is not None and record: trace.append((k, i, "gpu stage done", time.perf_counter() - t_run0[0]))
             if record:
                 local_stage += np.array(cx.last_stage_ms())
@@ -162,14 +204,20 @@ def main():
             with stage_lock:
                 stage[:] += local_stage
 
-    def run(steps, record=False):
+    def run(steps, record=False, static=False):
         out = [None] * ncx
         share = [steps // ncx + (1 if k < steps % ncx else 0) for k in range(ncx)]
+        queue_state["next"] = 0
+        queue_state["stages_done"] = 0
+        queue_state["total"] = 0 if (static or not use_queue or ncx == 1) else steps
         def guarded(k):
             try:
                 run_one(k, share[k], record, out)
             except BaseException as e:                                      # a thread's exception must fail the run, not shorten it
                 thread_errors.append(e)
+                with queue_lock:                                            # ... nor leave the others waiting for its GPU stages
+                    queue_state["next"] = queue_state["total"]
+                    queue_lock.notify_all()
         if ncx == 1:
             guarded(0)
         else:
@@ -196,7 +244,7 @@ def main():
             ncx = cand
             ctxs = [GpuContext(local, max_n=n + 4096) for _ in range(ncx)]
             pipes = [cx.pipe(args.depth, reuse_outputs=True) for cx in ctxs]
-            run(ncx * args.depth)
+            run(ncx * args.depth, static=True)          # every slot of every pipe once
             break
         except Exception as e:
             print(f"[bench] rank {rank}: {cand} context(s) x {args.depth} could not be set up ({e!r})" + ("; trying fewer" if cand > 1 else ""), file=sys.stderr)
@@ -258,6 +306,7 @@ def main():
         concat = None                                   # (N > 1: these blocks are not part of the job's output)
         ctxs[0].profile(True)
         ctxs[0].profile_reset()
+        queue_state["total"] = 0
         run_one(0, iso_blocks, False, [None] * ncx)
         torch.cuda.synchronize()
         ctxs[0].profile(False)
@@ -268,12 +317,13 @@ def main():
     # code, but every offset is known before it starts (rs_hist + rs_scan) — no tickets, no look-back, no scout wave.  What it reaches
     # on THIS box is the denominator `frac` lacks besides the spec sheet: the boxes of the pool differ by ~15 % for this access pattern.
     launches_ceiling = []
-    if rank == 0 and args.sorter == 1 and os.environ.get("BSC_RS_ONESWEEP", "1") != "0":
+    if rank == 0 and os.environ.get("BSC_RS_ONESWEEP", "1") != "0" and (args.sorter == 1 or os.environ.get("BSC_RS_ONESWEEP") in ("2", "3")):
         try:
             prev = ctxs[0].option_set(ctxs[0].OPT_RS_ONESWEEP, 0)
             ctxs[0].profile(True)
             ctxs[0].profile_reset()
             concat = None
+            queue_state["total"] = 0
             run_one(0, max(2, min(4, args.steps)), False, [None] * ncx)
             torch.cuda.synchronize()
             ctxs[0].profile(False)
@@ -282,6 +332,32 @@ def main():
         except Exception as e:                            # reporting only
             print(f"[bench] pattern-ceiling leg failed: {e!r}", file=sys.stderr)
     free_b, total_b = torch.cuda.mem_get_info(local)
+    # ---- the boundary C callers actually have: host pointers.  The same number of blocks twice through all pipes, once with the input
+    # resident in HBM (as the timed region) and once entering through bscgpu_pipe_submit_host from ordinary (pageable) host memory —
+    # one H2D copy per block in front of the same GPU stage.  Untimed legs, reported beside `value`, never as `value`.
+    boundary = None
+    if rank == 0 and world == 1:
+        try:
+            concat = None
+            hb = max(2 * ncx * args.depth, min(args.steps, 48))
+            legs = {}
+            for name, flag in (("device_resident", False), ("host_input", True)):
+                host_leg[0] = flag
+                torch.cuda.synchronize()
+                th0 = time.perf_counter()
+                blk_h = run(hb)
+                torch.cuda.synchronize()
+                legs[name] = hb * n / 1e6 / (time.perf_counter() - th0)
+                if flag:
+                    ok_h, _ = verify_block(blk_h, seed, n, args.sorter, args.coder)
+            host_leg[0] = False
+            boundary = {"blocks": hb, "device_resident_MBps": round(legs["device_resident"], 1), "host_input_MBps": round(legs["host_input"], 1),
+                        "host_over_device": round(legs["host_input"] / legs["device_resident"], 3), "host_input_verified": ok_h,
+                        "what": "bscgpu_pipe_submit_host on pageable host memory (one H2D per block, overlapped across the contexts) against bscgpu_pipe_submit on the "
+                                "resident block, same pipes, same number of blocks, fill and drain included in both"}
+        except Exception as e:                            # reporting only
+            print(f"[bench] boundary leg failed: {e!r}", file=sys.stderr)
+            host_leg[0] = False
     # what leaves this rank's GPU over PCIe in the timed region: 16 bits per binary decision of the device model (run arrays instead
     # for blocks on the host model: not counted) + nothing else of size (the input is resident, the sorted block never crosses);
     # the host's DRAM sees those bytes twice (DMA write, coder read) — with 8 ranks per node this, not xGMI, is the shared resource
@@ -303,11 +379,15 @@ def main():
         value = world * args.steps * n / 1e6 / dt
         rec_bytes = 12 if args.sorter == 1 else 8
 
-        onesweep = args.sorter == 1 and os.environ.get("BSC_RS_ONESWEEP", "1") != "0"
+        os_env = os.environ.get("BSC_RS_ONESWEEP", "1")
+        onesweep = os_env != "0" and (args.sorter == 1 or args.sorter == 8 or os_env in ("2", "3"))
         kernel_name = ("rs_onesweep_kernel<true> (one 8-bit LSD digit pass of the BWT's first sort, records read once and written once: u64 key + u32 value; "
-                       "15 streaming waves x 7680-record tiles + a scout wave that collects the tile offsets by decoupled look-back)") if onesweep else \
+                       "15 streaming waves x 7680-record tiles + a scout wave that collects the tile offsets by decoupled look-back)") if onesweep and args.sorter == 1 else \
+                      ("rs_onesweep_kernel<false> (one 8-bit LSD digit pass of the sort transform, u64 keys only, records read once and written once; "
+                       "tile offsets by decoupled look-back)") if onesweep else \
                       ("rs_scatter_tiled_kernel<true> (one 8-bit LSD digit pass, 1024 x 8 shape, tiles interleaved per XCD; offsets from rs_hist + rs_scan)"
-                       if args.sorter == 1 else "rs_scatter_kernel<false, 256, 16, 1> (one 8-bit LSD digit pass of the sort transform: u64 keys only)")
+                       if args.sorter == 1 else "rs_scatter_kernel<false, 256, 16, 1> (one 8-bit LSD digit pass of the sort transform: u64 keys only; offsets from rs_hist + rs_scan, "
+                       "whose read of the keys per pass is charged in sort_frac, not here)")
 
         def scatter_rate(launches):
             """the graded kernel only: launches over all n records (the sorter's digit passes; the device coder's keys-only passes over
@@ -364,9 +444,9 @@ def main():
                 roofline["pattern_ceiling"] = {
                     "achieved": round(c_ach, 1), "frac_of_peak": round(c_ach / HBM_PEAK_GBPS, 4), "avg_launch_ms": round(c_ms / len(cfull), 4), "launches": len(cfull),
                     "frac_of_ceiling": round(achieved / c_ach, 4),
-                    "what": "rs_scatter_tiled_kernel<true> on the same blocks in the same run and context: the same records into the same 256 runs per tile with the "
-                            "same ranking code, all offsets precomputed by rs_hist + rs_scan (whose 8 B per record and pass are NOT charged here) - "
-                            "the scatter pattern without any cross-workgroup protocol; frac_of_ceiling = graded kernel / this"}
+                    "what": ("rs_scatter_tiled_kernel<true>" if args.sorter == 1 else "rs_scatter_kernel<false>") + " on the same blocks in the same run and context: the same "
+                            "records into the same 256 runs per tile with the same ranking code, all offsets precomputed by rs_hist + rs_scan (whose 8 B per record and pass "
+                            "are NOT charged here) - the scatter pattern without any cross-workgroup protocol; frac_of_ceiling = graded kernel / this"}
         # share of a block's GPU time that is digit passes (the kernel's own rate, not the contended in-region durations: with several
         # contexts per GPU launches of different blocks overlap, and the sum of their durations exceeds the wall time)
         roofline["digit_pass_ms_per_block"] = round(tot_ms / iso_blocks, 3)
@@ -377,7 +457,7 @@ def main():
         if rc_adaptive:
             coder_desc = (f"per block either all eight sub-blocks in the SIMD lanes of one task ({simd}; {pool_modes['eight_lane_task']} of this rank's {args.steps} timed blocks) "
                           f"or four tasks of two interleaved scalar coders — blocks queued while >= 4 CPUs of the pool's budget were idle"
-                          + (f", and the last block of each of the {ncx} pipes, marked low-latency" if tail_low_latency else "") + f" ({pool_modes['pair_tasks']} blocks)"
+                          + ((f", and the job's last {ncx} blocks, marked low-latency" if (use_queue and ncx > 1) else f", and the last block of each of the {ncx} pipes, marked low-latency") if tail_low_latency else "") + f" ({pool_modes['pair_tasks']} blocks)"
                           + (f", or eight scalar tasks, a low-latency block that found >= 12 CPUs idle ({pool_modes['scalar_tasks']})" if pool_modes['scalar_tasks'] else ""))
         elif rc_x8:
             coder_desc = f"all eight sub-blocks of a block in the SIMD lanes of one task, {simd}"
@@ -392,7 +472,9 @@ def main():
                                    "Adler-32 + sorter + QLFC run/rank front end" + (" + the static coder's whole adaptive model on the GPU, 16 bits per binary decision over PCIe, "
                                    "range coding on host threads (" + coder_desc + ")" if args.coder == 1 else
                                    "; adaptive model and range coding on host threads (one task per sub-block)") +
-                                   f"; {ncx} GPU context(s) x {args.depth} = {ncx * args.depth} block(s) in flight per GPU feeding one pool of {coder_threads} coder threads; "
+                                   f"; {ncx} GPU context(s) x {args.depth} = {ncx * args.depth} block(s) in flight per GPU feeding one pool of {coder_threads} coder threads"
+                                   + ("; blocks are drawn from one queue, context k starts drawing when k GPU stages have finished and stops when k or fewer blocks are left (a job's "
+                                      "head and tail run on fewer contexts, so GPU stages end one after the other instead of in bursts of six)" if (use_queue and ncx > 1) else "") + "; "
                                    "output checked against the reference's (see verified)",
                        "block_bytes": n, "blocks_per_step": world, "sorter": "BWT" if args.sorter == 1 else f"ST{args.sorter}",
                        "coder": {1: "QLFC static (-e1)", 2: "QLFC adaptive (-e2)", 3: "QLFC fast (-e0)"}[args.coder],
@@ -408,6 +490,7 @@ def main():
             "sorter_only_MBps": round(n / 1e6 / max(stage[1] / args.steps / 1e3, 1e-9), 1),
             "hbm_bytes_in_use": int(total_b - free_b),
             "hbm_note": f"device memory in use on this GPU at the end of the run (hipMemGetInfo): {ncx} context arena(s), device-coder arenas, look-back tables, the resident input",
+            "boundary": boundary,
             "kernels": per_kernel,
             "kernels_note": "HIP-event time per kernel class and block, from the region named in roofline.measured_on",
             "host": {"cpus": os.cpu_count(), "effective_cpus": effective_cpus(), "coder_threads_per_gpu": coder_threads,

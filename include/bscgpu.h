@@ -202,13 +202,19 @@ BSCGPU_API const char* bscgpu_last_error(const bscgpu_ctx* ctx);
 /* ---- measurement / test knobs of one context ------------------------------------------------
  * BSCGPU_OPT_RS_ONESWEEP   which large (key, value) sorts take the single-read digit passes: 0 none (three-kernel passes: histogram,
  *                          scan and a scatter whose offsets are all known before it starts — what bench.py times as the digit pass's
- *                          `pattern_ceiling`), 1 the default, 2 every sort of >= 4 tiles (tests).  Results are identical.
+ *                          `pattern_ceiling`), 1 the default, 2 every sort of >= 4 tiles (tests), 3 large sorts including keys-only ones (the sort transform).
+ *                          Results are identical.
  * BSCGPU_CNT_OS_RETRIES    (get only) transforms this context has redone through the three-kernel passes because a single-read pass
  *                          gave up a wait (bounded polls; the block still comes out right).
  * set returns the previous value or a negative libbsc error code; get the value or a negative error code. */
 enum { BSCGPU_OPT_RS_ONESWEEP = 1, BSCGPU_CNT_OS_RETRIES = 2 };
 BSCGPU_API int bscgpu_option_set(bscgpu_ctx* ctx, int key, int value);
 BSCGPU_API int bscgpu_option_get(bscgpu_ctx* ctx, int key);
+/* Process-wide counts since start (tests, reports): blocks whose static model ran on the GPU, how many of those were LZP-preprocessed,
+ * and blocks that took the device model first and were redone with the model on the host (a sub-block that does not compress has to
+ * be stored raw from the run arrays, which the device path never copies). */
+enum { BSCGPU_PCNT_DEVICE_MODEL_BLOCKS = 1, BSCGPU_PCNT_REDONE_ON_HOST_MODEL = 2, BSCGPU_PCNT_DEVICE_MODEL_LZP_BLOCKS = 3 };
+BSCGPU_API long long bscgpu_process_counter(int key);
 
 /* ---- how the libbsc.h entry points spread concurrent callers over the GPUs of a node (pure functions, no GPU needed) -------------
  * The host-pointer API keeps ctx_per_dev default contexts per physical device = nphys * ctx_per_dev logical slots; slot s lives

@@ -55,6 +55,16 @@ def asan_env(extra_options=""):
     env["ASAN_OPTIONS"] = "detect_leaks=0:protect_shadow_gap=0:abort_on_error=1:halt_on_error=1:detect_stack_use_after_return=0" + (":" + extra_options if extra_options else "")
     env["UBSAN_OPTIONS"] = "print_stacktrace=1:halt_on_error=1"
     env["BSC_LIB_OVERRIDE"] = ASAN_LIB
+    # (under the preloaded runtime's dlopen interceptor torch's own RUNPATH is not honoured: "libcaffe2_nvrtc.so: cannot open shared
+    # object file" at the first CUDA call)
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.submodule_search_locations:
+            tl = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+            env["LD_LIBRARY_PATH"] = tl + (":" + env["LD_LIBRARY_PATH"] if env.get("LD_LIBRARY_PATH") else "")
+    except Exception:
+        pass
     return env
 
 

@@ -223,7 +223,7 @@ extern "C" int bscgpu_profile_scatter_launches(bscgpu_ctx* c, double* ms, uint64
 extern "C" int bscgpu_option_set(bscgpu_ctx* c, int key, int value)
 {
     if (!c) return BSC_BAD_PARAMETER;
-    if (key == BSCGPU_OPT_RS_ONESWEEP && value >= 0 && value <= 2 && (value == 0 || c->os_available)) { const int old = c->os_mode; c->os_mode = value; return old; }
+    if (key == BSCGPU_OPT_RS_ONESWEEP && value >= 0 && value <= 3 && (value == 0 || c->os_available)) { const int old = c->os_mode; c->os_mode = value; return old; }
     return BSC_BAD_PARAMETER;
 }
 extern "C" int bscgpu_option_get(bscgpu_ctx* c, int key)

@@ -99,7 +99,7 @@ struct bscgpu_ctx {
     u64* wc_sink = nullptr;  // [512 * 1024] write sink for predicated-off lanes of rs_scatter_wc
     // single-read digit passes (radix_onesweep.hip), allocated on first use
     int  num_cus = 256;           // hipDeviceAttributeMultiprocessorCount of the context's device
-    int  os_mode = 0;             // BSC_RS_ONESWEEP: 0 = off, 1 = large (key, value) sorts (default), 2 = every sort of >= 4 tiles (tests)
+    int  os_mode = 0;             // BSC_RS_ONESWEEP: 0 = off, 1 = large (key, value) sorts (default), 2 = every sort of >= 4 tiles (tests), 3 = large sorts, keys-only too
     u32* os_agg = nullptr;        // [tiles][256] tile rows {launch tag, digit count}
     u32* os_zero = nullptr;       // [8 passes] x {control block, digit totals, batch rows}: cleared per sort
     u32  os_tiles_cap = 0;

@@ -539,8 +539,8 @@ int radix_onesweep_setup(bscgpu_ctx* c)
 bool radix_onesweep_wanted(const bscgpu_ctx* c, u64 n, int npasses, bool has_val)
 {
     if (c->os_mode == 0 || npasses < 1 || npasses > OS_MAXP) return false;
-    if (!has_val && c->os_mode != 2) return false;                      // keys-only passes (ST): the 256 x 16 kernel wins on text digits
-    return n >= (u64)(c->os_mode == 2 ? 4 : 512) * OS_TILE;             // mode 2 (tests): every sort of >= 4 tiles
+    if (!has_val && c->os_mode < 2) return false;                       // keys-only passes (ST): mode 1 keeps the three-kernel passes (A/B: mode 3)
+    return n >= (u64)(c->os_mode == 2 ? 4 : 512) * OS_TILE;             // mode 2 (tests): every sort of >= 4 tiles; mode 3: large sorts, keys-only too
 }
 
 int radix_onesweep_sort(bscgpu_ctx* c, u64* keys, u64* keys_alt, u32* vals, u32* vals_alt, u64 n,

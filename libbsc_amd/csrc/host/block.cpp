@@ -368,6 +368,8 @@ static double ms_since(clk::time_point t0) { return std::chrono::duration<double
 static bool devcoder_enabled() { static const int v = [] { const char* e = getenv("BSC_DEVICE_CODER"); return e ? atoi(e) : 1; }(); return v != 0; }
 static int  devcoder_min_n() { static const int v = [] { const char* e = getenv("BSC_DEVICE_CODER_MIN_N"); return e ? atoi(e) : (1 << 20); }(); return v; }
 
+static std::atomic<uint64_t> g_count_devmodel{0}, g_count_redo{0}, g_count_devmodel_lzp{0};     // bscgpu_process_counter
+
 static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
 {
     J.sorter = blockSorter; J.use_ps = false; J.redo.store(false, std::memory_order_relaxed);
@@ -413,7 +415,9 @@ static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
     u32 m = 0;
     // static coder on a block with several sub-blocks: the adaptive model runs on the GPU too (devcoder.hip) and only the
     // probability stream crosses PCIe; anything that path declines falls back to the run arrays + host model
-    const bool try_dc = allow_devcoder && devcoder_enabled() && J.coder == LIBBSC_CODER_QLFC_STATIC && J.nblocks > 1 && n >= devcoder_min_n() && !J.lz;
+    // (an LZP-preprocessed block — the reference CLI's default, bsc.cpp:73-75 — is just another byte block to the sorter and the model;
+    // its LZP output stays alive until the block is done, because a redo on the host model uploads it again)
+    const bool try_dc = allow_devcoder && devcoder_enabled() && J.coder == LIBBSC_CODER_QLFC_STATIC && J.nblocks > 1 && n >= devcoder_min_n();
     rc = qlfc_front_runs(c, c->dL, (u32)n, J.nblocks, J.start, &m, J.run_first, J.first_run, *J.slot, !try_dc);
     if (rc < 0) return rc;
     if (try_dc) {
@@ -439,6 +443,8 @@ static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
                 c->ps_guard[pb] = J.slot->copy_ev; c->ps_toggle = pb ^ 1;
                 J.ps_ready = J.slot->copy_ev;
                 J.use_ps = true; J.ps = J.slot->hps; J.ndec = ndec; ok = true;
+                g_count_devmodel.fetch_add(1, std::memory_order_relaxed);
+                if (J.lz) g_count_devmodel_lzp.fetch_add(1, std::memory_order_relaxed);
             } else if (r2 != LIBBSC_NOT_SUPPORTED && r2 != LIBBSC_NO_ERROR) return r2;
         }
         if (!ok) { rc = qlfc_front_copy_runs(c, m, *J.slot); if (rc < 0) return rc; }
@@ -736,12 +742,24 @@ static int stage_host_h2d(BlockJob& J, bscgpu_ctx* c)
 // A block that took the device model but has a sub-block that does not compress (or needs the strictly serial framing) is
 // run again with the model on the host: raw sub-blocks are rebuilt from the run arrays, which that path never copied.  Rare
 // (such blocks are mostly caught before by their run count); the caller must be the thread that owns the context's GPU stage.
+extern "C" BSCGPU_API long long bscgpu_process_counter(int key)
+{
+    switch (key) {
+        case BSCGPU_PCNT_DEVICE_MODEL_BLOCKS:     return (long long)g_count_devmodel.load(std::memory_order_relaxed);
+        case BSCGPU_PCNT_REDONE_ON_HOST_MODEL:    return (long long)g_count_redo.load(std::memory_order_relaxed);
+        case BSCGPU_PCNT_DEVICE_MODEL_LZP_BLOCKS: return (long long)g_count_devmodel_lzp.load(std::memory_order_relaxed);
+    }
+    return LIBBSC_BAD_PARAMETER;
+}
+
 static int redo_on_host_model(BlockJob& J)
 {
+    g_count_redo.fetch_add(1, std::memory_order_relaxed);
     J.redo.store(false, std::memory_order_relaxed);
     int rc = LIBBSC_NO_ERROR;
     if (J.hInput) rc = stage_host_h2d(J, J.c);
     if (rc >= 0) rc = gpu_stage(J, J.sorter, false);
+    J.lz.reset();
     if (rc < 0) { J.result = rc; return rc; }
     host_stage(J);
     return J.result;
@@ -775,7 +793,7 @@ int bsc_compress(const unsigned char* input, unsigned char* output, int n, int l
         rc = stage_host_h2d(*J, c);
         if (rc < 0) return rc;
         rc = gpu_stage(*J, blockSorter);
-        J->lz.reset();
+        if (!J->use_ps) J->lz.reset();                          // (a device-model block may come back for a redo: redo_on_host_model)
         if (rc < 0) return rc;
     }
     host_stage(*J);                                             // host coder: overlaps the next caller's GPU stage
@@ -1016,7 +1034,7 @@ int bscgpu_pipe_submit(bscgpu_pipe* p, const void* dInput, uint8_t* output, int 
     J.slot = &p->c->slots[ticket % p->depth];
     J.done = false;
     rc = gpu_stage(J, blockSorter);
-    J.lz.reset();                                   // the LZP output lives in HBM from here on
+    J.lz.reset();                                   // (device-resident input: there is no LZP output)
     if (rc < 0) return rc;
     return pipe_enqueue(p, L, ticket);
 }
@@ -1048,7 +1066,7 @@ int bscgpu_pipe_submit_host(bscgpu_pipe* p, const uint8_t* input, uint8_t* outpu
     rc = stage_host_h2d(J, p->c);
     if (rc < 0) return rc;
     rc = gpu_stage(J, blockSorter);
-    J.lz.reset();                                   // the LZP output lives in HBM from here on
+    if (!J.use_ps) J.lz.reset();                    // the LZP output lives in HBM from here on; a device-model block keeps it for a possible redo
     if (rc < 0) return rc;
     return pipe_enqueue(p, L, ticket);
 }

@@ -204,6 +204,11 @@ struct Mixer {                       // predictor.h:74-213
 };
 
 #define BSC_ALWAYS_INLINE __attribute__((always_inline)) inline
+// The mixer's weighted sum and weight updates (predictor.h:102-183) are plain `int` expressions in the reference and do overflow on
+// some inputs (found by UBSan in round 4: fuzz seed 303); what the reference's binary computes is the two's-complement wrap, so that
+// is what the format is.  Spelled out in unsigned arithmetic here: defined behaviour, same bits.
+static BSC_ALWAYS_INLINE int wrap_mul(int a, int b) { return (int)((uint32_t)a * (uint32_t)b); }
+static BSC_ALWAYS_INLINE int wrap_add3(int a, int b, int c) { return (int)((uint32_t)a + (uint32_t)b + (uint32_t)c); }
 static BSC_ALWAYS_INLINE void bump(short& p, unsigned bit, int th0, int ar0, int th1, int ar1)
 {
     // predictor.h:53-61 (the four-argument form at :44-50 is algebraically the same map)
@@ -290,7 +295,7 @@ static BSC_ALWAYS_INLINE void decide(RangeEncoder& rc, LiveT& L, const QlfcTable
     const int p0 = ch, p1 = st, p2 = sp;
     (void)static_step<CLS, true>(bit, st, ch, sp);            // the three counter updates as one vector op
     const int s0 = T.stretch[p0], s1 = T.stretch[p1], s2 = T.stretch[p2];
-    short sp16 = (short)((s0 * mx->w0 + s1 * mx->w1 + s2 * mx->w2) >> 17);
+    short sp16 = (short)(wrap_add3(wrap_mul(s0, mx->w0), wrap_mul(s1, mx->w1), wrap_mul(s2, mx->w2)) >> 17);
     if (sp16 < -2047) sp16 = -2047;
     if (sp16 >  2047) sp16 =  2047;
     const int frac = sp16 & 255;
@@ -301,9 +306,9 @@ static BSC_ALWAYS_INLINE void decide(RangeEncoder& rc, LiveT& L, const QlfcTable
     bump(mx->map[idx],     bit, P[12], P[13], P[14], P[15]);
     bump(mx->map[idx + 1], bit, P[12], P[13], P[14], P[15]);
     const int eps = p - (bit ? 1 : 4095);
-    mx->w0 -= (P[16] * eps * s0) >> 16;
-    mx->w1 -= (P[17] * eps * s1) >> 16;
-    mx->w2 -= (P[18] * eps * s2) >> 16;
+    mx->w0 = (int)((uint32_t)mx->w0 - (uint32_t)(wrap_mul(wrap_mul(P[16], eps), s0) >> 16));
+    mx->w1 = (int)((uint32_t)mx->w1 - (uint32_t)(wrap_mul(wrap_mul(P[17], eps), s1) >> 16));
+    mx->w2 = (int)((uint32_t)mx->w2 - (uint32_t)(wrap_mul(wrap_mul(P[18], eps), s2) >> 16));
     rc.encode_live<12>(L, bit, p);
     }
 }
@@ -637,7 +642,7 @@ static BSC_ALWAYS_INLINE unsigned undecide(RangeDecoder& rd, const QlfcTables& T
         bit = rd.decode<12>((p0 * P[16] + p1 * P[17] + p2 * P[18]) >> 5);
     } else {
         const int s0 = T.stretch[p0], s1 = T.stretch[p1], s2 = T.stretch[p2];
-        short sp16 = (short)((s0 * mx->w0 + s1 * mx->w1 + s2 * mx->w2) >> 17);
+        short sp16 = (short)(wrap_add3(wrap_mul(s0, mx->w0), wrap_mul(s1, mx->w1), wrap_mul(s2, mx->w2)) >> 17);
         if (sp16 < -2047) sp16 = -2047;
         if (sp16 >  2047) sp16 =  2047;
         const int frac = sp16 & 255, idx = (sp16 + 2048) >> 8, sq = T.squash[2048 + sp16];
@@ -647,9 +652,9 @@ static BSC_ALWAYS_INLINE unsigned undecide(RangeDecoder& rd, const QlfcTables& T
         bump(mx->map[idx],     bit, P[12], P[13], P[14], P[15]);
         bump(mx->map[idx + 1], bit, P[12], P[13], P[14], P[15]);
         const int eps = p - (bit ? 1 : 4095);
-        mx->w0 -= (P[16] * eps * s0) >> 16;
-        mx->w1 -= (P[17] * eps * s1) >> 16;
-        mx->w2 -= (P[18] * eps * s2) >> 16;
+        mx->w0 = (int)((uint32_t)mx->w0 - (uint32_t)(wrap_mul(wrap_mul(P[16], eps), s0) >> 16));
+        mx->w1 = (int)((uint32_t)mx->w1 - (uint32_t)(wrap_mul(wrap_mul(P[17], eps), s1) >> 16));
+        mx->w2 = (int)((uint32_t)mx->w2 - (uint32_t)(wrap_mul(wrap_mul(P[18], eps), s2) >> 16));
     }
     bump(st, bit, P[0], P[1], P[2],  P[3]);
     bump(ch, bit, P[4], P[5], P[6],  P[7]);
