@@ -317,7 +317,7 @@ def main():
     # code, but every offset is known before it starts (rs_hist + rs_scan) — no tickets, no look-back, no scout wave.  What it reaches
     # on THIS box is the denominator `frac` lacks besides the spec sheet: the boxes of the pool differ by ~15 % for this access pattern.
     launches_ceiling = []
-    if rank == 0 and os.environ.get("BSC_RS_ONESWEEP", "1") != "0" and (args.sorter == 1 or os.environ.get("BSC_RS_ONESWEEP") in ("2", "3")):
+    if rank == 0 and os.environ.get("BSC_RS_ONESWEEP", "3") != "0" and (args.sorter == 1 or os.environ.get("BSC_RS_ONESWEEP", "3") in ("2", "3")):
         try:
             prev = ctxs[0].option_set(ctxs[0].OPT_RS_ONESWEEP, 0)
             ctxs[0].profile(True)
@@ -379,7 +379,7 @@ def main():
         value = world * args.steps * n / 1e6 / dt
         rec_bytes = 12 if args.sorter == 1 else 8
 
-        os_env = os.environ.get("BSC_RS_ONESWEEP", "1")
+        os_env = os.environ.get("BSC_RS_ONESWEEP", "3")
         onesweep = os_env != "0" and (args.sorter == 1 or args.sorter == 8 or os_env in ("2", "3"))
         kernel_name = ("rs_onesweep_kernel<true> (one 8-bit LSD digit pass of the BWT's first sort, records read once and written once: u64 key + u32 value; "
                        "15 streaming waves x 7680-record tiles + a scout wave that collects the tile offsets by decoupled look-back)") if onesweep and args.sorter == 1 else \

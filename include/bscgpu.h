@@ -202,7 +202,8 @@ BSCGPU_API const char* bscgpu_last_error(const bscgpu_ctx* ctx);
 /* ---- measurement / test knobs of one context ------------------------------------------------
  * BSCGPU_OPT_RS_ONESWEEP   which large (key, value) sorts take the single-read digit passes: 0 none (three-kernel passes: histogram,
  *                          scan and a scatter whose offsets are all known before it starts — what bench.py times as the digit pass's
- *                          `pattern_ceiling`), 1 the default, 2 every sort of >= 4 tiles (tests), 3 large sorts including keys-only ones (the sort transform).
+ *                          `pattern_ceiling`), 1 large (key, value) sorts only, 2 every sort of >= 4 tiles (tests), 3 large sorts including keys-only ones (the
+ *                          sort transform; the default).
  *                          Results are identical.
  * BSCGPU_CNT_OS_RETRIES    (get only) transforms this context has redone through the three-kernel passes because a single-read pass
  *                          gave up a wait (bounded polls; the block still comes out right).

@@ -99,7 +99,7 @@ struct bscgpu_ctx {
     u64* wc_sink = nullptr;  // [512 * 1024] write sink for predicated-off lanes of rs_scatter_wc
     // single-read digit passes (radix_onesweep.hip), allocated on first use
     int  num_cus = 256;           // hipDeviceAttributeMultiprocessorCount of the context's device
-    int  os_mode = 0;             // BSC_RS_ONESWEEP: 0 = off, 1 = large (key, value) sorts (default), 2 = every sort of >= 4 tiles (tests), 3 = large sorts, keys-only too
+    int  os_mode = 0;             // BSC_RS_ONESWEEP: 0 = off, 1 = large (key, value) sorts only, 2 = every sort of >= 4 tiles (tests), 3 = large sorts, keys-only too (default)
     u32* os_agg = nullptr;        // [tiles][256] tile rows {launch tag, digit count}
     u32* os_zero = nullptr;       // [8 passes] x {control block, digit totals, batch rows}: cleared per sort
     u32  os_tiles_cap = 0;
@@ -176,7 +176,7 @@ int ctx_ensure_pstream_slot(bscgpu_ctx* c, HostSlot& slot, size_t entries);     
 int ctx_ensure_run_slot(bscgpu_ctx* c, HostSlot& slot);                           // pinned landing zone for a block's run arrays
 // device-side model of the static QLFC coder (devcoder.hip): probability stream of a whole block from the front end's run arrays
 int  devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* dstart, u32 m, u32 n, int nb, const u32* run_first,
-                      const int* max_rank, u32* D_out, u32* poff_out, u16* dbg, int psbuf = 0);
+                      const int* max_rank, u32* D_out, u32* poff_out, u16* dbg, int psbuf = 0, int coder = 1 /* 1 static (-e1), 3 fast (-e0) */);
 const u16* devcoder_pstream_ptr(const bscgpu_ctx* c, int psbuf = 0);
 void devcoder_destroy(bscgpu_ctx* c);
 int64_t devcoder_arena_bytes(const bscgpu_ctx* c);

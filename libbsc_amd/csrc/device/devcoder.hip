@@ -85,7 +85,8 @@ struct DevCoder {
     DcRowBins* rowbins = nullptr;                              // row -> bin ranges of the counting pass
     u16* sink = nullptr;                                       // where stores past the end of an array go (1 KB)
     u8  *tab_rank = nullptr, *tab_run = nullptr;
-    ModelParams* mp = nullptr;                                 // device copy
+    ModelParams* mp = nullptr;                                 // device copy (static coder)
+    ModelParams* mp_fast = nullptr;                            // device copy (fast coder: dcm::model_params_fast)
     u32 *hmeta = nullptr;                                      // pinned: meta + poff
 };
 
@@ -581,6 +582,33 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
     if (wc == g.W - 1 && lane == 0) doff[g.m] = running;
 }
 
+// 2d. the fast coder (-e0) has ONE family, so the stream-order job has no chains to lay out — but the p stream still needs to know
+// where every run's entries go: doff[i] = decision index of item i's first decision, exactly what dc_part_scatter leaves behind.
+template <int SIDES>
+__global__ __launch_bounds__(WG) void dc_doff_kernel(const u64* __restrict__ items, DcGeom g, DcSub S, const u32* __restrict__ meta,
+                                                     const u32* __restrict__ wdecoff, u32* __restrict__ doff)
+{
+    if (meta[DM_FAIL] != 0u) return;
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 wc = blockIdx.x * WAVES + w;
+    if (wc >= g.W) return;
+    const u64 i0 = (u64)wc * g.per_wave;
+    u64 i1 = i0 + g.per_wave; if (i1 > g.m) i1 = g.m;
+    u32 running = wdecoff[wc];
+    for (u64 base = i0; base < i1; base += 64) {
+        const u64 i = base + lane;
+        const bool valid = i < i1;
+        const Item it = item_unpack(valid ? items[i] : 0ull);
+        const int maxr = (int)S.maxr[it.sb];
+        u32 nd = 0;
+        if (valid) { if (SIDES & 1) nd += (u32)count_rank_side(it, maxr); if (SIDES & 2) nd += (u32)count_run_side(it); }
+        const u32 incl = wave_incl_sum(nd);
+        if (valid) doff[i] = running + incl - nd;
+        running += (u32)__shfl((int)incl, 63, 64);
+    }
+    if (wc == g.W - 1 && lane == 0) doff[g.m] = running;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // 3. chain evaluation over chain-major events
 // ---------------------------------------------------------------------------------------------------------------------
@@ -614,6 +642,7 @@ __global__ __launch_bounds__(WG) void dc_mark_rows_kernel(DcEvalAll A)
     const u32 g = blockIdx.x * WG + threadIdx.x;
     if (g >= 4u * DC_ROWS) return;
     const DcEvalJob J = A.job[g / DC_ROWS];
+    if (J.E == 0) return;                                              // a job that does not run in this mode (its row table is not valid)
     const u32 r = g % DC_ROWS;
     const u32 rs = J.rowstart[r], re = J.rowstart[r + 1];
     if (re > rs) const_cast<u16*>(J.events)[rs] |= (u16)DC_ROWMARK;
@@ -622,7 +651,7 @@ __global__ __launch_bounds__(WG) void dc_mark_rows_kernel(DcEvalAll A)
 __device__ __forceinline__ int dc_class_first_row(int cls)
 {
     return cls == CLS_RF ? TAU_RF : cls == CLS_RE ? TAU_RE : cls == CLS_RM ? TAU_RM : cls == CLS_RP ? TAU_RP : cls == CLS_NF ? TAU_NF
-         : cls == CLS_NE ? TAU_NE : cls == CLS_NM ? TAU_NM : DC_ROWS;
+         : cls == CLS_NE ? TAU_NE : cls == CLS_NM ? TAU_NM : cls == CLS_NM2 ? TAU_NM2 : DC_ROWS;
 }
 
 // A wavefront is self-contained here (its own LDS slices, no workgroup barrier); four of them form a workgroup only so that the
@@ -630,7 +659,7 @@ __device__ __forceinline__ int dc_class_first_row(int cls)
 // two to a SIMD while other SIMDs stayed empty, and the kernel took 1.6 x as long as its median wavefront.
 constexpr int DC_EVAL_WAVES = 4;
 constexpr int DC_EVAL_LDS_WAVE = 2 * 64 * DC_EROW;                                             // sin + sout
-constexpr int DC_EVAL_LDS = DC_EVAL_WAVES * (DC_EVAL_LDS_WAVE + NUM_CLS * 4 + NUM_CLS * 16);   // + class ends, rates
+constexpr int DC_EVAL_LDS = DC_EVAL_WAVES * (DC_EVAL_LDS_WAVE + NUM_CLS * 4 + NUM_CLS * (int)sizeof(Rates));   // + class ends, rates
 __device__ __forceinline__ void dc_wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // LDS operations of one wavefront execute in order: only the compiler has to be told
@@ -678,12 +707,14 @@ __global__ __launch_bounds__(64 * DC_EVAL_WAVES) void dc_eval_wave_kernel(DcEval
     const u64 wave_k0 = (u64)wave * 64 * EV;
 
     u32 cls = 0, clsend = 0, prev = 0xffffu;
-    int lo = 2048, hi = 2048;
+    int init = mp->init[0];                                            // the value a chain of the current class starts from
+    int lo = init, hi = init;
     Rates R = srate[0];
     if (mine) {
         while (cls + 1 < (u32)NUM_CLS && sclsend[cls] <= (u32)k0) ++cls;                     // class of the row that owns event k0
         clsend = sclsend[cls];
         R = srate[cls];
+        init = mp->init[cls];
         // a chunk that starts a row starts with a marked event; otherwise the chain may continue from the event before
         prev = (k0 > 0) ? ((u32)J.events[k0 - 1] & DC_SIGMASK) : 0xffffu;
         if (WRITE) { lo = Sv[c]; hi = lo; } else { lo = mp->vmin[cls][J.fam]; hi = mp->vmax[cls][J.fam]; }
@@ -733,13 +764,13 @@ __global__ __launch_bounds__(64 * DC_EVAL_WAVES) void dc_eval_wave_kernel(DcEval
                     for (int x = 0; x < 8; ++x) {
                         const u32 e = (wds[x >> 1] >> (16 * (x & 1))) & 0xffffu;
                         const u32 sigm = e & (DC_SIGMASK | DC_ROWMARK);                      // a marked event never equals prev
-                        if (sigm != prev) { lo = 2048; hi = 2048; }
+                        if (sigm != prev) { lo = init; hi = init; }
                         prev = e & DC_SIGMASK;
                         // dcm::step with the target, rate and rounding picked by the bit first, so that both ends of the bracket
-                        // share the selects: bit 1 is v - (((v - t1) a1) >> 12) = v + (((t1 - v) a1 + 4095) >> 12) (floor of a
-                        // negated quotient = minus its ceiling), bit 0 is v + (((t0 - v) a0) >> 12)
+                        // share the selects (static coder: bit 1 is v - (((v - t1) a1) >> 12) = v + (((t1 - v) a1 + 4095) >> 12) —
+                        // floor of a negated quotient = minus its ceiling —, bit 0 is v + (((t0 - v) a0) >> 12); devcoder_model.h)
                         const bool b1 = (e & 0x800u) != 0u;
-                        const int T = b1 ? R.t1 : R.t0, Aa = b1 ? R.a1 : R.a0, rr = b1 ? 4095 : 0;
+                        const int T = b1 ? R.t1 : R.t0, Aa = b1 ? R.a1 : R.a0, rr = b1 ? R.r1 : R.r0;
                         if (WRITE) outw[x >> 1] |= (u32)lo << (16 * (x & 1));
                         lo += (__mul24(T - lo, Aa) + rr) >> 12;
                         if (!WRITE) hi += (__mul24(T - hi, Aa) + rr) >> 12;
@@ -754,9 +785,9 @@ __global__ __launch_bounds__(64 * DC_EVAL_WAVES) void dc_eval_wave_kernel(DcEval
                 const u32 cnt = (k1 - kb < (u32)DC_EB) ? k1 - kb : (u32)DC_EB;
                 for (u32 x = 0; x < cnt; ++x) {
                     const u32 k = kb + x;
-                    while (k >= clsend && cls + 1 < (u32)NUM_CLS) { ++cls; clsend = sclsend[cls]; R = srate[cls]; }
+                    while (k >= clsend && cls + 1 < (u32)NUM_CLS) { ++cls; clsend = sclsend[cls]; R = srate[cls]; init = mp->init[cls]; }
                     const u32 e = *reinterpret_cast<const u16*>(myrow + 2 * x);
-                    if ((e & (DC_SIGMASK | DC_ROWMARK)) != prev) { lo = 2048; hi = 2048; }
+                    if ((e & (DC_SIGMASK | DC_ROWMARK)) != prev) { lo = init; hi = init; }
                     prev = e & DC_SIGMASK;
                     const u32 bt = (e >> 11) & 1u;
                     if (WRITE) *reinterpret_cast<u16*>(orow + 2 * x) = (u16)lo;
@@ -804,17 +835,19 @@ __global__ __launch_bounds__(WG) void dc_eval_b_kernel(DcEvalAll A, const ModelP
     const u32 EV = A.ev;
     const u64 k0 = (u64)c * EV;
     if (k0 >= J.E) return;
-    if (!dc_chunk_continues(J, c, EV)) { Sv[c] = 2048; return; }
+    const int init_c = mp->init[tau_class((int)dc_find_row(J.rowstart, (u32)k0))];     // what a chain of this chunk's first row starts from
+    if (!dc_chunk_continues(J, c, EV)) { Sv[c] = (u16)init_c; return; }
     if (elo[c - 1] == ehi[c - 1]) { Sv[c] = elo[c - 1]; return; }
     // the predecessor did not coalesce: replay from the nearest chunk whose start value is known
+    // (the chunks walked here hold no chain boundary — see below —, so they are all of this chunk's row and class)
     u32 j = c - 1;
-    int start = 2048;
+    int start = init_c;
     u32 depth = 1;
     for (;;) {
-        if (!dc_chunk_continues(J, j, EV)) { start = 2048; break; }
+        if (!dc_chunk_continues(J, j, EV)) { start = init_c; break; }
         if (elo[j - 1] == ehi[j - 1]) { start = elo[j - 1]; break; }
         --j; ++depth;
-        if (depth > 64) { atomicOr(&meta[DM_FAIL], (u32)FAIL_REPLAY); Sv[c] = 2048; return; }
+        if (depth > 64) { atomicOr(&meta[DM_FAIL], (u32)FAIL_REPLAY); Sv[c] = (u16)init_c; return; }
     }
     atomicAdd(&meta[DM_REPLAYS], depth);
     // Exact walk over chunks j .. c - 1.  None of them coalesced, so none contains a chain boundary (a boundary resets both ends of the
@@ -866,6 +899,9 @@ struct __attribute__((packed, aligned(4))) DcU4 { u32 a, b, c, d; };
 constexpr u32 DC_PS_STAGE = DC_PS_STAGE_N;
 typedef __attribute__((address_space(3))) volatile u16 dc_lds_vu16;
 
+// FAST: the fast coder's stream — one counter per decision (the char family's value IS the probability, 13 / 11 bits), entries
+// {value, bit << 13, run start << 14, run side << 15} (devcoder_model.h PSF_*).
+template <bool FAST>
 __global__ __launch_bounds__(WG) void dc_pstream_kernel(DcGather G, DcSub S, const ModelParams* __restrict__ mp,
                                                         const u32* __restrict__ meta, u16* __restrict__ out, u16* __restrict__ dbg /*[3][D] or null*/, u32 dbgD)
 {
@@ -886,39 +922,48 @@ __global__ __launch_bounds__(WG) void dc_pstream_kernel(DcGather G, DcSub S, con
     dc_lds_vu16* sg = (dc_lds_vu16*)&stage[threadIdx.x >> 6][0];
     const u32* p_sp = G.pos_sp + b_sp;
     const u32* p_ch = G.pos_ch + (valid ? G.doff_ch[G.inv_ch[j]] : 0u);
-    const u32* p_sr = G.pos_sr + (valid ? G.doff_sr[G.inv_sr[j]] : 0u);
-    const u32* p_sn = G.pos_sn + (valid ? G.doff_sn[G.inv_sn[j]] : 0u);
+    const u32* p_sr = FAST ? G.pos_ch : G.pos_sr + (valid ? G.doff_sr[G.inv_sr[j]] : 0u);
+    const u32* p_sn = FAST ? G.pos_ch : G.pos_sn + (valid ? G.doff_sn[G.inv_sn[j]] : 0u);
     u16* o = out + b_sp;
     auto emit = [&](int k, u32 q_sp, u32 q_ch, u32 q_st, bool run_side, int tau, u32 bit) {
-        const int v_sp = G.V_sp[q_sp];
         const int v_ch = G.V_ch[q_ch];
-        const int v_st = run_side ? G.V_sn[q_st] : G.V_sr[q_st];
-        const int p = blend(v_ch, v_st, v_sp, mp->lr[tau_class(tau)]);
-        const u16 e = (u16)((u32)p | (bit << 12) | (k == 0 ? (u32)PS_RUN : 0u));
+        u16 e;
+        if (FAST) {
+            e = (u16)((u32)v_ch | (bit << 13) | (k == 0 ? (u32)PSF_RUN : 0u) | (run_side ? (u32)PSF_SIDE : 0u));
+        } else {
+            const int v_sp = G.V_sp[q_sp];
+            const int v_st = run_side ? G.V_sn[q_st] : G.V_sr[q_st];
+            const int p = blend(v_ch, v_st, v_sp, mp->lr[tau_class(tau)]);
+            e = (u16)((u32)p | (bit << 12) | (k == 0 ? (u32)PS_RUN : 0u));
+            if (dbg) { dbg[b_sp + k] = (u16)v_st; dbg[(size_t)dbgD + b_sp + k] = (u16)v_ch; dbg[2 * (size_t)dbgD + b_sp + k] = (u16)v_sp; }
+        }
         if (staged) sg[loc + (u32)k] = e; else o[k] = e;
-        if (dbg) { dbg[b_sp + k] = (u16)v_st; dbg[(size_t)dbgD + b_sp + k] = (u16)v_ch; dbg[2 * (size_t)dbgD + b_sp + k] = (u16)v_sp; }
     };
     // first 8 decisions: positions by wide loads (the arrays have slack behind their last entry), static register indices
     u32 qsp[8], qch[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { qsp[k] = 0; qch[k] = 0; }
     if (valid) {
-        const DcU4 a0 = *reinterpret_cast<const DcU4*>(p_sp), a1 = *reinterpret_cast<const DcU4*>(p_sp + 4);
         const DcU4 c0 = *reinterpret_cast<const DcU4*>(p_ch), c1 = *reinterpret_cast<const DcU4*>(p_ch + 4);
-        qsp[0] = a0.a; qsp[1] = a0.b; qsp[2] = a0.c; qsp[3] = a0.d; qsp[4] = a1.a; qsp[5] = a1.b; qsp[6] = a1.c; qsp[7] = a1.d;
         qch[0] = c0.a; qch[1] = c0.b; qch[2] = c0.c; qch[3] = c0.d; qch[4] = c1.a; qch[5] = c1.b; qch[6] = c1.c; qch[7] = c1.d;
+        if (!FAST) {
+            const DcU4 a0 = *reinterpret_cast<const DcU4*>(p_sp), a1 = *reinterpret_cast<const DcU4*>(p_sp + 4);
+            qsp[0] = a0.a; qsp[1] = a0.b; qsp[2] = a0.c; qsp[3] = a0.d; qsp[4] = a1.a; qsp[5] = a1.b; qsp[6] = a1.c; qsp[7] = a1.d;
+        }
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         if (k < nd) {
             u32 bit; bool rs;
             const int tau = nth_decision(it, maxr, n_rank, k, &bit, &rs);
-            const u32 q_st = rs ? p_sn[k - n_rank] : p_sr[k];
+            const u32 q_st = FAST ? 0u : (rs ? p_sn[k - n_rank] : p_sr[k]);
             emit(k, qsp[k], qch[k], q_st, rs, tau, bit);
         }
     }
     for (int k = 8; k < nd; ++k) {
         u32 bit; bool rs;
         const int tau = nth_decision(it, maxr, n_rank, k, &bit, &rs);
-        emit(k, p_sp[k], p_ch[k], rs ? p_sn[k - n_rank] : p_sr[k], rs, tau, bit);
+        emit(k, FAST ? 0u : p_sp[k], p_ch[k], FAST ? 0u : (rs ? p_sn[k - n_rank] : p_sr[k]), rs, tau, bit);
     }
     if (staged) {
         // the wavefront's piece [wbase, wbase + wtotal) of the stream: 4-byte stores from the first even entry on, the odd ends singly
@@ -1023,7 +1068,7 @@ int devcoder_ensure(bscgpu_ctx* c)
         {(void**)&d->elo, 2 * 4 * NCH}, {(void**)&d->ehi, 2 * 4 * NCH}, {(void**)&d->S, 2 * 4 * NCH},
         {(void**)&d->present, (size_t)DC_KIND_WORDS * 4}, {(void**)&d->rounds, 256},
         {(void**)&d->meta, DM_COUNT * 4}, {(void**)&d->poff, 16 * 4},
-        {(void**)&d->tab_rank, 32768}, {(void**)&d->tab_run, 8192}, {(void**)&d->mp, sizeof(ModelParams)},
+        {(void**)&d->tab_rank, 32768}, {(void**)&d->tab_run, 8192}, {(void**)&d->mp, sizeof(ModelParams)}, {(void**)&d->mp_fast, sizeof(ModelParams)},
         {(void**)&d->rowbins, DC_ROWS * sizeof(DcRowBins)}, {(void**)&d->sink, 4096},
     };
     size_t total = 0;
@@ -1034,6 +1079,7 @@ int devcoder_ensure(bscgpu_ctx* c)
     for (auto& cv : carve) { *cv.p = d->arena + off; off += dc_align(cv.bytes); }
     if (hipHostMalloc((void**)&d->hmeta, 64 * 4, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); hipFree(d->arena); delete d; c->dc_alloc_failed = true; return BSC_NOT_SUPPORTED; }
     ModelParams mp; model_params_from_table(bschost::qlfc_static_params(), mp);
+    ModelParams mpf; model_params_fast(mpf);
     // more than 64 KB of dynamic LDS is a per-device attribute of the function: set for every context's device
     if (hipFuncSetAttribute((const void*)dc_eval_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DC_EVAL_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)dc_eval_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DC_EVAL_LDS) != hipSuccess) {
@@ -1046,6 +1092,7 @@ int devcoder_ensure(bscgpu_ctx* c)
     const bschost::QlfcTables& QT = bschost::qlfc_tables();
     const uint8_t *rs = QT.rank_state, *ns = QT.run_state;
     const bool ok = hipMemcpyAsync(d->mp, &mp, sizeof mp, hipMemcpyHostToDevice, c->stream) == hipSuccess
+                 && hipMemcpyAsync(d->mp_fast, &mpf, sizeof mpf, hipMemcpyHostToDevice, c->stream) == hipSuccess
                  && hipMemcpyAsync(d->tab_rank, rs, 32768, hipMemcpyHostToDevice, c->stream) == hipSuccess
                  && hipMemcpyAsync(d->tab_run, ns, 8192, hipMemcpyHostToDevice, c->stream) == hipSuccess
                  && hipMemcpyAsync(d->rowbins, rowbins, sizeof rowbins, hipMemcpyHostToDevice, c->stream) == hipSuccess
@@ -1076,13 +1123,22 @@ static void dc_launch_partition(bscgpu_ctx* c, DevCoder* d, const u64* items, u3
 // the n-byte sorted block), the sub-blocks' run ranges and max_rank values.  On success *D_out decisions were written to the
 // device p stream (d->ps) and poff[0..nb] (decision offsets of the sub-blocks) to hmeta[32..]; returns BSC_NOT_SUPPORTED when
 // the block has to go through the host model instead.
+// The fast coder (-e0, qlfc.cpp:1135-1336) on the same machinery: its one counter per decision is indexed by the run's symbol, i.e. its
+// chains ARE the char family's — (sub-block, decision type, symbol) — with shift updates and per-class targets (dcm::model_params_fast),
+// no escape coding and the exponent always closed below 7 bits (max_rank = 7 in the static coder's terms).  So: items, ONE radix pass
+// (symbol-major order), ONE partition job, the stream offsets of the runs, evaluation of that one job, and a p stream whose entries
+// are the counter values themselves.  No contexts, no state tables, no blend: about a third of the static coder's device work.
+static int devcoder_pstream_fast(bscgpu_ctx* c, DevCoder* d, const u8* dsym, const u8* drank, const u32* dstart, u32 m, u32 n, int nb,
+                                 const u32* run_first, u32* D_out, u32* poff_out, int psbuf);
+
 int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* dstart, u32 m, u32 n, int nb, const u32* run_first,
-                     const int* max_rank, u32* D_out, u32* poff_out, u16* dbg, int psbuf)
+                     const int* max_rank, u32* D_out, u32* poff_out, u16* dbg, int psbuf, int coder)
 {
     int rc = devcoder_ensure(c);
     if (rc < 0) return rc;
     DevCoder* d = c->dc;
     if (m == 0 || m > d->Mcap || nb < 1 || nb > 8) return BSC_NOT_SUPPORTED;
+    if (coder == 3) return devcoder_pstream_fast(c, d, dsym, drank, dstart, m, n, nb, run_first, D_out, poff_out, psbuf);
     DcSub S; S.nb = (u32)nb;
     for (int b = 0; b < 9; ++b) S.first[b] = (b <= nb) ? run_first[b] : m;
     for (int b = 0; b < 8; ++b) S.maxr[b] = (b < nb) ? (u32)max_rank[b] : 0u;
@@ -1171,7 +1227,7 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     G.V_sp = d->V[0]; G.V_ch = d->V[1]; G.V_sr = d->V[2]; G.V_sn = d->V[3];
     prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)E[0] * 26, E[0]);
     if (c->ps_guard[psbuf & 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ps_guard[psbuf & 1], 0));     // the buffer's previous copy-out
-    hipLaunchKernelGGL(dc_pstream_kernel, dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, E[0]);
+    hipLaunchKernelGGL(dc_pstream_kernel<false>, dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, E[0]);
     hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, d->doff[0], S, m, d->poff);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
@@ -1196,6 +1252,90 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
 #endif
     if (getenv("BSCGPU_DEBUG")) fprintf(stderr, "[devcoder] decisions %u, types %u, rounds %u, chunks replayed %u\n", E[0], d->hmeta[DM_NTYPES], d->hmeta[DM_NROUNDS], d->hmeta[DM_REPLAYS]);
     *D_out = E[0];
+    for (int b = 0; b <= nb; ++b) poff_out[b] = d->hmeta[32 + b];
+    return BSC_NO_ERROR;
+}
+
+static int devcoder_pstream_fast(bscgpu_ctx* c, DevCoder* d, const u8* dsym, const u8* drank, const u32* dstart, u32 m, u32 n, int nb,
+                                 const u32* run_first, u32* D_out, u32* poff_out, int psbuf)
+{
+    DcSub S; S.nb = (u32)nb;
+    for (int b = 0; b < 9; ++b) S.first[b] = (b <= nb) ? run_first[b] : m;
+    for (int b = 0; b < 8; ++b) S.maxr[b] = 7u;                        // `if (bits < 7)` closes the exponent (qlfc.cpp:1204), whatever the alphabet
+    HIP_TRY(c, hipMemsetAsync(d->meta, 0, DM_COUNT * 4, c->stream));
+    const u32 gm = (m + WG - 1) / WG;
+    const u32 gm8 = (gm + 7u) / 8u * 8u;
+    prof_begin(c, BSCGPU_K_DC_CTX, (u64)m * 14, m);
+    HIP_TRY(c, hipMemsetAsync(d->ge32, 0, m, c->stream));              // no escape coding in this coder
+    hipLaunchKernelGGL(dc_items_kernel, dim3(gm), dim3(WG), 0, c->stream, dsym, drank, dstart, d->ge32, m, n, S, d->key_ch);
+    prof_end(c);
+    RadixPass top; top.shift = 56; top.bits = 8;
+    int in_alt = 0;
+    int rc = radix_sort_passes(c, d->key_ch, d->key_ch_s, nullptr, nullptr, m, &top, 1, &in_alt, d->inv_ch);
+    if (rc < 0) return rc;
+    // stream offsets of the runs (job 0: counts and scans only), then the one family's chains (job 1, symbol-major items)
+    {
+        const DcGeom g = dc_geom(m);
+        const u32 grid = (g.W + WAVES - 1) / WAVES;
+        prof_begin(c, BSCGPU_K_DC_PART, (u64)m * 8, m);
+        hipLaunchKernelGGL(dc_part_count_kernel<3>, dim3(grid), dim3(WG), 0, c->stream, d->key_ch, g, S, d->rowbins, d->cnt, d->wdec);
+        hipLaunchKernelGGL(dc_scan_rows_kernel, dim3(DC_ROWS), dim3(WG), 0, c->stream, d->cnt, g.W, d->rowtot);
+        hipLaunchKernelGGL(dc_scan_misc_kernel, dim3(1), dim3(WG), 0, c->stream, d->rowtot, d->rowstart, d->wdec, g.W, d->wdecoff, d->meta, 0, (u32)d->Dcap);
+        hipLaunchKernelGGL(dc_doff_kernel<3>, dim3(grid), dim3(WG), 0, c->stream, d->key_ch, g, S, d->meta, d->wdecoff, d->doff[0]);
+        prof_end(c);
+    }
+    dc_launch_partition<3>(c, d, d->key_ch_s, m, S, 1, 0u);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(d->hmeta, d->meta, DM_COUNT * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, ctx_sync(c));
+    prof_collect(c);
+    if (d->hmeta[DM_FAIL] != 0) { c->dc_last_fail = (int)d->hmeta[DM_FAIL]; return BSC_NOT_SUPPORTED; }
+    const u32 E = d->hmeta[DM_D0 + 1];
+    if (d->hmeta[DM_D0 + 0] != E) return ctx_fail(c, BSC_GPU_ERROR, "device coder (fast): decision counts of stream and chain order differ", hipSuccess);
+    {
+        DcEvalAll A;
+        A.sink = d->sink;
+        u64 ev = ((u64)E + 64ull * 1000 - 1) / (64ull * 1000);
+        ev = (ev + DC_EB - 1) / DC_EB * DC_EB;
+        A.ev = ev < (u64)DC_EV ? (u32)DC_EV : (u32)ev;
+        A.wstart[0] = 0; A.cstart[0] = 0;
+        for (int job = 0; job < 4; ++job) {
+            A.job[job].events = d->events[job]; A.job[job].E = job == 1 ? E : 0u; A.job[job].rowstart = d->rowstart + (DC_ROWS + 8) * job;
+            A.job[job].fam = FAM_CHAR;
+            A.V[job] = d->V[job];
+            const u32 nch = (A.job[job].E + A.ev - 1) / A.ev;
+            A.wstart[job + 1] = A.wstart[job] + (nch + 63) / 64;
+            A.cstart[job + 1] = A.cstart[job] + (nch + 63) / 64 * 64;
+        }
+        if (A.cstart[4] > 4 * d->nch_cap) return ctx_fail(c, BSC_GPU_ERROR, "device coder: chunk table too small", hipSuccess);
+        prof_begin(c, BSCGPU_K_DC_EVAL, (u64)E * 6, (u64)E);
+        if (A.wstart[4] > 0) {
+            hipLaunchKernelGGL(dc_mark_rows_kernel, dim3((4 * DC_ROWS + WG - 1) / WG), dim3(WG), 0, c->stream, A);
+            hipLaunchKernelGGL(dc_eval_wave_kernel<false>, dim3((A.wstart[4] + DC_EVAL_WAVES - 1) / DC_EVAL_WAVES), dim3(64 * DC_EVAL_WAVES), DC_EVAL_LDS, c->stream, A, d->mp_fast, d->meta, d->elo, d->ehi, (const u16*)nullptr, d->cnt);
+            hipLaunchKernelGGL(dc_eval_b_kernel, dim3((A.cstart[4] + WG - 1) / WG), dim3(WG), 0, c->stream, A, d->mp_fast, d->meta, d->elo, d->ehi, d->S);
+            hipLaunchKernelGGL(dc_eval_wave_kernel<true>, dim3((A.wstart[4] + DC_EVAL_WAVES - 1) / DC_EVAL_WAVES), dim3(64 * DC_EVAL_WAVES), DC_EVAL_LDS, c->stream, A, d->mp_fast, d->meta, (u16*)nullptr, (u16*)nullptr, d->S, d->cnt + 3 * 4096);
+        }
+        prof_end(c);
+    }
+    DcGather G;
+    G.key_ch = d->key_ch; G.m = m; G.inv_ch = d->inv_ch; G.inv_sr = d->inv_ch; G.inv_sn = d->inv_ch;
+    G.doff_sp = d->doff[0]; G.doff_ch = d->doff[1]; G.doff_sr = d->doff[1]; G.doff_sn = d->doff[1];
+    G.pos_sp = d->pos[1]; G.pos_ch = d->pos[1]; G.pos_sr = d->pos[1]; G.pos_sn = d->pos[1];
+    G.V_sp = d->V[1]; G.V_ch = d->V[1]; G.V_sr = d->V[1]; G.V_sn = d->V[1];
+    prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)E * 10, E);
+    if (c->ps_guard[psbuf & 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ps_guard[psbuf & 1], 0));     // the buffer's previous copy-out
+    hipLaunchKernelGGL(dc_pstream_kernel<true>, dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp_fast, d->meta, d->ps[psbuf & 1], (u16*)nullptr, E);
+    hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, d->doff[0], S, m, d->poff);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(d->hmeta, d->meta, DM_COUNT * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d->hmeta + 32, d->poff, 16 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, ctx_sync(c));
+    if (d->hmeta[DM_FAIL] != 0) { c->dc_last_fail = (int)d->hmeta[DM_FAIL]; return BSC_NOT_SUPPORTED; }
+    c->dc_last_fail = 0;
+    c->dc_replays = (int)d->hmeta[DM_REPLAYS];
+    if (getenv("BSCGPU_DEBUG")) fprintf(stderr, "[devcoder fast] decisions %u, chunks replayed %u\n", E, d->hmeta[DM_REPLAYS]);
+    *D_out = E;
     for (int b = 0; b <= nb; ++b) poff_out[b] = d->hmeta[32 + b];
     return BSC_NO_ERROR;
 }

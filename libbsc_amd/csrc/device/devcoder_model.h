@@ -30,7 +30,9 @@
 
 namespace dcm {
 
-enum : int { CLS_RF = 0, CLS_RE, CLS_RM, CLS_RP, CLS_NF, CLS_NE, CLS_NM, NUM_CLS };
+// (CLS_NM2: run-length mantissas of more than 5 bits — one node per depth instead of a tree.  The static coder gives them the rates of
+// CLS_NM; the fast coder, which runs on the same machinery, does not: qlfc.cpp:1316-1331)
+enum : int { CLS_RF = 0, CLS_RE, CLS_RM, CLS_RP, CLS_NF, CLS_NE, CLS_NM, CLS_NM2, NUM_CLS };
 enum : int { FAM_STATE = 0, FAM_CHAR = 1, FAM_STATIC = 2 };
 
 // ---- type ids -------------------------------------------------------------------------------------------------------
@@ -41,10 +43,11 @@ DC_HD int bsr(uint32_t x) { return x ? 31 - __builtin_clz(x) : 0; }
 DC_HD int rm_off(int B) { return (1 << B) - 1 - B; }                       // sum_{b<B} (2^b - 1)
 // NM: bits 1..5 are full trees (2^bits - 1 nodes), bits 6..31 are chains (ctx = 1..bits)
 DC_HD int nm_off(int bits) { return bits <= 6 ? (1 << bits) - 1 - bits : 57 + (bits * (bits - 1)) / 2 - 15; }
+constexpr int TAU_NM2 = TAU_NM + 57;                                         // = TAU_NM + nm_off(6): first type of the 6-bit chain
 DC_HD int tau_class(int tau)
 {
     return tau < TAU_RE ? CLS_RF : tau < TAU_RM ? CLS_RE : tau < TAU_RP ? CLS_RM : tau < TAU_NF ? CLS_RP
-         : tau < TAU_NE ? CLS_NF : tau < TAU_NM ? CLS_NE : CLS_NM;
+         : tau < TAU_NE ? CLS_NF : tau < TAU_NM ? CLS_NE : tau < TAU_NM2 ? CLS_NM : CLS_NM2;
 }
 
 // ---- canonical rounds ----------------------------------------------------------------------------------------------
@@ -202,17 +205,22 @@ DC_HD int nth_decision(const Item& it, int max_rank, int n_rank, int k, uint32_t
 
 // ---- counters --------------------------------------------------------------------------------------------------------
 // predictor.h:53-61 with the family's tuned constants: bit 0 moves towards 4096 - th0, bit 1 towards th1 (arithmetic shifts)
-struct Rates { int t0, a0, t1, a1; };                        // t0 = 4096 - th0, t1 = th1
+// One form for both coders: v <- v + (((t_bit - v) * a_bit + r_bit) >> 12), arithmetic shift.
+//   static coder (-e1): bit 0 moves towards t0 = 4096 - th0 with r0 = 0; bit 1 is v - (((v - t1) a1) >> 12), which is the same as
+//                       v + (((t1 - v) a1 + 4095) >> 12) (minus the floor of a quotient = the ceiling of its negation): r1 = 4095;
+//   fast coder (-e0):   p -= (p - target_bit) >> R (qlfc.cpp:1186-1331, shifts of 4..7) = v + ceil((target - v) / 2^R)
+//                       = v + (((target - v) * 2^(12-R) + 4095) >> 12): a = 2^(12-R), r0 = r1 = 4095.
+struct Rates { int t0, a0, t1, a1, r0, r1; };
 DC_HD int step(int v, uint32_t bit, const Rates& R)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // both directions with the full-rate 24-bit multiply (|t - v| < 2^13, rates < 2^11: exact), then one select: the plain form
+    // both directions with the full-rate 24-bit multiply (|t - v| < 2^14, rates < 2^11: exact), then one select: the plain form
     // compiles to two exec-masked branches around quarter-rate 32-bit multiplies, twice the cycles of this on the serial chains
-    const int up = v + (__mul24(R.t0 - v, R.a0) >> 12);
-    const int dn = v - (__mul24(v - R.t1, R.a1) >> 12);
+    const int up = v + ((__mul24(R.t0 - v, R.a0) + R.r0) >> 12);
+    const int dn = v + ((__mul24(R.t1 - v, R.a1) + R.r1) >> 12);
     return bit ? dn : up;
 #else
-    return bit ? v - (((v - R.t1) * R.a1) >> 12) : v + (((R.t0 - v) * R.a0) >> 12);
+    return bit ? v + (((R.t1 - v) * R.a1 + R.r1) >> 12) : v + (((R.t0 - v) * R.a0 + R.r0) >> 12);
 #endif
 }
 
@@ -220,28 +228,55 @@ DC_HD int step(int v, uint32_t bit, const Rates& R)
 struct ModelParams {
     Rates   rates[NUM_CLS][3];                               // [class][family]
     short   lr[NUM_CLS][3];                                  // blend weights: p = (ch * lr[0] + st * lr[1] + static * lr[2]) >> 5
-    short   vmin[NUM_CLS][3], vmax[NUM_CLS][3];              // attainable counter range from 2048 (tight two-sided brackets)
+    short   vmin[NUM_CLS][3], vmax[NUM_CLS][3];              // attainable counter range from the start value (tight two-sided brackets)
+    short   init[NUM_CLS];                                   // value a chain starts from (2048; fast coder: 4096 rank side, 1024 run side)
 };
+// attainable range: closure of {init} under both maps (monotone maps -> an interval)
+inline void model_closure(const Rates& R, int init, short* vmin, short* vmax)
+{
+    int lo = init, hi = init;
+    for (bool grown = true; grown;) {
+        grown = false;
+        for (int s = lo; s <= hi; ++s) for (uint32_t b = 0; b < 2; ++b) {
+            const int w = step(s, b, R);
+            if (w < lo) { lo = w; grown = true; }
+            if (w > hi) { hi = w; grown = true; }
+        }
+    }
+    *vmin = (short)lo; *vmax = (short)hi;
+}
 // kStaticParams row layout (tools/gen_qlfc_data.py): S{th0,ar0,th1,ar1} C{...} P{...} mixer{4} LR0 LR1 LR2
 inline void model_params_from_table(const short (*P)[19], ModelParams& M)
 {
     for (int c = 0; c < NUM_CLS; ++c) {
+        const int pc = c == CLS_NM2 ? CLS_NM : c;             // the table has one row for all run-length mantissas
         for (int f = 0; f < 3; ++f) {
             Rates& R = M.rates[c][f];
-            R.t0 = 4096 - P[c][4 * f + 0]; R.a0 = P[c][4 * f + 1]; R.t1 = P[c][4 * f + 2]; R.a1 = P[c][4 * f + 3];
-            // attainable range: closure of {2048} under both maps (monotone maps -> an interval)
-            int lo = 2048, hi = 2048;
-            for (bool grown = true; grown;) {
-                grown = false;
-                for (int s = lo; s <= hi; ++s) for (uint32_t b = 0; b < 2; ++b) {
-                    const int w = step(s, b, R);
-                    if (w < lo) { lo = w; grown = true; }
-                    if (w > hi) { hi = w; grown = true; }
-                }
-            }
-            M.vmin[c][f] = (short)lo; M.vmax[c][f] = (short)hi;
+            R.t0 = 4096 - P[pc][4 * f + 0]; R.a0 = P[pc][4 * f + 1]; R.t1 = P[pc][4 * f + 2]; R.a1 = P[pc][4 * f + 3];
+            R.r0 = 0; R.r1 = 4095;
+            model_closure(R, 2048, &M.vmin[c][f], &M.vmax[c][f]);
         }
-        M.lr[c][0] = P[c][16]; M.lr[c][1] = P[c][17]; M.lr[c][2] = P[c][18];
+        M.lr[c][0] = P[pc][16]; M.lr[c][1] = P[pc][17]; M.lr[c][2] = P[pc][18];
+        M.init[c] = 2048;
+    }
+}
+// The fast coder (-e0, qlfc.cpp:1135-1336): ONE counter per decision, indexed by the run's symbol — the chains of the char family
+// with other update maps (shifts instead of multiplications, targets per class and bit, qlfc.cpp:1186-1331; initial values
+// qlfc_model.cpp:74-75) and nothing to blend.  Only [class][FAM_CHAR] is used; RP (escape coding) does not exist in this coder.
+inline void model_params_fast(ModelParams& M)
+{
+    //                           RF     RE     RM     RP     NF     NE     NM    NM2
+    static const short T0[] = {8016,  8114,  7999,  7999,  2025,  1962,  1951,  1987};     // target of a coded 0
+    static const short T1[] = {  83,   122,   235,   235,    42,   142,   147,    46};     // target of a coded 1
+    static const short S0[] = {   4,     4,     7,     7,     5,     4,     6,     5};     // shift (RF / NF: both bits the same)
+    for (int c = 0; c < NUM_CLS; ++c) {
+        for (int f = 0; f < 3; ++f) {
+            Rates& R = M.rates[c][f];
+            R.t0 = T0[c]; R.t1 = T1[c]; R.a0 = R.a1 = 1 << (12 - S0[c]); R.r0 = R.r1 = 4095;
+            M.init[c] = (short)(c < CLS_NF ? 4096 : 1024);
+            model_closure(R, M.init[c], &M.vmin[c][f], &M.vmax[c][f]);
+            M.lr[c][f] = 0;
+        }
     }
 }
 DC_HD int blend(int v_char, int v_state, int v_static, const short* lr)
@@ -266,5 +301,8 @@ DC_HD uint32_t run_state_index(uint32_t ctx_rank0, uint32_t ctx_run, uint32_t ra
 
 // p-stream entry handed to the range coder: [11:0] probability, [12] bit, [13] first decision of a run
 constexpr uint16_t PS_BIT = 1u << 12, PS_RUN = 1u << 13;
+// ... of the fast coder: [12:0] probability (13 bits on the rank side, 11 on the run side), [13] bit, [14] first decision of a run,
+// [15] run side (the range coder's precision follows it: qlfc.cpp:1186 / :1259)
+constexpr uint16_t PSF_BIT = 1u << 13, PSF_RUN = 1u << 14, PSF_SIDE = 1u << 15;
 
 }  // namespace dcm

@@ -525,7 +525,7 @@ int radix_onesweep_setup(bscgpu_ctx* c)
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
     c->num_cus = cus;
     const char* e = getenv("BSC_RS_ONESWEEP");
-    c->os_mode = e ? atoi(e) : 1;
+    c->os_mode = e ? atoi(e) : 3;
     if (hipFuncSetAttribute((const void*)rs_onesweep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, OS_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)rs_onesweep_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, OS_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)rs_hist_all_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * OS_MAXP * 256 * 4) != hipSuccess) {
@@ -539,7 +539,8 @@ int radix_onesweep_setup(bscgpu_ctx* c)
 bool radix_onesweep_wanted(const bscgpu_ctx* c, u64 n, int npasses, bool has_val)
 {
     if (c->os_mode == 0 || npasses < 1 || npasses > OS_MAXP) return false;
-    if (!has_val && c->os_mode < 2) return false;                       // keys-only passes (ST): mode 1 keeps the three-kernel passes (A/B: mode 3)
+    if (!has_val && c->os_mode < 2) return false;                       // mode 1 (round 3's default): keys-only passes (ST) keep the three-kernel passes.  Round 4,
+                                                                        // ST5 / ST6 on 128 MiB blocks, one box: whole sort 0.38 -> 0.58 / 0.57 of 8 TB/s, job 4429 -> 4659 MB/s
     return n >= (u64)(c->os_mode == 2 ? 4 : 512) * OS_TILE;             // mode 2 (tests): every sort of >= 4 tiles; mode 3: large sorts, keys-only too
 }
 

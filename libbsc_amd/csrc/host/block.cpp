@@ -417,7 +417,11 @@ static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
     // probability stream crosses PCIe; anything that path declines falls back to the run arrays + host model
     // (an LZP-preprocessed block — the reference CLI's default, bsc.cpp:73-75 — is just another byte block to the sorter and the model;
     // its LZP output stays alive until the block is done, because a redo on the host model uploads it again)
-    const bool try_dc = allow_devcoder && devcoder_enabled() && J.coder == LIBBSC_CODER_QLFC_STATIC && J.nblocks > 1 && n >= devcoder_min_n();
+    // (the fast coder, -e0, runs on the same device machinery: its one counter per decision is the static coder's char family with
+    // other update maps — devcoder.hip: devcoder_pstream_fast; BSC_DEVICE_CODER_FAST=0 keeps it on the host)
+    static const bool dc_fast = [] { const char* e = getenv("BSC_DEVICE_CODER_FAST"); return e ? atoi(e) != 0 : true; }();
+    const bool try_dc = allow_devcoder && devcoder_enabled() && (J.coder == LIBBSC_CODER_QLFC_STATIC || (J.coder == LIBBSC_CODER_QLFC_FAST && dc_fast))
+                     && J.nblocks > 1 && n >= devcoder_min_n();
     rc = qlfc_front_runs(c, c->dL, (u32)n, J.nblocks, J.start, &m, J.run_first, J.first_run, *J.slot, !try_dc);
     if (rc < 0) return rc;
     if (try_dc) {
@@ -433,7 +437,7 @@ static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
             u32 ndec = 0;
             const int pb = c->ps_toggle;
             const int r2 = devcoder_pstream(c, reinterpret_cast<const u8*>(c->vA), reinterpret_cast<const u8*>(c->vB), c->SA, m, (u32)n, J.nblocks,
-                                            J.run_first, maxr, &ndec, J.poff, nullptr, pb);
+                                            J.run_first, maxr, &ndec, J.poff, nullptr, pb, J.coder);
             // (a pinned landing zone that cannot be had is a reason to take the host model, like an arena that does not fit)
             if (r2 == LIBBSC_NO_ERROR && ctx_ensure_pstream_slot(c, *J.slot, (size_t)ndec + 64) == LIBBSC_NO_ERROR) {
                 // the stream has been synchronised behind the last kernel; the copy goes to the copy stream and is NOT waited for
@@ -484,8 +488,8 @@ static void host_encode_sub(BlockJob& J, int b)
     if (J.scratch_cap[b] < need) { J.scratch[b].reset(new uint8_t[need + need / 8]); J.scratch_cap[b] = need + need / 8; }
     if (J.use_ps) {
         if (hipEventSynchronize(J.ps_ready) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); J.sub_res[b] = J.size[b]; return; }
-        const int r = qlfc_encode_static_pstream(J.views[b].first_seen, J.views[b].nsym, J.size[b], J.ps + J.poff[b], (size_t)(J.poff[b + 1] - J.poff[b]),
-                                                 J.scratch[b].get(), J.size[b]);
+        const int r = (J.coder == LIBBSC_CODER_QLFC_FAST ? qlfc_encode_fast_pstream : qlfc_encode_static_pstream)(
+                          J.views[b].first_seen, J.views[b].nsym, J.size[b], J.ps + J.poff[b], (size_t)(J.poff[b + 1] - J.poff[b]), J.scratch[b].get(), J.size[b]);
         if (r < 0) J.redo.store(true, std::memory_order_relaxed);      // would be stored raw: that needs the run arrays
         J.sub_res[b] = (r < 0) ? J.size[b] : r;
         return;
@@ -507,7 +511,8 @@ static void host_encode_pair(BlockJob& J, int b)
     }
     if (hipEventSynchronize(J.ps_ready) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); J.sub_res[b] = J.size[b]; J.sub_res[b + 1] = J.size[b + 1]; return; }
     int r0, r1;
-    qlfc_encode_static_pstream_pair(P[0], P[1], &r0, &r1);
+    if (J.coder == LIBBSC_CODER_QLFC_FAST) qlfc_encode_fast_pstream_pair(P[0], P[1], &r0, &r1);
+    else qlfc_encode_static_pstream_pair(P[0], P[1], &r0, &r1);
     if (r0 < 0 || r1 < 0) J.redo.store(true, std::memory_order_relaxed);
     J.sub_res[b] = r0 < 0 ? J.size[b] : r0;
     J.sub_res[b + 1] = r1 < 0 ? J.size[b + 1] : r1;
@@ -556,11 +561,14 @@ extern "C" BSCGPU_API int bscgpu_coder_task_shape(int forced, int low_latency, i
 static int ps_group(const BlockJob& J)
 {
     if (!J.use_ps || J.nblocks != 8) return 2;
+
     static const int adaptive = [] { const char* e = getenv("BSC_RC_ADAPTIVE"); return e ? atoi(e) : 1; }();
     static const int cpus = default_coder_threads();
     const int callers = g_sync_callers.load(std::memory_order_relaxed);
-    return bscgpu_coder_task_shape(ps_simd_env(), ((J.features & BSCGPU_FEATURE_LOW_LATENCY) || !J.pipelined) ? 1 : 0, J.pool_free,
-                                   cpus / (callers > 1 ? callers : 1), cpu_has_avx512vl() ? 1 : 0, adaptive);
+    const int g = bscgpu_coder_task_shape(ps_simd_env(), ((J.features & BSCGPU_FEATURE_LOW_LATENCY) || !J.pipelined) ? 1 : 0, J.pool_free,
+                                          cpus / (callers > 1 ? callers : 1), cpu_has_avx512vl() ? 1 : 0, adaptive);
+    // (the fast coder's stream has no eight-lane version — its precision varies per decision —: pairs instead)
+    return (g == 8 && J.coder == LIBBSC_CODER_QLFC_FAST) ? 2 : g;
 }
 // sub-blocks b .. b + g - 1 of a device-model block, g = ps_group(J)
 static void host_encode_group(BlockJob& J, int b)

@@ -145,6 +145,15 @@ public:
         low_  += (uint64_t)(r & m);
         range_ = r + (m & (range_ - r - r));
     }
+    // precision picked per decision (the fast coder behind the device model: 13 bits on the rank side, 11 on the run side)
+    __attribute__((always_inline)) inline void encode_live_var(Live& L, unsigned bit, unsigned p, unsigned prec, unsigned& is_full)
+    {
+        if (__builtin_expect(L.range < 0x10000u, 0)) { low_ = L.low; shift(); L.low = low_; L.range <<= 16; is_full = (unsigned)full(); }
+        const uint32_t r = (L.range >> prec) * (uint32_t)p;
+        const uint32_t m = 0u - bit;
+        L.low  += (uint64_t)(r & m);
+        L.range = r + (m & (L.range - r - r));
+    }
     inline void encode_half(unsigned bit) { encode<12>(bit, 2048); }     // rangecoder.h:179-182
     void encode_word(uint32_t w) { for (int b = 31; b >= 0; --b) encode_half((w >> b) & 1u); }
 
@@ -879,6 +888,62 @@ void qlfc_encode_static_pstream_pair(const PstreamJob& A, const PstreamJob& B, i
     // what is left of either stream, singly
     if (!fa) for (size_t k = i; k < A.count; ++k) { const unsigned x = pa[k]; if ((x & 0x2000u) && fulla) { fa = true; break; } ra.encode_live_f<12>(La, (x >> 12) & 1u, (int)(x & 0xfffu), fulla); }
     if (!fb) for (size_t k = i; k < B.count; ++k) { const unsigned y = pb[k]; if ((y & 0x2000u) && fullb) { fb = true; break; } rb.encode_live_f<12>(Lb, (y >> 12) & 1u, (int)(y & 0xfffu), fullb); }
+    ra.leave(La); rb.leave(Lb);
+    *resA = fa ? NOT_COMPRESSIBLE : ra.finish();
+    *resB = fb ? NOT_COMPRESSIBLE : rb.finish();
+}
+
+// The fast coder (-e0) behind the device model: one counter per decision, so an entry IS the probability; what differs from the
+// static coder's stream is the precision, which follows the side of the run the decision belongs to (bit 15), and the alphabet header,
+// whose bits go out at precision 1 (qlfc.cpp:1174).  The budget test sits on the run-start mark as in encode_model2 (qlfc.cpp:1191).
+static inline unsigned psf_prec(unsigned x) { return 13u - ((x >> 15) << 1); }
+int qlfc_encode_fast_pstream(const uint8_t* first_seen, int nsym, int in_size, const uint16_t* ps, size_t count, uint8_t* out, int out_size)
+{
+    if (in_size <= 0 || nsym <= 0) return BAD_PARAMETER;
+    RunView H; H.nsym = nsym; memcpy(H.first_seen, first_seen, (size_t)nsym);
+    RangeEncoder rc;
+    rc.init(out, out_size);
+    rc.encode_word((uint32_t)in_size);
+    (void)encode_alphabet(H, [&](unsigned b) { rc.encode<1>(b, 1); });
+    RangeEncoder::Live L = rc.enter();
+    unsigned is_full = (unsigned)rc.full();
+    for (size_t i = 0; i < count; ++i) {
+        const unsigned x = ps[i];
+        if ((x & 0x4000u) && is_full) return NOT_COMPRESSIBLE;
+        rc.encode_live_var(L, (x >> 13) & 1u, x & 0x1fffu, psf_prec(x), is_full);
+    }
+    rc.leave(L);
+    return rc.finish();
+}
+
+void qlfc_encode_fast_pstream_pair(const PstreamJob& A, const PstreamJob& B, int* resA, int* resB)
+{
+    RunView HA, HB;
+    HA.nsym = A.nsym; memcpy(HA.first_seen, A.first_seen, (size_t)A.nsym);
+    HB.nsym = B.nsym; memcpy(HB.first_seen, B.first_seen, (size_t)B.nsym);
+    RangeEncoder ra, rb;
+    ra.init(A.out, A.out_size); rb.init(B.out, B.out_size);
+    ra.encode_word((uint32_t)A.in_size); rb.encode_word((uint32_t)B.in_size);
+    (void)encode_alphabet(HA, [&](unsigned b) { ra.encode<1>(b, 1); });
+    (void)encode_alphabet(HB, [&](unsigned b) { rb.encode<1>(b, 1); });
+    RangeEncoder::Live La = ra.enter(), Lb = rb.enter();
+    const uint16_t* pa = A.ps; const uint16_t* pb = B.ps;
+    const size_t both = A.count < B.count ? A.count : B.count;
+    size_t i = 0;
+    bool fa = false, fb = false;
+    unsigned fulla = (unsigned)ra.full(), fullb = (unsigned)rb.full();
+    for (; i < both; ++i) {
+        const unsigned x = pa[i], y = pb[i];
+        const unsigned stop = ((x >> 14) & fulla) | ((y >> 14) & fullb);
+        if (__builtin_expect((stop & 1u) != 0, 0)) {
+            if ((x & 0x4000u) && fulla) { fa = true; break; }
+            fb = true; break;
+        }
+        ra.encode_live_var(La, (x >> 13) & 1u, x & 0x1fffu, psf_prec(x), fulla);
+        rb.encode_live_var(Lb, (y >> 13) & 1u, y & 0x1fffu, psf_prec(y), fullb);
+    }
+    if (!fa) for (size_t k = i; k < A.count; ++k) { const unsigned x = pa[k]; if ((x & 0x4000u) && fulla) { fa = true; break; } ra.encode_live_var(La, (x >> 13) & 1u, x & 0x1fffu, psf_prec(x), fulla); }
+    if (!fb) for (size_t k = i; k < B.count; ++k) { const unsigned y = pb[k]; if ((y & 0x4000u) && fullb) { fb = true; break; } rb.encode_live_var(Lb, (y >> 13) & 1u, y & 0x1fffu, psf_prec(y), fullb); }
     ra.leave(La); rb.leave(Lb);
     *resA = fa ? NOT_COMPRESSIBLE : ra.finish();
     *resB = fb ? NOT_COMPRESSIBLE : rb.finish();
