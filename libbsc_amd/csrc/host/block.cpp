@@ -565,10 +565,8 @@ static int ps_group(const BlockJob& J)
     static const int adaptive = [] { const char* e = getenv("BSC_RC_ADAPTIVE"); return e ? atoi(e) : 1; }();
     static const int cpus = default_coder_threads();
     const int callers = g_sync_callers.load(std::memory_order_relaxed);
-    const int g = bscgpu_coder_task_shape(ps_simd_env(), ((J.features & BSCGPU_FEATURE_LOW_LATENCY) || !J.pipelined) ? 1 : 0, J.pool_free,
-                                          cpus / (callers > 1 ? callers : 1), cpu_has_avx512vl() ? 1 : 0, adaptive);
-    // (the fast coder's stream has no eight-lane version — its precision varies per decision —: pairs instead)
-    return (g == 8 && J.coder == LIBBSC_CODER_QLFC_FAST) ? 2 : g;
+    return bscgpu_coder_task_shape(ps_simd_env(), ((J.features & BSCGPU_FEATURE_LOW_LATENCY) || !J.pipelined) ? 1 : 0, J.pool_free,
+                                   cpus / (callers > 1 ? callers : 1), cpu_has_avx512vl() ? 1 : 0, adaptive);
 }
 // sub-blocks b .. b + g - 1 of a device-model block, g = ps_group(J)
 static void host_encode_group(BlockJob& J, int b)
@@ -585,7 +583,10 @@ static void host_encode_group(BlockJob& J, int b)
     }
     if (hipEventSynchronize(J.ps_ready) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); for (int k = 0; k < g; ++k) J.sub_res[b + k] = J.size[b + k]; return; }
     int r[8];
-    if (!qlfc_encode_static_pstream_x8(P, r)) { for (int k = 0; k < g; k += 2) host_encode_pair(J, b + k); return; }      // a stream near its budget: the exact scalar coders
+    if (!(J.coder == LIBBSC_CODER_QLFC_FAST ? qlfc_encode_fast_pstream_x8(P, r) : qlfc_encode_static_pstream_x8(P, r))) {
+        for (int k = 0; k < g; k += 2) host_encode_pair(J, b + k);      // a stream near its budget: the exact scalar coders
+        return;
+    }
     for (int k = 0; k < g; ++k) {
         if (r[k] < 0) J.redo.store(true, std::memory_order_relaxed);
         J.sub_res[b + k] = r[k] < 0 ? J.size[b + k] : r[k];

@@ -994,10 +994,13 @@ struct alignas(32) X8State { uint32_t R[8], LO[8], CY[8]; };
     const __m128i t4 = _mm_unpacklo_epi64(c2, c6), t5 = _mm_unpackhi_epi64(c2, c6), t6 = _mm_unpacklo_epi64(c3, c7), t7 = _mm_unpackhi_epi64(c3, c7)
 
 // steps [i, end) (end - i a multiple of 8) of all eight streams; appends the renormalisation records, returns the log's new end
+// FAST: entries of the fast coder (13-bit value, bit at 13, precision 13 - 2 * bit 15: a per-lane shift count instead of the constant 12)
+template <bool FAST>
 static uint32_t* x8_steps_avx2(X8State& S, const uint16_t* const* ps, size_t i, size_t end, uint32_t* logp)
 {
     __m256i R = _mm256_load_si256((const __m256i*)S.R), LO = _mm256_load_si256((const __m256i*)S.LO), CY = _mm256_load_si256((const __m256i*)S.CY);
-    const __m256i zero = _mm256_setzero_si256(), m12 = _mm256_set1_epi32(0xfff), one = _mm256_set1_epi32(1);
+    const __m256i zero = _mm256_setzero_si256(), m12 = _mm256_set1_epi32(FAST ? 0x1fff : 0xfff), one = _mm256_set1_epi32(1);
+    const __m256i c13 = _mm256_set1_epi32(13);
     const __m256i lane_id = _mm256_setr_epi32(0 << 17, 1 << 17, 2 << 17, 3 << 17, 4 << 17, 5 << 17, 6 << 17, 7 << 17);
     const PackLut& lut = pack_lut();
     // one decision of every stream; x = the eight 16-bit entries, zero-extended
@@ -1011,8 +1014,9 @@ static uint32_t* x8_steps_avx2(X8State& S, const uint16_t* const* ps, size_t i, 
         CY = _mm256_andnot_si256(need, CY);
         R  = _mm256_blendv_epi8(R, _mm256_slli_epi32(R, 16), need);
         const __m256i p = _mm256_and_si256(x, m12);
-        const __m256i m = _mm256_sub_epi32(zero, _mm256_and_si256(_mm256_srli_epi32(x, 12), one));      // all ones where the bit is 1
-        const __m256i r = _mm256_mullo_epi32(_mm256_srli_epi32(R, 12), p);
+        const __m256i m = _mm256_sub_epi32(zero, _mm256_and_si256(_mm256_srli_epi32(x, FAST ? 13 : 12), one));      // all ones where the bit is 1
+        const __m256i r = FAST ? _mm256_mullo_epi32(_mm256_srlv_epi32(R, _mm256_sub_epi32(c13, _mm256_slli_epi32(_mm256_srli_epi32(x, 15), 1))), p)
+                               : _mm256_mullo_epi32(_mm256_srli_epi32(R, 12), p);
         const __m256i add = _mm256_and_si256(r, m);
         const __m256i lo2 = _mm256_add_epi32(LO, add);
         const __m256i ge = _mm256_cmpeq_epi32(_mm256_max_epu32(lo2, add), lo2);                        // all ones where lo2 >= add: no carry out
@@ -1032,11 +1036,13 @@ static uint32_t* x8_steps_avx2(X8State& S, const uint16_t* const* ps, size_t i, 
 // The same step with AVX-512VL on 256-bit vectors (chosen at run time): compares write mask registers, the renormalisation and the
 // two directions of the update are masked shifts / adds / subtracts, and the records are left-packed by vpcompressd: ~24
 // micro-ops per step instead of ~45.
+template <bool FAST>
 __attribute__((target("avx512f,avx512vl")))
 static uint32_t* x8_steps_avx512(X8State& S, const uint16_t* const* ps, size_t i, size_t end, uint32_t* logp)
 {
     __m256i R = _mm256_load_si256((const __m256i*)S.R), LO = _mm256_load_si256((const __m256i*)S.LO), CY = _mm256_load_si256((const __m256i*)S.CY);
-    const __m256i m12 = _mm256_set1_epi32(0xfff), one = _mm256_set1_epi32(1), lim = _mm256_set1_epi32(0x10000), b12 = _mm256_set1_epi32(0x1000);
+    const __m256i m12 = _mm256_set1_epi32(FAST ? 0x1fff : 0xfff), one = _mm256_set1_epi32(1), lim = _mm256_set1_epi32(0x10000), b12 = _mm256_set1_epi32(FAST ? 0x2000 : 0x1000);
+    const __m256i c13 = _mm256_set1_epi32(13), c16 = _mm256_set1_epi32(16);
     const __m256i lane_id = _mm256_setr_epi32(0 << 17, 1 << 17, 2 << 17, 3 << 17, 4 << 17, 5 << 17, 6 << 17, 7 << 17);
     // (a macro, not a lambda: a lambda does not inherit the function's target attribute)
 #define BSC_X8_STEP512(xv) do {                                                                                                    \
@@ -1050,7 +1056,10 @@ static uint32_t* x8_steps_avx512(X8State& S, const uint16_t* const* ps, size_t i
         /* the step is bound by the latency of range -> compare -> shift -> multiply -> subtract: both products are started at   */ \
         /* once (range >> 12 and, for a renormalised lane, (range << 16) >> 12 = range << 4) and the compare only selects          */ \
         const __m256i p = _mm256_and_si256(x, m12);                                                                                \
-        const __m256i ra = _mm256_mullo_epi32(_mm256_srli_epi32(R, 12), p), rb = _mm256_mullo_epi32(_mm256_slli_epi32(R, 4), p);   \
+        /* FAST: precision sh = 13 - 2 * (bit 15) per lane; a renormalised lane's (range << 16) >> sh = range << (16 - sh) */       \
+        const __m256i sh = _mm256_sub_epi32(c13, _mm256_slli_epi32(_mm256_srli_epi32(x, 15), 1));                                  \
+        const __m256i ra = FAST ? _mm256_mullo_epi32(_mm256_srlv_epi32(R, sh), p) : _mm256_mullo_epi32(_mm256_srli_epi32(R, 12), p); \
+        const __m256i rb = FAST ? _mm256_mullo_epi32(_mm256_sllv_epi32(R, _mm256_sub_epi32(c16, sh)), p) : _mm256_mullo_epi32(_mm256_slli_epi32(R, 4), p); \
         R  = _mm256_mask_slli_epi32(R, need, R, 16);                                                                               \
         const __mmask8 kb = _mm256_test_epi32_mask(x, b12);                                            /* the coded bit */         \
         const __m256i r = _mm256_mask_mov_epi32(ra, need, rb);                                                                     \
@@ -1070,7 +1079,8 @@ static uint32_t* x8_steps_avx512(X8State& S, const uint16_t* const* ps, size_t i
 }
 #endif
 
-bool qlfc_encode_static_pstream_x8(const PstreamJob* J, int* res)
+template <bool FAST>
+static bool encode_pstream_x8(const PstreamJob* J, int* res)
 {
 #if defined(__AVX2__)
     RunView H;
@@ -1080,7 +1090,8 @@ bool qlfc_encode_static_pstream_x8(const PstreamJob* J, int* res)
         H.nsym = J[l].nsym; memcpy(H.first_seen, J[l].first_seen, (size_t)J[l].nsym);
         rc[l].init(J[l].out, J[l].out_size);
         rc[l].encode_word((uint32_t)J[l].in_size);
-        (void)encode_alphabet(H, [&](unsigned b) { rc[l].encode_half(b); });
+        if (FAST) (void)encode_alphabet(H, [&](unsigned b) { rc[l].template encode<1>(b, 1); });
+        else      (void)encode_alphabet(H, [&](unsigned b) { rc[l].encode_half(b); });
         if (J[l].count < common) common = J[l].count;
     }
     X8State S;
@@ -1101,7 +1112,7 @@ bool qlfc_encode_static_pstream_x8(const PstreamJob* J, int* res)
     while (i + 8 <= common) {
         size_t end = i + CHUNK; if (end > common) end = common;
         end = i + ((end - i) & ~(size_t)7);
-        uint32_t* const logp = use512 ? x8_steps_avx512(S, ps, i, end, log0) : x8_steps_avx2(S, ps, i, end, log0);
+        uint32_t* const logp = use512 ? x8_steps_avx512<FAST>(S, ps, i, end, log0) : x8_steps_avx2<FAST>(S, ps, i, end, log0);
         i = end;
         for (const uint32_t* q = log0; q < logp; ++q) {              // replay: the only code that touches the outputs
             const uint32_t rec = *q;
@@ -1116,10 +1127,16 @@ bool qlfc_encode_static_pstream_x8(const PstreamJob* J, int* res)
         RangeEncoder::Live L{(uint64_t)S.LO[l] | ((uint64_t)S.CY[l] << 32), S.R[l]};
         bool failed = false;
         const uint16_t* q = ps[l];
+        unsigned is_full = (unsigned)rc[l].full();
         for (size_t k = i; k < J[l].count; ++k) {
             const unsigned x = q[k];
-            if ((x & 0x2000u) && rc[l].full()) { failed = true; break; }
-            rc[l].encode_live<12>(L, (x >> 12) & 1u, (int)(x & 0xfffu));
+            if (FAST) {
+                if ((x & 0x4000u) && is_full) { failed = true; break; }
+                rc[l].encode_live_var(L, (x >> 13) & 1u, x & 0x1fffu, psf_prec(x), is_full);
+            } else {
+                if ((x & 0x2000u) && rc[l].full()) { failed = true; break; }
+                rc[l].template encode_live<12>(L, (x >> 12) & 1u, (int)(x & 0xfffu));
+            }
         }
         rc[l].leave(L);
         res[l] = failed ? NOT_COMPRESSIBLE : rc[l].finish();
@@ -1130,6 +1147,8 @@ bool qlfc_encode_static_pstream_x8(const PstreamJob* J, int* res)
     return false;
 #endif
 }
+bool qlfc_encode_static_pstream_x8(const PstreamJob* J, int* res) { return encode_pstream_x8<false>(J, res); }
+bool qlfc_encode_fast_pstream_x8(const PstreamJob* J, int* res) { return encode_pstream_x8<true>(J, res); }
 
 int qlfc_encode_runs(const RunView& R, int in_size, uint8_t* out, int out_size, int coder)
 {

@@ -209,3 +209,18 @@ def test_coder_task_shape_rule():
     assert [shape(low=1, sync=c) for c in (2, 4, 7, 8, 16)] == [2, 2, 2, 1, 1]
     # forced
     assert shape(forced=8, low=1, free=24) == 8 and shape(forced=0, free=0) == 2
+
+
+def test_fast_coder_chain_model_matches_the_host_coder(tmp_path):
+    """The fast coder (-e0) as the device runs it — chains (decision type, symbol) with the shift updates of dcm::model_params_fast,
+    entries of 13 / 11 bits, qlfc_encode_fast_pstream and its pair version — walked serially on the CPU: the bytes must be those of
+    the host's own fast coder, which the tests above pin to the reference (tools/devcoder_fast_sim.cpp; random bytes, long runs,
+    text-like and one-symbol data, with room and at the format's budget out_size = in_size)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fast_sim")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-march=x86-64-v3", "-I", os.path.join(root, "libbsc_amd/csrc/host"), "-I", os.path.join(root, "libbsc_amd/csrc/device"),
+                    "-I", os.path.join(root, "include"), os.path.join(root, "tools/devcoder_fast_sim.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "all equal" in r.stdout, r.stdout + r.stderr

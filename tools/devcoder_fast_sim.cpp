@@ -72,6 +72,26 @@ int main()
             if (rw != r2 || (rw > 0 && memcmp(want.data(), got2.data(), (size_t)rw) != 0)) { ++bad; printf("PAIR MISMATCH n %zu budget %d: host %d pair %d\n", in.size(), budget_mode, rw, r2); }
         }
     }
+    {   // eight streams in SIMD lanes (qlfc_encode_fast_pstream_x8) against eight single coders; then with one output too small: it must give up
+        std::vector<std::vector<uint16_t>> ps(8); std::vector<QlfcRuns> R(8);
+        const size_t pick[8] = {2, 5, 8, 11, 1, 4, 7, 10};
+        for (int l = 0; l < 8; ++l) { qlfc_runs(inputs[pick[l]].data(), (int)inputs[pick[l]].size(), R[l]); ps[l] = chain_stream(R[l].view, M, &bad); }
+        for (int mode = 0; mode < 2; ++mode) {
+            std::vector<std::vector<uint8_t>> oa(8), ob(8); PstreamJob J[8]; int ra[8], rb[8];
+            for (int l = 0; l < 8; ++l) {
+                const size_t n = inputs[pick[l]].size();
+                const int osz = (mode == 1 && l == 0) ? 4096 : (int)n * 2 + 4096;      // lane 0 = 600 000 random bytes: far beyond 4 KB
+                oa[l].assign((size_t)osz + 64, 0); ob[l].assign((size_t)osz + 64, 0);
+                ra[l] = qlfc_encode_fast_pstream(R[l].view.first_seen, R[l].view.nsym, (int)n, ps[l].data(), ps[l].size(), oa[l].data(), osz);
+                J[l] = PstreamJob{R[l].view.first_seen, R[l].view.nsym, (int)n, ps[l].data(), ps[l].size(), ob[l].data(), osz};
+            }
+            const bool ok = qlfc_encode_fast_pstream_x8(J, rb);
+            ++cases;
+            if (mode == 1) { if (ra[0] >= 0 || (ok && rb[0] >= 0)) { ++bad; printf("x8: a stream past its budget was not noticed (%d, %d)\n", ra[0], rb[0]); } else printf("x8 budget case: %s\n", ok ? "coded, lane 0 NOT_COMPRESSIBLE" : "gave up"); continue; }
+            if (!ok) { ++bad; printf("x8 gave up with roomy outputs\n"); continue; }
+            for (int l = 0; l < 8; ++l) if (ra[l] != rb[l] || memcmp(oa[l].data(), ob[l].data(), (size_t)ra[l]) != 0) { ++bad; printf("X8 MISMATCH lane %d: %d vs %d\n", l, ra[l], rb[l]); }
+        }
+    }
     printf("%d cases, %d problems%s\n", cases, bad, bad ? "" : ": all equal");
     return bad != 0;
 }
