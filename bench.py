@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--contexts", type=int, default=6, help="GPU contexts (own stream, arena and pipe each) driven concurrently on every GPU: "
                     "kernels of different blocks interleave on the device, which fills what one block's latency-bound kernels leave idle "
                     "(one box, 320 / 20 steps: 3 x 4 4834, 4 x 4 4882 / 3655, 6 x 3 5054 / 3903, 5 x 3 - / 3640, 8 x 2 - / 3513 MB/s)")
+    ap.add_argument("--lzp", default="", help="H,M: LZP preprocessing as the reference CLI's default has it (-H15 -M128: --lzp 15,128).  The block then enters through "
+                    "bscgpu_pipe_submit_host from host memory (LZP is host code); a separate, labelled line — BASELINE's configs have LZP off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -137,6 +139,7 @@ def main():
     t_run0 = [0.0]
 
     host_leg = [False]              # the boundary leg after the timed region: blocks enter through bscgpu_pipe_submit_host (pageable host memory)
+    lzp = tuple(int(x) for x in args.lzp.split(",")) if args.lzp else (0, 0)
 
     # How the blocks of a run reach the contexts.  Steady state wants all contexts busy (kernels of different blocks interleave on the
     # GPU: +14 %), but the END of a job does not: six contexts that each hold one of the last six blocks finish their GPU stages in one
@@ -186,7 +189,7 @@ def main():
                 break
             feat = 3 | (LOW_LATENCY if (tail_low_latency and last) else 0)
             if trace is not None and record: trace.append((k, i, "submit", time.perf_counter() - t_run0[0]))
-            tickets.append(pipe.submit_host(host_in, args.sorter, args.coder, 0, 0, feat) if host_leg[0] else pipe.submit(d_in, n, args.sorter, args.coder, feat))
+            tickets.append(pipe.submit_host(host_in, args.sorter, args.coder, lzp[0], lzp[1], feat) if (host_leg[0] or lzp[0]) else pipe.submit(d_in, n, args.sorter, args.coder, feat))
             stage_finished()
             if trace is not None and record: trace.append((k, i, "gpu stage done", time.perf_counter() - t_run0[0]))
             if record:
@@ -290,6 +293,15 @@ def main():
     # region is checked against the reference output committed in tests/golden/golden_big.json (size + md5; generated
     # from the compiled reference by tests/golden/make_golden_big.py) — no reference is needed on this box.
     verified, verify_note = verify_block(blk, seed, n, args.sorter, args.coder)
+    if lzp[0]:                                            # no committed output for LZP runs: the compiled reference, where it travelled with the tree
+        try:
+            from oracle.refbind import Ref
+            want = Ref().compress(host_in, args.sorter, args.coder, lzp_hash=lzp[0], lzp_min=lzp[1])
+            verified = blk.tobytes() == want
+            verify_note = "last timed block against the compiled reference's bsc_compress with the same LZP parameters (oracle/_ref), outside the timed region"
+        except Exception as e:
+            verified, verify_note = None, f"LZP run, reference unavailable: {e}"
+
     stats = ctxs[0].profile_get()
     for cx in ctxs[1:]:
         for k, v in cx.profile_get().items():
@@ -467,10 +479,13 @@ def main():
             "metric": "MB/s compress (BWT+QLFC) on 64 MiB blocks", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{world} x {n >> 20} MiB synth-text-v1 block(s) per step (seed {'2' if world == 1 else '10..'+str(9+world)}), "
-                                   f"bsc_compress(lzp off, sorter={args.sorter}, coder={args.coder}); input resident in HBM; "
+            "config": {"workload": f"{world} x {n >> 20} MiB synth-text-v1 block(s) per step (seed {'2' if world == 1 else '10..'+str(9+world)}), " +
+                                   (f"bsc_compress(lzp off, sorter={args.sorter}, coder={args.coder}); input resident in HBM; " if not lzp[0] else
+                                    f"bsc_compress(lzp -H{lzp[0]} -M{lzp[1]}, sorter={args.sorter}, coder={args.coder}); input in HOST memory (LZP is host code: bscgpu_pipe_submit_host), one H2D of the LZP output per block; ") +
                                    "Adler-32 + sorter + QLFC run/rank front end" + (" + the static coder's whole adaptive model on the GPU, 16 bits per binary decision over PCIe, "
                                    "range coding on host threads (" + coder_desc + ")" if args.coder == 1 else
+                                   " + the fast coder's model on the GPU (one counter per decision: the static coder's char family with shift updates), 16 bits per binary decision "
+                                   "over PCIe, range coding on host threads (" + coder_desc + ")" if args.coder == 3 else
                                    "; adaptive model and range coding on host threads (one task per sub-block)") +
                                    f"; {ncx} GPU context(s) x {args.depth} = {ncx * args.depth} block(s) in flight per GPU feeding one pool of {coder_threads} coder threads"
                                    + ("; blocks are drawn from one queue, context k starts drawing when k GPU stages have finished and stops when k or fewer blocks are left (a job's "

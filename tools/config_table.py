@@ -60,7 +60,21 @@ for k in (5, 6):
     assert i5 == ir and np.array_equal(o2.cpu().numpy(), Lr)
     tw, got = best(lambda: ctx.compress_device(d2, n2, k, 1).tobytes(), 1)
     print(f"config 5  128 MiB ST{k} sort transform only                          ours {to*1e3:8.2f} ms ({n2/MB/to:7.0f} MB/s)   reference {tr*1e3:8.1f} ms ({n2/MB/tr:7.1f} MB/s)  identical;  ST{k} + QLFC static one block {tw*1e3:7.1f} ms ({n2/MB/tw:6.0f} MB/s)")
-# the other two coders (host models; BASELINE's configs all say -e1): 64 MiB blocks pipelined through one context
+# the reference CLI's default has LZP on (-H15 -M128, bsc.cpp:73-75): host input, LZP on host threads, then the same GPU stage (device model since round 4)
+from libbsc_amd.synth import synth_repeat_v1
+for name, TT in (("synth-text (LZP does not pay: dropped)", T), ("repeats (LZP pays)", synth_repeat_v1(9, n, 40_000, 48))):
+    want = ref.compress(TT, 1, 1, lzp_hash=15, lzp_min=128)
+    pipe = ctx.pipe(4, reuse_outputs=True); tick = []; last = [None]
+    def runl(k):
+        for _ in range(k):
+            tick.append(pipe.submit_host(TT, 1, 1, 15, 128, 3))
+            if len(tick) >= 4: last[0] = pipe.wait(tick.pop(0))
+        while tick: last[0] = pipe.wait(tick.pop(0))
+    runl(4); t = time.perf_counter(); runl(12); tp = (time.perf_counter() - t) / 12
+    assert last[0].tobytes() == want
+    pipe.close()
+    print(f"config 3l 64 MiB BWT + QLFC static, LZP -H15 -M128, host input, {name:40s} ours {tp*1e3:6.2f} ms/block pipelined ({n/MB/tp:7.0f} MB/s)  identical")
+# the other two coders (BASELINE's configs all say -e1): 64 MiB blocks pipelined through one context; -e0's model runs on the GPU since round 4, -e2's on host threads
 for coder, name in ((2, "QLFC adaptive (-e2)"), (3, "QLFC fast (-e0)")):
     want = ref.compress(T, 1, coder)
     pipe = ctx.pipe(4, reuse_outputs=True); tick = []; last = [None]
@@ -72,5 +86,5 @@ for coder, name in ((2, "QLFC adaptive (-e2)"), (3, "QLFC fast (-e0)")):
     runc(4); t = time.perf_counter(); runc(12); tp = (time.perf_counter() - t) / 12
     assert last[0].tobytes() == want
     pipe.close()
-    print(f"config 3' 64 MiB BWT + {name:20s} (device resident, host model)  ours {tp*1e3:6.2f} ms/block pipelined ({n/MB/tp:7.0f} MB/s)  identical")
+    print(f"config 3' 64 MiB BWT + {name:20s} (device resident)  ours {tp*1e3:6.2f} ms/block pipelined ({n/MB/tp:7.0f} MB/s)  identical")
 print("config 4  8 x 64 MiB across 8 GPUs: one process per GPU, `bench.py --gpus N` (this box has 1 GPU)")
