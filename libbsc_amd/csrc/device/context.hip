@@ -35,6 +35,8 @@ int ctx_ensure_slots(bscgpu_ctx* c, int count)
         // the device model never copies its run arrays, a block of the host model has no probability stream
         (void)N;
         if (hipEventCreateWithFlags(&s.copy_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) return BSC_NOT_ENOUGH_MEMORY;
+        for (int b = 0; b < 8; ++b)
+            if (hipEventCreateWithFlags(&s.part_ev[b], hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) return BSC_NOT_ENOUGH_MEMORY;
     }
     return BSC_NO_ERROR;
 }
@@ -153,6 +155,7 @@ extern "C" void bscgpu_destroy(bscgpu_ctx* c)
         if (s.hstart) hipHostFree(s.hstart);
         if (s.hps) hipHostFree(s.hps);
         if (s.copy_ev) hipEventDestroy(s.copy_ev);
+        for (int b = 0; b < 8; ++b) if (s.part_ev[b]) hipEventDestroy(s.part_ev[b]);
     }
     devcoder_destroy(c);
     if (c->arena) hipFree(c->arena);

@@ -59,7 +59,9 @@ struct HostSlot {
     u32* hstart = nullptr;   // run start positions
     u16* hps    = nullptr;   // probability stream of the device coder (allocated when that path is first used)
     size_t hps_cap = 0;      // entries
-    hipEvent_t copy_ev = nullptr;   // recorded on the copy stream behind the block's p-stream copy; the host coder waits on it
+    hipEvent_t copy_ev = nullptr;   // recorded on the copy stream behind the block's p-stream copy (its last piece); guards the device buffer's reuse
+    hipEvent_t part_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // behind the piece of each sub-block: a coder task waits
+                                    // for its own sub-blocks only (the stream leaves sub-block by sub-block, 366 MB in all for a 64 MiB text block)
 };
 constexpr int MAX_SLOTS = 8;
 

@@ -93,6 +93,11 @@ struct OsPasses { int np; int shift[OS_MAXP]; u32 mask[OS_MAXP]; };
 #define OS_STATIC_ORDER 0
 #endif
 #define OS_ADD(p, v)    __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// The ablation / static-order switches produce WRONG results by design (timing only): such an object must never end up in the shipped
+// library.  tools/build_variant.sh defines BSC_EXPERIMENT_BUILD for its side builds; libbsc_amd/build.py never does.
+#if (OS_ABL || OS_STATIC_ORDER) && !defined(BSC_EXPERIMENT_BUILD)
+#error "OS_ABL / OS_STATIC_ORDER are timing experiments with wrong results: build them with tools/build_variant.sh (-DBSC_EXPERIMENT_BUILD), never into the product"
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // rs_hist_all: totals[p][d] += number of keys whose digit p equals d, for every pass of the sort, in one read of the keys.

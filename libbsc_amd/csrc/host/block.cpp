@@ -348,7 +348,8 @@ struct BlockJob {
     int  pool_free = -1;           // CPUs of the pool's budget with nothing to do when the block was queued (-1: not a pipe's block)
     int  ps_g = 2;                 // device-model sub-blocks per coder task (ps_group), fixed when the block's host work starts
     bool use_ps = false; const uint16_t* ps = nullptr; u32 poff[9]; u32 ndec = 0; int sorter = 0;
-    hipEvent_t ps_ready = nullptr;   // the p stream's copy to the host (copy stream); coder tasks wait on it
+    hipEvent_t ps_ready = nullptr;   // the p stream's copy to the host (copy stream), all of it
+    hipEvent_t ps_part[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ... up to and including sub-block b: what a coder task waits on
     std::atomic<bool> redo{false};   // a sub-block did not compress: the block goes through the host model again (raw sub-blocks need the run arrays)
     bool stored_small = false;       // n <= header size: finished in the GPU stage
     int  result = 0;
@@ -442,8 +443,18 @@ static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
             if (r2 == LIBBSC_NO_ERROR && ctx_ensure_pstream_slot(c, *J.slot, (size_t)ndec + 64) == LIBBSC_NO_ERROR) {
                 // the stream has been synchronised behind the last kernel; the copy goes to the copy stream and is NOT waited for
                 // here: the next block's sort overlaps it, the coder tasks wait on the event
-                if (hipMemcpyAsync(J.slot->hps, devcoder_pstream_ptr(c, pb), (size_t)ndec * 2, hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess ||
-                    hipEventRecord(J.slot->copy_ev, c->copy_stream) != hipSuccess) return LIBBSC_GPU_ERROR;
+                // (sub-block by sub-block, an event behind each piece: the task that codes sub-blocks b.. starts when ITS entries have landed —
+                // 366 MB take 7-14 ms over PCIe, which the last block of a job and every synchronous call used to wait out in full)
+                {
+                    const uint16_t* dps = devcoder_pstream_ptr(c, pb);
+                    for (int b = 0; b < J.nblocks; ++b) {
+                        const size_t lo = J.poff[b], hi = J.poff[b + 1];
+                        if ((hi > lo && hipMemcpyAsync(J.slot->hps + lo, dps + lo, (hi - lo) * 2, hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess) ||
+                            hipEventRecord(J.slot->part_ev[b], c->copy_stream) != hipSuccess) return LIBBSC_GPU_ERROR;
+                        J.ps_part[b] = J.slot->part_ev[b];
+                    }
+                    if (hipEventRecord(J.slot->copy_ev, c->copy_stream) != hipSuccess) return LIBBSC_GPU_ERROR;
+                }
                 c->ps_guard[pb] = J.slot->copy_ev; c->ps_toggle = pb ^ 1;
                 J.ps_ready = J.slot->copy_ev;
                 J.use_ps = true; J.ps = J.slot->hps; J.ndec = ndec; ok = true;
@@ -487,7 +498,7 @@ static void host_encode_sub(BlockJob& J, int b)
     const size_t need = (size_t)J.size[b] + 64;
     if (J.scratch_cap[b] < need) { J.scratch[b].reset(new uint8_t[need + need / 8]); J.scratch_cap[b] = need + need / 8; }
     if (J.use_ps) {
-        if (hipEventSynchronize(J.ps_ready) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); J.sub_res[b] = J.size[b]; return; }
+        if (hipEventSynchronize(J.ps_part[b]) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); J.sub_res[b] = J.size[b]; return; }
         const int r = (J.coder == LIBBSC_CODER_QLFC_FAST ? qlfc_encode_fast_pstream : qlfc_encode_static_pstream)(
                           J.views[b].first_seen, J.views[b].nsym, J.size[b], J.ps + J.poff[b], (size_t)(J.poff[b + 1] - J.poff[b]), J.scratch[b].get(), J.size[b]);
         if (r < 0) J.redo.store(true, std::memory_order_relaxed);      // would be stored raw: that needs the run arrays
@@ -509,7 +520,7 @@ static void host_encode_pair(BlockJob& J, int b)
         if (J.scratch_cap[q] < need) { J.scratch[q].reset(new uint8_t[need + need / 8]); J.scratch_cap[q] = need + need / 8; }
         P[k] = PstreamJob{J.views[q].first_seen, J.views[q].nsym, J.size[q], J.ps + J.poff[q], (size_t)(J.poff[q + 1] - J.poff[q]), J.scratch[q].get(), J.size[q]};
     }
-    if (hipEventSynchronize(J.ps_ready) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); J.sub_res[b] = J.size[b]; J.sub_res[b + 1] = J.size[b + 1]; return; }
+    if (hipEventSynchronize(J.ps_part[b + 1]) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); J.sub_res[b] = J.size[b]; J.sub_res[b + 1] = J.size[b + 1]; return; }
     int r0, r1;
     if (J.coder == LIBBSC_CODER_QLFC_FAST) qlfc_encode_fast_pstream_pair(P[0], P[1], &r0, &r1);
     else qlfc_encode_static_pstream_pair(P[0], P[1], &r0, &r1);
@@ -581,7 +592,7 @@ static void host_encode_group(BlockJob& J, int b)
         if (J.scratch_cap[q] < need) { J.scratch[q].reset(new uint8_t[need + need / 8]); J.scratch_cap[q] = need + need / 8; }
         P[k] = PstreamJob{J.views[q].first_seen, J.views[q].nsym, J.size[q], J.ps + J.poff[q], (size_t)(J.poff[q + 1] - J.poff[q]), J.scratch[q].get(), J.size[q]};
     }
-    if (hipEventSynchronize(J.ps_ready) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); for (int k = 0; k < g; ++k) J.sub_res[b + k] = J.size[b + k]; return; }
+    if (hipEventSynchronize(J.ps_part[b + g - 1]) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); for (int k = 0; k < g; ++k) J.sub_res[b + k] = J.size[b + k]; return; }
     int r[8];
     if (!(J.coder == LIBBSC_CODER_QLFC_FAST ? qlfc_encode_fast_pstream_x8(P, r) : qlfc_encode_static_pstream_x8(P, r))) {
         for (int k = 0; k < g; k += 2) host_encode_pair(J, b + k);      // a stream near its budget: the exact scalar coders

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 NAME=$1; shift
 python -m libbsc_amd.build > /dev/null
 OUT=libbsc_amd/lib/variants; mkdir -p $OUT
-hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -I include -I libbsc_amd/csrc --offload-arch=gfx950 "$@" \
+hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -I include -I libbsc_amd/csrc --offload-arch=gfx950 -DBSC_EXPERIMENT_BUILD "$@" \
       -c libbsc_amd/csrc/device/${SRC:-radix_sort}.hip -o $OUT/${SRC:-radix_sort}_$NAME.o
 OBJS=$(ls libbsc_amd/lib/obj/*.o | grep -v "/${SRC:-radix_sort}.o")
 hipcc -shared -fPIC --offload-arch=gfx950 -o $OUT/libbsc_$NAME.so $OBJS $OUT/${SRC:-radix_sort}_$NAME.o
