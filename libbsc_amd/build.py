@@ -146,7 +146,26 @@ def build(force=False, verbose=True, asan=False):
             print(f"[libbsc_amd.build] linked {LIB} ({len(objs)} objects)")
     elif verbose:
         print(f"[libbsc_amd.build] up to date: {LIB}")
+    if not asan:
+        _build_driver(force or changed)
     return LIB
+
+
+DRIVER_SRC = os.path.join(CSRC, "driver", "bsc_mgpu.cpp")
+DRIVER_EXE = os.path.join(HERE, "lib", "bsc_mgpu")
+
+
+def _build_driver(force):
+    """the multi-GPU file compressor (csrc/driver/bsc_mgpu.cpp): plain C++ over include/*.h, linked against the library next to it"""
+    if not os.path.exists(DRIVER_SRC):
+        return
+    if not force and os.path.exists(DRIVER_EXE) and os.path.getmtime(DRIVER_EXE) >= max(os.path.getmtime(DRIVER_SRC), os.path.getmtime(LIB)):
+        return
+    cmd = [GXX, "-O2", "-std=c++17", "-I", INCLUDE, DRIVER_SRC, "-L", os.path.dirname(LIB), "-lbsc_mi355x",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-o", DRIVER_EXE]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("driver build failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
 
 
 if __name__ == "__main__":

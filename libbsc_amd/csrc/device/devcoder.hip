@@ -901,8 +901,11 @@ typedef __attribute__((address_space(3))) volatile u16 dc_lds_vu16;
 
 // FAST: the fast coder's stream — one counter per decision (the char family's value IS the probability, 13 / 11 bits), entries
 // {value, bit << 13, run start << 14, run side << 15} (devcoder_model.h PSF_*).
+#ifndef DC_PS_MINW
+#define DC_PS_MINW 1            // minimum waves per SIMD the register allocator must leave room for (A/B: 82 VGPRs = 5 waves by default)
+#endif
 template <bool FAST>
-__global__ __launch_bounds__(WG) void dc_pstream_kernel(DcGather G, DcSub S, const ModelParams* __restrict__ mp,
+__global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, DcSub S, const ModelParams* __restrict__ mp,
                                                         const u32* __restrict__ meta, u16* __restrict__ out, u16* __restrict__ dbg /*[3][D] or null*/, u32 dbgD)
 {
     __shared__ u16 stage[WAVES][DC_PS_STAGE];

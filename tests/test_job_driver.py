@@ -152,3 +152,15 @@ def test_job_creation_fails_as_a_whole_when_a_device_cannot_be_set_up():
     node2 = FakeNode({0: 1.0})
     assert _job(node2, [], 1, 2)[2] == -1                                    # "every visible device" is the default executor's notion
     assert _job(node2, [0], 0, 2)[2] == -1 and _job(node2, [0], 1, 9)[2] == -1
+
+
+def test_cxx_file_compressor_is_built_with_the_library():
+    """csrc/driver/bsc_mgpu.cpp (the reference CLI's block loop over bscgpu_job_*) is compiled by libbsc_amd.build next to the library;
+    without arguments it explains itself (its GPU test compares its files with the reference CLI's)."""
+    import os
+    import subprocess
+    from libbsc_amd.build import DRIVER_EXE, build
+    build(verbose=False)
+    assert os.path.exists(DRIVER_EXE)
+    r = subprocess.run([DRIVER_EXE], capture_output=True, text=True)
+    assert r.returncode == 2 and "bsc_mgpu e <in> <out>" in r.stderr
