@@ -137,8 +137,9 @@ BSCGPU_API int  bscgpu_pipe_wait(bscgpu_pipe* pipe, int ticket);
  * between GPUs; the RCCL concatenation belongs to the one-process-per-GPU layout, libbsc_amd/multigpu.py).
  *   devices / ndevices   device ordinals; ndevices = 0: every visible device
  *   input / output       host buffers, n and n + 28 bytes, valid until the block has been waited for
- * add() returns the block's number (0, 1, 2, ... in call order) or a negative code; it never blocks on the GPU.  One thread adds
- * and waits; destroy() finishes what is queued, then frees every context.  */
+ * add() returns the block's number (0, 1, 2, ... in call order) or a negative code; it never blocks on the GPU.  One thread adds;
+ * wait() may be called from another thread (for blocks that have been added); destroy() finishes what is queued, then frees every
+ * context.  */
 typedef struct bscgpu_job bscgpu_job;
 BSCGPU_API int  bscgpu_job_create(bscgpu_job** job, const int* devices, int ndevices, int contexts_per_device, int depth, int64_t max_block_bytes);
 BSCGPU_API int  bscgpu_job_add(bscgpu_job* job, const uint8_t* input, uint8_t* output, int n, int lzpHashSize, int lzpMinLen,

@@ -3,8 +3,15 @@
 // Mirrors the role of libcubwt's device storage object (libcubwt.cu:2239-2395) but is sized for
 // 288 GB of HBM3E: one hipMalloc of ~60 bytes per block byte, carved once, reused for every block.
 #include "dev_common.h"
+#include <sys/mman.h>
+#include <system_error>
+#include <thread>
+#include <vector>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 
 int ctx_fail(bscgpu_ctx* c, int code, const char* what, hipError_t e)
 {
@@ -15,6 +22,11 @@ int ctx_fail(bscgpu_ctx* c, int code, const char* what, hipError_t e)
     }
     return code;
 }
+
+bool ctx_timing_on() { static const bool on = getenv("BSCGPU_TIMING") != nullptr; return on; }
+static double ctx_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+CtxTimer::CtxTimer(const char* w) : what(w), t0(0), on(ctx_timing_on()) { if (on) t0 = ctx_now_ms(); }
+CtxTimer::~CtxTimer() { if (on) fprintf(stderr, "[bscgpu timing] %-34s %8.1f ms (thread %zu)\n", what, ctx_now_ms() - t0, std::hash<std::thread::id>()(std::this_thread::get_id()) % 1000); }
 
 hipError_t ctx_sync(bscgpu_ctx* c)
 {
@@ -41,14 +53,54 @@ int ctx_ensure_slots(bscgpu_ctx* c, int count)
     return BSC_NO_ERROR;
 }
 
+// ---- large pinned landing zones: anonymous memory, touched in parallel, then registered ------------------------------------------
+// hipHostMalloc of a block's landing zone (366 MB of probability stream for 64 MiB of text) takes 50-60 ms on this platform, the calls
+// of different threads serialise (six at once: 370 ms), and hipHostFree another 30 ms — a job of a few dozen blocks spent more time
+// allocating than compressing (round 4: 32 x 64 MiB through bsc_mgpu in 2.3 s, of which ~0.5 s of GPU work).  The same memory as an
+// anonymous mapping with transparent huge pages, first-touched by eight threads (2.5 ms; zeroing pages is the cost, 14 ms on one
+// thread) and then hipHostRegister'ed (0.7 ms) copies at the same 57 GB/s (tools/startup_probe.cpp, profiles/r04/startup_probe.txt).
+static constexpr size_t PIN_ALIGN = (size_t)2 << 20;
+static void* pinned_alloc(size_t bytes)
+{
+    CtxTimer tm("pinned landing zone");
+    bytes = align_up(bytes, PIN_ALIGN);
+    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return nullptr;
+    (void)madvise(m, bytes, MADV_HUGEPAGE);
+    const int nth = bytes >= ((size_t)32 << 20) ? 8 : 1;
+    auto touch = [m, bytes, nth](int k) {
+        volatile char* p = (volatile char*)m;
+        const size_t lo = bytes / (size_t)nth * (size_t)k, hi = (k == nth - 1) ? bytes : bytes / (size_t)nth * (size_t)(k + 1);
+        for (size_t i = lo; i < hi; i += 4096) p[i] = 0;
+    };
+    std::vector<std::thread> th;
+    int started = 0;
+    for (; started < nth - 1; ++started) {
+        try { th.emplace_back(touch, started); } catch (const std::system_error&) { break; }       // no more threads: the rest here
+    }
+    for (int k = started; k < nth; ++k) touch(k);
+    for (auto& t : th) t.join();
+    if (hipHostRegister(m, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); munmap(m, bytes); return nullptr; }
+    return m;
+}
+static void pinned_free(void* p, size_t bytes)
+{
+    if (!p) return;
+    (void)hipHostUnregister(p);
+    munmap(p, align_up(bytes, PIN_ALIGN));
+}
+
 int ctx_ensure_run_slot(bscgpu_ctx* c, HostSlot& s)
 {
     if (s.hsym && s.hrank && s.hstart) return BSC_NO_ERROR;
     const size_t N = align_up((size_t)c->max_n + 4096, 4096);
-    const bool ok = (s.hsym   || hipHostMalloc((void**)&s.hsym, N, hipHostMallocDefault) == hipSuccess)
-                 && (s.hrank  || hipHostMalloc((void**)&s.hrank, N, hipHostMallocDefault) == hipSuccess)
-                 && (s.hstart || hipHostMalloc((void**)&s.hstart, 4 * N, hipHostMallocDefault) == hipSuccess);
-    if (!ok) { (void)hipGetLastError(); return BSC_NOT_ENOUGH_MEMORY; }
+    // one mapping for the three run arrays: symbol (N), rank (N), start (4 N)
+    if (!s.run_base) {
+        s.run_bytes = 6 * N;
+        s.run_base = (u8*)pinned_alloc(s.run_bytes);
+        if (!s.run_base) { s.run_bytes = 0; return BSC_NOT_ENOUGH_MEMORY; }
+    }
+    s.hsym = s.run_base; s.hrank = s.run_base + N; s.hstart = reinterpret_cast<u32*>(s.run_base + 2 * N);
     return BSC_NO_ERROR;
 }
 
@@ -56,8 +108,10 @@ int ctx_ensure_pstream_slot(bscgpu_ctx* c, HostSlot& slot, size_t entries)
 {
     (void)c;
     if (slot.hps_cap >= entries) return BSC_NO_ERROR;
-    if (slot.hps) { hipHostFree(slot.hps); slot.hps = nullptr; slot.hps_cap = 0; }
-    if (hipHostMalloc((void**)&slot.hps, entries * 2, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return BSC_NOT_ENOUGH_MEMORY; }
+    if (slot.hps) { pinned_free(slot.hps, slot.hps_cap * 2); slot.hps = nullptr; slot.hps_cap = 0; }
+    entries += entries / 16;                                    // a little room: the next block's stream is rarely exactly this long
+    slot.hps = (u16*)pinned_alloc(entries * 2);
+    if (!slot.hps) return BSC_NOT_ENOUGH_MEMORY;
     slot.hps_cap = entries;
     return BSC_NO_ERROR;
 }
@@ -76,6 +130,7 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
 {
     if (!out || max_n < 0 || max_n >= 0x7fffffffll) return BSC_BAD_PARAMETER;
     *out = nullptr;
+    CtxTimer tm_all("bscgpu_create");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BSC_GPU_NOT_SUPPORTED;
     if (device < 0 || device >= ndev) return BSC_BAD_PARAMETER;
@@ -84,13 +139,16 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
     if (!getenv("BSCGPU_SPIN")) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
 
     bscgpu_ctx* c = new bscgpu_ctx();
+    { CtxTimer tm("  first HIP call on this thread"); (void)hipFree(nullptr); }
     c->device = device;
     c->max_n  = max_n;
     memset(c->kstat, 0, sizeof c->kstat);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BSC_GPU_ERROR; }
+    CtxTimer* tm_streams = new CtxTimer("  streams + events");
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete tm_streams; delete c; return BSC_GPU_ERROR; }
     if (hipEventCreateWithFlags(&c->sync_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return BSC_GPU_ERROR; }
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { hipEventDestroy(c->sync_ev); hipStreamDestroy(c->stream); delete c; return BSC_GPU_ERROR; }
 
+    delete tm_streams;
     const size_t N = align_up((size_t)max_n + 4096, 4096);
     struct Carve { void** p; size_t bytes; size_t lead; };
     Carve carve[] = {
@@ -114,7 +172,9 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
     };
     size_t total = 0;
     for (auto& cv : carve) total += align_up(cv.bytes, ARENA_ALIGN);
+    CtxTimer* tm_arena = new CtxTimer("  arena hipMalloc + memset + small pinned + engine setup");
     hipError_t e = hipMalloc((void**)&c->arena, total);
+    if (e != hipSuccess) delete tm_arena;
     if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return BSC_GPU_NOT_ENOUGH_MEMORY; }
     c->arena_bytes = total;
     size_t off = 0;
@@ -126,8 +186,9 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
            && hipHostMalloc((void**)&c->hadler, (size_t)MAX_CHUNKS * 16, hipHostMallocDefault) == hipSuccess
            && hipHostMalloc((void**)&c->hsplit, N / 256 + 64, hipHostMallocDefault) == hipSuccess
            && ctx_ensure_slots(c, 1) == BSC_NO_ERROR;
-    if (!ok || ctx_sync(c) != hipSuccess) { bscgpu_destroy(c); return BSC_GPU_NOT_ENOUGH_MEMORY; }
-    if (radix_engine_setup(c) != BSC_NO_ERROR) { bscgpu_destroy(c); return BSC_GPU_ERROR; }
+    if (!ok || ctx_sync(c) != hipSuccess) { delete tm_arena; bscgpu_destroy(c); return BSC_GPU_NOT_ENOUGH_MEMORY; }
+    if (radix_engine_setup(c) != BSC_NO_ERROR) { delete tm_arena; bscgpu_destroy(c); return BSC_GPU_ERROR; }
+    delete tm_arena;
     *out = c;
     return BSC_NO_ERROR;
 }
@@ -150,10 +211,8 @@ extern "C" void bscgpu_destroy(bscgpu_ctx* c)
     if (c->hsplit) hipHostFree(c->hsplit);
     for (int i = 0; i < MAX_SLOTS; ++i) {
         HostSlot& s = c->slots[i];
-        if (s.hsym) hipHostFree(s.hsym);
-        if (s.hrank) hipHostFree(s.hrank);
-        if (s.hstart) hipHostFree(s.hstart);
-        if (s.hps) hipHostFree(s.hps);
+        if (s.run_base) pinned_free(s.run_base, s.run_bytes);
+        if (s.hps) pinned_free(s.hps, s.hps_cap * 2);
         if (s.copy_ev) hipEventDestroy(s.copy_ev);
         for (int b = 0; b < 8; ++b) if (s.part_ev[b]) hipEventDestroy(s.part_ev[b]);
     }

@@ -57,6 +57,7 @@ struct HostSlot {
     u8*  hsym   = nullptr;   // run symbols
     u8*  hrank  = nullptr;   // QLFC ranks
     u32* hstart = nullptr;   // run start positions
+    u8*  run_base = nullptr; size_t run_bytes = 0;   // the one pinned mapping behind hsym / hrank / hstart
     u16* hps    = nullptr;   // probability stream of the device coder (allocated when that path is first used)
     size_t hps_cap = 0;      // entries
     hipEvent_t copy_ev = nullptr;   // recorded on the copy stream behind the block's p-stream copy (its last piece); guards the device buffer's reuse
@@ -138,6 +139,14 @@ struct bscgpu_ctx {
 };
 
 int  ctx_fail(bscgpu_ctx* c, int code, const char* what, hipError_t e);
+// BSCGPU_TIMING=1: one line on stderr per set-up step (context creation, arenas, landing zones) with its wall time — where a short
+// job's start-up goes
+bool ctx_timing_on();
+struct CtxTimer {
+    const char* what; double t0; bool on;
+    explicit CtxTimer(const char* w);
+    ~CtxTimer();
+};
 hipError_t ctx_sync(bscgpu_ctx* c);   // wait for everything queued on c->stream without burning a CPU
 #define HIP_TRY(ctx, expr)                                                         \
     do { hipError_t _e = (expr);                                                   \

@@ -1052,6 +1052,7 @@ int devcoder_ensure(bscgpu_ctx* c)
     // block takes the host model, as it did before the device model existed, and the allocation is not retried for every block.
     if (c->dc_alloc_failed) return BSC_NOT_SUPPORTED;
     if (getenv("BSC_DEVCODER_FAIL_ALLOC")) { c->dc_alloc_failed = true; return BSC_NOT_SUPPORTED; }      // tests: an arena that does not fit
+    CtxTimer tm("devcoder_ensure (arena, tables)");
     DevCoder* d = new DevCoder();
     const size_t N = ((size_t)c->max_n + 4096 + 4095) / 4096 * 4096;
     d->Mcap = N; d->Dcap = 4 * N + 65536;
@@ -1081,8 +1082,9 @@ int devcoder_ensure(bscgpu_ctx* c)
     size_t off = 0;
     for (auto& cv : carve) { *cv.p = d->arena + off; off += dc_align(cv.bytes); }
     if (hipHostMalloc((void**)&d->hmeta, 64 * 4, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); hipFree(d->arena); delete d; c->dc_alloc_failed = true; return BSC_NOT_SUPPORTED; }
-    ModelParams mp; model_params_from_table(bschost::qlfc_static_params(), mp);
-    ModelParams mpf; model_params_fast(mpf);
+    // (once per process: the attainable-range closures behind the brackets take ~60 ms to compute, and every context needs the same tables)
+    static const ModelParams mp = [] { ModelParams m; model_params_from_table(bschost::qlfc_static_params(), m); return m; }();
+    static const ModelParams mpf = [] { ModelParams m; model_params_fast(m); return m; }();
     // more than 64 KB of dynamic LDS is a per-device attribute of the function: set for every context's device
     if (hipFuncSetAttribute((const void*)dc_eval_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DC_EVAL_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)dc_eval_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DC_EVAL_LDS) != hipSuccess) {

@@ -8,14 +8,19 @@
 //   bsc_mgpu e <in> <out> [-b<MiB>] [-m0|-m3..8] [-e0|-e1|-e2] [-H<bits>] [-M<len>] [-p] [-G<gpus>] [-C<contexts per gpu>] [-D<depth>]
 //   bsc_mgpu d <in> <out>
 //
-// The input is streamed: at most (devices x contexts x depth + 2) blocks are in memory, each read in file order, added to the job,
-// and written — in file order — as soon as it and all blocks before it are done.
+// The input is streamed: at most (devices x contexts x depth + 4) blocks are in memory; reader threads fill their buffers straight from
+// the file, the main thread adds them to the job in file order, a writer appends them — in file order — as they are done.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 #include "../../../include/libbsc.h"
 #include "../../../include/bscgpu.h"
@@ -105,31 +110,74 @@ int main(int argc, char** argv)
     int rc = bscgpu_job_create(&job, devs.data(), ndev, contexts, depth, max_block);
     if (rc != LIBBSC_NO_ERROR) { fprintf(stderr, "bscgpu_job_create: %d\n", rc); return 1; }
 
-    const int window = ndev * contexts * depth + 2;             // blocks in memory
-    std::vector<std::vector<unsigned char>> ibuf((size_t)window), obuf((size_t)window);
-    std::vector<int> bsize((size_t)window, 0);
-    long long out_bytes = 8;
-    auto retire = [&](int b) -> int {
-        const int r = bscgpu_job_wait(job, b);
-        if (r < 0) { fprintf(stderr, "block %d: error %d\n", b, r); return r; }
-        BlockHeader h; h.offset = (long long)b * block; h.recordSize = 1; h.sortingContexts = 1;
-        if (fwrite(&h, sizeof h, 1, fo) != 1 || fwrite(obuf[(size_t)(b % window)].data(), 1, (size_t)r, fo) != (size_t)r) { perror(argv[3]); return -1; }
-        out_bytes += (long long)sizeof h + r;
-        return 0;
+    // Three roles around the job, so that none of them waits for the others' system calls: READERS fill block buffers straight from the
+    // file (pread: a 64 MiB block costs 15-25 ms of page-cache copy and page faults, which one thread in front of the GPUs cannot
+    // hide: 32 blocks were 0.6 s of a 1.2 s run), the main thread ADDS blocks to the job in file order as they become ready, a WRITER
+    // collects them in file order (bscgpu_job_wait) and appends them to the output; a buffer is reused once its block has been written.
+    const int window = ndev * contexts * depth + 4;             // blocks in memory
+    // (plain malloc, not zero-filled containers: a 64 MiB output buffer is touched only as far as the compressed block reaches)
+    struct Buf { unsigned char* p = nullptr; size_t cap = 0; void need(size_t n) { if (cap < n) { free(p); p = (unsigned char*)malloc(n); cap = p ? n : 0; } } ~Buf() { free(p); } };
+    std::vector<Buf> ibuf((size_t)window), obuf((size_t)window);
+    std::mutex mu; std::condition_variable cv;
+    int next_read = 0, added = 0, written = 0; bool failed = false;
+    std::vector<char> ready((size_t)nblocks > 0 ? (size_t)nblocks : 1, 0);
+    const int fd = fileno(fi);
+    auto block_len = [&](int b) -> long long { return (b == nblocks - 1) ? size - (long long)b * block : block; };
+    auto reader = [&] {
+        for (;;) {
+            int b;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                b = next_read;
+                if (b >= nblocks || failed) return;
+                ++next_read;
+                cv.wait(lk, [&] { return failed || b < written + window; });        // its buffers are free again
+                if (failed) return;
+            }
+            const size_t s = (size_t)(b % window);
+            const long long n = block_len(b);
+            ibuf[s].need((size_t)n); obuf[s].need((size_t)n + LIBBSC_HEADER_SIZE);
+            bool ok = ibuf[s].p && obuf[s].p;
+            for (long long got = 0; ok && got < n;) {
+                const ssize_t r = pread(fd, ibuf[s].p + got, (size_t)(n - got), (off_t)((long long)b * block + got));
+                if (r <= 0) ok = false; else got += r;
+            }
+            { std::lock_guard<std::mutex> lk(mu); if (ok) ready[(size_t)b] = 1; else failed = true; }
+            cv.notify_all();
+        }
     };
-    for (int b = 0; b < nblocks && rc >= 0; ++b) {
-        if (b >= window) rc = retire(b - window);                // its buffers are about to be reused
-        if (rc < 0) break;
+    long long out_bytes = 8;
+    auto writer = [&] {
+        for (int b = 0; b < nblocks; ++b) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return failed || added > b; }); if (failed) return; }
+            const int r = bscgpu_job_wait(job, b);
+            bool ok = r >= 0;
+            if (!ok) fprintf(stderr, "block %d: error %d\n", b, r);
+            if (ok) {
+                BlockHeader h; h.offset = (long long)b * block; h.recordSize = 1; h.sortingContexts = 1;
+                ok = fwrite(&h, sizeof h, 1, fo) == 1 && fwrite(obuf[(size_t)(b % window)].p, 1, (size_t)r, fo) == (size_t)r;
+                if (!ok) perror(argv[3]);
+                out_bytes += (long long)sizeof h + r;
+            }
+            { std::lock_guard<std::mutex> lk(mu); if (ok) written = b + 1; else failed = true; }
+            cv.notify_all();
+            if (!ok) return;
+        }
+    };
+    std::vector<std::thread> threads;
+    const int nreaders = nblocks < 3 ? (nblocks > 0 ? nblocks : 1) : 3;
+    for (int k = 0; k < nreaders; ++k) threads.emplace_back(reader);
+    threads.emplace_back(writer);
+    for (int b = 0; b < nblocks; ++b) {
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return failed || ready[(size_t)b]; }); if (failed) break; }
         const size_t s = (size_t)(b % window);
-        const long long n = (b == nblocks - 1) ? size - (long long)b * block : block;
-        if (ibuf[s].size() < (size_t)n) { ibuf[s].resize((size_t)n); obuf[s].resize((size_t)n + LIBBSC_HEADER_SIZE); }
-        if (fread(ibuf[s].data(), 1, (size_t)n, fi) != (size_t)n) { perror(argv[2]); rc = -1; break; }
-        bsize[s] = (int)n;
-        const int id = bscgpu_job_add(job, ibuf[s].data(), obuf[s].data(), (int)n, lzp ? lzpHash : 0, lzp ? lzpMin : 0, sorter, coder,
+        const int id = bscgpu_job_add(job, ibuf[s].p, obuf[s].p, (int)block_len(b), lzp ? lzpHash : 0, lzp ? lzpMin : 0, sorter, coder,
                                       LIBBSC_FEATURE_FASTMODE | LIBBSC_FEATURE_MULTITHREADING);
-        if (id != b) { fprintf(stderr, "bscgpu_job_add: %d\n", id); rc = id < 0 ? id : -1; }
+        { std::lock_guard<std::mutex> lk(mu); if (id == b) added = b + 1; else { fprintf(stderr, "bscgpu_job_add: %d\n", id); failed = true; } }
+        cv.notify_all();
     }
-    for (int b = nblocks > window ? nblocks - window : 0; b < nblocks && rc >= 0; ++b) rc = retire(b);
+    for (auto& t : threads) t.join();
+    rc = failed ? -1 : 0;
     bscgpu_job_destroy(job);
     fclose(fi); fclose(fo);
     if (rc < 0) return 1;

@@ -373,6 +373,7 @@ static std::atomic<uint64_t> g_count_devmodel{0}, g_count_redo{0}, g_count_devmo
 
 static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
 {
+    CtxTimer tm_stage("gpu_stage of one block");
     J.sorter = blockSorter; J.use_ps = false; J.redo.store(false, std::memory_order_relaxed);
     bscgpu_ctx* c = J.c;
     const int n = J.n;
@@ -939,6 +940,7 @@ static CoderPool* pool_acquire()
 {
     std::lock_guard<std::mutex> g(g_pool_mu);
     if (!g_pool) {
+        CtxTimer tm("coder pool threads");
         CoderPool* P = new CoderPool;
         int nworkers = default_coder_threads();
         if (const char* e = getenv("BSCGPU_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) nworkers = v; }
