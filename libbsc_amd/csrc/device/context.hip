@@ -66,7 +66,8 @@ static void* pinned_alloc(size_t bytes)
     bytes = align_up(bytes, PIN_ALIGN);
     void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (m == MAP_FAILED) return nullptr;
-    (void)madvise(m, bytes, MADV_HUGEPAGE);
+    static const bool thp = [] { const char* e = getenv("BSC_PIN_THP"); return e ? atoi(e) != 0 : true; }();
+    if (thp) (void)madvise(m, bytes, MADV_HUGEPAGE);
     const int nth = bytes >= ((size_t)32 << 20) ? 8 : 1;
     auto touch = [m, bytes, nth](int k) {
         volatile char* p = (volatile char*)m;
