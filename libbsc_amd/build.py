@@ -89,10 +89,11 @@ def _deps_hash(src, asan=False):
             for f in fs:
                 if f.endswith((".h", ".hpp", ".inc")):
                     files.append(os.path.join(dp, f))
+    root = os.path.dirname(HERE)
     for f in sorted(set(files)):
         with open(f, "rb") as fh:
-            h.update(f.encode() + b"\0" + fh.read())
-    h.update(" ".join(_command(src, "OBJ", asan)).encode())       # the full per-source command line: host-only flags included
+            h.update(os.path.relpath(f, root).encode() + b"\0" + fh.read())      # (relative: the tree is built here and used on the GPU box under another path)
+    h.update(" ".join(_command(src, "OBJ", asan)).replace(root, ".").encode())       # the full per-source command line: host-only flags included
     return h.hexdigest()
 
 
