@@ -74,17 +74,19 @@ void Job::run(Worker& w)
         cv_done.notify_all();
     };
     for (;;) {
-        size_t b = 0; bool have = false;
+        size_t b = 0; bool have = false; Block* Bp = nullptr;
         {
             std::unique_lock<std::mutex> lk(mu);
             // with blocks of its own in flight a worker never sleeps on the queue: their results must reach the collector
             if (inflight.empty()) cv_work.wait(lk, [&] { return closing || next < blocks.size(); });
-            if (next < blocks.size()) { b = next++; blocks[b].worker = w.id; have = true; ++w.blocks; }
+            // (the element's address is taken under the lock: a deque never moves its elements on push_back, but indexing it while
+            // another thread appends is a race on its block map)
+            if (next < blocks.size()) { b = next++; Bp = &blocks[b]; Bp->worker = w.id; have = true; ++w.blocks; }
             else if (inflight.empty()) break;             // closing and nothing left
         }
         if (have) {
             if ((int)inflight.size() == depth) retire();
-            Block& B = blocks[b];                         // (stable: a deque never moves its elements on push_back)
+            Block& B = *Bp;
             const int ticket = be.pipe_submit_host(be.user, w.pipe, B.input, B.output, B.n, B.lzpHashSize, B.lzpMinLen, B.sorter, B.coder, B.features);
             if (ticket < 0) {
                 { std::lock_guard<std::mutex> lk(mu); B.result = ticket; B.done = true; }
