@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 
 int ctx_fail(bscgpu_ctx* c, int code, const char* what, hipError_t e)
 {
@@ -144,12 +145,12 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
     c->device = device;
     c->max_n  = max_n;
     memset(c->kstat, 0, sizeof c->kstat);
-    CtxTimer* tm_streams = new CtxTimer("  streams + events");
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete tm_streams; delete c; return BSC_GPU_ERROR; }
+    auto tm_streams = std::make_unique<CtxTimer>("  streams + events");
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BSC_GPU_ERROR; }
     if (hipEventCreateWithFlags(&c->sync_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return BSC_GPU_ERROR; }
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { hipEventDestroy(c->sync_ev); hipStreamDestroy(c->stream); delete c; return BSC_GPU_ERROR; }
 
-    delete tm_streams;
+    tm_streams.reset();
     const size_t N = align_up((size_t)max_n + 4096, 4096);
     struct Carve { void** p; size_t bytes; size_t lead; };
     Carve carve[] = {
@@ -173,9 +174,8 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
     };
     size_t total = 0;
     for (auto& cv : carve) total += align_up(cv.bytes, ARENA_ALIGN);
-    CtxTimer* tm_arena = new CtxTimer("  arena hipMalloc + memset + small pinned + engine setup");
+    auto tm_arena = std::make_unique<CtxTimer>("  arena hipMalloc + memset + small pinned + engine setup");
     hipError_t e = hipMalloc((void**)&c->arena, total);
-    if (e != hipSuccess) delete tm_arena;
     if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return BSC_GPU_NOT_ENOUGH_MEMORY; }
     c->arena_bytes = total;
     size_t off = 0;
@@ -187,9 +187,9 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
            && hipHostMalloc((void**)&c->hadler, (size_t)MAX_CHUNKS * 16, hipHostMallocDefault) == hipSuccess
            && hipHostMalloc((void**)&c->hsplit, N / 256 + 64, hipHostMallocDefault) == hipSuccess
            && ctx_ensure_slots(c, 1) == BSC_NO_ERROR;
-    if (!ok || ctx_sync(c) != hipSuccess) { delete tm_arena; bscgpu_destroy(c); return BSC_GPU_NOT_ENOUGH_MEMORY; }
-    if (radix_engine_setup(c) != BSC_NO_ERROR) { delete tm_arena; bscgpu_destroy(c); return BSC_GPU_ERROR; }
-    delete tm_arena;
+    if (!ok || ctx_sync(c) != hipSuccess) { bscgpu_destroy(c); return BSC_GPU_NOT_ENOUGH_MEMORY; }
+    if (radix_engine_setup(c) != BSC_NO_ERROR) { bscgpu_destroy(c); return BSC_GPU_ERROR; }
+    tm_arena.reset();
     *out = c;
     return BSC_NO_ERROR;
 }

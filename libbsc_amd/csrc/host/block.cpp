@@ -573,7 +573,6 @@ extern "C" BSCGPU_API int bscgpu_coder_task_shape(int forced, int low_latency, i
 static int ps_group(const BlockJob& J)
 {
     if (!J.use_ps || J.nblocks != 8) return 2;
-
     static const int adaptive = [] { const char* e = getenv("BSC_RC_ADAPTIVE"); return e ? atoi(e) : 1; }();
     static const int cpus = default_coder_threads();
     const int callers = g_sync_callers.load(std::memory_order_relaxed);
@@ -760,9 +759,6 @@ static int stage_host_h2d(BlockJob& J, bscgpu_ctx* c)
     return LIBBSC_NO_ERROR;
 }
 
-// A block that took the device model but has a sub-block that does not compress (or needs the strictly serial framing) is
-// run again with the model on the host: raw sub-blocks are rebuilt from the run arrays, which that path never copied.  Rare
-// (such blocks are mostly caught before by their run count); the caller must be the thread that owns the context's GPU stage.
 extern "C" BSCGPU_API long long bscgpu_process_counter(int key)
 {
     switch (key) {
@@ -773,6 +769,10 @@ extern "C" BSCGPU_API long long bscgpu_process_counter(int key)
     return LIBBSC_BAD_PARAMETER;
 }
 
+// A block that took the device model but has a sub-block that does not compress (or needs the strictly serial framing) is
+// run again with the model on the host: raw sub-blocks are rebuilt from the run arrays, which that path never copied.  Rare
+// (such blocks are mostly caught before by their run count); the caller must be the thread that owns the context's GPU stage.
+// For an LZP-preprocessed block the sorter's input is the LZP output, which is why a device-model block keeps it until here.
 static int redo_on_host_model(BlockJob& J)
 {
     g_count_redo.fetch_add(1, std::memory_order_relaxed);
