@@ -47,6 +47,10 @@ def main():
                     "(one box, 320 / 20 steps: 3 x 4 4834, 4 x 4 4882 / 3655, 6 x 3 5054 / 3903, 5 x 3 - / 3640, 8 x 2 - / 3513 MB/s)")
     ap.add_argument("--lzp", default="", help="H,M: LZP preprocessing as the reference CLI's default has it (-H15 -M128: --lzp 15,128).  The block then enters through "
                     "bscgpu_pipe_submit_host from host memory (LZP is host code); a separate, labelled line — BASELINE's configs have LZP off")
+    ap.add_argument("--input", default="synth-text-v1", choices=["synth-text-v1", "python-source", "binary"],
+                    help="what the blocks hold.  synth-text-v1 is BASELINE's workload and the only `value` that counts; python-source / binary are the image's "
+                    "own *.py / *.so files (libbsc_amd.synth.image_corpus: long repeats, the sorter's hard classes) — separate, labelled lines, checked "
+                    "against the compiled reference at run time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -107,7 +111,13 @@ def main():
     # one 64 MiB synth-text v1 block per GPU: seed 2 at N=1 (BASELINE config 3), seeds 10..17 at N>1 (config 4)
     # (BASELINE config 5, the ST5 / ST6 ablation on 128 MiB blocks, has its committed reference output for seed 3)
     seed = (3 if (args.sorter in (5, 6) and n == (128 << 20)) else 2) if world == 1 else 10 + rank
-    host_in = api.synth_text_v1(seed, n)
+    if args.input == "synth-text-v1":
+        host_in = api.synth_text_v1(seed, n)
+    else:
+        from libbsc_amd.synth import image_corpus
+        host_in = image_corpus(args.input, n)
+        if host_in is None:
+            sys.exit(f"bench.py: this image holds no files for --input {args.input}")
     d_in = torch.from_numpy(host_in).to(dev)
     ctxs = []
 
@@ -293,14 +303,14 @@ def main():
     # region is checked against the reference output committed in tests/golden/golden_big.json (size + md5; generated
     # from the compiled reference by tests/golden/make_golden_big.py) — no reference is needed on this box.
     verified, verify_note = verify_block(blk, seed, n, args.sorter, args.coder)
-    if lzp[0]:                                            # no committed output for LZP runs: the compiled reference, where it travelled with the tree
+    if lzp[0] or args.input != "synth-text-v1":           # no committed output for these runs: the compiled reference, where it travelled with the tree
         try:
             from oracle.refbind import Ref
             want = Ref().compress(host_in, args.sorter, args.coder, lzp_hash=lzp[0], lzp_min=lzp[1])
             verified = blk.tobytes() == want
-            verify_note = "last timed block against the compiled reference's bsc_compress with the same LZP parameters (oracle/_ref), outside the timed region"
+            verify_note = "last timed block against the compiled reference's bsc_compress with the same parameters on the same input (oracle/_ref), outside the timed region"
         except Exception as e:
-            verified, verify_note = None, f"LZP run, reference unavailable: {e}"
+            verified, verify_note = None, f"no committed output for this run and the compiled reference is unavailable: {e}"
 
     stats = ctxs[0].profile_get()
     for cx in ctxs[1:]:
@@ -478,8 +488,9 @@ def main():
         out = {
             "metric": "MB/s compress (BWT+QLFC) on 64 MiB blocks", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{world} x {n >> 20} MiB synth-text-v1 block(s) per step (seed {'2' if world == 1 else '10..'+str(9+world)}), " +
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic" if args.input == "synth-text-v1" else f"files of the container image ({args.input})",
+            "config": {"workload": (f"{world} x {n >> 20} MiB synth-text-v1 block(s) per step (seed {'2' if world == 1 else '10..'+str(9+world)}), " if args.input == "synth-text-v1" else
+                                    f"NOT BASELINE's workload: {world} x {n >> 20} MiB block(s) of the image's own {args.input} files per step (libbsc_amd.synth.image_corpus), ") +
                                    (f"bsc_compress(lzp off, sorter={args.sorter}, coder={args.coder}); input resident in HBM; " if not lzp[0] else
                                     f"bsc_compress(lzp -H{lzp[0]} -M{lzp[1]}, sorter={args.sorter}, coder={args.coder}); input in HOST memory (LZP is host code: bscgpu_pipe_submit_host), one H2D of the LZP output per block; ") +
                                    "Adler-32 + sorter + QLFC run/rank front end" + (" + the static coder's whole adaptive model on the GPU, 16 bits per binary decision over PCIe, "

@@ -123,7 +123,10 @@ __global__ __launch_bounds__(WG) void bwt_pack_kernel(const u8* __restrict__ T, 
 // seg phase A: head / unsorted flags + per-chunk summaries.
 //   head(x)  = x == 0 || key[x] != key[x-1] || (INITIAL && (tail(sa[x]) || tail(sa[x-1])))
 //   uns(x)   = !(head(x) && head(x+1)), head(m) = 1
-//   flags[x] = head | uns << 1
+//   flags[x] = head | uns << 1 | oldhead << 2
+//   oldhead (doubling rounds, grp_shift = the width of the key's next-rank field): x is also the first record of a group of the round's
+//   INPUT — the group rank in the key's high bits changes there.  Records of a new group that starts at an old head keep their rank, and
+//   seg_apply skips their (random, 4-byte) ISA stores: most of them while the unsorted set shrinks slowly.
 // ---------------------------------------------------------------------------------------------
 //   grp (rounds on text keys, see bwt_round_textsort_kernel): the group rank of every record is a separate array and a head is
 //   also where it changes: head(x) |= grp[x] != grp[x-1]
@@ -131,7 +134,7 @@ template <bool INITIAL>
 __global__ __launch_bounds__(WG) void seg_reduce_kernel(const u64* __restrict__ keys, const u32* __restrict__ sa,
                                                         u32 m, u32 tail_lo, u32 smask, u32 chunk_tiles, u32 num_tiles,
                                                         u8* __restrict__ flags, u32* __restrict__ segsum /*[2][MAX_CHUNKS]*/,
-                                                        const u32* __restrict__ grp = nullptr)
+                                                        const u32* __restrict__ grp = nullptr, int grp_shift = 0)
 {
     __shared__ u32 scr[8];
     const u32 t = threadIdx.x;
@@ -177,18 +180,19 @@ __global__ __launch_bounds__(WG) void seg_reduce_kernel(const u64* __restrict__ 
                 }
             }
         }
-        u32 h[SEG_ITEMS + 1];
+        u32 h[SEG_ITEMS + 1], oh[SEG_ITEMS + 1];
 #pragma unroll
         for (int q = 0; q <= SEG_ITEMS; ++q) {
             const u32 x = j + q;
-            bool hd;
-            if (x == 0 || x >= m) hd = true;
+            bool hd, od = false;
+            if (x == 0 || x >= m) { hd = true; od = grp_shift > 0; }
             else {
                 hd = (k[q + 1] != k[q]);
                 if (INITIAL) hd = hd || (s[q + 1] >= tail_lo) || (s[q] >= tail_lo);
                 else if (grp != nullptr) hd = hd || (s[q + 1] != s[q]);
+                else if (grp_shift > 0) od = (k[q + 1] >> grp_shift) != (k[q] >> grp_shift);
             }
-            h[q] = hd ? 1u : 0u;
+            h[q] = hd ? 1u : 0u; oh[q] = od ? 1u : 0u;
         }
         u64 packed = 0;
 #pragma unroll
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(WG) void seg_reduce_kernel(const u64* __restrict__ 
             const u32 x = j + q;
             if (x < m) {
                 const u32 uns = (h[q] & h[q + 1]) ^ 1u;
-                packed |= (u64)(h[q] | (uns << 1)) << (8 * q);
+                packed |= (u64)(h[q] | (uns << 1) | (oh[q] << 2)) << (8 * q);
                 cnt += uns;
                 if (h[q]) last1 = x + 1;
             }
@@ -218,6 +222,9 @@ __global__ __launch_bounds__(WG) void seg_reduce_kernel(const u64* __restrict__ 
 // fits; seg_apply counts the groups that do not (see there).
 constexpr int RS_T = 2048, RS_G = 1024, RS_E = RS_T + RS_G;       // 24 KB of LDS per workgroup: 6 workgroups per CU hide the ISA gather
 constexpr int DS_NLONG = 5, DS_EXCESS = 6;                        // dscal slots: groups of > RS_G records in the new unsorted set, their records past the first RS_G
+// The same two counts for groups of more than HY_G records (hybrid doubling rounds, bwt_longrec_kernel): the segmented sort ranks a record by
+// counting inside its group — s comparisons per record of a group of s —, the radix engine costs ~50 ps per record whatever the group.
+constexpr int HY_G = 256, DS_NMID = 3, DS_MIDEXCESS = 4;
 
 // seg phase B: one workgroup scans the <= 1024 chunk summaries.
 //   segoff[c]            = exclusive sum of unsorted counts
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(WG) void seg_scan_kernel(const u32* __restrict__ se
         carrymax = (carrymax > totmax) ? carrymax : totmax;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { dscal[0] = carry; dscal[DS_NLONG] = 0; dscal[DS_EXCESS] = 0; }       // (seg_apply, the next launch, adds to the two counters)
+    if (threadIdx.x == 0) { dscal[0] = carry; dscal[DS_NLONG] = 0; dscal[DS_EXCESS] = 0; dscal[DS_NMID] = 0; dscal[DS_MIDEXCESS] = 0; }   // (seg_apply, the next launch, adds to the counters)
 }
 
 // seg phase C: ranks (position of the group head), SA / ISA write-back, compaction of unsorted records.
@@ -268,15 +275,17 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
     __shared__ u32 scr[8];
     __shared__ u32 sprev[WG];
     __shared__ u32 cstage[3 * SEG_TILE];            // SA slot, suffix, group rank of the tile's unsorted records
-    __shared__ u32 slong[2];
+    __shared__ u32 slong[4];
     const u32 t = threadIdx.x;
-    if (t < 2) slong[t] = 0;
-    u32 n_long = 0, n_excess = 0;
+    if (t < 4) slong[t] = 0;
+    u32 n_long = 0, n_excess = 0, n_mid = 0, n_midx = 0;
     const u32 tile0 = blockIdx.x * chunk_tiles;
     u32 tile1 = tile0 + chunk_tiles; if (tile1 > num_tiles) tile1 = num_tiles;
     u32 off   = segoff[blockIdx.x];                 // next compacted slot
+    // heads travel as (SA slot + 1) << 1 | oldhead: monotone in the slot, so the running maximum is still "the last head", and its low bit
+    // says whether the group it opens keeps the rank its records already have in ISA (seg_reduce: oldhead)
     u32 carry = segoff[MAX_CHUNKS + blockIdx.x];    // (head index + 1) carried in from the left
-    if (!INITIAL && carry) carry = cpos_in[carry - 1] + 1;   // compacted index -> SA slot of that head
+    if (carry) carry = INITIAL ? carry << 1 : (((cpos_in[carry - 1] + 1) << 1) | ((flags[carry - 1] >> 2) & 1u));   // compacted index -> SA slot of that head
 
     for (u32 tile = tile0; tile < tile1; ++tile) {
         const u32 j = tile * SEG_TILE + t * SEG_ITEMS;
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 f[q] = (u32)(fw >> (8 * q)) & 0xffu;
-                if (f[q] & 1u) lmax = pos[q] + 1;
+                if (f[q] & 1u) lmax = ((pos[q] + 1) << 1) | ((f[q] >> 2) & 1u);
                 lcnt += (f[q] >> 1) & 1u;
             }
         } else {
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
                     f[q]   = flags[x];
                     pos[q] = INITIAL ? x : cpos_in[x];
                     s[q]   = sa_sorted[x];
-                    if (f[q] & 1u) lmax = pos[q] + 1;
+                    if (f[q] & 1u) lmax = ((pos[q] + 1) << 1) | ((f[q] >> 2) & 1u);
                     lcnt += (f[q] >> 1) & 1u;
                 } else { f[q] = 0; pos[q] = 0; s[q] = 0; }
             }
@@ -325,14 +334,15 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
         for (int q = 0; q < SEG_ITEMS; ++q) {
             const u32 x = j + q;
             if (x < m) {
-                if (f[q] & 1u) run = pos[q] + 1;
-                const u32 rank = run - 1;
+                if (f[q] & 1u) run = ((pos[q] + 1) << 1) | ((f[q] >> 2) & 1u);
+                const u32 rank = (run >> 1) - 1;
                 if (!INITIAL || SA != sa_sorted) SA[pos[q]] = s[q];          // the first seg may run in place: SA = the sort's value array
-                if (WRITE_ISA) ISA[s[q] & smask] = rank;   // SA / csa keep the predecessor code in their high bits
+                if (WRITE_ISA && (INITIAL || !(run & 1u))) ISA[s[q] & smask] = rank;   // SA / csa keep the predecessor code in their high bits
                 if (f[q] & 2u) {
                     cstage[kslot] = pos[q]; cstage[SEG_TILE + kslot] = s[q]; cstage[2 * SEG_TILE + kslot] = rank; ++kslot;
                     const u32 dist = pos[q] - rank;
                     n_long += (u32)(dist == (u32)RS_G); n_excess += (u32)(dist >= (u32)RS_G);
+                    n_mid += (u32)(dist == (u32)HY_G); n_midx += (u32)(dist >= (u32)HY_G);
                 }
             }
         }
@@ -347,9 +357,15 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
         off += totcnt;
         __syncthreads();
     }
-    if (n_excess) { atomicAdd(&slong[1], n_excess); if (n_long) atomicAdd(&slong[0], n_long); }
+    if (n_midx) {
+        atomicAdd(&slong[3], n_midx); if (n_mid) atomicAdd(&slong[2], n_mid);
+        if (n_excess) { atomicAdd(&slong[1], n_excess); if (n_long) atomicAdd(&slong[0], n_long); }
+    }
     __syncthreads();
-    if (t == 0 && slong[1]) { atomicAdd(&dscal[DS_EXCESS], slong[1]); if (slong[0]) atomicAdd(&dscal[DS_NLONG], slong[0]); }
+    if (t == 0 && slong[3]) {
+        atomicAdd(&dscal[DS_MIDEXCESS], slong[3]); if (slong[2]) atomicAdd(&dscal[DS_NMID], slong[2]);
+        if (slong[1]) { atomicAdd(&dscal[DS_EXCESS], slong[1]); if (slong[0]) atomicAdd(&dscal[DS_NLONG], slong[0]); }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -382,7 +398,8 @@ __global__ __launch_bounds__(WG) void bwt_gather_kernel(const u32* __restrict__ 
 
 __global__ __launch_bounds__(WG) void bwt_round_segsort_kernel(const u32* __restrict__ csa, const u32* __restrict__ cgrp, const u32* __restrict__ ISA,
                                                                u32 U, u64 h, u64 n, int lo_bits, u32 smask,
-                                                               u64* __restrict__ keys_out, u32* __restrict__ vals_out, u32* __restrict__ fallback)
+                                                               u64* __restrict__ keys_out, u32* __restrict__ vals_out, u32* __restrict__ fallback,
+                                                               u32 skip_long = 0u)
 {
     __shared__ u32 snext[RS_E];                  // first the group ranks (for the head flags), then the gathered next ranks
     __shared__ short sgs[RS_E];                  // start of the record's group inside the window, -1: it started before the window
@@ -420,8 +437,11 @@ __global__ __launch_bounds__(WG) void bwt_round_segsort_kernel(const u32* __rest
         }
     }
     __syncthreads();
-    // a group of ours that is still open at the end of the window (and continues behind it) is too long for this kernel
-    if (t == 0 && base + ext < U) {
+    // a group of ours that is still open at the end of the window (and continues behind it) is too long for this kernel.
+    // skip_long (hybrid rounds, bwt_longrec_kernel): groups of more than HY_G records are somebody else's — the radix engine sorts them and
+    // bwt_longrec_place_kernel puts them into the same output arrays; this kernel leaves their slots alone.  (An open group of ours has
+    // its head below `own` and RS_G records of the window behind the tile: more than RS_G >= HY_G records, skipped like any closed one.)
+    if (!skip_long && t == 0 && base + ext < U) {
         const int gs = sgs[ext - 1];
         if (gs >= 0 && (u32)gs < own && cgrp[base + ext] == snext[ext - 1]) atomicOr(fallback, 1u);
     }
@@ -430,7 +450,7 @@ __global__ __launch_bounds__(WG) void bwt_round_segsort_kernel(const u32* __rest
     for (u32 i = t; i < ext; i += WG) {
         const int gs = sgs[i];
         u32 nx = 0;
-        if (gs >= 0 && (u32)gs < own) {
+        if (gs >= 0 && (u32)gs < own && !(skip_long && (u32)sge[gs] - (u32)gs > (u32)HY_G)) {
             const u64 p = (u64)(csa[base + i] & smask) + h;
             nx = (p < n) ? (ISA[p] + 1u) : 0u;
         }
@@ -443,11 +463,139 @@ __global__ __launch_bounds__(WG) void bwt_round_segsort_kernel(const u32* __rest
         if (gs < 0 || (u32)gs >= own) continue;
         const u32 mine = snext[i];
         const u32 ge = (u32)sge[gs];
+        if (skip_long && ge - (u32)gs > (u32)HY_G) continue;
         u32 r = 0;
         for (u32 k = (u32)gs; k < ge; ++k) { const u32 o = snext[k]; r += (u32)((o < mine) || (o == mine && k < i)); }
         const u64 dst = base + (u32)gs + r;
         keys_out[dst] = ((u64)cgrp[base + i] << lo_bits) | mine;
         vals_out[dst] = csa[base + i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hybrid doubling round (round 4): groups of more than HY_G records through the radix engine, everything else through the segmented sort.
+// Rounds with a group of more than RS_G records used to send ALL unsorted records through seven radix passes on (group rank, next rank) —
+// python sources, 64 MiB: 62 M records in the first doubling round, 18 M of them in 3783 such groups; the four rounds that have them cost
+// 17.6 of the block's 25 ms (profiles/r04/bwt_rounds_python-source.txt).  The large groups' records are pulled out in order (count / scan
+// / write: a stream compaction), keyed by (head index >> 8, next rank) — heads of groups of more than 256 records lie more than 256
+// apart, so the shifted head index still tells the groups apart and keeps their order, in 18 bits instead of 26 —, sorted by the radix
+// engine and put back: the j-th sorted record belongs into the slot the j-th extracted record came from (same groups, same sizes, same
+// order).  The threshold is HY_G, not RS_G: the segmented sort ranks by counting inside the group, and with the first version's 1024
+// the rounds of a block of shared objects (many groups of hundreds of records) got slower, not faster.  "More than HY_G" is what
+// seg_apply counted for this unsorted set (the record HY_G places behind the head exists), so the host knows the number of extracted
+// records without another round trip: dscal[DS_MIDEXCESS] + dscal[DS_NMID] * HY_G.
+// ---------------------------------------------------------------------------------------------
+constexpr int LR_ITEMS = 16, LR_TILE = WG * LR_ITEMS;
+constexpr int LR_HEAD_SHIFT = 8;                                  // 2^8 <= HY_G
+static_assert((1 << LR_HEAD_SHIFT) <= HY_G && HY_G <= RS_G, "heads of the extracted groups must differ after the shift; the segmented sort must be able to take the rest");
+// i = index among the unsorted records (a group is contiguous there and in SA: head index = i - (SA slot - group rank))
+__device__ __forceinline__ bool bwt_rec_is_long(const u32* __restrict__ cgrp, u32 i, u32 pos, u32 grp, u32 U)
+{
+    const u32 dist = pos - grp;
+    if (dist >= (u32)HY_G) return true;
+    const u64 far = (u64)(i - dist) + (u64)HY_G;
+    return far < (u64)U && cgrp[far] == grp;
+}
+
+// WRITE = false: cnt[chunk] = extracted records of the chunk.  WRITE = true: off[chunk] = where the chunk's extracted records go; writes
+// their index (lidx), key and suffix.  Lane-strided records (record = tile base + q * WG + t): loads are coalesced, a wavefront's
+// extracted records of one q leave to consecutive slots (ballot prefix), and the 16 x 4 (q, wavefront) counts of a tile are scanned in
+// LDS.  (The first version gave every thread 16 consecutive records and let it write its own run of slots: 64 lines per store
+// instruction and sixteen dependent csa -> ISA loads in a row per thread; a block of shared objects lost 1.4 ms in its first round.)
+template <bool WRITE>
+__global__ __launch_bounds__(WG) void bwt_longrec_kernel(const u32* __restrict__ cpos, const u32* __restrict__ csa, const u32* __restrict__ cgrp,
+                                                         const u32* __restrict__ ISA, u32 U, u64 h, u64 n, int lo_bits, u32 smask,
+                                                         u32 chunk_tiles, u32 num_tiles, u32* __restrict__ cnt_or_off,
+                                                         u32* __restrict__ lidx, u64* __restrict__ keys, u32* __restrict__ vals)
+{
+    __shared__ u32 scr[8];
+    __shared__ u32 swc[LR_ITEMS * WAVES];            // extracted records per (q, wavefront) of the tile, then their exclusive sums
+    __shared__ u32 stot;
+    const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const u32 tile0 = blockIdx.x * chunk_tiles;
+    u32 tile1 = tile0 + chunk_tiles; if (tile1 > num_tiles) tile1 = num_tiles;
+    u32 off = WRITE ? cnt_or_off[blockIdx.x] : 0u;
+    u32 mine_total = 0;
+    for (u32 tile = tile0; tile < tile1; ++tile) {
+        const u32 base = tile * (u32)LR_TILE;
+        u32 pp[LR_ITEMS], gg[LR_ITEMS];
+#pragma unroll
+        for (int q = 0; q < LR_ITEMS; ++q) {
+            const u32 i = base + (u32)q * WG + t;
+            const bool in = i < U;
+            pp[q] = in ? cpos[i] : 0u; gg[q] = in ? cgrp[i] : 0u;
+        }
+        u32 mask = 0, pre[LR_ITEMS];
+#pragma unroll
+        for (int q = 0; q < LR_ITEMS; ++q) {
+            const u32 i = base + (u32)q * WG + t;
+            const bool lg = i < U && bwt_rec_is_long(cgrp, i, pp[q], gg[q], U);
+            const u64 bal = __ballot(lg);
+            if (lg) mask |= 1u << q;
+            if (WRITE) {
+                pre[q] = (u32)__popcll(bal & ((1ull << lane) - 1ull));
+                if (lane == 0) swc[q * WAVES + wave] = (u32)__popcll(bal);
+            }
+        }
+        if (!WRITE) { mine_total += (u32)__popc(mask); continue; }
+        __syncthreads();
+        if (t < 64) {                                   // LR_ITEMS * WAVES = 64 counts: one wavefront scans them
+            const u32 v = swc[t];
+            const u32 incl = wave_incl_sum(v);
+            swc[t] = incl - v;
+            if (t == 63) stot = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < LR_ITEMS; ++q) {
+            if (mask & (1u << q)) {
+                const u32 i = base + (u32)q * WG + t;
+                const u32 o = off + swc[q * WAVES + wave] + pre[q];
+                const u32 s = csa[i];
+                const u64 p = (u64)(s & smask) + h;
+                const u32 nxt = (p < n) ? (ISA[p] + 1u) : 0u;
+                const u32 head = i - (pp[q] - gg[q]);
+                keys[o] = ((u64)(head >> LR_HEAD_SHIFT) << lo_bits) | nxt;
+                vals[o] = s;
+                lidx[o] = i;
+            }
+        }
+        off += stot;
+        __syncthreads();                                // swc / stot are rewritten by the next tile
+    }
+    if (!WRITE) {
+        u32 tot;
+        (void)block_excl_sum(mine_total, scr, &tot);
+        if (t == 0) cnt_or_off[blockIdx.x] = tot;
+    }
+}
+
+// one workgroup: off[c] = exclusive sum of cnt[0..c)
+__global__ __launch_bounds__(WG) void bwt_longrec_scan_kernel(const u32* __restrict__ cnt, u32 num_chunks, u32* __restrict__ off)
+{
+    __shared__ u32 scr[8];
+    u32 carry = 0;
+    for (u32 base = 0; base < num_chunks; base += WG) {
+        const u32 i = base + threadIdx.x;
+        const u32 v = (i < num_chunks) ? cnt[i] : 0u;
+        u32 tot;
+        const u32 ex = block_excl_sum(v, scr, &tot);
+        if (i < num_chunks) off[i] = carry + ex;
+        carry += tot;
+    }
+}
+
+// the j-th sorted long record goes where the j-th extracted one came from, with the key format of the round's other records
+__global__ __launch_bounds__(WG) void bwt_longrec_place_kernel(const u64* __restrict__ ks, const u32* __restrict__ vs, const u32* __restrict__ lidx,
+                                                               const u32* __restrict__ cgrp, u32 UL, int lo_bits,
+                                                               u64* __restrict__ keys_out, u32* __restrict__ vals_out)
+{
+    const u32 stride = gridDim.x * WG;
+    const u64 lomask = (1ull << lo_bits) - 1ull;
+    for (u32 j = blockIdx.x * WG + threadIdx.x; j < UL; j += stride) {
+        const u32 i = lidx[j];
+        keys_out[i] = ((u64)cgrp[i] << lo_bits) | (ks[j] & lomask);
+        vals_out[i] = vs[j];
     }
 }
 
@@ -776,12 +924,12 @@ static int bit_length(u64 x) { int b = 0; while (x) { ++b; x >>= 1; } return b; 
 
 template <bool INITIAL, bool WRITE_ISA>
 static int run_seg(bscgpu_ctx* c, const u64* keys, const u32* sa_sorted, const u32* cpos_in, u32 m, u32 tail_lo, u32 smask,
-                   u32* cpos_out, u32* csa_out, u32* cgrp_out, u32* U_out, u32* SA, const u32* grp_in = nullptr)
+                   u32* cpos_out, u32* csa_out, u32* cgrp_out, u32* U_out, u32* SA, const u32* grp_in = nullptr, int grp_shift = 0)
 {
     const Chunking ch = make_chunking(m, SEG_TILE);
     prof_begin(c, BSCGPU_K_SEG, (u64)m * (8 + (INITIAL ? 4 : 0) + 1), m);
     hipLaunchKernelGGL(seg_reduce_kernel<INITIAL>, dim3(ch.num_chunks), dim3(WG), 0, c->stream,
-                       keys, sa_sorted, m, tail_lo, smask, ch.chunk_tiles, ch.num_tiles, c->flags, c->segsum, grp_in);
+                       keys, sa_sorted, m, tail_lo, smask, ch.chunk_tiles, ch.num_tiles, c->flags, c->segsum, grp_in, grp_shift);
     prof_end(c);
     prof_begin(c, BSCGPU_K_SEG, 0, 0);
     hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(WG), 0, c->stream, c->segsum, ch.num_chunks, c->segoff, c->dscal);
@@ -900,6 +1048,7 @@ static int bwt_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_
         if (++rounds > 60) return ctx_fail(c, BSC_GPU_ERROR, "prefix doubling did not converge", hipSuccess);
         // what the seg that produced this unsorted set counted (seg_apply): groups no segmented sort of this round can take
         const u32 n_long = c->hscal[DS_NLONG], n_long_rec = c->hscal[DS_EXCESS] + c->hscal[DS_NLONG] * (u32)RS_G;
+        const u32 n_mid = c->hscal[DS_NMID], n_mid_rec = c->hscal[DS_MIDEXCESS] + c->hscal[DS_NMID] * (u32)HY_G;      // groups of > HY_G records (hybrid rounds)
         if (!isa_valid) {
             // a round on text keys; it hands over to doubling when a group does not fit a workgroup or the round did not pay
             static const int long_split_on = [] { const char* e = getenv("BSC_BWT_LONGSPLIT"); return e ? atoi(e) : 1; }();
@@ -983,7 +1132,13 @@ static int bwt_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_
         // segmented sort of the grouped records (falls back to the radix engine when a group is too long for one workgroup)
         static const int segsort_on = [] { const char* e = getenv("BSC_BWT_SEGSORT"); return e ? atoi(e) : 1; }();
         bool sorted = false;
-        if (segsort_on && c->hscal[DS_NLONG] == 0) {        // (with a group of > RS_G records the kernel would only find out and give up)
+        // A round with a group of > RS_G records is a hybrid round.  BSC_BWT_HYBRID=0: never (the whole round through the radix engine, as in
+        // round 3); BSC_BWT_HYBRID_PCT=<p>: only while the groups of > HY_G records hold at most p % of the round's records (shared objects, first
+        // rounds: 48 of 57 M records are extracted; same box, 64 MiB: 40.4 ms without, 36.3 at 50 %, 34.8 at 100 % = the default).
+        static const int hybrid_on = [] { const char* e = getenv("BSC_BWT_HYBRID"); return e ? atoi(e) : 1; }();
+        static const int hybrid_pct = [] { const char* e = getenv("BSC_BWT_HYBRID_PCT"); return e ? atoi(e) : 100; }();
+        const bool hybrid = segsort_on && hybrid_on && n_long != 0 && n_mid != 0 && (u64)n_mid_rec * 100ull <= (u64)U * (u64)hybrid_pct;
+        if (segsort_on && n_long == 0 && !hybrid) {        // (with a group of > RS_G records the kernel would only find out and give up)
             HIP_TRY(c, hipMemsetAsync(c->dscal + 2, 0, 4, c->stream));
             prof_begin(c, BSCGPU_K_GATHER, (u64)U * (4 + 4 + 4 + 8 + 4), U);
             hipLaunchKernelGGL(bwt_round_segsort_kernel, dim3((U + RS_T - 1) / RS_T), dim3(WG), 0, c->stream,
@@ -996,6 +1151,42 @@ static int bwt_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_
             ks = c->kB; vs = c->vB;
         }
         int np = 0;
+        if (!sorted && hybrid) {
+            // hybrid round: the long groups' records through the radix engine, the rest through the segmented sort (see bwt_longrec_kernel)
+            const u32 UL = n_mid_rec;                               // every record of a group of > HY_G records (seg_apply counted them)
+            if (SA == c->vA) {
+                HIP_TRY(c, hipMemcpyAsync(c->SA, c->vA, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));
+                SA = c->SA;
+            }
+            const Chunking lc = make_chunking(U, LR_TILE);
+            u32* lidx = c->cpos[cur ^ 1];                          // the half the seg behind this round writes: free until then
+            prof_begin(c, BSCGPU_K_GATHER, (u64)U * 16 + (u64)UL * (4 + 4 + 4 + 8 + 4), U);
+            hipLaunchKernelGGL(bwt_longrec_kernel<false>, dim3(lc.num_chunks), dim3(WG), 0, c->stream, c->cpos[cur], c->csa[cur], c->cgrp[cur], c->ISA,
+                               U, h, (u64)n, lo_bits, smask, lc.chunk_tiles, lc.num_tiles, c->segsum, lidx, c->kA, c->vA);
+            hipLaunchKernelGGL(bwt_longrec_scan_kernel, dim3(1), dim3(WG), 0, c->stream, c->segsum, lc.num_chunks, c->segoff);
+            hipLaunchKernelGGL(bwt_longrec_kernel<true>, dim3(lc.num_chunks), dim3(WG), 0, c->stream, c->cpos[cur], c->csa[cur], c->cgrp[cur], c->ISA,
+                               U, h, (u64)n, lo_bits, smask, lc.chunk_tiles, lc.num_tiles, c->segoff, lidx, c->kA, c->vA);
+            prof_end(c);
+            RadixPass rp[8];
+            const int kbits = lo_bits + bit_length((u64)(U - 1) >> LR_HEAD_SHIFT);      // 27 + 18 at 64 M unsorted records: 6 passes
+            for (int s = 0; s < kbits; s += 8) { rp[np].shift = s; rp[np].bits = (kbits - s < 8) ? kbits - s : 8; ++np; }
+            rc = radix_sort_passes(c, c->kA, c->kB, c->vA, c->vB, UL, rp, np, &in_alt);
+            if (rc < 0) return rc;
+            const u64* lks = in_alt ? c->kB : c->kA;
+            const u32* lvs = in_alt ? c->vB : c->vA;
+            u64* ko = in_alt ? c->kA : c->kB;                       // the pair the sorted long records are NOT in takes the round's output
+            u32* vo = in_alt ? c->vA : c->vB;
+            prof_begin(c, BSCGPU_K_GATHER, (u64)U * (4 + 4 + 4 + 8 + 4) + (u64)UL * (8 + 4 + 4 + 4 + 8 + 4), U);
+            hipLaunchKernelGGL(bwt_round_segsort_kernel, dim3((U + RS_T - 1) / RS_T), dim3(WG), 0, c->stream,
+                               c->csa[cur], c->cgrp[cur], c->ISA, U, h, (u64)n, lo_bits, smask, ko, vo, c->dscal + 2, 1u);
+            u32 pb = (UL + WG - 1) / WG; if (pb > 8192) pb = 8192;
+            hipLaunchKernelGGL(bwt_longrec_place_kernel, dim3(pb), dim3(WG), 0, c->stream, lks, lvs, lidx, c->cgrp[cur], UL, lo_bits, ko, vo);
+            prof_end(c);
+            HIP_TRY(c, hipGetLastError());
+            ks = ko; vs = vo;
+            sorted = true;
+            if (dbg) fprintf(stderr, "[bwt] round %d: hybrid, %u of %u records in %u group(s) of > 256\n", rounds, UL, U, n_mid);
+        }
         if (!sorted) {
             if (SA == c->vA) {                       // the radix engine is about to use vA: SA moves to its own buffer
                 HIP_TRY(c, hipMemcpyAsync(c->SA, c->vA, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -1017,7 +1208,9 @@ static int bwt_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_
         }
 
         u32 U2 = 0;
-        rc = run_seg<false, true>(c, ks, vs, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2, SA);
+        // (the keys' group field starts at lo_bits: a new group that begins where an old one did keeps its rank, its ISA stores are skipped)
+        static const int isa_skip = [] { const char* e = getenv("BSC_BWT_ISASKIP"); return e ? atoi(e) : 1; }();
+        rc = run_seg<false, true>(c, ks, vs, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2, SA, nullptr, isa_skip ? lo_bits : 0);
         if (rc < 0) return rc;
         cur ^= 1;
         if (dbg) fprintf(stderr, "[bwt] round %d h=%llu U %u -> %u (passes %d)  (%.2f ms)\n", rounds, (unsigned long long)h, U, U2, np, lap());

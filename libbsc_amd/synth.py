@@ -106,3 +106,30 @@ def synth_repeat_v1(seed: int, n: int, period: int, noise_every: int = 512) -> n
         val[::2] = 0xF2
         out[pos] = val          # duplicate positions: numpy assigns in index order, the last write wins
     return out
+
+
+IMAGE_CORPORA = {
+    # classes built from what the container image holds (there is no network for real corpora); the GPU boxes run the same image
+    "python-source": ["/usr/lib/python3*/**/*.py", "/usr/local/lib/python3*/**/*.py"],
+    "binary": ["/opt/rocm/lib/*.so*", "/usr/lib/x86_64-linux-gnu/*.so*"],
+}
+
+
+def image_corpus(kind: str, n: int):
+    """n bytes of the image's own files of one kind, concatenated in sorted path order ("python-source": the *.py of the Python
+    installations — identifiers, English comments, many duplicated files, LCPs up to 2^18; "binary": shared objects — zero runs,
+    tables, 256 symbols).  Repeated when the image holds less than n bytes.  None when it holds none."""
+    import glob
+    out = bytearray()
+    for pat in IMAGE_CORPORA[kind]:
+        for f in sorted(glob.glob(pat, recursive=True)):
+            try:
+                out += open(f, "rb").read()
+            except OSError:
+                continue
+            if len(out) >= n:
+                return np.frombuffer(bytes(out[:n]), dtype=np.uint8).copy()
+    if not out:
+        return None
+    reps = (n + len(out) - 1) // len(out)
+    return np.frombuffer((bytes(out) * reps)[:n], dtype=np.uint8).copy()

@@ -1,4 +1,4 @@
-"""BWT timing over input classes that are not synth-text v1 (the bench block): python tools/bwt_inputs.py [n_MiB]
+"""BWT timing over input classes that are not synth-text v1 (the bench block): python tools/bwt_inputs.py [n_MiB] [class] [--lzp H,M]
 Classes (64 MiB each by default, built from what the image holds — there is no network):
   synth-text v1     the bench block
   deep-lcp          3 MB passages repeated (the golden block of tests/golden/golden_big.json)
@@ -6,32 +6,22 @@ Classes (64 MiB each by default, built from what the image holds — there is no
   dna4              four-symbol pseudo-DNA with repeats (order-5 Markov source + copied segments)
   binary            concatenated shared objects (*.so) of the image
 Every output is compared with the reference (oracle/_ref, libsais) — bit-exact or the line says MISMATCH; the time is the best of
-three device-resident bscgpu_bwt_device calls, with the number of refinement rounds and the ratio to the synth-text time."""
+three device-resident bscgpu_bwt_device calls, with the number of refinement rounds and the ratio to the synth-text time.
+--lzp H,M: what the sorter sees under the CLI's defaults (bsc.cpp: -H15 -M128 unless -p is given) — every class first goes through
+bsc_lzp_compress(H, M) on the host, as bsc_compress does (libbsc.cpp:82-96; a block LZP does not shrink is sorted as it is), and the
+line gives the time for the (shorter) LZP output next to the size it has; the ratio is still against the 64 MiB synth-text block."""
 import glob, os, sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
 from libbsc_amd import GpuContext, api
-from libbsc_amd.synth import synth_text_v1, synth_repeat_v1
+from libbsc_amd.synth import synth_text_v1, synth_repeat_v1, image_corpus
 from oracle.refbind import Ref
 
+lzp = None
+if "--lzp" in sys.argv:
+    k = sys.argv.index("--lzp"); lzp = tuple(int(x) for x in sys.argv[k + 1].split(",")); del sys.argv[k:k + 2]
 n = (int(sys.argv[1]) if len(sys.argv) > 1 else 64) << 20
 only = sys.argv[2] if len(sys.argv) > 2 else None          # one class only (with BSCGPU_DEBUG=1: the sorter's round-by-round trace)
-
-
-def from_files(patterns, n):
-    out = bytearray()
-    for pat in patterns:
-        for f in sorted(glob.glob(pat, recursive=True)):
-            try:
-                out += open(f, "rb").read()
-            except OSError:
-                continue
-            if len(out) >= n:
-                return np.frombuffer(bytes(out[:n]), dtype=np.uint8).copy()
-    if not out:
-        return None
-    reps = (n + len(out) - 1) // len(out)                  # not enough material: repeat it (which is itself a long-repeat input)
-    return np.frombuffer((bytes(out) * reps)[:n], dtype=np.uint8).copy()
 
 
 def dna4(n, seed=5):
@@ -48,9 +38,9 @@ def dna4(n, seed=5):
 
 classes = [("synth-text v1", synth_text_v1(2, n)),
            ("deep-lcp", synth_repeat_v1(4, n, 3_000_000)),
-           ("python-source", from_files(["/usr/lib/python3*/**/*.py", "/usr/local/lib/python3*/**/*.py"], n)),
+           ("python-source", image_corpus("python-source", n)),
            ("dna4", dna4(n)),
-           ("binary", from_files(["/opt/rocm/lib/*.so*", "/usr/lib/x86_64-linux-gnu/*.so*"], n))]
+           ("binary", image_corpus("binary", n))]
 ref = Ref()
 ctx = GpuContext(0, max_n=n + 4096)
 out = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -61,6 +51,15 @@ for name, T in classes:
         continue
     if T is None:
         print(f"{name:16s} (no source files in this image)"); continue
+    note = ""
+    if lzp:
+        z = api.bsc_lzp_compress(T, lzp[0], lzp[1])
+        if isinstance(z, int):
+            note = f"  [LZP {lzp[0]},{lzp[1]}: not compressible, sorted as it is]"
+        else:
+            note = f"  [LZP {lzp[0]},{lzp[1]}: {T.size} -> {len(z)} bytes]"
+            T = np.frombuffer(z, dtype=np.uint8).copy()
+    n = T.size
     d = torch.from_numpy(T).cuda()
     r = 1 << ((n // 8).bit_length() - 1)
     best = None
@@ -71,6 +70,6 @@ for name, T in classes:
         best = dt if best is None or dt < best else best
     rounds = ctx.last_stage_ms()[5]
     L_ref, idx_ref, aux_ref = ref.bwt_encode(T)
-    ok = (idx == idx_ref) and np.array_equal(out.cpu().numpy(), np.frombuffer(L_ref, dtype=np.uint8)) and [I[t + 1] - 1 for t in range(len(aux_ref))] == list(aux_ref)
+    ok = (idx == idx_ref) and np.array_equal(out[:n].cpu().numpy(), np.frombuffer(L_ref, dtype=np.uint8)) and [I[t + 1] - 1 for t in range(len(aux_ref))] == list(aux_ref)
     if base_ms is None: base_ms = best
-    print(f"{name:16s} {best*1e3:8.2f} {best/base_ms:8.2f} {int(rounds):6d} {n/1e9/best:6.2f}  {'bit-exact' if ok else 'MISMATCH'}   ({np.unique(T).size})", flush=True)
+    print(f"{name:16s} {best*1e3:8.2f} {best/base_ms:8.2f} {int(rounds):6d} {n/1e9/best:6.2f}  {'bit-exact' if ok else 'MISMATCH'}   ({np.unique(T).size}){note}", flush=True)
