@@ -832,10 +832,15 @@ __global__ __launch_bounds__(WG) void bwt_long_scatter_kernel(const u8* __restri
 
 // ISA from the current order (when the text rounds hand over to prefix doubling): every suffix gets its SA slot, then the
 // still unsorted ones the rank of their group (the slot of the group's head).
-__global__ __launch_bounds__(WG) void bwt_isa_fill_kernel(const u32* __restrict__ SA, u32 n, u32 smask, u32* __restrict__ ISA)
+// (uns: the first seg's flags, while they are still there — a slot whose suffix is unsorted is left to bwt_isa_fix_kernel instead of being
+// stored twice: with long repeats nearly every slot, and a random 4-byte store costs a whole line of HBM traffic)
+__global__ __launch_bounds__(WG) void bwt_isa_fill_kernel(const u32* __restrict__ SA, u32 n, u32 smask, u32* __restrict__ ISA, const u8* __restrict__ uns)
 {
     const u32 stride = gridDim.x * WG;
-    for (u32 x = blockIdx.x * WG + threadIdx.x; x < n; x += stride) ISA[SA[x] & smask] = x;
+    for (u32 x = blockIdx.x * WG + threadIdx.x; x < n; x += stride) {
+        if (uns != nullptr && (uns[x] & 2u)) continue;
+        ISA[SA[x] & smask] = x;
+    }
 }
 __global__ __launch_bounds__(WG) void bwt_isa_fix_kernel(const u32* __restrict__ csa, const u32* __restrict__ cgrp, u32 U, u32 smask, u32* __restrict__ ISA)
 {
@@ -1035,6 +1040,7 @@ static int bwt_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_
     else           rc = run_seg<true, false>(c, ks, vs, nullptr, n, tail_lo, smask, c->cpos[cur], c->csa[cur], c->cgrp[cur], &U, SA);
     if (rc < 0) return rc;
 
+    bool first_flags = true;                    // c->flags still holds the first seg's flags, indexed by SA slot (bit 1: the slot's suffix is unsorted)
     const int lo_bits = bit_length(n);          // next-rank field: values 0 .. n
     const int hi_bits = bit_length(n - 1);      // group rank field: values 0 .. n-1
     u64 h = pp.w;
@@ -1083,6 +1089,7 @@ static int bwt_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_
                 const bool pays = fits;
                 if (pays) {
                     u8* subhead = c->flags;
+                    first_flags = false;
                     HIP_TRY(c, hipMemsetAsync(LT.nlong, 0, LT_BYTES, c->stream));
                     HIP_TRY(c, hipMemsetAsync(subhead, 0, (size_t)U + 1, c->stream));
                     HIP_TRY(c, hipMemsetAsync(c->dscal + 2, 0, 4, c->stream));
@@ -1107,6 +1114,7 @@ static int bwt_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_
             }
             if (round_done) {
                 u32 U2 = 0;
+                first_flags = false;
                 rc = run_seg<false, false>(c, c->kB, c->vB, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2, SA, c->cgrp[cur]);
                 if (rc < 0) return rc;
                 cur ^= 1;
@@ -1120,7 +1128,7 @@ static int bwt_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_
             // hand over: ISA from the current order
             u32 blocks = (n + WG - 1) / WG; if (blocks > 8192) blocks = 8192;
             prof_begin(c, BSCGPU_K_SEG, (u64)n * 8, n);
-            hipLaunchKernelGGL(bwt_isa_fill_kernel, dim3(blocks), dim3(WG), 0, c->stream, SA, n, smask, c->ISA);
+            hipLaunchKernelGGL(bwt_isa_fill_kernel, dim3(blocks), dim3(WG), 0, c->stream, SA, n, smask, c->ISA, first_flags ? c->flags : (const u8*)nullptr);
             prof_end(c);
             u32 fb = (U + WG - 1) / WG; if (fb > 8192) fb = 8192;
             prof_begin(c, BSCGPU_K_SEG, (u64)U * 12, U);

@@ -369,6 +369,65 @@ for plen in (13, 40):
     assert "handing over" in log or "not split" in log or "still too long" in log, log[-3000:]
 
 
+@pytest.mark.parametrize("env", [{}, {"BSC_BWT_HYBRID": "0", "BSC_BWT_ISASKIP": "0"}, {"BSC_BWT_HYBRID_PCT": "30"}],
+                         ids=["default", "no-hybrid-all-rank-stores", "hybrid-below-30pct"])
+def test_bwt_hybrid_doubling_rounds(torch_cuda, env):
+    """Prefix-doubling rounds with groups of more than 1024 records (bwt.hip: hybrid rounds — the large groups through the radix engine,
+    the rest through the segmented sort, rank stores skipped where the rank did not change).  Inputs of the two classes that need them:
+    indented source-like text over 256 symbols (runs of spaces, duplicated passages) and object-file-like data (zero runs, repeated
+    tables, noise) — synthetic and, where the image holds them, its own *.py / *.so files.  Every variant of the switches must give
+    libsais's output; the default must actually take hybrid rounds (debug log)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from libbsc_amd import GpuContext, api
+from libbsc_amd.synth import image_corpus
+from oracle.refbind import Ref
+ref = Ref()
+n = 6 << 20
+ctx = GpuContext(0, max_n=n + 4096)
+rng = np.random.default_rng(11)
+def source_like(n):
+    T = api.synth_text_v1(5, n).copy()
+    T[rng.integers(0, n, n // 300)] = rng.integers(128, 256, n // 300).astype(np.uint8)      # > 128 symbols: 8-bit codes, 8-character keys
+    for p in rng.integers(0, n - 64, n // 40):                                                # indentation: runs of 4 .. 40 spaces
+        T[p:p + int(rng.integers(4, 41))] = 32
+    for _ in range(40):                                                                       # duplicated passages (LCPs up to 60 000)
+        L = int(rng.integers(2000, 60000)); a, b = (int(x) for x in rng.integers(0, n - L, 2))
+        T[b:b + L] = T[a:a + L]
+    return T
+def object_like(n):
+    T = rng.integers(0, 256, n).astype(np.uint8)
+    for p in rng.integers(0, n - 5000, n // 2000):                                            # zero runs of 16 .. 4096 bytes
+        T[p:p + int(rng.integers(16, 4097))] = 0
+    tab = rng.integers(0, 256, 4096).astype(np.uint8)
+    for p in rng.integers(0, n - 4096, 300):                                                  # the same table many times
+        T[p:p + 4096] = tab
+    return T
+cases = [("source-like", source_like(n)), ("object-like", object_like(n))]
+for kind in ("python-source", "binary"):
+    T = image_corpus(kind, n)
+    if T is not None: cases.append((kind, T))
+for name, T in cases:
+    L, idx, _ = ctx.bwt(T)
+    wL, widx, _ = ref.bwt_encode(T, aux=False)
+    assert idx == widx and np.array_equal(L, wL), name
+    print(name, "ok", flush=True)
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, BSCGPU_DEBUG="1", **env), cwd=root)
+    log = r.stdout + r.stderr
+    assert r.returncode == 0 and "source-like ok" in log and "object-like ok" in log, log[-3000:]
+    if env.get("BSC_BWT_HYBRID") == "0":
+        assert ": hybrid," not in log, log[-3000:]
+    elif "BSC_BWT_HYBRID_PCT" not in env:
+        assert ": hybrid," in log, log[-3000:]
+
+
 @pytest.mark.parametrize("k", [3, 4, 5, 6, 7, 8])
 def test_st_matches_reference(ctx, ref, k):
     rng = np.random.default_rng(k)
