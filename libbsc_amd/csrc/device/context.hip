@@ -136,6 +136,7 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BSC_GPU_NOT_SUPPORTED;
     if (device < 0 || device >= ndev) return BSC_BAD_PARAMETER;
+    devcoder_warm_tables();                    // (a thread: the model tables are ready by the time the first block needs them)
     if (hipSetDevice(device) != hipSuccess) return BSC_GPU_ERROR;
     // waits should sleep, not spin: the host CPUs belong to the entropy coder (BSCGPU_SPIN=1 keeps the runtime's default)
     if (!getenv("BSCGPU_SPIN")) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }

@@ -191,6 +191,7 @@ int  devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32*
 const u16* devcoder_pstream_ptr(const bscgpu_ctx* c, int psbuf = 0);
 void devcoder_destroy(bscgpu_ctx* c);
 int64_t devcoder_arena_bytes(const bscgpu_ctx* c);
+void devcoder_warm_tables();               // starts the model tables' computation on a background thread (first context of the process)
 
 // ---------------------------------------------------------------------------------------------
 // Device helpers (wave64)

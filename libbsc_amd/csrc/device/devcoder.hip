@@ -28,6 +28,8 @@
 // handles exactly (more than 256 distinct decision types in a block, an avg_rank bracket that does not decide, capacity),
 // a flag is raised and the caller falls back to the host model; nothing approximate is ever emitted.
 #include "dev_common.h"
+#include <thread>
+#include <system_error>
 #include "devcoder_model.h"
 #include "../host/qlfc.h"
 #include <cstdio>
@@ -1045,6 +1047,30 @@ void devcoder_destroy(bscgpu_ctx* c)
 }
 
 
+// The two parameter sets with their attainable-value closures: function-local statics, so whoever comes first computes them and
+// everybody else waits for that.
+static const ModelParams& dc_model_static()
+{
+    static const ModelParams mp = [] { ModelParams m; model_params_from_table(bschost::qlfc_static_params(), m); return m; }();
+    return mp;
+}
+static const ModelParams& dc_model_fast()
+{
+    static const ModelParams mpf = [] { ModelParams m; model_params_fast(m); return m; }();
+    return mpf;
+}
+// Called at the top of the process's first bscgpu_create: the ~60 ms of closure computation run beside the ~190 ms the HIP runtime
+// takes to come up, instead of in front of the first block (a file of a few dozen blocks is done in about a second: bsc_mgpu, the CLI).
+void devcoder_warm_tables()
+{
+    struct Warm {
+        std::thread th;
+        Warm() { try { th = std::thread([] { (void)dc_model_static(); (void)dc_model_fast(); }); } catch (const std::system_error&) {} }
+        ~Warm() { if (th.joinable()) th.join(); }
+    };
+    static Warm warm;
+}
+
 int devcoder_ensure(bscgpu_ctx* c)
 {
     if (c->dc) return BSC_NO_ERROR;
@@ -1082,9 +1108,10 @@ int devcoder_ensure(bscgpu_ctx* c)
     size_t off = 0;
     for (auto& cv : carve) { *cv.p = d->arena + off; off += dc_align(cv.bytes); }
     if (hipHostMalloc((void**)&d->hmeta, 64 * 4, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); hipFree(d->arena); delete d; c->dc_alloc_failed = true; return BSC_NOT_SUPPORTED; }
-    // (once per process: the attainable-range closures behind the brackets take ~60 ms to compute, and every context needs the same tables)
-    static const ModelParams mp = [] { ModelParams m; model_params_from_table(bschost::qlfc_static_params(), m); return m; }();
-    static const ModelParams mpf = [] { ModelParams m; model_params_fast(m); return m; }();
+    // (once per process: the attainable-range closures behind the brackets take ~60 ms to compute, and every context needs the same tables;
+    // devcoder_warm_tables starts them on a thread of their own while the first context is still being created)
+    const ModelParams& mp = dc_model_static();
+    const ModelParams& mpf = dc_model_fast();
     // more than 64 KB of dynamic LDS is a per-device attribute of the function: set for every context's device
     if (hipFuncSetAttribute((const void*)dc_eval_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DC_EVAL_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void*)dc_eval_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DC_EVAL_LDS) != hipSuccess) {
