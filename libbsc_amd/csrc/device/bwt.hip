@@ -225,6 +225,7 @@ constexpr int DS_NLONG = 5, DS_EXCESS = 6;                        // dscal slots
 // The same two counts for groups of more than HY_G records (hybrid doubling rounds, bwt_longrec_kernel): the segmented sort ranks a record by
 // counting inside its group — s comparisons per record of a group of s —, the radix engine costs ~50 ps per record whatever the group.
 constexpr int HY_G = 256, DS_NMID = 3, DS_MIDEXCESS = 4;
+constexpr int DS_LRTOTAL = 7;                                     // what a hybrid round's extraction really found (must equal the host's count)
 
 // seg phase B: one workgroup scans the <= 1024 chunk summaries.
 //   segoff[c]            = exclusive sum of unsorted counts
@@ -570,8 +571,9 @@ __global__ __launch_bounds__(WG) void bwt_longrec_kernel(const u32* __restrict__
     }
 }
 
-// one workgroup: off[c] = exclusive sum of cnt[0..c)
-__global__ __launch_bounds__(WG) void bwt_longrec_scan_kernel(const u32* __restrict__ cnt, u32 num_chunks, u32* __restrict__ off)
+// one workgroup: off[c] = exclusive sum of cnt[0..c); *total = their sum (the host sized the round's radix sort from seg_apply's counts:
+// the two numbers are compared after the round, a difference fails the transform instead of leaving a wrong order behind)
+__global__ __launch_bounds__(WG) void bwt_longrec_scan_kernel(const u32* __restrict__ cnt, u32 num_chunks, u32* __restrict__ off, u32* __restrict__ total)
 {
     __shared__ u32 scr[8];
     u32 carry = 0;
@@ -583,6 +585,7 @@ __global__ __launch_bounds__(WG) void bwt_longrec_scan_kernel(const u32* __restr
         if (i < num_chunks) off[i] = carry + ex;
         carry += tot;
     }
+    if (threadIdx.x == 0) *total = carry;
 }
 
 // the j-th sorted long record goes where the j-th extracted one came from, with the key format of the round's other records
@@ -945,7 +948,7 @@ static int run_seg(bscgpu_ctx* c, const u64* keys, const u32* sa_sorted, const u
                        SA, c->ISA, cpos_out, csa_out, cgrp_out, c->dscal);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->hscal, c->dscal, (DS_EXCESS + 1) * 4, hipMemcpyDeviceToHost, c->stream));   // U, (slots of other kernels), long groups, excess
+    HIP_TRY(c, hipMemcpyAsync(c->hscal, c->dscal, (DS_LRTOTAL + 1) * 4, hipMemcpyDeviceToHost, c->stream));  // U, (slots of other kernels), group counts, a hybrid round's extracted records
     HIP_TRY(c, ctx_sync(c));
     prof_collect(c);
     *U_out = c->hscal[0];
@@ -1171,7 +1174,7 @@ static int bwt_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_
             prof_begin(c, BSCGPU_K_GATHER, (u64)U * 16 + (u64)UL * (4 + 4 + 4 + 8 + 4), U);
             hipLaunchKernelGGL(bwt_longrec_kernel<false>, dim3(lc.num_chunks), dim3(WG), 0, c->stream, c->cpos[cur], c->csa[cur], c->cgrp[cur], c->ISA,
                                U, h, (u64)n, lo_bits, smask, lc.chunk_tiles, lc.num_tiles, c->segsum, lidx, c->kA, c->vA);
-            hipLaunchKernelGGL(bwt_longrec_scan_kernel, dim3(1), dim3(WG), 0, c->stream, c->segsum, lc.num_chunks, c->segoff);
+            hipLaunchKernelGGL(bwt_longrec_scan_kernel, dim3(1), dim3(WG), 0, c->stream, c->segsum, lc.num_chunks, c->segoff, c->dscal + DS_LRTOTAL);
             hipLaunchKernelGGL(bwt_longrec_kernel<true>, dim3(lc.num_chunks), dim3(WG), 0, c->stream, c->cpos[cur], c->csa[cur], c->cgrp[cur], c->ISA,
                                U, h, (u64)n, lo_bits, smask, lc.chunk_tiles, lc.num_tiles, c->segoff, lidx, c->kA, c->vA);
             prof_end(c);
@@ -1220,6 +1223,7 @@ static int bwt_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_
         static const int isa_skip = [] { const char* e = getenv("BSC_BWT_ISASKIP"); return e ? atoi(e) : 1; }();
         rc = run_seg<false, true>(c, ks, vs, c->cpos[cur], U, 0, smask, c->cpos[cur ^ 1], c->csa[cur ^ 1], c->cgrp[cur ^ 1], &U2, SA, nullptr, isa_skip ? lo_bits : 0);
         if (rc < 0) return rc;
+        if (hybrid && c->hscal[DS_LRTOTAL] != n_mid_rec) return ctx_fail(c, BSC_GPU_ERROR, "hybrid round: extracted records differ from the counted ones", hipSuccess);
         cur ^= 1;
         if (dbg) fprintf(stderr, "[bwt] round %d h=%llu U %u -> %u (passes %d)  (%.2f ms)\n", rounds, (unsigned long long)h, U, U2, np, lap());
         U = U2;
