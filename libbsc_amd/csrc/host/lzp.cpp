@@ -18,6 +18,8 @@
 #include <thread>
 #include "par.h"
 #include <vector>
+#include <memory>
+#include <new>
 
 #include "qlfc.h"
 #include "lzp.h"
@@ -225,11 +227,13 @@ int lzp_compress(const uint8_t* in, uint8_t* out, int n, int hashSize, int minLe
     const int chunk = n / nc;
     if (features & 2 /* LIBBSC_FEATURE_MULTITHREADING */) {
         // concurrent chunks, each with a budget of its own size (lzp.cpp:736-790)
-        std::vector<uint8_t> tmp((size_t)n);
+        std::unique_ptr<uint8_t[]> tmp_buf(new (std::nothrow) uint8_t[(size_t)n]);        // (not a vector: no reason to zero 64 MiB per block first)
+        if (!tmp_buf) return NOT_ENOUGH_MEMORY;
+        uint8_t* const tmp = tmp_buf.get();
         int res[8];
         run_tasks(nc, [&](int b) {
             const int st = b * chunk, sz = (b != nc - 1) ? chunk : n - st;
-            const int r = lzp_encode_chunk(in + st, sz, tmp.data() + st, sz, hashSize, minLen);
+            const int r = lzp_encode_chunk(in + st, sz, tmp + st, sz, hashSize, minLen);
             res[b] = (r < 0) ? sz : r;
         });
         int64_t total = 1 + 8 * nc;
@@ -240,7 +244,7 @@ int lzp_compress(const uint8_t* in, uint8_t* out, int n, int hashSize, int minLe
         for (int b = 0; b < nc; ++b) {
             const int st = b * chunk, sz = (b != nc - 1) ? chunk : n - st;
             put_le32(out + 1 + 8 * b, sz); put_le32(out + 1 + 8 * b + 4, res[b]);
-            memcpy(out + optr, (res[b] != sz) ? tmp.data() + st : in + st, (size_t)res[b]);
+            memcpy(out + optr, (res[b] != sz) ? tmp + st : in + st, (size_t)res[b]);
             optr += res[b];
         }
         return optr;
