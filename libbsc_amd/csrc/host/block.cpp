@@ -737,7 +737,7 @@ static int stage_host_lzp(BlockJob& J, const unsigned char* input, unsigned char
     int lzSize = n;
     J.lz.reset();
     if (mode != (mode & 0xff)) {
-        J.lz = std::unique_ptr<unsigned char, void (*)(void*)>((unsigned char*)bsc_malloc((size_t)n), bsc_free);
+        J.lz = std::unique_ptr<unsigned char, void (*)(void*)>((unsigned char*)bigbuf_get((size_t)n), bigbuf_put);   // (par.h: a few block-sized buffers are kept)
         if (!J.lz) return LIBBSC_NOT_ENOUGH_MEMORY;
         const int r = lzp_compress(input, J.lz.get(), n, lzpHashSize, lzpMinLen, features);
         if (r < LIBBSC_NO_ERROR) { mode &= 0xff; J.lz.reset(); }            // libbsc.cpp:266-269: the block goes on without LZP

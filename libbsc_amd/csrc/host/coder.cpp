@@ -90,9 +90,11 @@ static int compress_parallel(const uint8_t* in, uint8_t* out, int n, int coder)
     const int nblocks = coder_num_blocks(n);
     int start[8], size[8], res[8];
     coder_split_blocks(in, n, nblocks, start, size);
-    std::vector<uint8_t> scratch((size_t)n + 64);
+    std::unique_ptr<uint8_t, void (*)(void*)> scratch_buf((uint8_t*)bigbuf_get((size_t)n + 64), bigbuf_put);      // (not zeroed, not a fresh mapping per call)
+    if (!scratch_buf) return NOT_ENOUGH_MEMORY;
+    uint8_t* const scratch = scratch_buf.get();
     run_tasks(nblocks, [&](int b) {
-        int r = qlfc_encode_block(in + start[b], scratch.data() + start[b], size[b], size[b], coder);
+        int r = qlfc_encode_block(in + start[b], scratch + start[b], size[b], size[b], coder);
         res[b] = (r < 0) ? size[b] : r;                     // failed sub-block is stored raw (coder.cpp:194)
     });
     int total = 1 + 8 * nblocks;
@@ -104,7 +106,7 @@ static int compress_parallel(const uint8_t* in, uint8_t* out, int n, int coder)
     for (int b = 0; b < nblocks; ++b) {
         put_i32(out + 1 + 8 * b, size[b]);
         put_i32(out + 1 + 8 * b + 4, res[b]);
-        memcpy(out + optr, (res[b] != size[b] ? scratch.data() : in) + start[b], (size_t)res[b]);
+        memcpy(out + optr, (res[b] != size[b] ? scratch : in) + start[b], (size_t)res[b]);
         optr += res[b];
     }
     return total;

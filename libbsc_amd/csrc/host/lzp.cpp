@@ -19,6 +19,7 @@
 #include "par.h"
 #include <vector>
 #include <memory>
+#include <mutex>
 #include <new>
 
 #include "qlfc.h"
@@ -183,6 +184,57 @@ int narrow_guard(int minLen)
 
 }  // namespace
 
+// ---- bigbuf: see par.h ----------------------------------------------------------------------------------------------------------------
+namespace {
+struct BigBuf { void* p; size_t cap; bool used; };
+struct BigBufCache {
+    std::mutex mu;
+    std::vector<BigBuf> all;                     // buffers handed out (used) and idle ones
+    const bool on = [] { const char* e = getenv("BSC_HOST_BUFFER_CACHE"); return e ? atoi(e) != 0 : true; }();
+    ~BigBufCache() { for (auto& b : all) if (!b.used) free(b.p); }      // (a buffer still handed out at exit belongs to its holder)
+};
+BigBufCache& bigbufs() { static BigBufCache c; return c; }
+constexpr size_t BIG_MIN = (size_t)1 << 20, BIG_IDLE_MAX = 8, BIG_IDLE_BYTES = (size_t)1 << 30;
+}  // namespace
+
+void* bigbuf_get(size_t bytes)
+{
+    BigBufCache& C = bigbufs();
+    if (!C.on || bytes < BIG_MIN) return malloc(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> lk(C.mu);
+        BigBuf* best = nullptr;
+        for (auto& b : C.all)
+            if (!b.used && b.cap >= bytes && b.cap / 4 <= bytes && (!best || b.cap < best->cap)) best = &b;     // (no 1 GiB buffer for a 2 MiB request)
+        if (best) { best->used = true; return best->p; }
+    }
+    const size_t cap = bytes + bytes / 16 + 4096;                     // the next block is rarely exactly this long
+    void* p = malloc(cap);
+    if (!p) return nullptr;
+    std::lock_guard<std::mutex> lk(C.mu);
+    C.all.push_back(BigBuf{p, cap, true});
+    return p;
+}
+
+void bigbuf_put(void* p)
+{
+    if (!p) return;
+    BigBufCache& C = bigbufs();
+    {
+        std::lock_guard<std::mutex> lk(C.mu);
+        size_t idle = 0, idle_bytes = 0; long at = -1;
+        for (size_t i = 0; i < C.all.size(); ++i) {
+            if (C.all[i].p == p) at = (long)i;
+            else if (!C.all[i].used) { ++idle; idle_bytes += C.all[i].cap; }
+        }
+        if (at >= 0) {
+            if (idle < BIG_IDLE_MAX && idle_bytes + C.all[(size_t)at].cap <= BIG_IDLE_BYTES) { C.all[(size_t)at].used = false; return; }
+            C.all.erase(C.all.begin() + at);                           // enough idle ones already: this one goes back to the system
+        }
+    }
+    free(p);                                                            // (also: a small request that never entered the cache)
+}
+
 int lzp_num_chunks(int n)                                   // lzp.cpp:44-51
 {
     if (n < 256 * 1024) return 1;
@@ -227,7 +279,7 @@ int lzp_compress(const uint8_t* in, uint8_t* out, int n, int hashSize, int minLe
     const int chunk = n / nc;
     if (features & 2 /* LIBBSC_FEATURE_MULTITHREADING */) {
         // concurrent chunks, each with a budget of its own size (lzp.cpp:736-790)
-        std::unique_ptr<uint8_t[]> tmp_buf(new (std::nothrow) uint8_t[(size_t)n]);        // (not a vector: no reason to zero 64 MiB per block first)
+        std::unique_ptr<uint8_t, void (*)(void*)> tmp_buf((uint8_t*)bigbuf_get((size_t)n), bigbuf_put);   // (not a zeroed vector, not a fresh mapping per block)
         if (!tmp_buf) return NOT_ENOUGH_MEMORY;
         uint8_t* const tmp = tmp_buf.get();
         int res[8];

@@ -5,6 +5,7 @@
 // on the calling thread instead, so the result is the same and only the parallelism degrades.  The last task always
 // runs on the caller (one thread fewer to create).
 #pragma once
+#include <cstddef>
 #include <system_error>
 #include <thread>
 #include <vector>
@@ -25,5 +26,11 @@ inline void run_tasks(int n, F&& fn)
     for (int b = next; b < n; ++b) fn(b);
     for (auto& t : pool) t.join();
 }
+
+// Block-sized scratch that lives for one block (the LZP output, the staging area of the parallel LZP encoder).  A fresh allocation of that
+// size is an mmap per block: 16 K page faults and 64 MiB of page zeroing each time, under the process's mmap lock with thirty threads around.
+// A few idle buffers are kept instead (lzp.cpp; at most 8 and 1 GiB, BSC_HOST_BUFFER_CACHE=0: none).  Plain malloc / free underneath.
+void* bigbuf_get(size_t bytes);          // nullptr: out of memory
+void  bigbuf_put(void* p);               // nullptr is fine
 
 }  // namespace bschost
