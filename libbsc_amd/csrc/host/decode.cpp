@@ -270,8 +270,10 @@ int bsc_decompress(const unsigned char* input, int inputSize, unsigned char* out
                                                 : bsc_st_decode(output, lzSize, sorter, index, features);
     if (rc < LIBBSC_NO_ERROR) return rc;
     if (lzpHashSize != 0 || lzpMinLen != 0) {                  // undo LZP (libbsc.cpp:594-609); encoding it is not built (f3)
-        std::vector<unsigned char> tmp(output, output + lzSize);
-        const int r = lzp_decompress(tmp.data(), output, lzSize, dataSize, lzpHashSize, lzpMinLen);
+        std::unique_ptr<unsigned char, void (*)(void*)> tmp((unsigned char*)bschost::bigbuf_get((size_t)lzSize + 1), bschost::bigbuf_put);   // (par.h: kept buffers)
+        if (!tmp) return LIBBSC_NOT_ENOUGH_MEMORY;
+        memcpy(tmp.get(), output, (size_t)lzSize);
+        const int r = lzp_decompress(tmp.get(), output, lzSize, dataSize, lzpHashSize, lzpMinLen);
         if (r < LIBBSC_NO_ERROR) return r;
         if (r != dataSize) return LIBBSC_DATA_CORRUPT;
     } else if (lzSize != dataSize) return LIBBSC_DATA_CORRUPT;
