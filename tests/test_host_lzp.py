@@ -92,3 +92,28 @@ def test_lzp_golden_vectors_eight_chunks():
         got = api.bsc_lzp_compress(T, e["hash"], e["minlen"], features=e["features"])
         assert len(got) == e["size"] and hashlib.md5(got).hexdigest() == e["md5"], e
         assert api.bsc_lzp_decompress(got, T.size, e["hash"], e["minlen"]) == T.tobytes()
+
+
+def test_lzp_concurrent_callers_share_the_kept_buffers(ref):
+    """The parallel framing stages its chunks in a block-sized buffer that is kept between calls (par.h: bigbuf_get / bigbuf_put, one
+    cache per process).  Eight threads compress and restore blocks of different sizes at the same time (ctypes releases the GIL): every
+    result must be the reference's, whoever had the buffer before."""
+    import threading
+    blocks = [synth_repeat_v1(20 + k, (1 << 20) + k * 300_001, 20_000 + 1000 * k) for k in range(6)]
+    want = [ref.lzp_compress(T, 15, 32, features=3) for T in blocks]
+    errors = []
+
+    def worker(t):
+        try:
+            for it in range(12):
+                k = (t + it) % len(blocks)
+                got = api.bsc_lzp_compress(blocks[k], 15, 32, features=3)
+                assert got == want[k], (t, it, k)
+                assert api.bsc_lzp_decompress(got, blocks[k].size, 15, 32) == blocks[k].tobytes(), (t, it, k)
+        except Exception as e:                  # noqa: BLE001 - reported by the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads: th.start()
+    for th in threads: th.join()
+    assert not errors, errors[:3]
