@@ -383,11 +383,19 @@ def main():
     # what leaves this rank's GPU over PCIe in the timed region: 16 bits per binary decision of the device model (run arrays instead
     # for blocks on the host model: not counted) + nothing else of size (the input is resident, the sorted block never crosses);
     # the host's DRAM sees those bytes twice (DMA write, coder read) — with 8 ranks per node this, not xGMI, is the shared resource
-    decisions = stats.get("dc_pstream", {}).get("records", 0)
-    d2h_bytes = 2.0 * decisions
+    # (decisions per block from the p-stream kernel's own launches: the profile of the timed region folds a launch in at the context's next
+    # sync, so its SUM misses the blocks still in flight at the end — round 4's line said 256.6 MB per block at 20 steps for that reason,
+    # where every block of this workload has 183.2 M decisions = 366.4 MB)
+    dps = stats.get("dc_pstream", {})
+    decisions_per_block = dps.get("records", 0) / max(dps.get("launches", 0), 1)
+    d2h_bytes = 2.0 * decisions_per_block * args.steps
     mine = {"rank": rank, "verified": verified, "gpu_stage_total_ms": round(float(stage[0] + stage[1] + stage[2]) / args.steps, 2),
             "pcie_d2h_MBps": round(d2h_bytes / 1e6 / dt, 1), "pcie_d2h_MB_per_block": round(d2h_bytes / 1e6 / args.steps, 1),
             "host_dram_MBps_estimate": round(2 * d2h_bytes / 1e6 / dt, 1),
+            # host DRAM traffic of one block (8 ranks per node share the host's memory system, not xGMI): the p stream is written once by the
+            # DMA engine and read once by the range coder; the compressed block is written once; a host-resident input is read once for the H2D
+            "host_dram_bytes_per_block": {"pstream_dma_write": int(2 * decisions_per_block), "pstream_coder_read": int(2 * decisions_per_block),
+                                          "compressed_block_write": int(blk.size), "input_read_for_h2d": int(n if (lzp[0] or host_leg[0]) else 0)},
             "sorter_only_MBps": round(n / 1e6 / max(stage[1] / args.steps / 1e3, 1e-9), 1),
             "cpu_seconds_per_block": round(cpu_used / args.steps, 3), "coder_threads": coder_threads,
             "effective_cpus_of_process": effective_cpus()}

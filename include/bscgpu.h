@@ -144,6 +144,14 @@ typedef struct bscgpu_job bscgpu_job;
 BSCGPU_API int  bscgpu_job_create(bscgpu_job** job, const int* devices, int ndevices, int contexts_per_device, int depth, int64_t max_block_bytes);
 BSCGPU_API int  bscgpu_job_add(bscgpu_job* job, const uint8_t* input, uint8_t* output, int n, int lzpHashSize, int lzpMinLen,
                                int blockSorter, int coder, int features);
+/* Optional: how many blocks the job will have in all (a file's block count).  With the total known the job's LAST blocks are handled
+ * for latency instead of throughput — the drain of the pipeline is the caller's time: the k-th context of a device takes a block only
+ * while more than k x devices are left (the GPU stages of the tail end one after the other and their host coding overlaps the GPU work
+ * still to come, instead of all contexts finishing one last block each in a burst), and the last (devices x contexts) blocks are
+ * submitted with BSCGPU_FEATURE_LOW_LATENCY.  Adding more blocks than announced is allowed (the rule is dropped).  Independently of
+ * this call the START of a job (and of every later burst, when the caller had let the job run dry) is tapered: a first context begins,
+ * the k-th context of a device joins once k GPU stages of the burst have finished there. */
+BSCGPU_API int  bscgpu_job_expect(bscgpu_job* job, int total_blocks);
 BSCGPU_API int  bscgpu_job_wait(bscgpu_job* job, int block);
 /* which worker (= pipe; return value) on which device took the block — known once a worker has claimed it */
 BSCGPU_API int  bscgpu_job_block_worker(bscgpu_job* job, int block, int* device);

@@ -154,19 +154,31 @@ def build(force=False, verbose=True, asan=False):
 
 DRIVER_SRC = os.path.join(CSRC, "driver", "bsc_mgpu.cpp")
 DRIVER_EXE = os.path.join(HERE, "lib", "bsc_mgpu")
+JOB_BENCH_SRC = os.path.join(os.path.dirname(HERE), "tools", "job_bench.cpp")
+JOB_BENCH_EXE = os.path.join(HERE, "lib", "job_bench")
 
 
 def _build_driver(force):
     """the multi-GPU file compressor (csrc/driver/bsc_mgpu.cpp): plain C++ over include/*.h, linked against the library next to it"""
     if not os.path.exists(DRIVER_SRC):
         return
-    if not force and os.path.exists(DRIVER_EXE) and os.path.getmtime(DRIVER_EXE) >= max(os.path.getmtime(DRIVER_SRC), os.path.getmtime(LIB)):
+    srcs = [DRIVER_SRC, LIB] + ([JOB_BENCH_SRC] if os.path.exists(JOB_BENCH_SRC) else [])
+    exes = [DRIVER_EXE] + ([JOB_BENCH_EXE] if os.path.exists(JOB_BENCH_SRC) else [])
+    if not force and all(os.path.exists(e) for e in exes) and min(os.path.getmtime(e) for e in exes) >= max(os.path.getmtime(x) for x in srcs):
         return
     cmd = [GXX, "-O2", "-std=c++17", "-I", INCLUDE, DRIVER_SRC, "-L", os.path.dirname(LIB), "-lbsc_mi355x",
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-o", DRIVER_EXE]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("driver build failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    # tools/job_bench.cpp: bench.py's workload through bscgpu_job_* alone (a C caller of the product's C ABI); built next to the library so
+    # that it travels to the GPU box
+    if os.path.exists(JOB_BENCH_SRC):
+        cmd = [GXX, "-O2", "-std=c++17", "-I", INCLUDE, JOB_BENCH_SRC, "-L", os.path.dirname(LIB), "-lbsc_mi355x",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-o", JOB_BENCH_EXE]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("job_bench build failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
 
 
 if __name__ == "__main__":

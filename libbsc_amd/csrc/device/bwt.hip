@@ -278,6 +278,10 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
     __shared__ u32 cstage[3 * SEG_TILE];            // SA slot, suffix, group rank of the tile's unsorted records
     __shared__ u32 slong[4];
     const u32 t = threadIdx.x;
+    // A single-read digit pass in front of this seg gave up a wait (radix_onesweep.hip): its output is in bounds but not sorted, and the
+    // workgroups that stopped claiming tiles left stale records behind — suffix numbers that, masked, can exceed n.  Nothing of that may
+    // be scattered into SA / ISA (the host finds the word raised right after this launch and redoes the transform).
+    if (dscal[OS_ERR_SLOT] != 0u) return;
     if (t < 4) slong[t] = 0;
     u32 n_long = 0, n_excess = 0, n_mid = 0, n_midx = 0;
     const u32 tile0 = blockIdx.x * chunk_tiles;
@@ -967,7 +971,9 @@ int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64
     if (rc == BSC_GPU_ERROR && c->os_gave_up) {
         const int mode = c->os_mode;
         c->os_mode = 0; c->os_gave_up = false; ++c->os_retries;
-        rc = bwt_device_once(c, dT_user, dL_user, n64, r, I_host, primary_out, true);
+        // (the text is copied again: the caller's buffer is untouched until the last kernel of a transform, while the private copy may
+        // not be — kernels that consume a failed sort's output run before the check, on stale keys and values: see seg_apply_kernel)
+        rc = bwt_device_once(c, dT_user, dL_user, n64, r, I_host, primary_out, false);
         c->os_mode = mode;
     }
     return rc;

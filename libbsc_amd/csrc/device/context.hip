@@ -13,6 +13,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 
 int ctx_fail(bscgpu_ctx* c, int code, const char* what, hipError_t e)
 {
@@ -61,6 +62,8 @@ int ctx_ensure_slots(bscgpu_ctx* c, int count)
 // anonymous mapping with transparent huge pages, first-touched by eight threads (2.5 ms; zeroing pages is the cost, 14 ms on one
 // thread) and then hipHostRegister'ed (0.7 ms) copies at the same 57 GB/s (tools/startup_probe.cpp, profiles/r04/startup_probe.txt).
 static constexpr size_t PIN_ALIGN = (size_t)2 << 20;
+static std::mutex g_hostmalloc_mu;
+static std::vector<void*> g_hostmalloc;          // landing zones that came from hipHostMalloc (registration refused): freed accordingly
 static void* pinned_alloc(size_t bytes)
 {
     CtxTimer tm("pinned landing zone");
@@ -82,12 +85,26 @@ static void* pinned_alloc(size_t bytes)
     }
     for (int k = started; k < nth; ++k) touch(k);
     for (auto& t : th) t.join();
-    if (hipHostRegister(m, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); munmap(m, bytes); return nullptr; }
-    return m;
+    static const bool refuse = getenv("BSC_PIN_REGISTER_FAIL") != nullptr;                          // tests: a platform that refuses the registration
+    if (!refuse && hipHostRegister(m, bytes, hipHostRegisterDefault) == hipSuccess) return m;
+    // Registration refused (RLIMIT_MEMLOCK, a container without large-page registration, other THP settings): the runtime's own pinned
+    // allocation — slower to get (50-60 ms), but the block keeps its landing zone instead of failing outright.
+    (void)hipGetLastError();
+    munmap(m, bytes);
+    void* h = nullptr;
+    if (hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (ctx_timing_on()) fprintf(stderr, "[bscgpu] hipHostRegister refused %zu bytes: hipHostMalloc instead\n", bytes);
+    { std::lock_guard<std::mutex> g(g_hostmalloc_mu); g_hostmalloc.push_back(h); }
+    return h;
 }
 static void pinned_free(void* p, size_t bytes)
 {
     if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_hostmalloc_mu);
+        for (size_t i = 0; i < g_hostmalloc.size(); ++i)
+            if (g_hostmalloc[i] == p) { g_hostmalloc[i] = g_hostmalloc.back(); g_hostmalloc.pop_back(); (void)hipHostFree(p); return; }
+    }
     (void)hipHostUnregister(p);
     munmap(p, align_up(bytes, PIN_ALIGN));
 }

@@ -109,6 +109,7 @@ int main(int argc, char** argv)
     bscgpu_job* job = nullptr;
     int rc = bscgpu_job_create(&job, devs.data(), ndev, contexts, depth, max_block);
     if (rc != LIBBSC_NO_ERROR) { fprintf(stderr, "bscgpu_job_create: %d\n", rc); return 1; }
+    (void)bscgpu_job_expect(job, nblocks);                    // a file's block count is known: the job tapers its tail and marks the last blocks low-latency
 
     // Three roles around the job, so that none of them waits for the others' system calls: READERS fill block buffers straight from the
     // file (pread: a 64 MiB block costs 15-25 ms of page-cache copy and page faults, which one thread in front of the GPUs cannot

@@ -942,9 +942,14 @@ static CoderPool* pool_acquire()
     if (!g_pool) {
         CtxTimer tm("coder pool threads");
         CoderPool* P = new CoderPool;
-        int nworkers = default_coder_threads();
-        if (const char* e = getenv("BSCGPU_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) nworkers = v; }
-        P->budget = nworkers < default_coder_threads() ? nworkers : default_coder_threads();
+        // Half as many threads again as CPUs (round 5: the library's default, as bench.py had been setting it since round 3): threads are
+        // cheap, a task spends part of its life waiting for its sub-blocks' copy from the GPU, and the idle test behind the task shapes
+        // counts against the CPU budget, not against the threads.
+        const int cpus = default_coder_threads();
+        int nworkers = (3 * cpus + 1) / 2; if (nworkers > 96) nworkers = 96;
+        bool forced = false;
+        if (const char* e = getenv("BSCGPU_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) { nworkers = v; forced = true; } }
+        P->budget = (forced && nworkers < cpus) ? nworkers : cpus;
         if (const char* e = getenv("BSCGPU_HOST_CPUS")) { int v = atoi(e); if (v >= 1 && v <= 256) P->budget = v; }
         for (int i = 0; i < nworkers; ++i) P->workers.emplace_back([P] { P->worker_loop(); });
         g_pool = P;
@@ -987,6 +992,7 @@ static void lane_join(bscgpu_pipe* p, bscgpu_pipe::Lane& L)
         if (hipSetDevice(p->c->device) == hipSuccess) redo_on_host_model(*L.job);
         else L.job->result = LIBBSC_GPU_ERROR;
     }
+    L.job->lz.reset();                              // a device-model block kept its LZP output for that redo only: a lane must not sit on a block-sized buffer until its next block
 }
 
 int bscgpu_pipe_create(bscgpu_ctx* c, int depth, bscgpu_pipe** out)

@@ -37,6 +37,8 @@ struct Block {
 struct Job;
 struct Worker {
     Job* job = nullptr; int id = 0, device = 0;
+    int dev_index = 0, ordinal = 0;      // index of the device in the job's list; this worker is the device's ordinal-th context
+    unsigned burst_seen = ~0u;           // the burst (see Job::burst) this worker last took a block in
     void* ctx = nullptr; void* pipe = nullptr;
     std::thread th;
     int setup_rc = 0; bool ready = false;
@@ -53,6 +55,30 @@ struct Job {
     size_t next = 0;                    // first block nobody has taken yet
     bool closing = false;
     std::vector<Worker> workers;
+    int ndev = 1;
+    long long expected = -1;            // blocks the caller has announced (bscgpu_job_expect); -1: unknown
+    std::vector<unsigned> stages_done;  // per device: GPU stages (submits) that have returned in the current burst
+    size_t active = 0;                  // blocks taken and not finished yet
+    unsigned burst = 0;                 // a burst begins when a block is taken while nothing is in flight anywhere (job start, or the caller let it run dry)
+
+    // Which blocks a worker may take (caller holds mu).  Steady state wants every context busy — kernels of different blocks interleave on
+    // a GPU —, the two ENDS of a job do not (measured with bench.py's block queue, rounds 3-4):
+    //   head  all contexts of a GPU starting at once interleave their first GPU stages, which then end together after contexts x 13 ms
+    //         while the coder threads idle: a burst is begun by a first context, and the k-th context of a device joins it once k GPU
+    //         stages of the burst have finished there;
+    //   tail  contexts that each hold one of the last blocks finish them in one burst, and the host coding of all of them is left for
+    //         the end: with the total announced, the k-th context of a device takes a block only while more than k x devices are left
+    //         (the last block of the job goes to a first context alone, the last 2 x devices to first and second contexts, ...).
+    bool may_take(const Worker& w) const
+    {
+        if (next >= blocks.size()) return false;
+        if (!closing) {
+            if (active == 0) { if (w.ordinal != 0) return false; }
+            else if (w.burst_seen != burst && stages_done[(size_t)w.dev_index] < (unsigned)w.ordinal) return false;
+        }
+        if (expected >= 0 && (long long)blocks.size() <= expected && expected - (long long)next <= (long long)w.ordinal * ndev) return false;
+        return true;
+    }
 
     void run(Worker& w);
 };
@@ -61,7 +87,10 @@ void Job::run(Worker& w)
 {
     // the worker owns its context and pipe: created here so that context creation (arena, pinned buffers) runs in parallel over devices
     int rc = be.ctx_create(be.user, &w.ctx, w.device, max_block);
-    if (rc == LIBBSC_NO_ERROR) rc = be.pipe_create(be.user, w.ctx, depth, &w.pipe);
+    if (rc == LIBBSC_NO_ERROR) {
+        rc = be.pipe_create(be.user, w.ctx, depth, &w.pipe);
+        if (rc != LIBBSC_NO_ERROR) { w.pipe = nullptr; be.ctx_destroy(be.user, w.ctx); w.ctx = nullptr; }     // a failed set-up leaves nothing behind
+    } else w.ctx = nullptr;
     { std::lock_guard<std::mutex> lk(mu); w.setup_rc = rc; w.ready = true; }
     cv_ready.notify_all();
     if (rc != LIBBSC_NO_ERROR) return;
@@ -70,29 +99,45 @@ void Job::run(Worker& w)
     auto retire = [&] {
         const auto [ticket, b] = inflight.front(); inflight.pop_front();
         const int res = be.pipe_wait(be.user, w.pipe, ticket);
-        { std::lock_guard<std::mutex> lk(mu); blocks[b].result = res; blocks[b].done = true; }
+        bool idle;
+        { std::lock_guard<std::mutex> lk(mu); blocks[b].result = res; blocks[b].done = true; idle = --active == 0; }
         cv_done.notify_all();
+        if (idle) cv_work.notify_all();                       // the next burst is a first context's to begin
     };
     for (;;) {
-        size_t b = 0; bool have = false; Block* Bp = nullptr;
+        // Room first, then a claim: a worker that claimed with `depth` blocks in flight would sit on a block no idle worker can take
+        // while it waits for its own oldest one (the tail of a job, uneven block times).
+        if ((int)inflight.size() == depth) { retire(); continue; }
+        size_t b = 0; bool have = false; Block* Bp = nullptr; int features = 0;
         {
             std::unique_lock<std::mutex> lk(mu);
             // with blocks of its own in flight a worker never sleeps on the queue: their results must reach the collector
-            if (inflight.empty()) cv_work.wait(lk, [&] { return closing || next < blocks.size(); });
+            // (closing = no more blocks will be added; what is still queued is processed, by the contexts the tail rule leaves it to)
+            const auto all_taken = [&] { return closing && next >= blocks.size(); };
+            if (inflight.empty()) cv_work.wait(lk, [&] { return all_taken() || may_take(w); });
             // (the element's address is taken under the lock: a deque never moves its elements on push_back, but indexing it while
             // another thread appends is a race on its block map)
-            if (next < blocks.size()) { b = next++; Bp = &blocks[b]; Bp->worker = w.id; have = true; ++w.blocks; }
-            else if (inflight.empty()) break;             // closing and nothing left
+            if (may_take(w)) {
+                if (active == 0) { ++burst; for (auto& sd : stages_done) sd = 0; }
+                ++active; w.burst_seen = burst;
+                b = next++; Bp = &blocks[b]; Bp->worker = w.id; have = true; ++w.blocks;
+                features = Bp->features;
+                // the job's last blocks: short host tasks whatever the coder pool's load — the drain of the pipeline is the caller's time
+                if (expected >= 0 && (long long)blocks.size() <= expected && expected - (long long)b <= (long long)workers.size())
+                    features |= BSCGPU_FEATURE_LOW_LATENCY;
+            } else if (inflight.empty()) {
+                if (all_taken()) break;
+                continue;
+            }
         }
         if (have) {
-            if ((int)inflight.size() == depth) retire();
             Block& B = *Bp;
-            const int ticket = be.pipe_submit_host(be.user, w.pipe, B.input, B.output, B.n, B.lzpHashSize, B.lzpMinLen, B.sorter, B.coder, B.features);
-            if (ticket < 0) {
-                { std::lock_guard<std::mutex> lk(mu); B.result = ticket; B.done = true; }
-                cv_done.notify_all();
-            } else inflight.emplace_back(ticket, b);
-        } else retire();                                  // queue empty: drain the oldest, then look again
+            const int ticket = be.pipe_submit_host(be.user, w.pipe, B.input, B.output, B.n, B.lzpHashSize, B.lzpMinLen, B.sorter, B.coder, features);
+            { std::lock_guard<std::mutex> lk(mu); ++stages_done[(size_t)w.dev_index]; if (ticket < 0) { B.result = ticket; B.done = true; --active; } }
+            cv_work.notify_all();                             // a context waiting for this device's k-th stage may start now
+            if (ticket < 0) cv_done.notify_all();
+            else inflight.emplace_back(ticket, b);
+        } else retire();                                      // nothing to take right now: drain the oldest, then look again
     }
     be.pipe_destroy(be.user, w.pipe); w.pipe = nullptr;
     be.ctx_destroy(be.user, w.ctx); w.ctx = nullptr;
@@ -134,7 +179,12 @@ int bscgpu_job_create_ex(bscgpu_job** out, const int* devices, int ndevices, int
     j.depth = depth; j.max_block = max_block_bytes;
     // worker w: context w / ndev of device w % ndev — the first context of every device comes before anybody's second
     j.workers.resize(devs.size() * (size_t)contexts_per_device);
-    for (size_t w = 0; w < j.workers.size(); ++w) { j.workers[w].job = &j; j.workers[w].id = (int)w; j.workers[w].device = devs[w % devs.size()]; }
+    j.ndev = (int)devs.size();
+    j.stages_done.assign(devs.size(), 0u);
+    for (size_t w = 0; w < j.workers.size(); ++w) {
+        Worker& W = j.workers[w];
+        W.job = &j; W.id = (int)w; W.dev_index = (int)(w % devs.size()); W.ordinal = (int)(w / devs.size()); W.device = devs[(size_t)W.dev_index];
+    }
     for (auto& w : j.workers) w.th = std::thread([&j, &w] { j.run(w); });
     // all contexts up before the first block: a device that cannot be set up fails the job here, not in the middle of it
     int rc = LIBBSC_NO_ERROR;
@@ -162,8 +212,17 @@ int bscgpu_job_add(bscgpu_job* J, const uint8_t* input, uint8_t* output, int n, 
         number = (int)j.blocks.size();
         j.blocks.push_back(Block{input, output, n, lzpHashSize, lzpMinLen, blockSorter, coder, features});
     }
-    j.cv_work.notify_one();
+    j.cv_work.notify_all();             // (all: the worker a notify_one picks may be one the head / tail rule keeps waiting)
     return number;
+}
+
+int bscgpu_job_expect(bscgpu_job* J, int total_blocks)
+{
+    if (!J || total_blocks < 0) return LIBBSC_BAD_PARAMETER;
+    Job& j = J->j;
+    { std::lock_guard<std::mutex> lk(j.mu); j.expected = total_blocks; }
+    j.cv_work.notify_all();
+    return LIBBSC_NO_ERROR;
 }
 
 int bscgpu_job_wait(bscgpu_job* J, int block)

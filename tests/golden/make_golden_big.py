@@ -4,6 +4,7 @@ checks without /root/reference (the GPU box does not have it):
   config 3 — the 64 MiB seed-2 block of `bench.py` at N=1;
   config 4 — eight independent 64 MiB synth-text v1 blocks, seeds 10..17, BWT + QLFC static (the N>1 bench blocks);
   config 5 — one 128 MiB synth-text v1 block, seed 3, ST5 and ST6 + QLFC static (SURVEY.md §8c pins the same md5s);
+  config3-e2 / -e0, config5-e0 — the config 3 block through the adaptive and the fast coder, the config 5 block through the fast one;
   deep-LCP — one 64 MiB block of long repeated passages (synth_repeat_v1), BWT + QLFC static: many doubling rounds.
 Run in the build container: python tests/golden/make_golden_big.py   (needs oracle/_ref, i.e. /root/reference)."""
 import hashlib
@@ -33,12 +34,20 @@ def add(tag, gen, T, sorter, coder, features):
     print(tag, gen, e["size"], e["md5"], flush=True)
 
 
-add("config3", {"kind": "synth", "seed": 2}, api.synth_text_v1(2, 64 << 20), 1, 1, 3)      # the N=1 bench block
+T2 = api.synth_text_v1(2, 64 << 20)
+add("config3", {"kind": "synth", "seed": 2}, T2, 1, 1, 3)      # the N=1 bench block
+# the same block through the other two coders (round 5: `bench.py --coder 2 / 3` lines are checked at the size they are quoted on;
+# SURVEY.md 8c pins the -e2 output: 15 148 620 B, md5 bea58a30...)
+add("config3-e2", {"kind": "synth", "seed": 2}, T2, 1, 2, 3)
+add("config3-e0", {"kind": "synth", "seed": 2}, T2, 1, 3, 3)
+del T2
 for seed in range(10, 18):
     add("config4", {"kind": "synth", "seed": seed}, api.synth_text_v1(seed, 64 << 20), 1, 1, 3)
 T = api.synth_text_v1(3, 128 << 20)
 add("config5", {"kind": "synth", "seed": 3}, T, 5, 1, 3)
 add("config5", {"kind": "synth", "seed": 3}, T, 6, 1, 3)
+add("config5-e0", {"kind": "synth", "seed": 3}, T, 5, 3, 3)
+add("config5-e0", {"kind": "synth", "seed": 3}, T, 6, 3, 3)
 add("deep-lcp", {"kind": "repeat", "seed": 7, "period": 3_000_000}, synth_repeat_v1(7, 64 << 20, 3_000_000), 1, 1, 3)
 json.dump({"reference": "libbsc 3.3.5 (oracle/_ref)", "blocks": out},
           open(os.path.join(ROOT, "tests/golden/golden_big.json"), "w"), indent=1)

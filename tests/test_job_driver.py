@@ -37,6 +37,9 @@ class FakeNode:
         self.pipes = {}        # pipe id -> dict(device, depth, tickets {ticket: (in, out, n)}, next, max_inflight, blocks)
         self.destroyed = []
         self.ids = 0
+        self.submit_ms = 0.0   # time a submit (= the GPU stage of a block) takes
+        self.stages = {}       # device -> submits that have returned
+        self.seen = {}         # input address -> (features, stages of the device finished when the submit began)
         self.cb = Backend(None, CTX_CREATE(self.ctx_create), CTX_DESTROY(self.ctx_destroy), PIPE_CREATE(self.pipe_create),
                           PIPE_DESTROY(self.pipe_destroy), SUBMIT(self.submit), WAIT(self.wait))
 
@@ -69,6 +72,12 @@ class FakeNode:
         if sorter == self.fail_sorter:
             return -1
         with self.lock:
+            dev = self.pipes[pipe]["device"]
+            self.seen[inp] = (features, self.stages.get(dev, 0))
+        if self.submit_ms:
+            time.sleep(self.submit_ms / 1e3)
+        with self.lock:
+            self.stages[dev] = self.stages.get(dev, 0) + 1
             p = self.pipes[pipe]
             t = p["next"]; p["next"] += 1
             p["tickets"][t] = (inp, out, n)
@@ -142,6 +151,46 @@ def test_job_destroy_finishes_queued_blocks_and_errors_reach_the_caller():
         if b != 11:
             assert o[28:].tobytes() == a.tobytes(), b
     assert sum(p["blocks"] for p in node.pipes.values()) == 29
+
+
+def test_job_head_and_tail_are_tapered_when_the_total_is_announced():
+    """bscgpu_job_expect: the k-th context of a device draws its FIRST block once k GPU stages have finished there, takes a block only
+    while more than k x devices are left, and the last devices x contexts blocks are marked low-latency; without the call (or with more
+    blocks than announced) every block is still processed."""
+    LOW = 0x10000
+    ndev, cpd, total = 2, 3, 26
+    node = FakeNode({0: 4.0, 1: 4.0})
+    node.submit_ms = 1.0
+    L, h, rc = _job(node, [0, 1], cpd, 2)
+    assert rc == 0
+    L.bscgpu_job_expect.argtypes = [vp, ci]
+    assert L.bscgpu_job_expect(h, total) == 0 and L.bscgpu_job_expect(h, -1) == -1
+    ins = [np.full(64 + b, b, np.uint8) for b in range(total)]
+    outs = [np.zeros(a.size + 28, np.uint8) for a in ins]
+    for b, (a, o) in enumerate(zip(ins, outs)):
+        assert L.bscgpu_job_add(h, N.np_ptr(a), N.np_ptr(o), a.size, 0, 0, 1, 1, 3) == b
+    first = {}
+    for b, (a, o) in enumerate(zip(ins, outs)):
+        assert L.bscgpu_job_wait(h, b) == a.size + 28 and o[28:].tobytes() == a.tobytes()
+        dev = ci(-1)
+        w = L.bscgpu_job_block_worker(h, b, C.byref(dev))
+        k = w // ndev                                            # the worker is its device's k-th context
+        assert total - b > k * ndev, (b, w)                      # tail: the last block to a first context, the last 2 x ndev to first and second ...
+        feat, stages_before = node.seen[a.ctypes.data]
+        assert bool(feat & LOW) == (total - b <= ndev * cpd), b  # the last devices x contexts blocks are low-latency
+        assert feat & 0xffff == 3
+        if w not in first:
+            first[w] = b
+            assert stages_before >= k, (b, w, stages_before)     # head: k stages of the device had finished before its k-th context began
+    assert set(first) == set(range(ndev * cpd))                  # the middle of the job uses every context
+    # more blocks than announced: the tail rule is dropped, nothing is left behind
+    extra = [np.full(50, 7, np.uint8) for _ in range(5)]
+    eouts = [np.zeros(78, np.uint8) for _ in extra]
+    for i, (a, o) in enumerate(zip(extra, eouts)):
+        assert L.bscgpu_job_add(h, N.np_ptr(a), N.np_ptr(o), a.size, 0, 0, 1, 1, 3) == total + i
+    L.bscgpu_job_destroy(h)
+    assert all(o[28:].tobytes() == a.tobytes() for a, o in zip(extra, eouts))
+    assert sum(p["blocks"] for p in node.pipes.values()) == total + 5
 
 
 def test_job_creation_fails_as_a_whole_when_a_device_cannot_be_set_up():
