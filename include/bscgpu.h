@@ -125,6 +125,10 @@ BSCGPU_API int  bscgpu_pipe_submit(bscgpu_pipe* pipe, const void* dInput, uint8_
 BSCGPU_API int  bscgpu_pipe_submit_host(bscgpu_pipe* pipe, const uint8_t* input, uint8_t* output, int n,
                                         int lzpHashSize, int lzpMinLen, int blockSorter, int coder, int features);
 BSCGPU_API int  bscgpu_pipe_wait(bscgpu_pipe* pipe, int ticket);
+/* From ANY thread: block until the host stage of `ticket` is over; 1 and *result (what bscgpu_pipe_wait will return) when the block is
+ * complete — its output buffer is final —, 0 when it needs its submitting thread after all (redo on the host model) or has been retired
+ * already.  Does not retire the ticket.  For in-order collectors running beside the submitting thread (the job driver). */
+BSCGPU_API int  bscgpu_pipe_peek(bscgpu_pipe* pipe, int ticket, int* result);
 
 /* ---- multi-GPU job: every GPU of a node from one process, C/C++ callers ----------------------------------------------------
  * The reference parallelises over blocks with the CLI's OpenMP team (bsc.cpp:182-199: next block under critical(input),

@@ -174,7 +174,7 @@ def _build_driver(force):
     # tools/job_bench.cpp: bench.py's workload through bscgpu_job_* alone (a C caller of the product's C ABI); built next to the library so
     # that it travels to the GPU box
     if os.path.exists(JOB_BENCH_SRC):
-        cmd = [GXX, "-O2", "-std=c++17", "-I", INCLUDE, JOB_BENCH_SRC, "-L", os.path.dirname(LIB), "-lbsc_mi355x",
+        cmd = [GXX, "-O2", "-std=c++17", "-I", INCLUDE, JOB_BENCH_SRC, "-L", os.path.dirname(LIB), "-lbsc_mi355x", "-L", os.path.join(ROCM, "lib"), "-lamdhip64",
                "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-o", JOB_BENCH_EXE]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

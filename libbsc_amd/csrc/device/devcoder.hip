@@ -906,10 +906,7 @@ typedef __attribute__((address_space(3))) volatile u16 dc_lds_vu16;
 #ifndef DC_PS_MINW
 #define DC_PS_MINW 1            // minimum waves per SIMD the register allocator must leave room for (A/B: 82 VGPRs = 5 waves by default)
 #endif
-// ROUNDS: a run's decisions eight at a time, every round like the first (wide position loads, eight independent gather chains per lane).
-// Without it the decisions beyond the eighth went one at a time, each a serial position -> value round trip, and a wavefront is as slow as
-// its longest run: nearly every wavefront of the bench block has a run of 12-20 decisions.
-template <bool FAST, bool ROUNDS>
+template <bool FAST>
 __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, DcSub S, const ModelParams* __restrict__ mp,
                                                         const u32* __restrict__ meta, u16* __restrict__ out, u16* __restrict__ dbg /*[3][D] or null*/, u32 dbgD)
 {
@@ -947,35 +944,31 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, 
         }
         if (staged) sg[loc + (u32)k] = e; else o[k] = e;
     };
-    // eight decisions per round: positions by wide loads (the arrays have slack behind their last entry), static register indices
-    for (int kb = 0; ROUNDS ? __ballot(kb < nd) != 0ull : kb == 0; kb += 8) {
-        u32 qsp[8], qch[8];
+    // first 8 decisions: positions by wide loads (the arrays have slack behind their last entry), static register indices
+    u32 qsp[8], qch[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { qsp[k] = 0; qch[k] = 0; }
-        if (valid && kb < nd) {
-            const DcU4 c0 = *reinterpret_cast<const DcU4*>(p_ch + kb), c1 = *reinterpret_cast<const DcU4*>(p_ch + kb + 4);
-            qch[0] = c0.a; qch[1] = c0.b; qch[2] = c0.c; qch[3] = c0.d; qch[4] = c1.a; qch[5] = c1.b; qch[6] = c1.c; qch[7] = c1.d;
-            if (!FAST) {
-                const DcU4 a0 = *reinterpret_cast<const DcU4*>(p_sp + kb), a1 = *reinterpret_cast<const DcU4*>(p_sp + kb + 4);
-                qsp[0] = a0.a; qsp[1] = a0.b; qsp[2] = a0.c; qsp[3] = a0.d; qsp[4] = a1.a; qsp[5] = a1.b; qsp[6] = a1.c; qsp[7] = a1.d;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (kb + k < nd) {
-                u32 bit; bool rs;
-                const int tau = nth_decision(it, maxr, n_rank, kb + k, &bit, &rs);
-                const u32 q_st = FAST ? 0u : (rs ? p_sn[kb + k - n_rank] : p_sr[kb + k]);
-                emit(kb + k, qsp[k], qch[k], q_st, rs, tau, bit);
-            }
+    for (int k = 0; k < 8; ++k) { qsp[k] = 0; qch[k] = 0; }
+    if (valid) {
+        const DcU4 c0 = *reinterpret_cast<const DcU4*>(p_ch), c1 = *reinterpret_cast<const DcU4*>(p_ch + 4);
+        qch[0] = c0.a; qch[1] = c0.b; qch[2] = c0.c; qch[3] = c0.d; qch[4] = c1.a; qch[5] = c1.b; qch[6] = c1.c; qch[7] = c1.d;
+        if (!FAST) {
+            const DcU4 a0 = *reinterpret_cast<const DcU4*>(p_sp), a1 = *reinterpret_cast<const DcU4*>(p_sp + 4);
+            qsp[0] = a0.a; qsp[1] = a0.b; qsp[2] = a0.c; qsp[3] = a0.d; qsp[4] = a1.a; qsp[5] = a1.b; qsp[6] = a1.c; qsp[7] = a1.d;
         }
     }
-    if (!ROUNDS) {
-        for (int k = 8; k < nd; ++k) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k < nd) {
             u32 bit; bool rs;
             const int tau = nth_decision(it, maxr, n_rank, k, &bit, &rs);
-            emit(k, FAST ? 0u : p_sp[k], p_ch[k], FAST ? 0u : (rs ? p_sn[k - n_rank] : p_sr[k]), rs, tau, bit);
+            const u32 q_st = FAST ? 0u : (rs ? p_sn[k - n_rank] : p_sr[k]);
+            emit(k, qsp[k], qch[k], q_st, rs, tau, bit);
         }
+    }
+    for (int k = 8; k < nd; ++k) {
+        u32 bit; bool rs;
+        const int tau = nth_decision(it, maxr, n_rank, k, &bit, &rs);
+        emit(k, FAST ? 0u : p_sp[k], p_ch[k], FAST ? 0u : (rs ? p_sn[k - n_rank] : p_sr[k]), rs, tau, bit);
     }
     if (staged) {
         // the wavefront's piece [wbase, wbase + wtotal) of the stream: 4-byte stores from the first even entry on, the odd ends singly
@@ -988,13 +981,6 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, 
         for (u32 t = lane; t < body; t += 64) ow32[t] = (u32)sg[head + 2 * t] | ((u32)sg[head + 2 * t + 1] << 16);
         if (lane == 0 && wtotal > head && ((wtotal - head) & 1u)) ow[wtotal - 1] = sg[wtotal - 1];
     }
-}
-
-// BSC_DC_PSTREAM=tail: decisions beyond a run's eighth one at a time (rounds 2-4), for A/B on one box
-static bool dc_pstream_rounds()
-{
-    static const bool on = [] { const char* e = getenv("BSC_DC_PSTREAM"); return !(e && strcmp(e, "tail") == 0); }();
-    return on;
 }
 
 __global__ void dc_poff_kernel(const u32* __restrict__ doff_sp, DcSub S, u32 m, u32* __restrict__ poff)
@@ -1273,10 +1259,7 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     G.V_sp = d->V[0]; G.V_ch = d->V[1]; G.V_sr = d->V[2]; G.V_sn = d->V[3];
     prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)E[0] * 26, E[0]);
     if (c->ps_guard[psbuf & 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ps_guard[psbuf & 1], 0));     // the buffer's previous copy-out
-    if (dc_pstream_rounds())
-        hipLaunchKernelGGL((dc_pstream_kernel<false, true>), dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, E[0]);
-    else
-        hipLaunchKernelGGL((dc_pstream_kernel<false, false>), dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, E[0]);
+    hipLaunchKernelGGL(dc_pstream_kernel<false>, dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, E[0]);
     hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, d->doff[0], S, m, d->poff);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
@@ -1373,10 +1356,7 @@ static int devcoder_pstream_fast(bscgpu_ctx* c, DevCoder* d, const u8* dsym, con
     G.V_sp = d->V[1]; G.V_ch = d->V[1]; G.V_sr = d->V[1]; G.V_sn = d->V[1];
     prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)E * 10, E);
     if (c->ps_guard[psbuf & 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ps_guard[psbuf & 1], 0));     // the buffer's previous copy-out
-    if (dc_pstream_rounds())
-        hipLaunchKernelGGL((dc_pstream_kernel<true, true>), dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp_fast, d->meta, d->ps[psbuf & 1], (u16*)nullptr, E);
-    else
-        hipLaunchKernelGGL((dc_pstream_kernel<true, false>), dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp_fast, d->meta, d->ps[psbuf & 1], (u16*)nullptr, E);
+    hipLaunchKernelGGL(dc_pstream_kernel<true>, dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp_fast, d->meta, d->ps[psbuf & 1], (u16*)nullptr, E);
     hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, d->doff[0], S, m, d->poff);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());

@@ -17,6 +17,7 @@
 // The host coder then consumes (sym, rank, start) directly; L itself never crosses PCIe unless a sub-block turns
 // out incompressible and must be stored raw.
 #include "dev_common.h"
+#include <type_traits>
 
 constexpr int QF_BYTES = 16;                 // bytes per thread per tile
 constexpr int QF_TILE  = WG * QF_BYTES;      // 4096 bytes per tile
@@ -198,69 +199,85 @@ template <> struct QfSet<false> {
 #endif
 constexpr u32 QF_SHORT = QF_SHORT_N;
 
-template <bool DENSE>
+// NARROW (<= 32 distinct symbols, any lower-case text): the lifted tables hold 32-bit sets.
+template <bool DENSE, bool NARROW>
 __global__ __launch_bounds__(WG) void qf_rank_kernel(const u8* __restrict__ sym, u32 m, QfRuns rb, const u8* __restrict__ lut,
                                                      const u64* __restrict__ masks, const u64* __restrict__ super,
                                                      u8* __restrict__ rank)
 {
     constexpr int W = DENSE ? 1 : 4;
-    __shared__ u8 scode[WG];
+    constexpr u32 R = 2 * WG;                   // a lifted tile looks at its own 256 runs and the 256 behind them
+    __shared__ u8 scode[R];
     __shared__ u8 slut[256];
     __shared__ u32 qn;
     __shared__ u8 qt[WG];
     __shared__ u16 qi[WG];
     __shared__ u64 qset[WG * W];
     const u32 base = blockIdx.x * WG, t = threadIdx.x;
-    if (DENSE) slut[t] = lut[t];
-    if (t == 0) qn = 0;
-    {
-        const u32 j = base + t;
-        const u32 raw = (j < m) ? sym[j] : 0u;
-        __syncthreads();
-        scode[t] = (u8)(DENSE ? slut[raw] : raw);
-    }
-    __syncthreads();
     auto sub_end = [&](u32 j) {
         u32 re = m;
 #pragma unroll
         for (int b = 8; b >= 1; --b) if ((u32)b <= rb.nblocks && j < rb.first[b]) re = rb.first[b];
         return re;
     };
-    // Tiles that lie inside one sub-block, sets of one word: binary lifting instead of a walk.  win[k][p] = the symbols at tile
-    // positions (p, p + 2^k] (cut at the tile's end), built level by level (one OR per lane and level); a lane then takes the windows
-    // 128, 64, .. 1 that do not contain its symbol, greedily — eight uniform steps whatever the distance, where the walk below is as
-    // slow as the wavefront's slowest lane (up to QF_SHORT serial LDS reads; 30 % of the kernel's wave cycles were executing, half of
-    // that scalar loop control).  A lane whose symbol does not come back inside the tile goes on from the tile's end as before.
     const u32 tile_end = (base + WG < m) ? base + WG : m;
-    const bool lifted = DENSE && WG == 256 && sub_end(base) >= tile_end;       // workgroup-uniform
+    const u32 re0 = sub_end(base);
+    const u32 region_end = (base + R < re0) ? base + R : re0;             // the halo stops at the sub-block's end
+    if (DENSE) slut[t] = lut[t];
+    if (t == 0) qn = 0;
+    {
+        const u32 j = base + t, jh = base + WG + t;
+        const u32 raw = (j < m) ? sym[j] : 0u, rawh = (jh < region_end) ? sym[jh] : 0u;
+        __syncthreads();
+        scode[t] = (u8)(DENSE ? slut[raw] : raw);
+        scode[WG + t] = (u8)(DENSE ? slut[rawh] : rawh);
+    }
+    __syncthreads();
+    // Tiles that lie inside one sub-block, sets of one word: binary lifting instead of a walk.  win[k][p] = the symbols at region
+    // positions (p, p + 2^k] (cut at the region's end), built level by level (one OR per entry and level); a lane then takes the windows
+    // 256, 128, .. 1 that do not contain its symbol, greedily — nine uniform steps whatever the distance, where a walk is as slow as the
+    // wavefront's slowest lane.  Round 5: the region is the tile AND the 256 runs behind it.  With the tile alone every lane near the
+    // tile's end — a tenth of them on text — went on into the next tile with serial 16-byte loads, compacted into the workgroup's first
+    // wavefront, which then took as long as ITS slowest lane: 83 % of the kernel's 5.4e8 VALU wave-instructions per 64 MiB block
+    // (profiles/r03/pmc_sq_one_block.txt; the lifting itself is ~200 per wavefront).  Now only a symbol that does not come back within
+    // 256 runs of the tile's end takes that path.
+    const bool lifted = DENSE && WG == 256 && re0 >= tile_end;       // workgroup-uniform
     if (lifted) {
-        __shared__ u64 win[8][WG];
-        const u32 j = base + t;
-        win[0][t] = (j + 1 < tile_end) ? (1ull << scode[t + 1]) : 0ull;
+        typedef typename std::conditional<NARROW, u32, u64>::type MT;
+        __shared__ MT win[9][R];
+#pragma unroll
+        for (u32 q = 0; q < 2; ++q) {
+            const u32 p = t + q * WG;
+            win[0][p] = (base + p + 1 < region_end) ? (MT)1 << scode[p + 1 < R ? p + 1 : p] : (MT)0;
+        }
         __syncthreads();
 #pragma unroll
-        for (int k = 1; k < 8; ++k) {
+        for (int k = 1; k < 9; ++k) {
             const u32 h = 1u << (k - 1);
-            win[k][t] = win[k - 1][t] | ((t + h < (u32)WG) ? win[k - 1][t + h] : 0ull);
+#pragma unroll
+            for (u32 q = 0; q < 2; ++q) {
+                const u32 p = t + q * WG;
+                win[k][p] = win[k - 1][p] | ((p + h < R) ? win[k - 1][p + h] : (MT)0);
+            }
             __syncthreads();
         }
+        const u32 j = base + t;
         if (j < m) {
-            const u32 re = sub_end(j);
-            if (j + 1 == re) rank[j] = 1;
+            if (j + 1 == re0) rank[j] = 1;
             else {
                 const u32 c = scode[t];
-                u64 set = 0; u32 p = t;
+                MT set = 0; u32 p = t;
 #pragma unroll
-                for (int k = 7; k >= 0; --k) {
-                    const u64 w = (p < (u32)WG) ? win[k][p] : 0ull;
-                    if (!((w >> c) & 1ull)) { set |= w; p += 1u << k; }
+                for (int k = 8; k >= 0; --k) {
+                    const MT w = (p < R) ? win[k][p] : (MT)0;
+                    if (!((w >> c) & (MT)1)) { set |= w; p += 1u << k; }
                 }
-                // p = last tile position known to be free of c (possibly past the end): the symbol comes back at p + 1, or not in this tile
-                const bool found = base + p + 1 < tile_end;
-                if (found || tile_end == re) rank[j] = (u8)__popcll(set);
+                // p = last region position known to be free of c (possibly past the end): the symbol comes back at p + 1, or not in this region
+                const bool found = base + p + 1 < region_end;
+                if (found || region_end == re0) rank[j] = (u8)(NARROW ? __popc((u32)set) : __popcll((u64)set));
                 else {
                     const u32 slot = atomicAdd(&qn, 1u);
-                    qt[slot] = (u8)t; qi[slot] = (u16)WG; qset[slot * W] = set;             // goes on at the tile's end
+                    qt[slot] = (u8)t; qi[slot] = (u16)R; qset[slot * W] = (u64)set;            // goes on at the region's end (a multiple of 256)
                 }
             }
         }
@@ -453,8 +470,9 @@ int qlfc_front_runs(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, const int* 
     }
     prof_end(c);
     prof_begin(c, BSCGPU_K_GATHER, (u64)m * 2, m);
-    if (dense) hipLaunchKernelGGL(qf_rank_kernel<true>, dim3((m + WG - 1) / WG), dim3(WG), 0, c->stream, dsym, m, rb, dlut, dmask, dsuper, drank);
-    else       hipLaunchKernelGGL(qf_rank_kernel<false>, dim3((m + WG - 1) / WG), dim3(WG), 0, c->stream, dsym, m, rb, dlut, dmask, dsuper, drank);
+    if (dense && K <= 32) hipLaunchKernelGGL((qf_rank_kernel<true, true>), dim3((m + WG - 1) / WG), dim3(WG), 0, c->stream, dsym, m, rb, dlut, dmask, dsuper, drank);
+    else if (dense)       hipLaunchKernelGGL((qf_rank_kernel<true, false>), dim3((m + WG - 1) / WG), dim3(WG), 0, c->stream, dsym, m, rb, dlut, dmask, dsuper, drank);
+    else                  hipLaunchKernelGGL((qf_rank_kernel<false, false>), dim3((m + WG - 1) / WG), dim3(WG), 0, c->stream, dsym, m, rb, dlut, dmask, dsuper, drank);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     (void)dstart;

@@ -489,7 +489,7 @@ __global__ __launch_bounds__(RSB_WG) void rs_scatter_tiled_kernel(const u64* __r
 // Measured (same box, 64 Mi pairs): BWT first-sort pass 0.370 ms against 0.389 ms for rs_scatter (the two lowest digits
 // 0.47 -> 0.40 and 0.42 -> 0.38, the other six tie), uniform digits 0.403 against 0.414, text-skewed 0.307 against 0.284.
 // A later version that merges the pending records in front of the new ones, so that every line leaves in ONE instruction
-// (what tools/ubench_wc.hip says the memory system wants), is VALU-bound and no faster: tools/experiments/.
+// (what tools/ubench_wc.hip says the memory system wants), is VALU-bound and no faster; it was removed in round 5 (history: NOTES_r01-r04.md).
 //
 // Shape: the 1024 x 8 shape of rs_scatter (8192-record tiles, one workgroup per CU walking four of rs_hist's chunks), so
 // that the fixed per-tile work (digit scan, flushes, barriers) is spread over 8 records per lane; the first version of

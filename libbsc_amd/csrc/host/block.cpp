@@ -973,7 +973,7 @@ struct bscgpu_pipe {
     bscgpu_ctx* c = nullptr;
     int depth = 1;
     int next_ticket = 0;
-    struct Lane { std::unique_ptr<BlockJob> job; int ticket = -1; bool busy = false; };
+    struct Lane { std::unique_ptr<BlockJob> job; int ticket = -1; bool busy = false; bool joined = true; };   // ticket / joined / job->done: under the pool's mutex
     Lane lanes[MAX_SLOTS];
     CoderPool* pool = nullptr;
 };
@@ -984,7 +984,9 @@ static void lane_join(bscgpu_pipe* p, bscgpu_pipe::Lane& L)
     {
         std::unique_lock<std::mutex> lk(p->pool->mu);
         p->pool->cv_done.wait(lk, [&] { return L.job->done; });
+        L.joined = true;                            // (bscgpu_pipe_peek: from here on the lane may be reused; a peeker goes back to its caller's own bookkeeping)
     }
+    p->pool->cv_done.notify_all();
     L.busy = false;
     // lane_join only runs on the pipe's submitting thread (submit / wait / destroy), which owns the GPU stage
     // (a redo that cannot be run must not leave the stale result of a block whose output was never written)
@@ -1021,12 +1023,13 @@ void bscgpu_pipe_destroy(bscgpu_pipe* p)
 static int pipe_enqueue(bscgpu_pipe* p, bscgpu_pipe::Lane& L, int ticket)
 {
     BlockJob& J = *L.job;
-    L.ticket = ticket; L.busy = true;
+    L.busy = true;
     J.pipelined = p->depth >= 3;
     CoderPool* P = p->pool;
     J.pipe_workers = (int)P->workers.size();
     {
         std::lock_guard<std::mutex> lk(P->mu);
+        L.ticket = ticket; L.joined = false;
         J.pool_free = P->free_cpus();
         if (job_uses_tasks(J)) {
             host_prepare(J);
@@ -1097,6 +1100,23 @@ int bscgpu_pipe_submit_host(bscgpu_pipe* p, const uint8_t* input, uint8_t* outpu
     if (!J.use_ps) J.lz.reset();                    // the LZP output lives in HBM from here on; a device-model block keeps it for a possible redo
     if (rc < 0) return rc;
     return pipe_enqueue(p, L, ticket);
+}
+
+// Any thread: block until the HOST stage of `ticket` has finished and, if the block is then complete, hand out its result — without
+// retiring the ticket (bscgpu_pipe_wait on the submitting thread still does that).  Returns 1 with *result set; 0 when the block needs
+// its submitting thread after all (a redo on the host model runs the GPU stage again) or the ticket has already been retired / its
+// lane reused; a negative code for bad arguments.  For collectors that take blocks in order while the submitting thread is busy
+// with the GPU stages of later blocks (job.cpp): a finished block's output buffer is final from here on.
+int bscgpu_pipe_peek(bscgpu_pipe* p, int ticket, int* result)
+{
+    if (!p || !result || ticket < 0) return LIBBSC_BAD_PARAMETER;
+    bscgpu_pipe::Lane& L = p->lanes[ticket % p->depth];
+    std::unique_lock<std::mutex> lk(p->pool->mu);
+    p->pool->cv_done.wait(lk, [&] { return L.ticket != ticket || L.joined || L.job->done; });
+    if (L.ticket != ticket || L.joined) return 0;
+    if (L.job->redo.load(std::memory_order_relaxed)) return 0;
+    *result = L.job->result;
+    return 1;
 }
 
 int bscgpu_pipe_wait(bscgpu_pipe* p, int ticket)

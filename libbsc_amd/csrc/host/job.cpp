@@ -32,6 +32,7 @@ namespace {
 struct Block {
     const uint8_t* input; uint8_t* output; int n, lzpHashSize, lzpMinLen, sorter, coder, features;
     int result = 0; int worker = -1; bool done = false;
+    int ticket = -1;                    // on its worker's pipe, once the GPU stage has run
 };
 
 struct Job;
@@ -55,6 +56,7 @@ struct Job {
     size_t next = 0;                    // first block nobody has taken yet
     bool closing = false;
     std::vector<Worker> workers;
+    bool own_pipes = false;             // the default executor: a collector may look at a pipe's finished blocks itself (bscgpu_pipe_peek)
     int ndev = 1;
     long long expected = -1;            // blocks the caller has announced (bscgpu_job_expect); -1: unknown
     std::vector<unsigned> stages_done;  // per device: GPU stages (submits) that have returned in the current burst
@@ -100,7 +102,7 @@ void Job::run(Worker& w)
         const auto [ticket, b] = inflight.front(); inflight.pop_front();
         const int res = be.pipe_wait(be.user, w.pipe, ticket);
         bool idle;
-        { std::lock_guard<std::mutex> lk(mu); blocks[b].result = res; blocks[b].done = true; idle = --active == 0; }
+        { std::lock_guard<std::mutex> lk(mu); blocks[b].result = res; blocks[b].done = true; blocks[b].ticket = -1; idle = --active == 0; }
         cv_done.notify_all();
         if (idle) cv_work.notify_all();                       // the next burst is a first context's to begin
     };
@@ -133,10 +135,10 @@ void Job::run(Worker& w)
         if (have) {
             Block& B = *Bp;
             const int ticket = be.pipe_submit_host(be.user, w.pipe, B.input, B.output, B.n, B.lzpHashSize, B.lzpMinLen, B.sorter, B.coder, features);
-            { std::lock_guard<std::mutex> lk(mu); ++stages_done[(size_t)w.dev_index]; if (ticket < 0) { B.result = ticket; B.done = true; --active; } }
+            { std::lock_guard<std::mutex> lk(mu); ++stages_done[(size_t)w.dev_index]; if (ticket < 0) { B.result = ticket; B.done = true; --active; } else B.ticket = ticket; }
             cv_work.notify_all();                             // a context waiting for this device's k-th stage may start now
-            if (ticket < 0) cv_done.notify_all();
-            else inflight.emplace_back(ticket, b);
+            cv_done.notify_all();                             // a collector waiting for this block: it failed, or it has a ticket to look at now
+            if (ticket >= 0) inflight.emplace_back(ticket, b);
         } else retire();                                      // nothing to take right now: drain the oldest, then look again
     }
     be.pipe_destroy(be.user, w.pipe); w.pipe = nullptr;
@@ -175,7 +177,7 @@ int bscgpu_job_create_ex(bscgpu_job** out, const int* devices, int ndevices, int
     bscgpu_job* J = new bscgpu_job;
     Job& j = J->j;
     if (backend) j.be = *backend;
-    else j.be = bscgpu_job_backend{nullptr, d_ctx_create, d_ctx_destroy, d_pipe_create, d_pipe_destroy, d_submit, d_wait};
+    else { j.be = bscgpu_job_backend{nullptr, d_ctx_create, d_ctx_destroy, d_pipe_create, d_pipe_destroy, d_submit, d_wait}; j.own_pipes = true; }
     j.depth = depth; j.max_block = max_block_bytes;
     // worker w: context w / ndev of device w % ndev — the first context of every device comes before anybody's second
     j.workers.resize(devs.size() * (size_t)contexts_per_device);
@@ -231,8 +233,28 @@ int bscgpu_job_wait(bscgpu_job* J, int block)
     Job& j = J->j;
     std::unique_lock<std::mutex> lk(j.mu);
     if ((size_t)block >= j.blocks.size()) return LIBBSC_BAD_PARAMETER;
-    j.cv_done.wait(lk, [&] { return j.blocks[(size_t)block].done; });
-    return j.blocks[(size_t)block].result;
+    Block& B = j.blocks[(size_t)block];
+    // A worker publishes a block when it RETIRES it — when it needs the lane again or has nothing else to do —, which for a block that
+    // was coded long ago can be a GPU stage or two later: an in-order collector (a file writer, job_bench) then holds its buffers back
+    // and the queue runs dry (round 5: 4005 MB/s through the job against 5100 through bench.py's independent pipes).  So the collector
+    // looks at the pipe itself: the block is final as soon as its host stage is over.
+    while (!B.done) {
+        if (j.own_pipes && B.ticket >= 0) {
+            bscgpu_pipe* pipe = (bscgpu_pipe*)j.workers[(size_t)B.worker].pipe;
+            const int ticket = B.ticket;
+            lk.unlock();
+            int res = 0;
+            const int got = bscgpu_pipe_peek(pipe, ticket, &res);
+            lk.lock();
+            if (got == 1) return res;                     // (the worker still retires the ticket and publishes the same result)
+            if (B.done) break;
+            // needs its worker (redo) or was retired meanwhile: the worker's publication follows
+            j.cv_done.wait(lk, [&] { return B.done; });
+            break;
+        }
+        j.cv_done.wait(lk, [&] { return B.done || (j.own_pipes && B.ticket >= 0); });
+    }
+    return B.result;
 }
 
 int bscgpu_job_block_worker(bscgpu_job* J, int block, int* device)

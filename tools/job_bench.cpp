@@ -24,6 +24,8 @@
 #include "../include/libbsc.h"
 #include "../include/bscgpu.h"
 
+extern "C" int hipHostRegister(void* p, size_t bytes, unsigned flags);        // (--pin-input only; the HIP runtime the library is linked against)
+
 // ---- MD5 (RFC 1321), for the golden check only ----------------------------------------------------------------------------------
 namespace {
 struct Md5 {
@@ -84,6 +86,7 @@ int main(int argc, char** argv)
 {
     int steps = 320, warmup = 4, contexts = 6, depth = 3, gpus = 1, sorter = 1, coder = 1, lzpH = 0, lzpM = 0;
     long long n = 64ll << 20; unsigned long long seed = 2; const char* dump = nullptr;
+    bool pin_input = false, upfront = false;
     for (int a = 1; a < argc; ++a) {
         auto val = [&]() -> const char* { return a + 1 < argc ? argv[++a] : "0"; };
         const std::string k = argv[a];
@@ -92,6 +95,8 @@ int main(int argc, char** argv)
         else if (k == "--sorter") sorter = atoi(val()); else if (k == "--coder") coder = atoi(val()); else if (k == "--seed") seed = strtoull(val(), nullptr, 10);
         else if (k == "--lzp") { const char* v = val(); lzpH = atoi(v); const char* c = strchr(v, ','); lzpM = c ? atoi(c + 1) : 0; }
         else if (k == "--dump") dump = val();
+        else if (k == "--pin-input") pin_input = true;           // the input buffer page-locked (hipHostRegister): what an embedder with pinned I/O buffers has
+        else if (k == "--upfront") upfront = true;               // every block of a phase added at once, own output buffer each: no collector in the way
         else { fprintf(stderr, "job_bench: unknown option %s\n", k.c_str()); return 2; }
     }
     if (steps < 1 || warmup < 0 || n < 1 || n > (1ll << 30)) return 2;
@@ -104,10 +109,12 @@ int main(int argc, char** argv)
 
     std::vector<unsigned char> input((size_t)n);
     if (bsc_synth_text_v1(seed, input.data(), n) != LIBBSC_NO_ERROR) return 1;
+    if (pin_input && hipHostRegister(input.data(), (size_t)n, 0) != 0) { fprintf(stderr, "job_bench: hipHostRegister failed\n"); return 1; }
     // output buffers are recycled in a ring longer than what can be in flight: block b's buffer is free again once b has been waited for
-    const int window = ndev * contexts * depth + 2;
-    std::vector<std::vector<unsigned char>> outs((size_t)window);
-    for (auto& o : outs) o.resize((size_t)n + LIBBSC_HEADER_SIZE);
+    // (--upfront: one buffer per block of the longest phase; plain malloc — a buffer is touched only as far as its compressed block reaches)
+    const int window = upfront ? (steps > ndev * contexts * depth + warmup ? steps : ndev * contexts * depth + warmup) + 1 : ndev * contexts * (depth + 1) + 2;
+    std::vector<unsigned char*> outs((size_t)window);
+    for (auto& o : outs) { o = (unsigned char*)malloc((size_t)n + LIBBSC_HEADER_SIZE); if (!o) return 1; }
 
     int last_size = 0; const unsigned char* last_block = nullptr;
     auto run = [&](bscgpu_job* job, int first, int count, bool announce) -> int {
@@ -116,13 +123,13 @@ int main(int argc, char** argv)
         int added = first, waited = first;
         while (waited < first + count) {
             while (added < first + count && added - waited < window - 1) {
-                const int id = bscgpu_job_add(job, input.data(), outs[(size_t)(added % window)].data(), (int)n, lzpH, lzpM, sorter, coder, features);
+                const int id = bscgpu_job_add(job, input.data(), outs[(size_t)(added % window)], (int)n, lzpH, lzpM, sorter, coder, features);
                 if (id != added) { fprintf(stderr, "job_bench: bscgpu_job_add -> %d\n", id); return id < 0 ? id : -1; }
                 ++added;
             }
             const int r = bscgpu_job_wait(job, waited);
             if (r < 0) { fprintf(stderr, "job_bench: block %d -> %d\n", waited, r); return r; }
-            last_size = r; last_block = outs[(size_t)(waited % window)].data();
+            last_size = r; last_block = outs[(size_t)(waited % window)];
             ++waited;
         }
         return 0;
