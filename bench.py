@@ -98,7 +98,7 @@ def main():
         if os.environ.get("BSC_RC_X8") == "1" or (args.coder == 1 and not has_avx512vl and cpus_rank < 14):
             os.environ["BSC_RC_SIMD"] = "8"
     rc_simd = int(os.environ.get("BSC_RC_SIMD", "-1"))
-    rc_adaptive = rc_simd < 0 and has_avx512vl and os.environ.get("BSC_RC_ADAPTIVE", "1") != "0"
+    rc_adaptive = rc_simd < 0 and has_avx512vl and os.environ.get("BSC_RC_ADAPTIVE", "0") != "0"
     rc_x8 = rc_simd == 8 or (rc_simd < 0 and has_avx512vl)
     if args.depth <= 0:                                 # blocks in flight per context
         args.depth = max(2, min(4, 8 // ncx))
@@ -278,6 +278,7 @@ def main():
     sync()
     from libbsc_amd.gpu import coder_pool_stats
     coder_pool_stats(reset=True)
+    cg0 = cgroup_cpu_stat()
     cpu0 = time.process_time()
     t0 = time.perf_counter()
     t_run0[0] = t0
@@ -287,6 +288,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     cpu_used = time.process_time() - cpu0               # all threads of this rank
+    cg1 = cgroup_cpu_stat()
     if trace is not None and rank == 0:
         for k, i, what, t in sorted(trace, key=lambda x: x[3]):
             print(f"[trace] {t * 1e3:8.1f} ms  pipe {k} block {i}: {what}", file=sys.stderr)
@@ -491,7 +493,10 @@ def main():
                           + ((f", and the job's last {ncx} blocks, marked low-latency" if (use_queue and ncx > 1) else f", and the last block of each of the {ncx} pipes, marked low-latency") if tail_low_latency else "") + f" ({pool_modes['pair_tasks']} blocks)"
                           + (f", or eight scalar tasks, a low-latency block that found >= 12 CPUs idle ({pool_modes['scalar_tasks']})" if pool_modes['scalar_tasks'] else ""))
         elif rc_x8:
-            coder_desc = f"all eight sub-blocks of a block in the SIMD lanes of one task, {simd}"
+            coder_desc = (f"all eight sub-blocks of a block in the SIMD lanes of one task, {simd} ({pool_modes['eight_lane_task']} of this rank's {args.steps} timed blocks)"
+                          + ((f"; the job's last {ncx} blocks" if (use_queue and ncx > 1) else f"; the last block of each of the {ncx} pipes") +
+                             f", marked low-latency, as four tasks of two interleaved scalar coders ({pool_modes['pair_tasks']})"
+                             + (f" or, finding >= 12 CPUs idle, eight scalar tasks ({pool_modes['scalar_tasks']})" if pool_modes['scalar_tasks'] else "") if tail_low_latency else ""))
         else:
             coder_desc = "two sub-blocks per task, interleaved scalar coders"
         out = {
@@ -531,6 +536,10 @@ def main():
             "host": {"cpus": os.cpu_count(), "effective_cpus": effective_cpus(), "coder_threads_per_gpu": coder_threads,
                      "range_coder": coder_desc, "blocks_by_coder_task_shape_rank0": pool_modes, "cpu_budget_of_pool": int(os.environ.get("BSCGPU_HOST_CPUS", cpus_rank)),
                      "cpu_seconds_per_block_rank0": round(cpu_used / args.steps, 3),
+                     # the box grants CPU TIME (cgroup cpu.max), not cores: a process that runs more threads than its quota for part of a
+                     # 100 ms period is stopped — GPU-driving threads included — for the rest of it
+                     "cgroup_throttled_ms_in_timed_region": (round((cg1["throttled_usec"] - cg0["throttled_usec"]) / 1e3, 1) if cg0 and cg1 else None),
+                     "cgroup_throttled_periods_in_timed_region": ((cg1["nr_throttled"] - cg0["nr_throttled"]) if cg0 and cg1 else None),
                      "cpu_busy_fraction_of_effective": round(cpu_used / (dt * max(effective_cpus() / max(local_world, 1), 1)), 3)},
         }
         if not args.no_cpu_baseline and world == 1:
@@ -554,6 +563,14 @@ def verify_block(blk, seed, n, sorter, coder):
             return ok, ("last timed block of every rank: size + md5 equal the reference libbsc output committed in tests/golden/golden_big.json"
                         if ok else f"MISMATCH against tests/golden/golden_big.json for seed {seed}")
     return None, f"no committed reference output for seed {seed}, n {n}, sorter {sorter}, coder {coder}"
+
+
+def cgroup_cpu_stat():
+    """cgroup v2 CPU statistics of this container (usage and quota throttling), or None"""
+    try:
+        return {k: int(v) for k, v in (line.split() for line in open("/sys/fs/cgroup/cpu.stat"))}
+    except Exception:
+        return None
 
 
 def effective_cpus():

@@ -536,7 +536,8 @@ static void host_encode_pair(BlockJob& J, int b)
 //   2  four tasks of two interleaved scalar coders: 0.228 CPU-s, ~52 ms
 //   1  eight tasks of one scalar coder: 0.35 CPU-s, ~44 ms
 // bscgpu_coder_task_shape is the rule (a pure function, unit-tested on CPU); ps_group feeds it.  BSC_RC_SIMD=8 / 0 forces eight lanes /
-// pairs everywhere, BSC_RC_ADAPTIVE=0 turns the idle test off (eight lanes for every block that is not marked low-latency).
+// pairs everywhere, BSC_RC_ADAPTIVE=1 turns the idle test on (round 3-4's default: pairs for a block that finds >= 4 CPUs idle; off,
+// every block that is not marked low-latency is one eight-lane task).
 static int ps_simd_env()
 {
     static const int mode = [] {
@@ -573,7 +574,11 @@ extern "C" BSCGPU_API int bscgpu_coder_task_shape(int forced, int low_latency, i
 static int ps_group(const BlockJob& J)
 {
     if (!J.use_ps || J.nblocks != 8) return 2;
-    static const int adaptive = [] { const char* e = getenv("BSC_RC_ADAPTIVE"); return e ? atoi(e) : 1; }();
+    // Round 5: off by default.  Pairs for blocks that find idle CPUs double the CPU time of exactly the blocks at the HEAD of a job, and
+    // that work is still queued when the tail arrives: at the driver's 20 steps, one box, three alternating runs each — 3396 / 3572 / 3971
+    // MB/s with the idle test, 3841 / 3862 / 4018 without; 160 steps the same (5257 / 5205) at 0.127 instead of 0.164 CPU-s per block.
+    // The job's tail is still coded as short tasks: its blocks are marked low-latency by whoever knows where the job ends.
+    static const int adaptive = [] { const char* e = getenv("BSC_RC_ADAPTIVE"); return e ? atoi(e) : 0; }();
     static const int cpus = default_coder_threads();
     const int callers = g_sync_callers.load(std::memory_order_relaxed);
     return bscgpu_coder_task_shape(ps_simd_env(), ((J.features & BSCGPU_FEATURE_LOW_LATENCY) || !J.pipelined) ? 1 : 0, J.pool_free,
