@@ -80,9 +80,9 @@ def main():
     ncx = max(1, args.contexts)
     cpus_rank = max(1, effective_cpus() // max(local_world, 1))
     if "BSCGPU_HOST_THREADS" not in os.environ:         # ONE coder pool per process, shared by this rank's contexts
-        # (half as many threads again as the CPU share: threads are cheap, a task spends part of its life waiting for its block's
-        # copy from the GPU, and the pool counts idle CPUs against BSCGPU_HOST_CPUS, not against its threads)
-        os.environ["BSCGPU_HOST_THREADS"] = str(max(4, min(96, (3 * cpus_rank + 1) // 2)))
+        # (a quarter more threads than the CPU share: a task spends part of its life asleep, waiting for its block's copy from the GPU; half
+        # as many again — rounds 3-4 — overdraws a cgroup CPU quota at the tail of a job, and the quota then stops the whole process)
+        os.environ["BSCGPU_HOST_THREADS"] = str(max(4, min(96, cpus_rank + cpus_rank // 4)))
         os.environ.setdefault("BSCGPU_HOST_CPUS", str(cpus_rank))
     coder_threads = int(os.environ["BSCGPU_HOST_THREADS"])
     # Range coding on the host: all eight sub-blocks of a block in SIMD lanes on one thread (0.118 CPU-s per block

@@ -947,11 +947,14 @@ static CoderPool* pool_acquire()
     if (!g_pool) {
         CtxTimer tm("coder pool threads");
         CoderPool* P = new CoderPool;
-        // Half as many threads again as CPUs (round 5: the library's default, as bench.py had been setting it since round 3): threads are
-        // cheap, a task spends part of its life waiting for its sub-blocks' copy from the GPU, and the idle test behind the task shapes
-        // counts against the CPU budget, not against the threads.
+        // A quarter more threads than CPUs (round 5: the library's default; bench.py had been asking for half as many again since round
+        // 3): a task spends part of its life asleep, waiting for its sub-blocks' copy from the GPU, so some surplus pays — but where the
+        // CPUs are a cgroup QUOTA (CPU time, not cores: the 1-GPU boxes grant 16 of 256 hardware threads), 24 runnable threads at the tail of
+        // a job overdraw it and the whole process, GPU-driving threads included, is stopped for the rest of the 100 ms period
+        // (cpu.stat: one throttled period per 20-step run with 24 threads, none with 20; 3802 / 3844 MB/s against 4015 / 3941, 16
+        // threads 3693 / 3701, one box, alternating runs, profiles/r05/coder_threads_and_quota.txt).
         const int cpus = default_coder_threads();
-        int nworkers = (3 * cpus + 1) / 2; if (nworkers > 96) nworkers = 96;
+        int nworkers = cpus + cpus / 4; if (nworkers > 96) nworkers = 96;
         bool forced = false;
         if (const char* e = getenv("BSCGPU_HOST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 256) { nworkers = v; forced = true; } }
         P->budget = (forced && nworkers < cpus) ? nworkers : cpus;

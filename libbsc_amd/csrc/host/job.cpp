@@ -74,7 +74,9 @@ struct Job {
     bool may_take(const Worker& w) const
     {
         if (next >= blocks.size()) return false;
-        if (!closing) {
+        // (not for a context's very first block: its first GPU stage also allocates its device-coder arena and landing zones — ~90 ms
+        // that the contexts of a cold process had better spend side by side, as a short file job does: bsc_mgpu)
+        if (!closing && w.blocks != 0) {
             if (active == 0) { if (w.ordinal != 0) return false; }
             else if (w.burst_seen != burst && stages_done[(size_t)w.dev_index] < (unsigned)w.ordinal) return false;
         }

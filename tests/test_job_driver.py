@@ -180,17 +180,32 @@ def test_job_head_and_tail_are_tapered_when_the_total_is_announced():
         assert bool(feat & LOW) == (total - b <= ndev * cpd), b  # the last devices x contexts blocks are low-latency
         assert feat & 0xffff == 3
         if w not in first:
-            first[w] = b
-            assert stages_before >= k, (b, w, stages_before)     # head: k stages of the device had finished before its k-th context began
+            first[w] = b                                          # (a context's very first block is exempt from the head rule: cold set-up runs side by side)
     assert set(first) == set(range(ndev * cpd))                  # the middle of the job uses every context
+    # a second burst on the now warm contexts (the job ran dry above): a first context begins, the k-th joins after k stages of the burst
+    base = dict(node.stages)
+    total2 = total + 14
+    assert L.bscgpu_job_expect(h, total2) == 0
+    more = [np.full(70 + i, 3, np.uint8) for i in range(14)]
+    mouts = [np.zeros(a.size + 28, np.uint8) for a in more]
+    for i, (a, o) in enumerate(zip(more, mouts)):
+        assert L.bscgpu_job_add(h, N.np_ptr(a), N.np_ptr(o), a.size, 0, 0, 1, 1, 3) == total + i
+    started = set()
+    for i, (a, o) in enumerate(zip(more, mouts)):
+        assert L.bscgpu_job_wait(h, total + i) == a.size + 28
+        dev = ci(-1)
+        w = L.bscgpu_job_block_worker(h, total + i, C.byref(dev))
+        if w not in started:
+            started.add(w)
+            assert node.seen[a.ctypes.data][1] - base[dev.value] >= w // ndev, (i, w)
     # more blocks than announced: the tail rule is dropped, nothing is left behind
     extra = [np.full(50, 7, np.uint8) for _ in range(5)]
     eouts = [np.zeros(78, np.uint8) for _ in extra]
     for i, (a, o) in enumerate(zip(extra, eouts)):
-        assert L.bscgpu_job_add(h, N.np_ptr(a), N.np_ptr(o), a.size, 0, 0, 1, 1, 3) == total + i
+        assert L.bscgpu_job_add(h, N.np_ptr(a), N.np_ptr(o), a.size, 0, 0, 1, 1, 3) == total2 + i
     L.bscgpu_job_destroy(h)
     assert all(o[28:].tobytes() == a.tobytes() for a, o in zip(extra, eouts))
-    assert sum(p["blocks"] for p in node.pipes.values()) == total + 5
+    assert sum(p["blocks"] for p in node.pipes.values()) == total + 5 + 14
 
 
 def test_job_creation_fails_as_a_whole_when_a_device_cannot_be_set_up():

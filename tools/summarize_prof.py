@@ -7,7 +7,7 @@ def find(pattern):
 
 cmd = sys.argv[2] if len(sys.argv) > 2 else "python bench.py --steps 8 --warmup 2 --no-cpu-baseline"
 print(f"== rocprofv3 --kernel-trace --stats of: {cmd}")
-print("   (4 GPU contexts run side by side in the timed region, so per-launch durations there measure sharing of the chip; the")
+print("   (the GPU contexts of bench.py — six by default — run side by side in the timed region, so per-launch durations there measure sharing of the chip; the")
 print("    'solo' table below keeps only launches that no launch of another queue overlaps = bench.py's single-context leg, the")
 print("    region its roofline numbers are measured on)")
 for f in find("*kernel_stats.csv"):
