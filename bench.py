@@ -144,6 +144,7 @@ def main():
     # the last block of every pipe is marked BSCGPU_FEATURE_LOW_LATENCY (short host tasks whatever the pool's load): the pipeline's drain
     # is part of the timed region, and only the caller knows where a job ends
     tail_low_latency = os.environ.get("BSC_BENCH_TAIL", "1") != "0"
+    ll_blocks = int(os.environ.get("BSC_BENCH_LL", "0"))     # how many of a job's last blocks are marked (0: one per context)
 
     trace = [] if os.environ.get("BSC_BENCH_TRACE") else None      # (pipe, block, what, seconds since the run started): where a short run's time goes
     t_run0 = [0.0]
@@ -176,7 +177,7 @@ def main():
             if left <= k:
                 return False, False
             queue_state["next"] += 1
-            return True, left <= ncx
+            return True, left <= ll_blocks
 
     def stage_finished():
         if queue_state["total"]:
@@ -268,6 +269,7 @@ def main():
             if cand == 1:
                 raise
     ctx = ctxs[0]
+    if ll_blocks <= 0: ll_blocks = ncx
     blk = run(args.warmup)
     if concat is not None:
         concat.close()
@@ -490,11 +492,11 @@ def main():
         if rc_adaptive:
             coder_desc = (f"per block either all eight sub-blocks in the SIMD lanes of one task ({simd}; {pool_modes['eight_lane_task']} of this rank's {args.steps} timed blocks) "
                           f"or four tasks of two interleaved scalar coders — blocks queued while >= 4 CPUs of the pool's budget were idle"
-                          + ((f", and the job's last {ncx} blocks, marked low-latency" if (use_queue and ncx > 1) else f", and the last block of each of the {ncx} pipes, marked low-latency") if tail_low_latency else "") + f" ({pool_modes['pair_tasks']} blocks)"
+                          + ((f", and the job's last {ll_blocks} blocks, marked low-latency" if (use_queue and ncx > 1) else f", and the last block of each of the {ncx} pipes, marked low-latency") if tail_low_latency else "") + f" ({pool_modes['pair_tasks']} blocks)"
                           + (f", or eight scalar tasks, a low-latency block that found >= 12 CPUs idle ({pool_modes['scalar_tasks']})" if pool_modes['scalar_tasks'] else ""))
         elif rc_x8:
             coder_desc = (f"all eight sub-blocks of a block in the SIMD lanes of one task, {simd} ({pool_modes['eight_lane_task']} of this rank's {args.steps} timed blocks)"
-                          + ((f"; the job's last {ncx} blocks" if (use_queue and ncx > 1) else f"; the last block of each of the {ncx} pipes") +
+                          + ((f"; the job's last {ll_blocks} blocks" if (use_queue and ncx > 1) else f"; the last block of each of the {ncx} pipes") +
                              f", marked low-latency, as four tasks of two interleaved scalar coders ({pool_modes['pair_tasks']})"
                              + (f" or, finding >= 12 CPUs idle, eight scalar tasks ({pool_modes['scalar_tasks']})" if pool_modes['scalar_tasks'] else "") if tail_low_latency else ""))
         else:

@@ -952,7 +952,9 @@ static CoderPool* pool_acquire()
         // CPUs are a cgroup QUOTA (CPU time, not cores: the 1-GPU boxes grant 16 of 256 hardware threads), 24 runnable threads at the tail of
         // a job overdraw it and the whole process, GPU-driving threads included, is stopped for the rest of the 100 ms period
         // (cpu.stat: one throttled period per 20-step run with 24 threads, none with 20; 3802 / 3844 MB/s against 4015 / 3941, 16
-        // threads 3693 / 3701, one box, alternating runs, profiles/r05/coder_threads_and_quota.txt).
+        // threads 3693 / 3701, one box, alternating runs, profiles/r05/coder_threads_and_quota.txt).  A cap on the tasks CODING at the same
+        // time (budget - 1 slots, taken after a task's input has landed) was built and measured as well: no gain at 20 or 28 threads
+        // (3565 against 3690 MB/s, means of three alternating runs, profiles/r05/coding_slots_and_tail_marks.txt) — removed.
         const int cpus = default_coder_threads();
         int nworkers = cpus + cpus / 4; if (nworkers > 96) nworkers = 96;
         bool forced = false;
