@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <type_traits>
 
 using namespace dcm;
 
@@ -502,6 +503,13 @@ __global__ __launch_bounds__(WG) void dc_scan_misc_kernel(const u32* __restrict_
     if (threadIdx.x == 0) wdecoff[W] = carry;
 }
 
+// lane `lane` of v <- val, both wave-uniform (v_writelane takes one SGPR operand besides m0)
+__device__ __forceinline__ int dc_writelane(int v, int val, int lane)
+{
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(lane) : "m0");
+    return v;
+}
+
 // 2c. scatter.  One wavefront per wave-chunk walks its items 64 at a time; per canonical round the lanes that have a decision
 // are ranked stably inside their row (same type -> same round, so rows never interleave across rounds) and write
 //   events[row offset]            = X | sub-block << 8 | bit << 11
@@ -530,8 +538,6 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
     if (wc >= g.W) return;
     dc_lds_vu32* vg = (dc_lds_vu32*)&goff[w][0];
     dc_lds_vu32* sp = (dc_lds_vu32*)&spos[w][0];
-    const u64 lt = lanemask_lt();
-    const u32 lt_lo = (u32)lt, lt_hi = (u32)(lt >> 32);
     int sreg = (lane < (u32)DC_SLOTS) ? (int)goff[w][dc_slot_tau((int)lane)] : 0;     // running offsets of the single-row types
     const u64 i0 = (u64)wc * g.per_wave;
     u64 i1 = i0 + g.per_wave; if (i1 > g.m) i1 = g.m;
@@ -549,35 +555,40 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
         const u32 incl = wave_incl_sum(nd);
         const u32 loc = incl - nd;                                    // first decision of this item inside the tile
         if (valid) doff[i] = running + loc;
-        const u32 tile_total = (u32)__shfl((int)incl, 63, 64);
-        const bool staged = tile_total <= DC_POS_STAGE;               // wave-uniform
+        const u32 tile_total = (u32)__builtin_amdgcn_readfirstlane(__shfl((int)incl, 63, 64));      // a scalar: `staged` below is then a scalar
+        const bool staged = tile_total <= DC_POS_STAGE;               // branch around every round's position store, not an exec-mask dance
         const u32 sig = (ignoreX ? 0u : item_X(key)) | (it.sb << 8);
         u32* mypos = pos + running + loc;
-        u32 ord = 0;
-        auto put = [&](u32 p) { if (staged) sp[loc + ord] = p; else mypos[ord] = p; ++ord; };
-        dc_item_rounds<SIDES>(it, valid, maxr,
-            [&](int slot, bool on, u32 bit) {
-                const u64 m = __ballot(on);
-                const u32 bs = (u32)__builtin_amdgcn_readlane(sreg, slot);
-                if (on) {
-                    const u32 p = bs + (u32)(__popc((u32)m & lt_lo) + __popc((u32)(m >> 32) & lt_hi));
-                    events[p] = (u16)(sig | (bit << 11));
-                    put(p);
-                }
-                if ((int)lane == slot) sreg = (int)(bs + (u32)__popcll(m));
-            },
-            [&](int tau, bool on, u32 bit, u32 mlo, u32 mhi) {
-                const u32 h = on ? (u32)tau : 0u;
-                const u32 before = vg[h];
-                const u32 rr = (u32)(__popc(mlo & lt_lo) + __popc(mhi & lt_hi));
-                const u32 cn = (u32)(__popc(mlo) + __popc(mhi));
-                if (on) {
-                    const u32 p = before + rr;
-                    if (rr == cn - 1) vg[h] = before + cn;                // highest peer publishes
-                    events[p] = (u16)(sig | (bit << 11));
-                    put(p);
-                }
-            });
+        // (two copies of the rounds, chosen once per tile: with the test inside `put` every round carried a branch around its position store)
+        auto rounds = [&](auto staged_tag) __attribute__((always_inline)) {
+            constexpr bool STAGED = decltype(staged_tag)::value;
+            u32 ord = 0;
+            auto put = [&](u32 p) { if (STAGED) sp[loc + ord] = p; else mypos[ord] = p; ++ord; };
+            dc_item_rounds<SIDES>(it, valid, maxr,
+                [&](int slot, bool on, u32 bit) {
+                    const u64 m = __ballot(on);
+                    const u32 bs = (u32)__builtin_amdgcn_readlane(sreg, slot);
+                    if (on) {
+                        const u32 p = bs + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));   // peers in lower lanes
+                        events[p] = (u16)(sig | (bit << 11));
+                        put(p);
+                    }
+                    sreg = dc_writelane(sreg, (int)(bs + (u32)__popcll(m)), slot);                    // (was: compare, move, select)
+                },
+                [&](int tau, bool on, u32 bit, u32 mlo, u32 mhi) {
+                    const u32 h = on ? (u32)tau : 0u;
+                    const u32 before = vg[h];
+                    const u32 rr = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+                    const u32 cn = (u32)(__popc(mlo) + __popc(mhi));
+                    if (on) {
+                        const u32 p = before + rr;
+                        vg[h] = before + cn;                                  // every peer writes the same value (was: the highest one, behind a compare and a branch)
+                        events[p] = (u16)(sig | (bit << 11));
+                        put(p);
+                    }
+                });
+        };
+        if (staged) rounds(std::true_type()); else rounds(std::false_type());
         if (staged) for (u32 t = lane; t < tile_total; t += 64) pos[running + t] = sp[t];
         running += tile_total;
     }
@@ -757,6 +768,7 @@ __global__ __launch_bounds__(64 * DC_EVAL_WAVES) void dc_eval_wave_kernel(DcEval
             const u32 lim = k1 < clsend ? k1 : clsend;
             if (kb + DC_EB <= lim) {
                 // whole batch inside one class (one set of rates): straight-line walk from registers
+                const int c0 = R.t0 * R.a0 + R.r0, c1 = R.t1 * R.a1 + R.r1;
 #pragma unroll
                 for (int g8 = 0; g8 < 8; ++g8) {
                     const uint4 q = *reinterpret_cast<const uint4*>(myrow + g8 * 16);
@@ -771,11 +783,13 @@ __global__ __launch_bounds__(64 * DC_EVAL_WAVES) void dc_eval_wave_kernel(DcEval
                         // dcm::step with the target, rate and rounding picked by the bit first, so that both ends of the bracket
                         // share the selects (static coder: bit 1 is v - (((v - t1) a1) >> 12) = v + (((t1 - v) a1 + 4095) >> 12) —
                         // floor of a negated quotient = minus its ceiling —, bit 0 is v + (((t0 - v) a0) >> 12); devcoder_model.h)
+                        // (round 5: (t - v) a + r = (t a + r) - v a with c = t a + r fixed per class and bit — two selects and three operations
+                        // per step instead of three and four; all products stay below 2^24: |v| < 2^13, a < 2^11, c < 2^24)
                         const bool b1 = (e & 0x800u) != 0u;
-                        const int T = b1 ? R.t1 : R.t0, Aa = b1 ? R.a1 : R.a0, rr = b1 ? R.r1 : R.r0;
+                        const int Cc = b1 ? c1 : c0, Aa = b1 ? R.a1 : R.a0;
                         if (WRITE) outw[x >> 1] |= (u32)lo << (16 * (x & 1));
-                        lo += (__mul24(T - lo, Aa) + rr) >> 12;
-                        if (!WRITE) hi += (__mul24(T - hi, Aa) + rr) >> 12;
+                        lo += (Cc - __mul24(lo, Aa)) >> 12;
+                        if (!WRITE) hi += (Cc - __mul24(hi, Aa)) >> 12;
                     }
                     if (WRITE) *reinterpret_cast<uint4*>(orow + g8 * 16) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
                 }
@@ -911,7 +925,12 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, 
                                                         const u32* __restrict__ meta, u16* __restrict__ out, u16* __restrict__ dbg /*[3][D] or null*/, u32 dbgD)
 {
     __shared__ u16 stage[WAVES][DC_PS_STAGE];
+    __shared__ short s_lr[NUM_CLS][4];                                // blend weights per class: an LDS read per decision instead of global loads at a per-lane address
     if (meta[DM_FAIL] != 0u) return;
+    if (!FAST) {
+        if (threadIdx.x < (u32)NUM_CLS * 3u) s_lr[threadIdx.x / 3u][threadIdx.x % 3u] = mp->lr[threadIdx.x / 3u][threadIdx.x % 3u];
+        __syncthreads();
+    }
     const u32 j = dc_virtual_block() * WG + threadIdx.x;
     const u32 lane = threadIdx.x & 63u;
     const bool valid = j < G.m;                                       // (whole wavefronts past the end still take part in the shuffles below)
@@ -938,7 +957,7 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, 
         } else {
             const int v_sp = G.V_sp[q_sp];
             const int v_st = run_side ? G.V_sn[q_st] : G.V_sr[q_st];
-            const int p = blend(v_ch, v_st, v_sp, mp->lr[tau_class(tau)]);
+            const int p = blend(v_ch, v_st, v_sp, s_lr[tau_class(tau)]);
             e = (u16)((u32)p | (bit << 12) | (k == 0 ? (u32)PS_RUN : 0u));
             if (dbg) { dbg[b_sp + k] = (u16)v_st; dbg[(size_t)dbgD + b_sp + k] = (u16)v_ch; dbg[2 * (size_t)dbgD + b_sp + k] = (u16)v_sp; }
         }

@@ -51,6 +51,28 @@ def test_bsc_compress_matches_reference(ref, sorter, coder):
             assert got_ip == api.NOT_COMPRESSIBLE or got_ip == want, (name, "inplace-store")
 
 
+@pytest.mark.parametrize("K", [2, 17, 32, 33, 48, 64, 65, 200])
+def test_front_end_rank_paths_by_alphabet_size(ref, K):
+    """qf_rank's three set layouts — 32-bit sets (<= 32 symbols), one 64-bit word (<= 64), four words — on skewed alphabets: frequent
+    symbols come back inside the lifted tile, middling ones inside the 256-run halo behind it (round 5), rare ones only after thousands
+    of runs (tile / super-tile sets, then the serial walk) or never again before the sub-block ends.  Four sub-blocks, so tiles straddle
+    sub-block ends too.  Whole blocks against the reference, static and fast coder (device model) and the adaptive one (host model)."""
+    rng = np.random.default_rng(1000 + K)
+    p = 1.0 / np.arange(1, K + 1) ** 1.6
+    p /= p.sum()
+    n = 5 << 20
+    T = rng.choice(K, size=n, p=p).astype(np.uint8)
+    # runs, and order: sort inside short windows so that the BWT input has structure (the front end sees the SORTED block anyway)
+    T = np.repeat(T[: n // 3 + 1], 3)[:n].copy()
+    T[::97] = (K - 1)                                    # the rarest symbol at a fixed stride as well
+    syms = rng.permutation(256)[:K].astype(np.uint8)     # not the low byte values only
+    T = syms[T]
+    for coder in (1, 3, 2):
+        want = ref.compress(T, 1, coder)
+        got = api.bsc_compress(T, 1, coder)
+        assert got == want, (K, coder)
+
+
 def test_reference_decoder_accepts_our_blocks(ref):
     for name, T in _inputs():
         for sorter, coder in ((1, 1), (1, 2), (5, 3), (6, 1), (3, 1), (4, 2), (7, 1), (8, 1)):
