@@ -423,16 +423,25 @@ __global__ __launch_bounds__(WG) void dc_part_count_kernel(const u64* __restrict
     if (wc < g.W) {
         const u64 i0 = (u64)wc * g.per_wave;
         u64 i1 = i0 + g.per_wave; if (i1 > g.m) i1 = g.m;
-        for (u64 i = i0 + lane; i < i1; i += 64) {
-            const Item it = item_unpack(items[i]);
-            const int maxr = (int)S.maxr[it.sb];
-            if (SIDES & 1) {
-                total += (u32)count_rank_side(it, maxr);
-                if (it.ge32) {
-                    for (int d = 0; d <= maxr; ++d) atomicAdd(&hrp[w][((1u << d) | ((it.rank >> (maxr + 1 - d)) & ((1u << d) - 1u))) - 1u], 1u);
-                } else atomicAdd(&bw[dc_rank_bin(it.rank, maxr)], 1u);
+        // four items per lane and trip, their loads issued together: with one load in flight per wavefront the ~108 trips of a wave-chunk
+        // each waited out a full memory latency (0.17 ms per job for 225 MB: round 5 counters, 80 % of the wave cycles parked)
+        for (u64 base = i0; base < i1; base += 256) {
+            u64 kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const u64 i = base + 64u * (u32)u + lane; kk[u] = items[i < i1 ? i : i0]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (base + 64u * (u32)u + lane >= i1) continue;
+                const Item it = item_unpack(kk[u]);
+                const int maxr = (int)S.maxr[it.sb];
+                if (SIDES & 1) {
+                    total += (u32)count_rank_side(it, maxr);
+                    if (it.ge32) {
+                        for (int d = 0; d <= maxr; ++d) atomicAdd(&hrp[w][((1u << d) | ((it.rank >> (maxr + 1 - d)) & ((1u << d) - 1u))) - 1u], 1u);
+                    } else atomicAdd(&bw[dc_rank_bin(it.rank, maxr)], 1u);
+                }
+                if (SIDES & 2) { total += (u32)count_run_side(it); atomicAdd(&bw[dc_run_bin(it.run)], 1u); }
             }
-            if (SIDES & 2) { total += (u32)count_run_side(it); atomicAdd(&bw[dc_run_bin(it.run)], 1u); }
         }
     }
     __syncthreads();
@@ -608,10 +617,12 @@ __global__ __launch_bounds__(WG) void dc_doff_kernel(const u64* __restrict__ ite
     const u64 i0 = (u64)wc * g.per_wave;
     u64 i1 = i0 + g.per_wave; if (i1 > g.m) i1 = g.m;
     u32 running = wdecoff[wc];
+    u64 knext = (i0 + lane < i1) ? items[i0 + lane] : 0ull;          // the next tile's items are requested one tile ahead
     for (u64 base = i0; base < i1; base += 64) {
         const u64 i = base + lane;
         const bool valid = i < i1;
-        const Item it = item_unpack(valid ? items[i] : 0ull);
+        const Item it = item_unpack(knext);
+        knext = (i + 64 < i1) ? items[i + 64] : 0ull;
         const int maxr = (int)S.maxr[it.sb];
         u32 nd = 0;
         if (valid) { if (SIDES & 1) nd += (u32)count_rank_side(it, maxr); if (SIDES & 2) nd += (u32)count_run_side(it); }

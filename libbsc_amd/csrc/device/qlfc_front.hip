@@ -132,17 +132,47 @@ __global__ __launch_bounds__(WG) void qf_apply_kernel(const u8* __restrict__ L, 
 // Symbol sets per 256 runs ("tile") and per 65 536 runs ("super tile").  Two layouts:
 //   DENSE (<= 64 distinct symbols in the block, e.g. any text): symbols are renumbered 0..K-1 (lut) and a set is ONE u64;
 //   otherwise a set is four u64 indexed by the raw byte.
+// One wavefront per tile of 256 runs: a lane takes four consecutive symbols with one load, the sets are OR-ed across the wavefront by
+// shuffles — no LDS, no barrier, a quarter of the workgroups (round 5; one 256-thread workgroup per tile with an LDS atomic per run was
+// bound by workgroup dispatch: 110 K workgroups for 0.12 ms of nothing).
 template <bool DENSE>
 __global__ __launch_bounds__(WG) void qf_tile_masks_kernel(const u8* __restrict__ sym, u32 m, const u8* __restrict__ lut, u64* __restrict__ masks)
 {
-    __shared__ u32 bits[8];
-    if (threadIdx.x < 8) bits[threadIdx.x] = 0;
-    __syncthreads();
-    const u32 j = blockIdx.x * WG + threadIdx.x;
-    if (j < m) { const u32 c = DENSE ? lut[sym[j]] : sym[j]; atomicOr(&bits[c >> 5], 1u << (c & 31)); }
-    __syncthreads();
-    constexpr u32 W = DENSE ? 1 : 4;
-    if (threadIdx.x < W) masks[(size_t)blockIdx.x * W + threadIdx.x] = (u64)bits[2 * threadIdx.x] | ((u64)bits[2 * threadIdx.x + 1] << 32);
+    constexpr int W = DENSE ? 1 : 4;
+    __shared__ u8 slut[256];
+    if (DENSE) { slut[threadIdx.x] = lut[threadIdx.x]; __syncthreads(); }
+    const u32 tile = blockIdx.x * WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const u32 j0 = tile * 256u + 4u * lane;
+    if (tile * 256u >= m) return;                                      // (whole wavefronts only: the shuffles below need all 64 lanes)
+    u32 word = 0;
+    if (j0 + 4u <= m) word = *reinterpret_cast<const u32*>(sym + j0);   // sym is a carved arena buffer: 4-byte aligned at every multiple of four
+    else for (u32 b = 0; b < 4u; ++b) if (j0 + b < m) word |= (u32)sym[j0 + b] << (8u * b);
+    u64 v[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) v[k] = 0;
+#pragma unroll
+    for (u32 b = 0; b < 4u; ++b) {
+        if (j0 + b < m) {
+            const u32 raw = (word >> (8u * b)) & 0xffu;
+            const u32 c = DENSE ? slut[raw] : raw;
+            if (DENSE) v[0] |= 1ull << c;
+            else {
+#pragma unroll
+                for (int k = 0; k < W; ++k) v[k] |= ((c >> 6) == (u32)k) ? (1ull << (c & 63u)) : 0ull;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v[k] |= __shfl_xor(v[k], d, 64);
+    }
+    if (lane < (u32)W) {
+        u64 out = v[0];
+#pragma unroll
+        for (int k = 1; k < W; ++k) if (lane == (u32)k) out = v[k];
+        masks[(size_t)tile * W + lane] = out;
+    }
 }
 template <bool DENSE>
 __global__ __launch_bounds__(WG) void qf_super_masks_kernel(const u64* __restrict__ masks, u32 ntiles, u64* __restrict__ super)
@@ -462,10 +492,10 @@ int qlfc_front_runs(bscgpu_ctx* c, const u8* dL, u32 n, int nblocks, const int* 
     const u32 ntiles = (m + 255) / 256, nsuper = (ntiles + 255) / 256;
     prof_begin(c, BSCGPU_K_MISC, m, 0);
     if (dense) {
-        hipLaunchKernelGGL(qf_tile_masks_kernel<true>, dim3(ntiles), dim3(WG), 0, c->stream, dsym, m, dlut, dmask);
+        hipLaunchKernelGGL(qf_tile_masks_kernel<true>, dim3((ntiles + WAVES - 1) / WAVES), dim3(WG), 0, c->stream, dsym, m, dlut, dmask);
         hipLaunchKernelGGL(qf_super_masks_kernel<true>, dim3(nsuper), dim3(WG), 0, c->stream, dmask, ntiles, dsuper);
     } else {
-        hipLaunchKernelGGL(qf_tile_masks_kernel<false>, dim3(ntiles), dim3(WG), 0, c->stream, dsym, m, dlut, dmask);
+        hipLaunchKernelGGL(qf_tile_masks_kernel<false>, dim3((ntiles + WAVES - 1) / WAVES), dim3(WG), 0, c->stream, dsym, m, dlut, dmask);
         hipLaunchKernelGGL(qf_super_masks_kernel<false>, dim3(nsuper), dim3(WG), 0, c->stream, dmask, ntiles, dsuper);
     }
     prof_end(c);
