@@ -228,3 +228,21 @@ def test_cxx_file_compressor_is_built_with_the_library():
     assert os.path.exists(DRIVER_EXE)
     r = subprocess.run([DRIVER_EXE], capture_output=True, text=True)
     assert r.returncode == 2 and "bsc_mgpu e <in> <out>" in r.stderr
+
+
+def test_job_scheduler_under_thread_sanitizer(tmp_path):
+    """tools/job_tsan_check.cpp: job.cpp itself compiled with -fsanitize=thread against a stand-in executor (threads adding with pauses so
+    that bursts restart, an in-order collector, announced totals on every other job, a failing block): no data race report, every block
+    collected, head / tail rules hold."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "job_tsan_check")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-Wno-subobject-linkage", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "tools", "job_tsan_check.cpp"), "-o", exe, "-lpthread"], capture_output=True, text=True)
+    if r.returncode != 0 and "tsan" in (r.stderr or "").lower():
+        pytest.skip("this g++ has no ThreadSanitizer runtime")
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS", "UBSAN_OPTIONS")}
+    for _ in range(3):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0 and "0 failure(s)" in r.stdout and "ThreadSanitizer:" not in r.stderr, r.stdout + r.stderr[-3000:]
