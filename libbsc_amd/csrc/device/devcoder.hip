@@ -960,7 +960,7 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, 
     const u32* p_sr = FAST ? G.pos_ch : G.pos_sr + (valid ? G.doff_sr[G.inv_sr[j]] : 0u);
     const u32* p_sn = FAST ? G.pos_ch : G.pos_sn + (valid ? G.doff_sn[G.inv_sn[j]] : 0u);
     u16* o = out + b_sp;
-    auto emit = [&](int k, u32 q_sp, u32 q_ch, u32 q_st, bool run_side, int tau, u32 bit) {
+    auto emit = [&](int k, u32 q_sp, u32 q_ch, u32 q_st, bool run_side, int cls, u32 bit) {
         const int v_ch = G.V_ch[q_ch];
         u16 e;
         if (FAST) {
@@ -968,7 +968,7 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, 
         } else {
             const int v_sp = G.V_sp[q_sp];
             const int v_st = run_side ? G.V_sn[q_st] : G.V_sr[q_st];
-            const int p = blend(v_ch, v_st, v_sp, s_lr[tau_class(tau)]);
+            const int p = blend(v_ch, v_st, v_sp, s_lr[cls]);
             e = (u16)((u32)p | (bit << 12) | (k == 0 ? (u32)PS_RUN : 0u));
             if (dbg) { dbg[b_sp + k] = (u16)v_st; dbg[(size_t)dbgD + b_sp + k] = (u16)v_ch; dbg[2 * (size_t)dbgD + b_sp + k] = (u16)v_sp; }
         }
@@ -990,15 +990,15 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, 
     for (int k = 0; k < 8; ++k) {
         if (k < nd) {
             u32 bit; bool rs;
-            const int tau = nth_decision(it, maxr, n_rank, k, &bit, &rs);
+            const int cls = nth_class(it, maxr, n_rank, k, &bit, &rs);
             const u32 q_st = FAST ? 0u : (rs ? p_sn[k - n_rank] : p_sr[k]);
-            emit(k, qsp[k], qch[k], q_st, rs, tau, bit);
+            emit(k, qsp[k], qch[k], q_st, rs, cls, bit);
         }
     }
     for (int k = 8; k < nd; ++k) {
         u32 bit; bool rs;
-        const int tau = nth_decision(it, maxr, n_rank, k, &bit, &rs);
-        emit(k, FAST ? 0u : p_sp[k], p_ch[k], FAST ? 0u : (rs ? p_sn[k - n_rank] : p_sr[k]), rs, tau, bit);
+        const int cls = nth_class(it, maxr, n_rank, k, &bit, &rs);
+        emit(k, FAST ? 0u : p_sp[k], p_ch[k], FAST ? 0u : (rs ? p_sn[k - n_rank] : p_sr[k]), rs, cls, bit);
     }
     if (staged) {
         // the wavefront's piece [wbase, wbase + wtotal) of the stream: 4-byte stores from the first even entry on, the odd ends singly

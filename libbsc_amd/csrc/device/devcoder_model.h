@@ -203,6 +203,32 @@ DC_HD int nth_decision(const Item& it, int max_rank, int n_rank, int k, uint32_t
     return TAU_NM + nm_off(nb) + (int)ctx - 1;
 }
 
+// The CLASS (update rates, blend weights) and the coded bit of a run's k-th decision — what the probability stream needs; the type itself
+// (which tree node) only matters to the partition.  Same case analysis as nth_decision without the node arithmetic
+// (tools/devcoder_sim.cpp checks tau_class(nth_decision(...)) == nth_class(...) and the bits on every run it walks).
+DC_HD int nth_class(const Item& it, int max_rank, int n_rank, int k, uint32_t* bit, bool* run_side)
+{
+    if (k < n_rank) {
+        const uint32_t rank = it.rank;
+        *run_side = false;
+        if (it.ge32) { *bit = (rank >> (max_rank - k)) & 1u; return CLS_RP; }
+        if (k == 0) { *bit = rank != 1u ? 1u : 0u; return CLS_RF; }
+        const int B = bsr(rank);
+        const int e = (B - 1) + (B < max_rank ? 1 : 0);
+        if (k <= e) { *bit = k < B ? 1u : 0u; return CLS_RE; }
+        *bit = (rank >> (B - 1 - (k - 1 - e))) & 1u;
+        return CLS_RM;
+    }
+    const int kk = k - n_rank;
+    const uint32_t run = it.run;
+    *run_side = true;
+    if (kk == 0) { *bit = run != 1u ? 1u : 0u; return CLS_NF; }
+    const int nb = bsr(run);
+    if (kk <= nb) { *bit = kk < nb ? 1u : 0u; return CLS_NE; }
+    *bit = (run >> (nb - 1 - (kk - 1 - nb))) & 1u;
+    return nb <= 5 ? CLS_NM : CLS_NM2;
+}
+
 // ---- counters --------------------------------------------------------------------------------------------------------
 // predictor.h:53-61 with the family's tuned constants: bit 0 moves towards 4096 - th0, bit 1 towards th1 (arithmetic shifts)
 // One form for both coders: v <- v + (((t_bit - v) * a_bit + r_bit) >> 12), arithmetic shift.

@@ -111,6 +111,9 @@ int main(int argc, char** argv)
                     const int t2 = dcm::nth_decision(it, max_rank, n_rank, k, &b2, &rs2);
                     const Dec& d = D[rf[j] + k];
                     if (t2 != tau || b2 != bit || rs2 != rs || (dcm::tau_class(tau) == dcm::CLS_NM2 ? (int)dcm::CLS_NM : dcm::tau_class(tau)) != d.cls || bit != d.bit) { if (bad++ < 10) printf("nth/enumerate mismatch run %zu k %d\n", j, k); }
+                    uint32_t b3 = 9; bool rs3 = !rs;                                        // the class-only form the p-stream kernel uses
+                    const int c3 = dcm::nth_class(it, max_rank, n_rank, k, &b3, &rs3);
+                    if (c3 != dcm::tau_class(tau) || b3 != bit || rs3 != rs) { if (bad++ < 10) printf("nth_class mismatch run %zu k %d: class %d vs %d\n", j, k, c3, dcm::tau_class(tau)); }
                     ++k;
                 });
                 if (k != cnt) { if (bad++ < 10) printf("enumerate count mismatch\n"); }
