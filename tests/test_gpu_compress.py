@@ -693,3 +693,28 @@ def test_cxx_multi_gpu_file_compressor(tmp_path, torch_cuda):
         assert r.returncode == 0 and np.array_equal(np.fromfile(back, np.uint8), data), flags
         r = subprocess.run([exe, "d", str(theirs), str(back)], capture_output=True, text=True, env=env)
         assert r.returncode == 0 and np.array_equal(np.fromfile(back, np.uint8), data), (flags, r.stdout + r.stderr)
+
+
+@pytest.mark.slow
+def test_large_odd_sized_block_takes_the_device_model(ref, torch_cuda):
+    """One block well beyond the benchmark's size and not a power of two (200 000 033 bytes: 12 GB of sorter arena + 46 GB of device
+    model): BWT and ST5 through the static coder against the compiled reference, with the process counter proving that the model ran on
+    the GPU.  (The API's limit is 1 GiB per block, libbsc.cpp:259; there the device model's arena — 230 bytes per block byte — no longer
+    fits next to the sorter's and the block takes the host model: a decline, covered by test_device_coder_arena_that_does_not_fit_...)"""
+    from libbsc_amd import GpuContext, _native as N
+    import ctypes as C
+    torch = torch_cuda
+    n = 200_000_033
+    T = api.synth_text_v1(77, n)
+    L = N.lib()
+    L.bscgpu_process_counter.restype = C.c_longlong
+    before = L.bscgpu_process_counter(1)
+    ctx = GpuContext(0, max_n=n + 4096)
+    try:
+        d = torch.from_numpy(T).cuda()
+        for sorter in (1, 5):
+            got = ctx.compress_device(d, n, sorter, 1).tobytes()
+            assert got == ref.compress(T, sorter, 1), sorter
+    finally:
+        ctx.close()
+    assert L.bscgpu_process_counter(1) - before == 2
