@@ -610,13 +610,16 @@ __global__ __launch_bounds__(WG) void bwt_longrec_place_kernel(const u64* __rest
 // min(n - p, a) — "a proper prefix sorts first" among equal padded keys, 0 for the empty suffix.  lut: byte -> code (LDS or global).
 // (two halves so that a caller can have the loads of several records in flight before it packs the first key)
 struct TextWin { u32 d[5]; };
-__device__ __forceinline__ TextWin bwt_text_window(const u32* __restrict__ T32, u64 p64, u32 n)
+__device__ __forceinline__ TextWin bwt_text_window(const u32* __restrict__ T32, u64 p64, u32 n, u32 a = 16)
 {
     TextWin w;
     const u32 p = p64 < n ? (u32)p64 : 0u;                // (past the end: any valid address, the key is 0 anyway)
     const u32* q = T32 + (p >> 2);                         // T is 4-byte aligned at T[0] and zero padded for 32 bytes past n
 #pragma unroll
-    for (int i = 0; i < 5; ++i) w.d[i] = q[i];
+    for (int i = 0; i < 4; ++i) w.d[i] = q[i];
+    // the fifth word only holds characters 13.. of the window (a <= 12, any text: characters 0..11 + an offset of <= 3 bytes end inside
+    // the fourth): one gather in five saved per record; `a` is a kernel argument, the branch is scalar
+    w.d[4] = a > 12u ? q[4] : 0u;
     return w;
 }
 template <class LUT>
@@ -644,7 +647,7 @@ template <class LUT>
 __device__ __forceinline__ u64 bwt_text_round_key(const u32* __restrict__ T32, LUT lut, u64 p64, u32 n, u32 cb, u32 a)
 {
     if (p64 >= n) return 0;
-    const TextWin w = bwt_text_window(T32, p64, n);
+    const TextWin w = bwt_text_window(T32, p64, n, a);
     return bwt_text_key_of(w, lut, p64, n, cb, a);
 }
 

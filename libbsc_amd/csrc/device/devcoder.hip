@@ -531,6 +531,7 @@ __device__ __forceinline__ int dc_writelane(int v, int val, int lane)
 #define DC_POS_STAGE_N 1280
 #endif
 constexpr u32 DC_POS_STAGE = DC_POS_STAGE_N;
+struct __attribute__((packed, aligned(4))) DcPos4 { u32 a, b, c, d; };      // four positions, 4-byte aligned: one dwordx4 store
 template <int SIDES>
 __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restrict__ items, DcGeom g, DcSub S, const u32* __restrict__ meta,
                                                              const u32* __restrict__ cnt, const u32* __restrict__ rowstart,
@@ -598,7 +599,15 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
                 });
         };
         if (staged) rounds(std::true_type()); else rounds(std::false_type());
-        if (staged) for (u32 t = lane; t < tile_total; t += 64) pos[running + t] = sp[t];
+        // the tile's positions leave as 16-byte stores (four entries per lane: two store instructions for an average tile instead of seven)
+        if (staged) {
+            for (u32 t = 4u * lane; t < tile_total; t += 256u) {
+                if (t + 4u <= tile_total) {
+                    DcPos4 v; v.a = sp[t]; v.b = sp[t + 1]; v.c = sp[t + 2]; v.d = sp[t + 3];
+                    *reinterpret_cast<DcPos4*>(pos + running + t) = v;
+                } else for (u32 x = t; x < tile_total; ++x) pos[running + x] = sp[x];
+            }
+        }
         running += tile_total;
     }
     if (wc == g.W - 1 && lane == 0) doff[g.m] = running;
@@ -986,12 +995,30 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, 
             qsp[0] = a0.a; qsp[1] = a0.b; qsp[2] = a0.c; qsp[3] = a0.d; qsp[4] = a1.a; qsp[5] = a1.b; qsp[6] = a1.c; qsp[7] = a1.d;
         }
     }
+    // the state family's positions: the first eight of each side by two wide loads each (was: one 4-byte load per decision); which of the
+    // sixteen a decision takes is a select chain on (side, index inside the side)
+    u32 sr8[8], sn8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sr8[k] = 0; sn8[k] = 0; }
+    if (!FAST && valid) {
+        const DcU4 r0 = *reinterpret_cast<const DcU4*>(p_sr), r1 = *reinterpret_cast<const DcU4*>(p_sr + 4);
+        const DcU4 n0 = *reinterpret_cast<const DcU4*>(p_sn), n1 = *reinterpret_cast<const DcU4*>(p_sn + 4);
+        sr8[0] = r0.a; sr8[1] = r0.b; sr8[2] = r0.c; sr8[3] = r0.d; sr8[4] = r1.a; sr8[5] = r1.b; sr8[6] = r1.c; sr8[7] = r1.d;
+        sn8[0] = n0.a; sn8[1] = n0.b; sn8[2] = n0.c; sn8[3] = n0.d; sn8[4] = n1.a; sn8[5] = n1.b; sn8[6] = n1.c; sn8[7] = n1.d;
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         if (k < nd) {
             u32 bit; bool rs;
             const int cls = nth_class(it, maxr, n_rank, k, &bit, &rs);
-            const u32 q_st = FAST ? 0u : (rs ? p_sn[k - n_rank] : p_sr[k]);
+            u32 q_st = 0;
+            if (!FAST) {
+                // rank side: index k (static); run side: k - n_rank in 0 .. k
+                u32 qn = sn8[0];
+#pragma unroll
+                for (int j = 1; j <= k; ++j) qn = (k - n_rank == j) ? sn8[j] : qn;
+                q_st = rs ? qn : sr8[k];
+            }
             emit(k, qsp[k], qch[k], q_st, rs, cls, bit);
         }
     }
