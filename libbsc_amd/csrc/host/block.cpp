@@ -530,11 +530,11 @@ static void host_encode_pair(BlockJob& J, int b)
     J.sub_res[b + 1] = r1 < 0 ? J.size[b + 1] : r1;
 }
 
-// How the eight sub-blocks of a device-model block are coded on the host (EPYC 9575F, per 64 MiB block with framing):
-//   8  all eight in the lanes of one SIMD range-coder loop (qlfc_encode_static_pstream_x8): one task, 0.118 CPU-s with AVX-512VL
-//      (0.141 with AVX2), ~90 ms
-//   2  four tasks of two interleaved scalar coders: 0.228 CPU-s, ~52 ms
-//   1  eight tasks of one scalar coder: 0.35 CPU-s, ~44 ms
+// How the eight sub-blocks of a device-model block are coded on the host (EPYC 9575F, the coding loops alone on one quiet thread, per 64 MiB
+// bench block: tools/rc_host_bench.cpp, profiles/r05/host_coder_on_box_cpu.txt; round 4's figures in brackets):
+//   8  all eight in the lanes of one SIMD range-coder loop (qlfc_encode_static_pstream_x8): one task of 96 ms [104] with AVX-512VL (126 with AVX2)
+//   2  four tasks of two interleaved scalar coders: 48 ms each [54], 0.19 CPU-s
+//   1  eight tasks of one scalar coder: 35 ms each [46], 0.28 CPU-s [0.37]
 // bscgpu_coder_task_shape is the rule (a pure function, unit-tested on CPU); ps_group feeds it.  BSC_RC_SIMD=8 / 0 forces eight lanes /
 // pairs everywhere, BSC_RC_ADAPTIVE=1 turns the idle test on (round 3-4's default: pairs for a block that finds >= 4 CPUs idle; off,
 // every block that is not marked low-latency is one eight-lane task).
@@ -558,8 +558,10 @@ extern "C" BSCGPU_API int bscgpu_coder_task_shape(int forced, int low_latency, i
     if (forced >= 0) return forced == 8 ? 8 : 2;
     if (low_latency) {
         // a pipe's block marked low-latency: pairs — the blocks around it are still being coded, eight more tasks would queue behind
-        // them — unless the pool is nearly idle
-        if (pool_free >= 0) return pool_free >= 12 ? 1 : 2;
+        // them — unless eight CPUs of the pool have nothing to do: then eight single-stream tasks all start at once and the block is out
+        // after 35 instead of 48 ms (round 5: the single-stream loop lost its mispredicted branch and two cycles of its chain; before that
+        // its tasks took as long as the pairs' and the threshold was 12)
+        if (pool_free >= 0) return pool_free >= 8 ? 1 : 2;
         // a synchronous call: eight threads only if its share of the CPUs has room for them (the reference CLI calls bsc_compress from
         // an OpenMP team: four callers x eight threads on 16 CPUs took 1.29 s for 8 x 64 MiB, sized by share 1.15 s)
         return sync_cpus >= 8 ? 1 : 2;

@@ -119,13 +119,25 @@ public:
     struct Live { uint64_t low; uint32_t range; };
     __attribute__((always_inline)) inline Live enter() const { return Live{low_, range_}; }
     __attribute__((always_inline)) inline void leave(const Live& L) { low_ = L.low; range_ = L.range; }
+    // The range after a decision: bit ? range - r : r.  Written as a select (cmov: the mantissa bits are close to coin flips, a branch
+    // would mispredict) the chain a coder's next decision waits for is shift, multiply, subtract, select = 6 cycles; the arithmetic form
+    // r + (m & (range - r - r)) of rounds 1-4 was 8.  The scalar and two-stream coders are bound by exactly that chain.
+    static __attribute__((always_inline)) inline uint32_t next_range(uint32_t range, uint32_t r, unsigned bit)
+    {
+        const uint32_t alt = range - r;
+#if defined(__clang__)
+        return __builtin_unpredictable(bit != 0u) ? alt : r;
+#else
+        return bit != 0u ? alt : r;
+#endif
+    }
     template <int P> __attribute__((always_inline)) inline void encode_live(Live& L, unsigned bit, int p)
     {
         if (__builtin_expect(L.range < 0x10000u, 0)) { low_ = L.low; shift(); L.low = low_; L.range <<= 16; }
         const uint32_t r = (L.range >> P) * (uint32_t)p;
         const uint32_t m = 0u - bit;
         L.low  += (uint64_t)(r & m);
-        L.range = r + (m & (L.range - r - r));
+        L.range = next_range(L.range, r, bit);
     }
     // the same, keeping `is_full` (= full(), which only changes inside shift()) in a caller's register: the run-start budget test of
     // the p-stream coders costs three loads and a compare per decision otherwise
@@ -135,7 +147,7 @@ public:
         const uint32_t r = (L.range >> P) * (uint32_t)p;
         const uint32_t m = 0u - bit;
         L.low  += (uint64_t)(r & m);
-        L.range = r + (m & (L.range - r - r));
+        L.range = next_range(L.range, r, bit);
     }
     template <int P> __attribute__((always_inline)) inline void encode(unsigned bit, int p)
     {
@@ -143,7 +155,7 @@ public:
         const uint32_t r = (range_ >> P) * (uint32_t)p;
         const uint32_t m = 0u - bit;                 // branch-free: mantissa bits are close to coin flips
         low_  += (uint64_t)(r & m);
-        range_ = r + (m & (range_ - r - r));
+        range_ = next_range(range_, r, bit);
     }
     // precision picked per decision (the fast coder behind the device model: 13 bits on the rank side, 11 on the run side)
     __attribute__((always_inline)) inline void encode_live_var(Live& L, unsigned bit, unsigned p, unsigned prec, unsigned& is_full)
@@ -152,7 +164,7 @@ public:
         const uint32_t r = (L.range >> prec) * (uint32_t)p;
         const uint32_t m = 0u - bit;
         L.low  += (uint64_t)(r & m);
-        L.range = r + (m & (L.range - r - r));
+        L.range = next_range(L.range, r, bit);
     }
     inline void encode_half(unsigned bit) { encode<12>(bit, 2048); }     // rangecoder.h:179-182
     void encode_word(uint32_t w) { for (int b = 31; b >= 0; --b) encode_half((w >> b) & 1u); }
@@ -849,10 +861,13 @@ int qlfc_encode_static_pstream(const uint8_t* first_seen, int nsym, int in_size,
     rc.encode_word((uint32_t)in_size);
     (void)encode_alphabet(H, [&](unsigned b) { rc.encode_half(b); });
     RangeEncoder::Live L = rc.enter();
+    unsigned is_full = (unsigned)rc.full();                             // full() looks at the output cursor only: kept current by encode_live_f
     for (size_t i = 0; i < count; ++i) {
         const unsigned x = ps[i];
-        if ((x & 0x2000u) && rc.full()) return NOT_COMPRESSIBLE;        // full() looks at the output cursor only
-        rc.encode_live<12>(L, (x >> 12) & 1u, (int)(x & 0xfffu));
+        // one test that practically never fires instead of a branch on the run-start mark itself (which is set on every third or fourth
+        // decision, irregularly: mispredicted, it cost this loop more than its arithmetic)
+        if (__builtin_expect(((x >> 13) & is_full) != 0u, 0)) return NOT_COMPRESSIBLE;
+        rc.encode_live_f<12>(L, (x >> 12) & 1u, (int)(x & 0xfffu), is_full);
     }
     rc.leave(L);
     return rc.finish();
@@ -909,7 +924,7 @@ int qlfc_encode_fast_pstream(const uint8_t* first_seen, int nsym, int in_size, c
     unsigned is_full = (unsigned)rc.full();
     for (size_t i = 0; i < count; ++i) {
         const unsigned x = ps[i];
-        if ((x & 0x4000u) && is_full) return NOT_COMPRESSIBLE;
+        if (__builtin_expect(((x >> 14) & is_full) != 0u, 0)) return NOT_COMPRESSIBLE;
         rc.encode_live_var(L, (x >> 13) & 1u, x & 0x1fffu, psf_prec(x), is_full);
     }
     rc.leave(L);
@@ -993,10 +1008,22 @@ struct alignas(32) X8State { uint32_t R[8], LO[8], CY[8]; };
     const __m128i t0 = _mm_unpacklo_epi64(c0, c4), t1 = _mm_unpackhi_epi64(c0, c4), t2 = _mm_unpacklo_epi64(c1, c5), t3 = _mm_unpackhi_epi64(c1, c5); \
     const __m128i t4 = _mm_unpacklo_epi64(c2, c6), t5 = _mm_unpackhi_epi64(c2, c6), t6 = _mm_unpacklo_epi64(c3, c7), t7 = _mm_unpackhi_epi64(c3, c7)
 
+// A step reads 16 bytes of each stream, i.e. every stream crosses a cache line every fourth step and a 4 KiB page every 256th; the
+// entries were written by the GPU's DMA engine, so every line comes from DRAM.  Two of the eight streams per step get a software
+// prefetch `pf` entries ahead (each stream one per line): it runs across page boundaries, where the hardware stream prefetchers stop.
+// pf = 0: none.  (A prefetch past the end of a stream is harmless: it does not fault.)
+#define BSC_X8_PREFETCH(ps, i, pf) do {                                                                                            \
+        if (pf) {                                                                                                                  \
+            const unsigned l2 = ((unsigned)((i) >> 3) & 3u) * 2u;                                                                  \
+            _mm_prefetch((const char*)((ps)[l2] + (i) + (pf)), _MM_HINT_T0);                                                        \
+            _mm_prefetch((const char*)((ps)[l2 + 1] + (i) + (pf)), _MM_HINT_T0);                                                    \
+        }                                                                                                                          \
+    } while (0)
+
 // steps [i, end) (end - i a multiple of 8) of all eight streams; appends the renormalisation records, returns the log's new end
 // FAST: entries of the fast coder (13-bit value, bit at 13, precision 13 - 2 * bit 15: a per-lane shift count instead of the constant 12)
 template <bool FAST>
-static uint32_t* x8_steps_avx2(X8State& S, const uint16_t* const* ps, size_t i, size_t end, uint32_t* logp)
+static uint32_t* x8_steps_avx2(X8State& S, const uint16_t* const* ps, size_t i, size_t end, uint32_t* logp, size_t pf)
 {
     __m256i R = _mm256_load_si256((const __m256i*)S.R), LO = _mm256_load_si256((const __m256i*)S.LO), CY = _mm256_load_si256((const __m256i*)S.CY);
     const __m256i zero = _mm256_setzero_si256(), m12 = _mm256_set1_epi32(FAST ? 0x1fff : 0xfff), one = _mm256_set1_epi32(1);
@@ -1025,6 +1052,7 @@ static uint32_t* x8_steps_avx2(X8State& S, const uint16_t* const* ps, size_t i, 
         R = _mm256_add_epi32(r, _mm256_and_si256(m, _mm256_sub_epi32(_mm256_sub_epi32(R, r), r)));
     };
     for (; i < end; i += 8) {
+        BSC_X8_PREFETCH(ps, i, pf);
         BSC_X8_TRANSPOSE(ps, i);
         step(_mm256_cvtepu16_epi32(t0)); step(_mm256_cvtepu16_epi32(t1)); step(_mm256_cvtepu16_epi32(t2)); step(_mm256_cvtepu16_epi32(t3));
         step(_mm256_cvtepu16_epi32(t4)); step(_mm256_cvtepu16_epi32(t5)); step(_mm256_cvtepu16_epi32(t6)); step(_mm256_cvtepu16_epi32(t7));
@@ -1036,13 +1064,14 @@ static uint32_t* x8_steps_avx2(X8State& S, const uint16_t* const* ps, size_t i, 
 // The same step with AVX-512VL on 256-bit vectors (chosen at run time): compares write mask registers, the renormalisation and the
 // two directions of the update are masked shifts / adds / subtracts, and the records are left-packed by vpcompressd: ~24
 // micro-ops per step instead of ~45.
-template <bool FAST>
+// VSEL: 0 the round-4 step (BSC_RC_VSEL=0), 2 round 5's
+template <bool FAST, int VSEL>
 __attribute__((target("avx512f,avx512vl")))
-static uint32_t* x8_steps_avx512(X8State& S, const uint16_t* const* ps, size_t i, size_t end, uint32_t* logp)
+static uint32_t* x8_steps_avx512(X8State& S, const uint16_t* const* ps, size_t i, size_t end, uint32_t* logp, size_t pf)
 {
     __m256i R = _mm256_load_si256((const __m256i*)S.R), LO = _mm256_load_si256((const __m256i*)S.LO), CY = _mm256_load_si256((const __m256i*)S.CY);
     const __m256i m12 = _mm256_set1_epi32(FAST ? 0x1fff : 0xfff), one = _mm256_set1_epi32(1), lim = _mm256_set1_epi32(0x10000), b12 = _mm256_set1_epi32(FAST ? 0x2000 : 0x1000);
-    const __m256i c13 = _mm256_set1_epi32(13), c16 = _mm256_set1_epi32(16);
+    const __m256i c13 = _mm256_set1_epi32(13), c16 = _mm256_set1_epi32(16), zero = _mm256_setzero_si256();
     const __m256i lane_id = _mm256_setr_epi32(0 << 17, 1 << 17, 2 << 17, 3 << 17, 4 << 17, 5 << 17, 6 << 17, 7 << 17);
     // (a macro, not a lambda: a lambda does not inherit the function's target attribute)
 #define BSC_X8_STEP512(xv) do {                                                                                                    \
@@ -1068,17 +1097,74 @@ static uint32_t* x8_steps_avx512(X8State& S, const uint16_t* const* ps, size_t i
         LO = lo2;                                                                                                                  \
         R = _mm256_mask_sub_epi32(r, kb, R, r);                                                        /* bit ? range - r : r */   \
     } while (0)
+    /* Round 5's step.  Measured on the EPYC 9575F hosts (tools/rc_host_bench.cpp, profiles/r05/host_coder_on_box_cpu.txt) the round-4 step */
+    /* takes 17.6 cycles: the chain range -> compare into a mask register -> masked shift -> multiply -> subtract -> masked move, with     */
+    /* two-cycle vector integer operations.  Here (16.4 cycles; the range's chain alone runs in 13)                                         */
+    /*  - "range < 2^16" is a VECTOR mask m made by a VEX compare (inline assembly: written with intrinsics the compiler goes through a     */
+    /*    mask register again), both products (range >> sh and, renormalised, range << (16 - sh)) start at once and m only selects;         */
+    /*  - the coded bit is folded into the multiplier: range' - (range' >> sh) * p = (range' >> sh) * (2^sh - p) + (range' mod 2^sh), so    */
+    /*    with q = bit ? 2^sh - p : p the next range is ONE product plus the low bits of range' where the bit is 1 (none for a              */
+    /*    renormalised lane: (range << 16) mod 2^sh = 0) — no subtract and no select by the bit behind the multiply;                        */
+    /*  - what the low word needs, r = range' - next range where the bit is 1, hangs off that chain.                                        */
+    /* Variants that also kept the low word out of the mask registers, or only did the first item, measured the same or slower.            */
+#define BSC_X8_STEP512W(xv) do {                                                                                                   \
+        const __m256i x = (xv);                                                                                                    \
+        __m256i m;                     /* all ones where range < 2^16, as a VECTOR (VEX compare; intrinsics would go through a mask register) */ \
+        asm("vpsrld $16, %1, %0\n\tvpcmpeqd %2, %0, %0" : "=&x"(m) : "x"(R), "x"(zero));                                             \
+        const __mmask8 need = _mm256_cmplt_epu32_mask(R, lim);                                         /* the same, for the log and the low word */ \
+        const __m256i rec = _mm256_ternarylogic_epi32(_mm256_srli_epi32(LO, 16), _mm256_slli_epi32(CY, 16), lane_id, 0xfe);         \
+        _mm256_storeu_si256((__m256i*)logp, _mm256_maskz_compress_epi32(need, rec));                                               \
+        logp += __builtin_popcount((unsigned)need);                                                                                \
+        LO = _mm256_mask_slli_epi32(LO, need, LO, 16);                                                                             \
+        CY = _mm256_maskz_mov_epi32((__mmask8)~need, CY);                                                                          \
+        /* from the entry alone: p, the bit as a vector, q, and the mask of the low bits that survive where the bit is 1 */          \
+        const __m256i p = _mm256_and_si256(x, m12);                                                                                \
+        const __m256i bv = _mm256_srai_epi32(_mm256_slli_epi32(x, FAST ? 18 : 19), 31);                                            \
+        const __m256i sh = _mm256_sub_epi32(c13, _mm256_slli_epi32(_mm256_srli_epi32(x, 15), 1));                                  \
+        const __m256i full = FAST ? _mm256_sllv_epi32(one, sh) : b12;                                  /* 2^sh (static coder: 4096 = the bit's own mask) */ \
+        const __m256i q = _mm256_add_epi32(_mm256_xor_si256(p, bv), _mm256_and_si256(bv, _mm256_add_epi32(full, one)));            \
+        const __m256i bm = _mm256_and_si256(bv, _mm256_sub_epi32(full, one));                                                      \
+        const __m256i ra = FAST ? _mm256_mullo_epi32(_mm256_srlv_epi32(R, sh), q) : _mm256_mullo_epi32(_mm256_srli_epi32(R, 12), q); \
+        const __m256i rb = FAST ? _mm256_mullo_epi32(_mm256_sllv_epi32(R, _mm256_sub_epi32(c16, sh)), q) : _mm256_mullo_epi32(_mm256_slli_epi32(R, 4), q); \
+        const __m256i Rn = _mm256_ternarylogic_epi32(m, _mm256_slli_epi32(R, 16), R, 0xca);            /* m ? range << 16 : range */ \
+        const __m256i keep = _mm256_ternarylogic_epi32(m, R, bm, 0x08);                                /* ~m & range & bm */       \
+        R = _mm256_add_epi32(_mm256_ternarylogic_epi32(m, rb, ra, 0xca), keep);                                                    \
+        const __mmask8 kb = _mm256_test_epi32_mask(x, b12);                                            /* the coded bit */         \
+        const __m256i lo2 = _mm256_mask_add_epi32(LO, kb, LO, _mm256_sub_epi32(Rn, R));                /* bit: low += r = range' - next */ \
+        CY = _mm256_mask_add_epi32(CY, _mm256_cmplt_epu32_mask(lo2, LO), CY, one);                     /* wrapped: carry out */    \
+        LO = lo2;                                                                                                                  \
+    } while (0)
     for (; i < end; i += 8) {
+        BSC_X8_PREFETCH(ps, i, pf);
         BSC_X8_TRANSPOSE(ps, i);
-        BSC_X8_STEP512(_mm256_cvtepu16_epi32(t0)); BSC_X8_STEP512(_mm256_cvtepu16_epi32(t1)); BSC_X8_STEP512(_mm256_cvtepu16_epi32(t2)); BSC_X8_STEP512(_mm256_cvtepu16_epi32(t3));
-        BSC_X8_STEP512(_mm256_cvtepu16_epi32(t4)); BSC_X8_STEP512(_mm256_cvtepu16_epi32(t5)); BSC_X8_STEP512(_mm256_cvtepu16_epi32(t6)); BSC_X8_STEP512(_mm256_cvtepu16_epi32(t7));
+        if (VSEL == 2) {
+            BSC_X8_STEP512W(_mm256_cvtepu16_epi32(t0)); BSC_X8_STEP512W(_mm256_cvtepu16_epi32(t1)); BSC_X8_STEP512W(_mm256_cvtepu16_epi32(t2)); BSC_X8_STEP512W(_mm256_cvtepu16_epi32(t3));
+            BSC_X8_STEP512W(_mm256_cvtepu16_epi32(t4)); BSC_X8_STEP512W(_mm256_cvtepu16_epi32(t5)); BSC_X8_STEP512W(_mm256_cvtepu16_epi32(t6)); BSC_X8_STEP512W(_mm256_cvtepu16_epi32(t7));
+        } else {
+            BSC_X8_STEP512(_mm256_cvtepu16_epi32(t0)); BSC_X8_STEP512(_mm256_cvtepu16_epi32(t1)); BSC_X8_STEP512(_mm256_cvtepu16_epi32(t2)); BSC_X8_STEP512(_mm256_cvtepu16_epi32(t3));
+            BSC_X8_STEP512(_mm256_cvtepu16_epi32(t4)); BSC_X8_STEP512(_mm256_cvtepu16_epi32(t5)); BSC_X8_STEP512(_mm256_cvtepu16_epi32(t6)); BSC_X8_STEP512(_mm256_cvtepu16_epi32(t7));
+        }
     }
 #undef BSC_X8_STEP512
+#undef BSC_X8_STEP512W
     _mm256_store_si256((__m256i*)S.R, R); _mm256_store_si256((__m256i*)S.LO, LO); _mm256_store_si256((__m256i*)S.CY, CY);
     return logp;
 }
 #endif
 
+// entries (of 2 bytes) the eight-lane coder prefetches ahead in every stream; BSC_RC_PREFETCH overrides, 0 = off
+static int g_x8_prefetch_override = -1;                              // tools/rc_host_bench.cpp (which includes this file) varies both inside one process
+static int g_x8_vsel_override = -1;
+static int x8_vector_select()                                        // BSC_RC_VSEL=0: the round-4 step (see x8_steps_avx512)
+{
+    static const int env = [] { const char* e = getenv("BSC_RC_VSEL"); return e ? atoi(e) : 2; }();
+    return g_x8_vsel_override >= 0 ? g_x8_vsel_override : env;
+}
+static int x8_prefetch_entries()
+{
+    static const int env = [] { const char* e = getenv("BSC_RC_PREFETCH"); return e ? atoi(e) : 256; }();      // 512 bytes ahead: -2 % (104 -> 102 -> 96 ms per block with the new step)
+    return g_x8_prefetch_override >= 0 ? g_x8_prefetch_override : env;
+}
 template <bool FAST>
 static bool encode_pstream_x8(const PstreamJob* J, int* res)
 {
@@ -1101,6 +1187,8 @@ static bool encode_pstream_x8(const PstreamJob* J, int* res)
         return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl");
     }();
 
+    const size_t pf = (size_t)x8_prefetch_entries();
+    const int vsel = x8_vector_select();
     constexpr size_t CHUNK = 32768;                                  // steps between two replays of the log (1 MiB of records at most)
     static thread_local std::unique_ptr<uint32_t[]> log_mem;
     if (!log_mem) log_mem.reset(new uint32_t[CHUNK * 8 + 16]);
@@ -1112,7 +1200,8 @@ static bool encode_pstream_x8(const PstreamJob* J, int* res)
     while (i + 8 <= common) {
         size_t end = i + CHUNK; if (end > common) end = common;
         end = i + ((end - i) & ~(size_t)7);
-        uint32_t* const logp = use512 ? x8_steps_avx512<FAST>(S, ps, i, end, log0) : x8_steps_avx2<FAST>(S, ps, i, end, log0);
+        uint32_t* const logp = !use512 ? x8_steps_avx2<FAST>(S, ps, i, end, log0, pf)
+                             : vsel != 0 ? x8_steps_avx512<FAST, 2>(S, ps, i, end, log0, pf) : x8_steps_avx512<FAST, 0>(S, ps, i, end, log0, pf);
         i = end;
         for (const uint32_t* q = log0; q < logp; ++q) {              // replay: the only code that touches the outputs
             const uint32_t rec = *q;
@@ -1131,11 +1220,11 @@ static bool encode_pstream_x8(const PstreamJob* J, int* res)
         for (size_t k = i; k < J[l].count; ++k) {
             const unsigned x = q[k];
             if (FAST) {
-                if ((x & 0x4000u) && is_full) { failed = true; break; }
+                if (__builtin_expect(((x >> 14) & is_full) != 0u, 0)) { failed = true; break; }
                 rc[l].encode_live_var(L, (x >> 13) & 1u, x & 0x1fffu, psf_prec(x), is_full);
             } else {
-                if ((x & 0x2000u) && rc[l].full()) { failed = true; break; }
-                rc[l].template encode_live<12>(L, (x >> 12) & 1u, (int)(x & 0xfffu));
+                if (__builtin_expect(((x >> 13) & is_full) != 0u, 0)) { failed = true; break; }
+                rc[l].template encode_live_f<12>(L, (x >> 12) & 1u, (int)(x & 0xfffu), is_full);
             }
         }
         rc[l].leave(L);

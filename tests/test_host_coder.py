@@ -203,8 +203,8 @@ def test_coder_task_shape_rule():
     assert [shape(free=k) for k in (0, 3, 4, 16)] == [8, 8, 2, 2]
     assert shape(free=16, adaptive=0) == 8                      # BSC_RC_ADAPTIVE=0
     assert shape(free=0, wide=0) == 2 and shape(free=16, wide=0) == 2      # no AVX-512VL: pairs (bench.py forces the AVX2 lanes where the CPU share is small)
-    # marked low-latency in a pipe: never the eight-lane task; eight scalar tasks only on a nearly idle pool
-    assert [shape(low=1, free=k) for k in (0, 4, 11, 12, 24)] == [2, 2, 2, 1, 1]
+    # marked low-latency in a pipe: never the eight-lane task; eight scalar tasks only when eight CPUs of the pool are idle
+    assert [shape(low=1, free=k) for k in (0, 4, 7, 8, 24)] == [2, 2, 2, 1, 1]
     # synchronous calls: by the share of the CPUs per caller
     assert [shape(low=1, sync=c) for c in (2, 4, 7, 8, 16)] == [2, 2, 2, 1, 1]
     # forced

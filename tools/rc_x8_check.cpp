@@ -62,6 +62,33 @@ int main(int argc, char** argv)
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         printf("scalar pair: %.1f ms, %.3f ns/decision\n", ms, ms * 1e6 / (ps[0].size() + ps[1].size()));
     }
+    // the fast coder's entries (13-bit value, bit at 13, run start at 14, bit 15 = run side: 11-bit precision): eight lanes against the scalar coder
+    {
+        std::vector<uint16_t> fs[8];
+        for (int l = 0; l < 8; ++l) {
+            const size_t cnt = base + (rng() % (base / 20 + 1));
+            fs[l].resize(cnt);
+            for (size_t i = 0; i < cnt; ++i) {
+                const unsigned side = (unsigned)(rng() & 1), sh = 13u - 2u * side;
+                unsigned pv = 1 + (unsigned)(rng() % ((1u << sh) - 1));
+                if (rng() & 3) pv = (rng() & 1) ? 1 + pv / 16 : ((1u << sh) - 1) - pv / 16;
+                const unsigned bit = ((rng() % (1u << sh)) >= pv) ? 1u : 0u;
+                fs[l][i] = (uint16_t)(pv | (bit << 13) | ((rng() % 3 == 0) ? 0x4000u : 0u) | (side << 15));
+            }
+        }
+        std::vector<uint8_t> oa[8], ob[8];
+        PstreamJob J[8]; int ra[8], rb[8];
+        for (int l = 0; l < 8; ++l) {
+            const int osz = (int)fs[l].size() * 2 + 1024;
+            oa[l].assign(osz + 64, 0); ob[l].assign(osz + 64, 0);
+            J[l] = PstreamJob{first_seen[l], nsym[l], (int)fs[l].size(), fs[l].data(), fs[l].size(), ob[l].data(), osz};
+            ra[l] = qlfc_encode_fast_pstream(first_seen[l], nsym[l], (int)fs[l].size(), fs[l].data(), fs[l].size(), oa[l].data(), osz);
+        }
+        if (!qlfc_encode_fast_pstream_x8(J, rb)) { printf("FAIL: fast x8 gave up with roomy outputs\n"); ++bad; }
+        else for (int l = 0; l < 8; ++l)
+            if (ra[l] != rb[l] || memcmp(oa[l].data(), ob[l].data(), (size_t)(ra[l] > 0 ? ra[l] : 0)) != 0) { printf("FAIL fast lane %d: scalar %d bytes, x8 %d bytes\n", l, ra[l], rb[l]); ++bad; }
+        printf("fast coder, eight lanes: %s\n", bad ? "differs" : "equal");
+    }
     printf(bad ? "FAILED\n" : "all equal\n");
     return bad != 0;
 }
