@@ -85,8 +85,8 @@ def main():
         os.environ["BSCGPU_HOST_THREADS"] = str(max(4, min(96, cpus_rank + cpus_rank // 4)))
         os.environ.setdefault("BSCGPU_HOST_CPUS", str(cpus_rank))
     coder_threads = int(os.environ["BSCGPU_HOST_THREADS"])
-    # Range coding on the host: all eight sub-blocks of a block in SIMD lanes on one thread (0.118 CPU-s per block
-    # with AVX-512VL, 0.141 with AVX2, ~0.09 s latency) or pairs of sub-blocks per task (0.228 CPU-s per block, 0.05 s latency).
+    # Range coding on the host: all eight sub-blocks of a block in SIMD lanes on one thread (one task of ~0.10 s with
+    # AVX-512VL, 0.13 with AVX2) or pairs of sub-blocks per task (four tasks of ~0.05 s, 0.19 CPU-s per block).
     # The library picks per block (block.cpp: ps_group): pairs while at least four CPUs of the pool's budget are idle, eight lanes
     # when the coder threads are busy; without AVX-512VL it takes pairs, and then a rank whose share of the CPUs could not feed its
     # GPU with pairs (~68 blocks/s x 0.228 s = 15 CPUs) is given the AVX2 lanes here.  BSC_RC_SIMD=8 / 0 forces one of the two.

@@ -102,12 +102,13 @@ BSCGPU_API int bscgpu_compress_device(bscgpu_ctx* ctx, const void* dInput, uint8
  * process's pool of coder threads, shared by all pipes (default: the CPUs the process may use — affinity and cgroup quota —
  * clamped to 4..64; BSCGPU_HOST_THREADS overrides the thread count, BSCGPU_HOST_CPUS the CPU budget idle CPUs are counted
  * against), so a depth of 3-4 keeps those threads and the GPU busy.  A device-model block is one eight-lane SIMD task (half the
- * CPU time, ~90 ms) when the pool is busy and four tasks of two interleaved sub-blocks (~50 ms) while at least four CPUs of
+ * CPU time, ~100 ms) when the pool is busy and four tasks of two interleaved sub-blocks (~50 ms) while at least four CPUs of
  * the budget are idle if BSC_RC_ADAPTIVE=1 (round 5: off by default — every block that is not marked low-latency is the former;
  * BSC_RC_SIMD=8 / 0 forces one of the two). */
 typedef struct bscgpu_pipe bscgpu_pipe;
 /* Extra `features` bit for bscgpu_pipe_submit*: code this block's sub-blocks as several short host tasks (two interleaved scalar range
- * coders per task, ~50 ms for a 64 MiB block) instead of one eight-lane SIMD task (~90 ms, half the CPU time).  For the LAST blocks
+ * coders per task, ~50 ms for a 64 MiB block; one coder per task, ~35 ms, when eight CPUs of the pool are idle) instead of one
+ * eight-lane SIMD task (~100 ms, half the CPU time).  For the LAST blocks
  * of a job, where latency — the drain of the pipeline — counts and the coder threads are running dry anyway.  Output is identical. */
 #define BSCGPU_FEATURE_LOW_LATENCY 0x10000
 BSCGPU_API int  bscgpu_pipe_create(bscgpu_ctx* ctx, int depth, bscgpu_pipe** out);

@@ -567,7 +567,7 @@ extern "C" BSCGPU_API int bscgpu_coder_task_shape(int forced, int low_latency, i
         return sync_cpus >= 8 ? 1 : 2;
     }
     if (!wide_simd) return 2;
-    // A pipe's block: the eight-lane task costs half the CPU time of four pair tasks but takes 90 instead of 52 ms.  While the pool has
+    // A pipe's block: the eight-lane task costs half the CPU time of four pair tasks but takes 96 instead of 48 ms.  While the pool has
     // four CPUs with nothing to do the pairs cost nothing and the block is out 40 ms earlier (a short job is mostly pipeline fill and
     // drain); when the coder threads are busy — many GPUs per host, a small quota — every block is one eight-lane task and the pool's
     // throughput is what counts.

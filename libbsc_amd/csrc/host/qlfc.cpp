@@ -977,7 +977,8 @@ void qlfc_encode_fast_pstream_pair(const PstreamJob& A, const PstreamJob& B, int
 // The run-start budget test (qlfc.cpp:894) is not made per run: the output position only moves in emit_unit, so if it never
 // reaches the limit there the test would never have fired; if it does, the function gives up (returns false, nothing
 // about the outputs is defined) and the caller runs the scalar coders, which reproduce the reference's decision exactly.
-// Measured on the EPYC 9575F (CPU-seconds per 64 MiB block, framing included): pairs 0.238, this 0.144; a four-lane SSE version
+// Measured on the EPYC 9575F in rounds 2-4 (CPU-seconds per 64 MiB block in the loaded pool, framing included; round 5's figures of the
+// loops alone are at x8_steps_avx512): pairs 0.238, this 0.144; a four-lane SSE version
 // of the same step (two tasks per block) 0.221 — a step costs about the same micro-ops whatever its width, so only the full
 // eight lanes pay (that version was removed again).
 // ------------------------------------------------------------------------------------------------
