@@ -123,18 +123,29 @@ def test_native_library_exports_every_declared_symbol():
 
 
 def test_avx2_eight_lane_range_coder_matches_scalar(tmp_path):
-    """qlfc_encode_static_pstream_x8 (eight sub-block streams in AVX2 lanes, renormalisation log) against the scalar coder fed
-    by the same probability streams: byte-identical outputs, and it must give up (never mis-code) when a stream reaches its
-    output budget.  tools/rc_x8_check.cpp compiles the host coder directly (no test hook in the product library)."""
+    """qlfc_encode_static_pstream_x8 / qlfc_encode_fast_pstream_x8 (eight sub-block streams in SIMD lanes, renormalisation log) against
+    the scalar coders fed by the same probability streams: byte-identical outputs, and it must give up (never mis-code) when a stream
+    reaches its output budget.  Every step the product can run is covered — round 5's AVX-512VL step, round 4's (BSC_RC_VSEL=0), the AVX2
+    step (BSC_RC_AVX512=0) where the CPU has them — at stream lengths below one step, around it and across the replay chunk, built with
+    g++ and with the product's own host compiler (the select in RangeEncoder::next_range is compiler-specific).
+    tools/rc_x8_check.cpp compiles the host coder directly (no test hook in the product library)."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "rc_x8_check")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-march=x86-64-v3", "-I", os.path.join(root, "libbsc_amd/csrc/host"), "-I", os.path.join(root, "include"),
-                    os.path.join(root, "tools/rc_x8_check.cpp"), "-o", exe], check=True)
-    r = subprocess.run([exe, "400000"], capture_output=True, text=True)
-    assert r.returncode == 0 and "all equal" in r.stdout, r.stdout + r.stderr
-    assert "gave up" in r.stdout            # the budget case bails out to the scalar coders
+    compilers = [("g++", ["-O2"])]
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if os.path.exists(clang):
+        compilers.append((clang, ["-O3", "-mtune=znver4"]))
+    for k, (cxx, flags) in enumerate(compilers):
+        exe = str(tmp_path / f"rc_x8_check_{k}")
+        subprocess.run([cxx, *flags, "-std=c++17", "-march=x86-64-v3", "-I", os.path.join(root, "libbsc_amd/csrc/host"), "-I", os.path.join(root, "include"),
+                        os.path.join(root, "tools/rc_x8_check.cpp"), "-o", exe], check=True)
+        for extra in ({}, {"BSC_RC_VSEL": "0"}, {"BSC_RC_AVX512": "0"}, {"BSC_RC_PREFETCH": "0"}):
+            for size in ("1", "9", "400000"):
+                r = subprocess.run([exe, size], capture_output=True, text=True, env={**os.environ, **extra})
+                assert r.returncode == 0 and "all equal" in r.stdout and "fast coder, eight lanes: equal" in r.stdout, (cxx, extra, size, r.stdout + r.stderr)
+                if size == "400000":
+                    assert "gave up" in r.stdout            # the budget case bails out to the scalar coders
 
 
 @pytest.mark.parametrize("nphys", [1, 2, 4, 8])
