@@ -384,6 +384,16 @@ def main():
         except Exception as e:                            # reporting only
             print(f"[bench] boundary leg failed: {e!r}", file=sys.stderr)
             host_leg[0] = False
+    # ---- BASELINE's other configurations, after the timed region (reported under `configs`, never as `value`): config 1 (1 MiB, -e1:
+    # latency of one synchronous call), config 2 (forward BWT alone on the 64 MiB block), config 5 (the ST5 / ST6 ablation on 128 MiB
+    # blocks).  Each is checked against the committed reference outputs (tests/golden/golden.json, golden_big.json).
+    other_configs = None
+    if rank == 0 and world == 1 and args.sorter == 1 and args.coder == 1 and not lzp[0] and args.input == "synth-text-v1" and n == BLOCK \
+            and os.environ.get("BSC_BENCH_CONFIGS", "1") != "0":
+        try:
+            other_configs = baseline_configs(torch, dev, local, ctxs[0], d_in, n, GpuContext, api)
+        except Exception as e:                            # reporting only
+            print(f"[bench] configs leg failed: {e!r}", file=sys.stderr)
     # what leaves this rank's GPU over PCIe in the timed region: 16 bits per binary decision of the device model (run arrays instead
     # for blocks on the host model: not counted) + nothing else of size (the input is resident, the sorted block never crosses);
     # the host's DRAM sees those bytes twice (DMA write, coder read) — with 8 ranks per node this, not xGMI, is the shared resource
@@ -493,12 +503,12 @@ def main():
             coder_desc = (f"per block either all eight sub-blocks in the SIMD lanes of one task ({simd}; {pool_modes['eight_lane_task']} of this rank's {args.steps} timed blocks) "
                           f"or four tasks of two interleaved scalar coders — blocks queued while >= 4 CPUs of the pool's budget were idle"
                           + ((f", and the job's last {ll_blocks} blocks, marked low-latency" if (use_queue and ncx > 1) else f", and the last block of each of the {ncx} pipes, marked low-latency") if tail_low_latency else "") + f" ({pool_modes['pair_tasks']} blocks)"
-                          + (f", or eight scalar tasks, a low-latency block that found >= 12 CPUs idle ({pool_modes['scalar_tasks']})" if pool_modes['scalar_tasks'] else ""))
+                          + (f", or eight scalar tasks, a low-latency block that found >= 8 CPUs idle ({pool_modes['scalar_tasks']})" if pool_modes['scalar_tasks'] else ""))
         elif rc_x8:
             coder_desc = (f"all eight sub-blocks of a block in the SIMD lanes of one task, {simd} ({pool_modes['eight_lane_task']} of this rank's {args.steps} timed blocks)"
                           + ((f"; the job's last {ll_blocks} blocks" if (use_queue and ncx > 1) else f"; the last block of each of the {ncx} pipes") +
                              f", marked low-latency, as four tasks of two interleaved scalar coders ({pool_modes['pair_tasks']})"
-                             + (f" or, finding >= 12 CPUs idle, eight scalar tasks ({pool_modes['scalar_tasks']})" if pool_modes['scalar_tasks'] else "") if tail_low_latency else ""))
+                             + (f" or, finding >= 8 CPUs idle, eight scalar tasks ({pool_modes['scalar_tasks']})" if pool_modes['scalar_tasks'] else "") if tail_low_latency else ""))
         else:
             coder_desc = "two sub-blocks per task, interleaved scalar coders"
         out = {
@@ -533,6 +543,7 @@ def main():
             "hbm_bytes_in_use": int(total_b - free_b),
             "hbm_note": f"device memory in use on this GPU at the end of the run (hipMemGetInfo): {ncx} context arena(s), device-coder arenas, look-back tables, the resident input",
             "boundary": boundary,
+            "configs": other_configs,
             "kernels": per_kernel,
             "kernels_note": "HIP-event time per kernel class and block, from the region named in roofline.measured_on",
             "host": {"cpus": os.cpu_count(), "effective_cpus": effective_cpus(), "coder_threads_per_gpu": coder_threads,
@@ -550,6 +561,93 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def baseline_configs(torch, dev, local, ctx64, d_in64, n64, GpuContext, api):
+    """BASELINE.json configs 1, 2 and 5 on this GPU, each checked against committed reference outputs.  A few seconds in all."""
+    import hashlib
+    t_leg = time.perf_counter()
+    res = {}
+    small = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["blocks"]
+    big = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_big.json")))["blocks"]
+
+    def md5(x):
+        return hashlib.md5(x.tobytes() if hasattr(x, "tobytes") else x).hexdigest()
+
+    # config 1: one 1 MiB block (synth-text v1, seed 1: the stand-in for the enwik slice, SURVEY 8d), BWT + QLFC static, one synchronous
+    # call with the input resident in HBM: latency, best and median of 9
+    e1 = next(e for e in small if e.get("kind") == "synth" and (e["seed"], e["n"], e["sorter"], e["coder"]) == (1, 1 << 20, 1, 1))
+    d1 = torch.from_numpy(api.synth_text_v1(1, 1 << 20)).to(dev)
+    blk = ctx64.compress_device(d1, 1 << 20, 1, 1)
+    lat = []
+    for _ in range(9):
+        t0 = time.perf_counter()
+        blk = ctx64.compress_device(d1, 1 << 20, 1, 1)
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lat.sort()
+    res["config1_1MiB_bwt_qlfc_static"] = {
+        "latency_ms_best": round(lat[0], 3), "latency_ms_median": round(lat[len(lat) // 2], 3), "MBps_at_best": round((1 << 20) / 1e3 / lat[0], 1),
+        "compressed_bytes": int(blk.size), "verified": (int(blk.size), md5(blk)) == (e1["size"], e1["md5"]),
+        "what": "bscgpu_compress_device on one 1 MiB synth-text v1 block (seed 1), synchronous, input in HBM, output on the host; checked against tests/golden/golden.json"}
+
+    # config 2: forward BWT alone on the bench block (the bsc_bwt_encode-equivalent device entry point: bscgpu_bwt_device), best of 3
+    e2 = next(e for e in big if e["tag"] == "config3")
+    out = torch.empty_like(d_in64)
+    idx, _ = ctx64.bwt_device(d_in64, out, n64)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        idx, _ = ctx64.bwt_device(d_in64, out, n64)
+        dtb = time.perf_counter() - t0
+        best = dtb if best is None or dtb < best else best
+    res["config2_64MiB_bwt_only"] = {
+        "ms": round(best * 1e3, 3), "GBps_of_input": round(n64 / 1e9 / best, 2), "MBps": round(n64 / 1e6 / best, 1), "primary_index": int(idx),
+        "verified": int(idx) == e2["bwt_index"] and md5(out.cpu().numpy()) == e2["bwt_md5"],
+        "what": "bscgpu_bwt_device on the 64 MiB bench block (seed 2), text and L resident in HBM, wall time of one synchronous call; index and md5(L) "
+                "against tests/golden/golden_big.json (the reference's libsais path took 2.6 s on 8 threads, SURVEY 8a)"}
+    del out
+
+    # config 5: 128 MiB blocks (seed 3) through ST5 and ST6 + QLFC static, 4 blocks each through one pipe of depth 2
+    n5 = 128 << 20
+    T3 = api.synth_text_v1(3, n5)
+    d3 = torch.from_numpy(T3).to(dev)
+    cx = GpuContext(local, max_n=n5 + 4096)
+    try:
+        pipe = cx.pipe(2, reuse_outputs=True)
+        for k in (5, 6):
+            e5 = next(e for e in big if e["tag"] == "config5" and e["sorter"] == k)
+            pipe.wait(pipe.submit(d3, n5, k, 1, 3))                      # every buffer of the path once
+            pipe.wait(pipe.submit(d3, n5, k, 1, 3))
+            cx.profile(True); cx.profile_reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tickets, b5 = [], None
+            for _ in range(4):
+                tickets.append(pipe.submit(d3, n5, k, 1, 3))
+                if len(tickets) >= 2:
+                    b5 = pipe.wait(tickets.pop(0))
+            while tickets:
+                b5 = pipe.wait(tickets.pop(0))
+            dt5 = time.perf_counter() - t0
+            cx.profile(False)
+            st = cx.profile_get()
+            launches = cx.scatter_launches(65536)
+            ms_sort = sum(st[x]["ms"] for x in ("radix_hist_all", "radix_hist", "radix_scan", "radix_scatter") if x in st)
+            full = [(ms, rec) for ms, rec in launches if rec == n5]
+            b_sort = sum(16 * rec for _, rec in full) + 8 * n5 * max(st.get("radix_hist_all", {}).get("launches", 0), 0)
+            res[f"config5_128MiB_st{k}_qlfc_static"] = {
+                "MBps": round(4 * n5 / 1e6 / dt5, 1), "ms_per_block": round(dt5 / 4 * 1e3, 2), "blocks": 4,
+                "sort_frac": round(b_sort / 1e6 / max(ms_sort, 1e-9) / HBM_PEAK_GBPS, 4),
+                "digit_pass_frac": round(sum(16 * rec for _, rec in full) / 1e6 / max(sum(ms for ms, _ in full), 1e-9) / HBM_PEAK_GBPS, 4),
+                "digit_passes_per_block": len(full) // 4,
+                "compressed_bytes": int(b5.size), "verified": (int(b5.size), md5(b5)) == (e5["size"], e5["md5"]),
+                "what": f"4 x 128 MiB synth-text v1 blocks (seed 3) through bscgpu_pipe_submit(ST{k}, QLFC static), one context, two blocks in flight, fill and "
+                        f"drain included; sort_frac = SURVEY 8d's B_sort (m*8 + {k}*2*m*8) over the time of every radix kernel; checked against golden_big.json"}
+        pipe.close()
+    finally:
+        cx.close()
+    res["leg_seconds"] = round(time.perf_counter() - t_leg, 2)
+    return res
 
 
 def verify_block(blk, seed, n, sorter, coder):

@@ -158,6 +158,8 @@ BSCGPU_API int  bscgpu_job_add(bscgpu_job* job, const uint8_t* input, uint8_t* o
  * this call the START of a job (and of every later burst, when the caller had let the job run dry) is tapered: a first context begins,
  * the k-th context of a device joins once k GPU stages of the burst have finished there. */
 BSCGPU_API int  bscgpu_job_expect(bscgpu_job* job, int total_blocks);
+/* (bscgpu_job_wait looks at the worker's pipe while it waits: it must have RETURNED before bscgpu_job_destroy is called on the same
+ * job — destroy finishes the queued blocks, then frees the pipes a concurrent wait would still be peeking into) */
 BSCGPU_API int  bscgpu_job_wait(bscgpu_job* job, int block);
 /* which worker (= pipe; return value) on which device took the block — known once a worker has claimed it */
 BSCGPU_API int  bscgpu_job_block_worker(bscgpu_job* job, int block, int* device);

@@ -281,6 +281,7 @@ __global__ __launch_bounds__(WG) void seg_apply_kernel(const u8* __restrict__ fl
     // A single-read digit pass in front of this seg gave up a wait (radix_onesweep.hip): its output is in bounds but not sorted, and the
     // workgroups that stopped claiming tiles left stale records behind — suffix numbers that, masked, can exceed n.  Nothing of that may
     // be scattered into SA / ISA (the host finds the word raised right after this launch and redoes the transform).
+    // (this relies on the word being STICKY: only radix_onesweep_check, on the host behind this launch, clears it — dev_common.h)
     if (dscal[OS_ERR_SLOT] != 0u) return;
     if (t < 4) slong[t] = 0;
     u32 n_long = 0, n_excess = 0, n_mid = 0, n_midx = 0;
@@ -966,7 +967,8 @@ static int bwt_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_
 
 // A single-read digit pass that gave up a wait (radix_onesweep.hip: bounded polls; pre-emption, a debugger, a hogged CU) fails the
 // sort, not the block: the transform is redone once with the three-kernel passes, which have no cross-workgroup protocol at all.
-// Every sort is checked (run_seg) before anything is written to the caller's buffer, and the private copy of the text is still there.
+// Every sort is checked (run_seg) before anything is written to the caller's buffer; the private copy of the text is NOT relied on
+// for the second attempt (it may have been clobbered by kernels that ran behind the failed sort): the text is copied again.
 int bwt_device(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_t n64, int64_t r, u32* I_host, int64_t* primary_out)
 {
     c->os_gave_up = false;

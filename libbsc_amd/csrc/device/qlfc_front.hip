@@ -257,10 +257,10 @@ __global__ __launch_bounds__(WG) void qf_rank_kernel(const u8* __restrict__ sym,
     if (t == 0) qn = 0;
     {
         const u32 j = base + t, jh = base + WG + t;
-        const u32 raw = (j < m) ? sym[j] : 0u, rawh = (jh < region_end) ? sym[jh] : 0u;
+        const u32 raw = (j < m) ? sym[j] : 0u, rawh = (DENSE && jh < region_end) ? sym[jh] : 0u;
         __syncthreads();
         scode[t] = (u8)(DENSE ? slut[raw] : raw);
-        scode[WG + t] = (u8)(DENSE ? slut[rawh] : rawh);
+        if (DENSE) scode[WG + t] = slut[rawh];                       // the halo is only read by the lifted tiles
     }
     __syncthreads();
     // Tiles that lie inside one sub-block, sets of one word: binary lifting instead of a walk.  win[k][p] = the symbols at region
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(WG) void qf_rank_kernel(const u8* __restrict__ sym,
     const bool lifted = DENSE && WG == 256 && re0 >= tile_end;       // workgroup-uniform
     if (lifted) {
         typedef typename std::conditional<NARROW, u32, u64>::type MT;
-        __shared__ MT win[9][R];
+        __shared__ MT win[DENSE ? 9 : 1][DENSE ? R : 1];           // (static LDS is reserved whether or not the branch runs: only the dense kernels pay for it)
 #pragma unroll
         for (u32 q = 0; q < 2; ++q) {
             const u32 p = t + q * WG;

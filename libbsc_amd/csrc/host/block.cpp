@@ -227,7 +227,9 @@ int bsc_bwt_encode(unsigned char* T, int n, unsigned char* num_indexes, int* ind
 {
     (void)features;
     if (T == nullptr || n < 0) return LIBBSC_BAD_PARAMETER;
-    if (n == 0) { if (num_indexes) *num_indexes = 0; return 0; }
+    // n = 0: the reference hands libsais an empty text; with the secondary indexes asked for, r = 1 is rejected first (libsais.c:6711)
+    if (n == 0) return (num_indexes != nullptr && indexes != nullptr) ? LIBBSC_BAD_PARAMETER : 0;
+    if (num_indexes != nullptr && indexes != nullptr && aux_rate(n) < 2) return LIBBSC_BAD_PARAMETER;     // (no GPU needed to say so)
     DefaultGpuUser user(n, false);
     if (user.rc != LIBBSC_NO_ERROR) return user.rc;
     bscgpu_ctx* c = user.c;
@@ -804,6 +806,10 @@ int bsc_compress(const unsigned char* input, unsigned char* output, int n, int l
     if (rc != LIBBSC_NO_ERROR) return rc;
     if (!input || !output) return LIBBSC_BAD_PARAMETER;
     if (n < 0 || n > (inplace ? 2146435072 : 1073741824)) return LIBBSC_BAD_PARAMETER;
+    // The reference's in-place twin takes blocks up to 2047 MiB (libbsc.cpp:124).  The device sorter is sized and tested up to the
+    // format's regular maximum, 1 GiB (tests/test_gpu_compress.py: test_max_block_1gib_golden); above it this library says so
+    // instead of running an arena layout nobody has ever exercised.
+    if (n > 1073741824) return LIBBSC_NOT_SUPPORTED;
     if (n <= LIBBSC_HEADER_SIZE) return bsc_store(input, output, n, features);
 
     std::unique_ptr<BlockJob> J(new BlockJob);
@@ -1042,6 +1048,8 @@ static int pipe_enqueue(bscgpu_pipe* p, bscgpu_pipe::Lane& L, int ticket)
     {
         std::lock_guard<std::mutex> lk(P->mu);
         L.ticket = ticket; L.joined = false;
+        J.done = false;                                          // (with the other fields a peeker reads, under the pool's mutex)
+        p->next_ticket = ticket + 1;
         J.pool_free = P->free_cpus();
         if (job_uses_tasks(J)) {
             host_prepare(J);
@@ -1061,7 +1069,6 @@ static int pipe_enqueue(bscgpu_pipe* p, bscgpu_pipe::Lane& L, int ticket)
         }
     }
     P->cv_work.notify_all();
-    p->next_ticket = ticket + 1;
     return ticket;
 }
 
@@ -1075,7 +1082,6 @@ int bscgpu_pipe_submit(bscgpu_pipe* p, const void* dInput, uint8_t* output, int 
     int rc = prepare_job(J, p->c, dInput, output, n, blockSorter, coder, features);
     if (rc < 0) return rc;
     J.slot = &p->c->slots[ticket % p->depth];
-    J.done = false;
     rc = gpu_stage(J, blockSorter);
     J.lz.reset();                                   // (device-resident input: there is no LZP output)
     if (rc < 0) return rc;
@@ -1096,7 +1102,6 @@ int bscgpu_pipe_submit_host(bscgpu_pipe* p, const uint8_t* input, uint8_t* outpu
     bscgpu_pipe::Lane& L = p->lanes[ticket % p->depth];
     lane_join(p, L);
     BlockJob& J = *L.job;
-    J.done = false;
     J.slot = &p->c->slots[ticket % p->depth];
     if (n <= LIBBSC_HEADER_SIZE) {
         J.c = p->c; J.n = J.n_orig = n; J.output = output; J.lz.reset();
@@ -1124,6 +1129,7 @@ int bscgpu_pipe_peek(bscgpu_pipe* p, int ticket, int* result)
     if (!p || !result || ticket < 0) return LIBBSC_BAD_PARAMETER;
     bscgpu_pipe::Lane& L = p->lanes[ticket % p->depth];
     std::unique_lock<std::mutex> lk(p->pool->mu);
+    if (ticket >= p->next_ticket) return LIBBSC_BAD_PARAMETER;       // not submitted (yet): nothing to wait for
     p->pool->cv_done.wait(lk, [&] { return L.ticket != ticket || L.joined || L.job->done; });
     if (L.ticket != ticket || L.joined) return 0;
     if (L.job->redo.load(std::memory_order_relaxed)) return 0;

@@ -241,7 +241,7 @@ int bscgpu_job_wait(bscgpu_job* J, int block)
     // and the queue runs dry (round 5: 4005 MB/s through the job against 5100 through bench.py's independent pipes).  So the collector
     // looks at the pipe itself: the block is final as soon as its host stage is over.
     while (!B.done) {
-        if (j.own_pipes && B.ticket >= 0) {
+        if (j.own_pipes && B.ticket >= 0 && !j.closing) {        // (a closing job's workers tear their pipes down: no peeking then)
             bscgpu_pipe* pipe = (bscgpu_pipe*)j.workers[(size_t)B.worker].pipe;
             const int ticket = B.ticket;
             lk.unlock();
@@ -254,7 +254,7 @@ int bscgpu_job_wait(bscgpu_job* J, int block)
             j.cv_done.wait(lk, [&] { return B.done; });
             break;
         }
-        j.cv_done.wait(lk, [&] { return B.done || (j.own_pipes && B.ticket >= 0); });
+        j.cv_done.wait(lk, [&] { return B.done || (j.own_pipes && B.ticket >= 0 && !j.closing); });
     }
     return B.result;
 }

@@ -376,6 +376,8 @@ def test_full_size_baseline_configs_golden(torch_cuda):
     try:
         cache = {}
         for e in g["blocks"]:
+            if e["tag"] == "max-block":          # 1 GiB: test_max_block_1gib_golden
+                continue
             key = json.dumps(e["gen"], sort_keys=True) + str(e["n"])
             if key not in cache:
                 cache.clear()
@@ -391,6 +393,36 @@ def test_full_size_baseline_configs_golden(torch_cuda):
                 idx, _ = ctx.bwt_device(d, out, T.size)
                 assert idx == e["bwt_index"] and hashlib.md5(out.cpu().numpy().tobytes()).hexdigest() == e["bwt_md5"], (e["tag"], e["gen"])
             del d
+    finally:
+        ctx.close()
+
+
+@pytest.mark.slow
+def test_max_block_1gib_golden(torch_cuda):
+    """The format's maximum block, n = 2^30 (libbsc.cpp:221), BWT + QLFC static, against the reference's size + md5 committed in
+    tests/golden/golden_big.json (row `max-block`, tests/golden/make_golden_big.py).  The device model's arena (230 bytes per block
+    byte) does not fit beside a 1 GiB sorter arena, so the model runs on the host: sorter, QLFC front end and container at
+    their largest shapes are what this pins."""
+    import json, os
+    from libbsc_amd import GpuContext
+    torch = torch_cuda
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_big.json")))
+    rows = [e for e in g["blocks"] if e["tag"] == "max-block"]
+    assert rows, "golden_big.json has no max-block row"
+    e = rows[0]
+    n = e["n"]
+    assert n == 1 << 30
+    T = api.synth_text_v1(e["gen"]["seed"], n)
+    assert hashlib.md5(T.tobytes()).hexdigest() == e["input_md5"]
+    ctx = GpuContext(0, max_n=n)
+    try:
+        d = torch.from_numpy(T).cuda()
+        out = torch.empty_like(d)
+        idx, _ = ctx.bwt_device(d, out, n)
+        assert idx == e["bwt_index"] and hashlib.md5(out.cpu().numpy().tobytes()).hexdigest() == e["bwt_md5"]
+        del out
+        blk = ctx.compress_device(d, n, e["sorter"], e["coder"], e["features"]).tobytes()
+        assert (len(blk), hashlib.md5(blk).hexdigest()) == (e["size"], e["md5"])
     finally:
         ctx.close()
 
