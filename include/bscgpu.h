@@ -197,7 +197,8 @@ enum {
     BSCGPU_K_DC_PSTREAM    = 11, /* device coder: probability stream */
     BSCGPU_K_RADIX_HISTALL = 12, /* single-read sorts: the one histogram read per sort (all digits at once) */
     BSCGPU_K_RADIX_AUX     = 13, /* keys-only passes that also emit the permutation (device coder's orders, inverse BWT): not the graded kernel */
-    BSCGPU_K_COUNT         = 14
+    BSCGPU_K_DC_STATIC     = 14, /* device coder: the context-free counter family walked in stream order (round 6) */
+    BSCGPU_K_COUNT         = 15
 };
 typedef struct bscgpu_kstat {
     double   ms;        /* accumulated HIP-event time */
@@ -224,8 +225,12 @@ BSCGPU_API const char* bscgpu_last_error(const bscgpu_ctx* ctx);
  *                          Results are identical.
  * BSCGPU_CNT_OS_RETRIES    (get only) transforms this context has redone through the three-kernel passes because a single-read pass
  *                          gave up a wait (bounded polls; the block still comes out right).
+ * BSCGPU_OPT_DC_STREAM_STATIC  device model of the static coder: 1 (BSC_DC_SPF=1 in the environment) evaluates the context-free
+ *                          counter family in stream order for blocks of at most 32 symbols per sub-block (devcoder_static.h);
+ *                          0 (default) sends it through partition / evaluation / gather like the other two families.  Same
+ *                          output either way; round 6 measured the stream-order form slower (profiles/r06/static_family_stream_order.txt).
  * set returns the previous value or a negative libbsc error code; get the value or a negative error code. */
-enum { BSCGPU_OPT_RS_ONESWEEP = 1, BSCGPU_CNT_OS_RETRIES = 2 };
+enum { BSCGPU_OPT_RS_ONESWEEP = 1, BSCGPU_CNT_OS_RETRIES = 2, BSCGPU_OPT_DC_STREAM_STATIC = 3 };
 BSCGPU_API int bscgpu_option_set(bscgpu_ctx* ctx, int key, int value);
 BSCGPU_API int bscgpu_option_get(bscgpu_ctx* ctx, int key);
 /* Process-wide counts since start (tests, reports): blocks whose static model ran on the GPU, how many of those were LZP-preprocessed,

@@ -13,7 +13,7 @@ i32p = C.POINTER(C.c_int)
 u32p = C.POINTER(C.c_uint32)
 
 K_NAMES = ["radix_scatter", "radix_hist", "radix_scan", "pack", "seg", "gather", "emit", "misc",
-           "dc_ctx", "dc_part", "dc_eval", "dc_pstream", "radix_hist_all", "radix_aux"]      # order of the BSCGPU_K_* enum (include/bscgpu.h)
+           "dc_ctx", "dc_part", "dc_eval", "dc_pstream", "radix_hist_all", "radix_aux", "dc_static"]      # order of the BSCGPU_K_* enum (include/bscgpu.h)
 
 
 class KStat(C.Structure):

@@ -112,6 +112,7 @@ struct bscgpu_ctx {
     bool os_check_pending = false;   // hscal[OS_ERR_SLOT] has not been looked at since the last single-read sort
     bool os_available = true;        // the single-read kernels could be set up on this device (radix_onesweep_setup)
     int  os_retries = 0;             // transforms redone through the three-kernel passes after a give-up (bscgpu_debug_counter)
+    int  dc_spf = 0;                 // BSCGPU_OPT_DC_STREAM_STATIC (context.hip reads BSC_DC_SPF at creation)
     bool os_gave_up = false;         // radix_onesweep_check found a give-up: the caller may redo its sorts through the three-kernel passes
     // pinned host
     u32* hscal  = nullptr;   // 1024 u32 (slot map: the users' comments; OS_ERR_SLOT = 1000)

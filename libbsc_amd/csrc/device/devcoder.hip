@@ -31,6 +31,7 @@
 #include <thread>
 #include <system_error>
 #include "devcoder_model.h"
+#include "devcoder_static.h"
 #include "../host/qlfc.h"
 #include <cstdio>
 #include <cstdlib>
@@ -64,10 +65,10 @@ constexpr u32 DC_SIGMASK  = 0x7ffu;    // event = X | sub-block << 8 | bit << 11
 constexpr int DC_ROWS     = 1088;      // rows of the chain-major layout = decision types (NUM_TAU = 1080), padded to whole wavefronts
 
 // meta scalars (device u32 array)
-enum { DM_FAIL = 0, DM_NTYPES, DM_NROUNDS, DM_AVG_UND, DM_REPLAYS, DM_D0, DM_D1, DM_D2, DM_D3, DM_HIST_FAIL, DM_COUNT = 16 };
+enum { DM_FAIL = 0, DM_NTYPES, DM_NROUNDS, DM_AVG_UND, DM_REPLAYS, DM_D0, DM_D1, DM_D2, DM_D3, DM_HIST_FAIL, DM_DFULL /* = DM_D0 + 5 */, DM_SP_OPEN, DM_SP_REWALKS, DM_COUNT = 16 };
 enum { FAIL_TYPES = 1, FAIL_AVG = 2, FAIL_HIST = 4, FAIL_CAP = 8, FAIL_REPLAY = 16 };
 
-struct DcSub { u32 nb; u32 first[9]; u32 maxr[8]; };            // run index range and max_rank of each sub-block
+typedef dcs::SpSub DcSub;                                       // { u32 nb; u32 first[9]; u32 maxr[8]; }: run index range and max_rank of each sub-block
 struct DcRowBins { u16 lo1, hi1, lo2, hi2; };                   // counting pass: count(row) = P[hi1] - P[lo1] + P[hi2] - P[lo2] over bin prefix sums
 
 struct DevCoder {
@@ -90,6 +91,11 @@ struct DevCoder {
     u8  *tab_rank = nullptr, *tab_run = nullptr;
     ModelParams* mp = nullptr;                                 // device copy (static coder)
     ModelParams* mp_fast = nullptr;                            // device copy (fast coder: dcm::model_params_fast)
+    // the static family in stream order (devcoder_static.h): rank planes, per-sub-block descriptors, chunk summaries, chunk start
+    // values, sub-tile values, the 8 x u16 record of every run, and the runs' offsets in the p stream
+    u64* sp_planes = nullptr; dcs::SpDesc* sp_desc = nullptr; dcs::SpSum* sp_sums = nullptr; dcs::SpGroupSum* sp_gsum = nullptr; u16* sp_gv = nullptr; u16* sp_sv = nullptr; u16* sp_state = nullptr;
+    uint4* sp_rec = nullptr; u32* doff_full = nullptr;
+    dcs::SpDesc sp_desc_host[5][dcs::SP_SLOTS]; bool sp_ok = false;   // descriptors by max_rank (built once; sp_ok: every type representable)
     u32 *hmeta = nullptr;                                      // pinned: meta + poff
 };
 
@@ -100,6 +106,18 @@ __device__ __forceinline__ u32 dc_sb_of(u32 j, const DcSub& S)
     for (int b = 1; b < 8; ++b) if ((u32)b < S.nb && j >= S.first[b]) sb = b;
     return sb;
 }
+// max_rank of an item's sub-block WITHOUT a memory access: indexing the by-value kernel argument with a per-lane index is a vector load
+// from the argument segment (a select chain over S.maxr[b] is turned back into a load of a selected address), and inside the partition
+// kernels' tile loops the wait for it (a vmcnt(0): the stores around it cannot be counted) also waited out the request for the next
+// tile's items that had just gone out — round 6, from the ISA.  So: the eight values packed into one scalar word at the kernel's top.
+__device__ __forceinline__ u32 dc_maxr_pack(const DcSub& S)
+{
+    u32 p = 0;
+#pragma unroll
+    for (u32 b = 0; b < 8; ++b) p |= (S.maxr[b] & 15u) << (4u * b);
+    return (u32)__builtin_amdgcn_readfirstlane((int)p);
+}
+__device__ __forceinline__ int dc_maxr_of(u32 sb, u32 packed) { return (int)((packed >> (4u * sb)) & 15u); }
 __device__ __forceinline__ u32 dc_run_len(const u32* __restrict__ start, u32 j, u32 m, u32 n) { return ((j + 1 < m) ? start[j + 1] : n) - start[j]; }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -131,12 +149,21 @@ __global__ __launch_bounds__(WG) void dc_avg_kernel(const u8* __restrict__ rank,
 }
 
 // 1b. packed items in stream order: X = symbol (the char family's sort digit; the static family ignores it)
+// (+ the rank bit planes of every tile of 64 runs, when the static family is evaluated in stream order: devcoder_static.h)
 __global__ __launch_bounds__(WG) void dc_items_kernel(const u8* __restrict__ sym, const u8* __restrict__ rank, const u32* __restrict__ start,
-                                                      const u8* __restrict__ ge32, u32 m, u32 n, DcSub S, u64* __restrict__ key_ch)
+                                                      const u8* __restrict__ ge32, u32 m, u32 n, DcSub S, u64* __restrict__ key_ch, u64* __restrict__ planes)
 {
     const u32 j = blockIdx.x * WG + threadIdx.x;
-    if (j >= m) return;
-    key_ch[j] = item_pack(sym[j], dc_sb_of(j, S), ge32[j], rank[j], dc_run_len(start, j, m, n));
+    const u32 r = (j < m) ? rank[j] : 0u;
+    if (j < m) key_ch[j] = item_pack(sym[j], dc_sb_of(j, S), ge32[j], r, dc_run_len(start, j, m, n));
+    if (planes) {                                                     // (wave-uniform; a wavefront is a tile: WG is a multiple of 64)
+        const u32 lane = threadIdx.x & 63u;
+        u64 mine = 0;
+#pragma unroll
+        for (int b = 0; b < dcs::SP_PLANES; ++b) { const u64 bal = __ballot((r >> b) & 1u); if (lane == (u32)b) mine = bal; }
+        const u32 tile = j >> 6;
+        if (lane < (u32)dcs::SP_PLANES && (tile << 6) < m) planes[(size_t)tile * dcs::SP_PLANES + lane] = mine;
+    }
 }
 
 // kinds of run for the "which decision types occur" bitmap: 8 sub-blocks x escape flag x 256 ranks, then 96 run-length classes
@@ -238,6 +265,7 @@ __global__ __launch_bounds__(WG) void dc_ctx_kernel(const u64* __restrict__ key_
 // 1d. the canonical rounds that occur (and how many decision types: diagnostics).  One workgroup.
 __global__ __launch_bounds__(WG) void dc_setup_kernel(const u32* __restrict__ kinds, DcSub S, u8* __restrict__ rounds, u32* __restrict__ meta)
 {
+    const u32 mrp = dc_maxr_pack(S);                                  // max_rank of the eight sub-blocks, one scalar word
     __shared__ u32 present[(NUM_TAU + 31) / 32];
     __shared__ u32 rbits[3];
     __shared__ u32 ntypes;
@@ -251,7 +279,7 @@ __global__ __launch_bounds__(WG) void dc_setup_kernel(const u32* __restrict__ ki
         Item it; it.sb = 0; it.ge32 = 0; it.rank = 1; it.run = 1;
         if (k < DC_KIND_RUN) {                                                    // the rank side of a run of this kind
             it.sb = k >> 9; it.ge32 = (k >> 8) & 1u; it.rank = k & 255u;
-            const int maxr = (int)S.maxr[it.sb];
+            const int maxr = dc_maxr_of(it.sb, mrp);
             if (it.ge32) { for (int d = 0; d <= maxr; ++d) { u32 bit; mark(decision(it, maxr, ROUND_RP + d, &bit)); } }
             else {
                 mark(TAU_RF);
@@ -378,7 +406,7 @@ __device__ __forceinline__ void dc_item_rounds(const Item& it, bool valid, int m
     if (SIDES & 2) {
         const u32 run = it.run;
         const int nb = (valid && run != 1u) ? bsr(run) : 0;
-        if (__ballot(valid)) es(8, valid, run != 1u ? 1u : 0u);
+        if (!(SIDES & 4) && __ballot(valid)) es(8, valid, run != 1u ? 1u : 0u);     // (SIDES & 4: the run side without its first decision, NF)
         for (int sx = 0; sx < 31; ++sx) { const bool on = sx < nb; if (!__ballot(on)) break; es(9 + sx, on, sx + 1 < nb ? 1u : 0u); }
         if (__ballot(nb != 0)) {
             u32 mlo, mhi;
@@ -411,6 +439,7 @@ template <int SIDES>
 __global__ __launch_bounds__(WG) void dc_part_count_kernel(const u64* __restrict__ items, DcGeom g, DcSub S, const DcRowBins* __restrict__ rowbins,
                                                            u32* __restrict__ cnt /*[DC_ROWS][W]*/, u32* __restrict__ wdec)
 {
+    const u32 mrp = dc_maxr_pack(S);                                  // max_rank of the eight sub-blocks, one scalar word
     __shared__ u32 bins[WAVES][DC_BINS + 8];
     __shared__ u32 hrp[WAVES][256];                                             // escape rows (TAU_RP + ctx - 1), counted directly
     for (u32 i = threadIdx.x; i < WAVES * (DC_BINS + 8); i += WG) (&bins[0][0])[i] = 0;
@@ -425,22 +454,29 @@ __global__ __launch_bounds__(WG) void dc_part_count_kernel(const u64* __restrict
         u64 i1 = i0 + g.per_wave; if (i1 > g.m) i1 = g.m;
         // four items per lane and trip, their loads issued together: with one load in flight per wavefront the ~108 trips of a wave-chunk
         // each waited out a full memory latency (0.17 ms per job for 225 MB: round 5 counters, 80 % of the wave cycles parked)
+        // (round 6: the NEXT trip's four loads are in flight while this trip's items are counted — nothing but LDS atomics between them, so
+        // the compiler waits with an exact vmcnt; before, every one of a wave-chunk's ~27 trips waited out a full memory round trip)
+        u64 nx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const u64 i = i0 + 64u * (u32)u + lane; nx[u] = items[i < i1 ? i : i0]; }
         for (u64 base = i0; base < i1; base += 256) {
             u64 kk[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const u64 i = base + 64u * (u32)u + lane; kk[u] = items[i < i1 ? i : i0]; }
+            for (int u = 0; u < 4; ++u) kk[u] = nx[u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const u64 i = base + 256u + 64u * (u32)u + lane; nx[u] = items[i < i1 ? i : i0]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (base + 64u * (u32)u + lane >= i1) continue;
                 const Item it = item_unpack(kk[u]);
-                const int maxr = (int)S.maxr[it.sb];
+                const int maxr = dc_maxr_of(it.sb, mrp);
                 if (SIDES & 1) {
                     total += (u32)count_rank_side(it, maxr);
                     if (it.ge32) {
                         for (int d = 0; d <= maxr; ++d) atomicAdd(&hrp[w][((1u << d) | ((it.rank >> (maxr + 1 - d)) & ((1u << d) - 1u))) - 1u], 1u);
                     } else atomicAdd(&bw[dc_rank_bin(it.rank, maxr)], 1u);
                 }
-                if (SIDES & 2) { total += (u32)count_run_side(it); atomicAdd(&bw[dc_run_bin(it.run)], 1u); }
+                if (SIDES & 2) { total += (u32)count_run_side(it) - ((SIDES & 4) ? 1u : 0u); atomicAdd(&bw[dc_run_bin(it.run)], 1u); }
             }
         }
     }
@@ -460,6 +496,7 @@ __global__ __launch_bounds__(WG) void dc_part_count_kernel(const u64* __restrict
             const DcRowBins rb = rowbins[h];
             u32 v = bw[rb.hi1] - bw[rb.lo1] + bw[rb.hi2] - bw[rb.lo2];
             if (h >= (u32)TAU_RP && h < (u32)TAU_NF) v += hrp[w][h - TAU_RP];
+            if ((SIDES & 4) && h == (u32)TAU_NF) v = 0;
             cnt[(size_t)h * g.W + wc] = v;
         }
         if (lane == 63) wdec[wc] = total;
@@ -538,6 +575,7 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
                                                              const u32* __restrict__ wdecoff, u32 ignoreX,
                                                              u16* __restrict__ events, u32* __restrict__ pos, u32* __restrict__ doff)
 {
+    const u32 mrp = dc_maxr_pack(S);                                  // max_rank of the eight sub-blocks, one scalar word
     __shared__ u32 goff[WAVES][DC_ROWS];
     __shared__ u32 spos[WAVES][DC_POS_STAGE];
     if (meta[DM_FAIL] != 0u) return;
@@ -557,11 +595,16 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
         const u64 i = base + lane;
         const bool valid = i < i1;
         const u64 key = knext;
+        // The request for the next tile's items goes out BEHIND the wait for this tile's.  (Round 6, from the ISA: the compiler cannot count the
+        // stores of the rounds below — they sit in data-dependent loops — so the wait for `key` is a vmcnt(0); with the request in front of
+        // it, as the source order had it, that wait covered the request itself: no prefetch at all, one full memory round trip per tile and
+        // wavefront, 0.35 ms of every partition job whatever it had to scatter.)
+        asm volatile("" :: "v"(key) : "memory");
         knext = (i + 64 < i1) ? items[i + 64] : 0ull;
         const Item it = item_unpack(key);
-        const int maxr = (int)S.maxr[it.sb];
+        const int maxr = dc_maxr_of(it.sb, mrp);
         u32 nd = 0;
-        if (valid) { if (SIDES & 1) nd += (u32)count_rank_side(it, maxr); if (SIDES & 2) nd += (u32)count_run_side(it); }
+        if (valid) { if (SIDES & 1) nd += (u32)count_rank_side(it, maxr); if (SIDES & 2) nd += (u32)count_run_side(it) - ((SIDES & 4) ? 1u : 0u); }
         const u32 incl = wave_incl_sum(nd);
         const u32 loc = incl - nd;                                    // first decision of this item inside the tile
         if (valid) doff[i] = running + loc;
@@ -619,6 +662,7 @@ template <int SIDES>
 __global__ __launch_bounds__(WG) void dc_doff_kernel(const u64* __restrict__ items, DcGeom g, DcSub S, const u32* __restrict__ meta,
                                                      const u32* __restrict__ wdecoff, u32* __restrict__ doff)
 {
+    const u32 mrp = dc_maxr_pack(S);                                  // max_rank of the eight sub-blocks, one scalar word
     if (meta[DM_FAIL] != 0u) return;
     const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 wc = blockIdx.x * WAVES + w;
@@ -630,9 +674,11 @@ __global__ __launch_bounds__(WG) void dc_doff_kernel(const u64* __restrict__ ite
     for (u64 base = i0; base < i1; base += 64) {
         const u64 i = base + lane;
         const bool valid = i < i1;
-        const Item it = item_unpack(knext);
+        const u64 key = knext;
+        asm volatile("" :: "v"(key) : "memory");                     // (wait for this tile's items, THEN request the next tile's: dc_part_scatter_kernel)
+        const Item it = item_unpack(key);
         knext = (i + 64 < i1) ? items[i + 64] : 0ull;
-        const int maxr = (int)S.maxr[it.sb];
+        const int maxr = dc_maxr_of(it.sb, mrp);
         u32 nd = 0;
         if (valid) { if (SIDES & 1) nd += (u32)count_rank_side(it, maxr); if (SIDES & 2) nd += (u32)count_run_side(it); }
         const u32 incl = wave_incl_sum(nd);
@@ -911,6 +957,115 @@ __global__ __launch_bounds__(WG) void dc_eval_b_kernel(DcEvalAll A, const ModelP
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// 3s. the static (context-free) family's rank side in STREAM ORDER (round 6; devcoder_static.h has the method and every lane
+// function — the kernels below only map lanes to work).  Replaces, for blocks of at most 32 symbols per sub-block, the
+// partition / evaluation / gather of that family: qlfc.cpp:829-1129's third counter of every rank decision.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SpArgs {
+    dcs::SpGeom g; DcSub S; u32 slots; u32 uniform;                     // slots: bit s = slot s occurs for some sub-block's max_rank; uniform: one max_rank for all sub-blocks
+    const u64* planes; const dcs::SpDesc* desc; const ModelParams* mp;
+    dcs::SpSum* sums; dcs::SpGroupSum* gsum; u16* gv; u16* sv; u16* state; uint4* rec; u32* meta;
+};
+// phase A (brackets) and phase C (exact walk): block = 256 consecutive chunks of one slot (blockIdx.y), heavy slots first
+template <bool EXACT>
+__global__ __launch_bounds__(WG) void sp_walk_kernel(SpArgs A)
+{
+    if (A.meta[DM_FAIL] != 0u) return;
+    const int slot = (int)blockIdx.y;
+    if (!((A.slots >> slot) & 1u)) return;
+    const u32 chunk = blockIdx.x * WG + threadIdx.x;
+    if (chunk >= dcs::sp_nchunks(A.g, slot)) return;
+    // every sub-block with the same max_rank (one alphabet for the whole block: the common case): the slot's descriptor is one scalar value
+    const dcs::SpDesc dval = A.desc[A.S.maxr[0] * dcs::SP_SLOTS + (u32)slot];
+    const dcs::SpDesc* du = A.uniform ? &dval : nullptr;
+    const dcs::SpParams P = dcs::sp_params(*A.mp, slot);
+    if (EXACT) dcs::sp_phase_c(slot, chunk, A.g, A.S, A.planes, A.desc, P, A.sv, A.state, du);
+    else {
+        const dcs::SpSum s = dcs::sp_phase_a(slot, chunk, A.g, A.S, A.planes, A.desc, P, du);
+        A.sums[(size_t)slot * A.g.cstride + chunk] = s;
+    }
+}
+// Resolve steps 1 and 3: one WAVEFRONT per (slot, group).  The walk through a group's 64 chunk summaries is serial, but fetching them
+// is not: the lanes load one summary each, and all of them then run the same uniform code, reading summary i out of lane i's registers
+// (v_readlane; a lane per group waited out a memory latency per chunk: 0.9 ms for the step, nearly all of it in the lanes of rare types).
+__device__ __forceinline__ u32 dc_readlane(u32 x, u32 i) { return (u32)__builtin_amdgcn_readlane((int)x, (int)i); }
+template <int STEP>
+__global__ __launch_bounds__(WG) void sp_resolve_kernel(SpArgs A)
+{
+    if (A.meta[DM_FAIL] != 0u) return;
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const int slot = (int)blockIdx.y;
+    if (!((A.slots >> slot) & 1u)) return;
+    const u32 grp = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));
+    if (grp >= dcs::sp_ngroups(A.g, slot)) return;
+    const u32 nch = dcs::sp_nchunks(A.g, slot);
+    const u32 c = grp * dcs::SP_RG + lane;
+    const uint4 mine4 = (c < nch) ? reinterpret_cast<const uint4*>(A.sums + (size_t)slot * A.g.cstride)[c] : make_uint4(0, 0, 0, 0);
+    auto get = [&](int i) {
+        const u32 ii = (u32)__builtin_amdgcn_readfirstlane(i);
+        const u32 x = dc_readlane(mine4.x, ii), y = dc_readlane(mine4.y, ii), z = dc_readlane(mine4.z, ii), ww = dc_readlane(mine4.w, ii);
+        dcs::SpSum s; s.lo = (u16)(x & 0xffffu); s.hi = (u16)(x >> 16); s.cnt = (u16)(y & 0xffffu); s.flags = (u16)(y >> 16); s.hist = (u64)z | ((u64)ww << 32);
+        return s;
+    };
+    const dcs::SpParams P = dcs::sp_params(*A.mp, slot);
+    if (STEP == 1) {
+        dcs::SpGroupSum o;
+        const bool ok = dcs::sp_resolve_group_g(slot, grp, A.g, A.S, A.planes, A.desc, P, get, &o);
+        if (lane == 0) { if (ok) A.gsum[(size_t)slot * A.g.gstride + grp] = o; else atomicOr(&A.meta[DM_FAIL], (u32)FAIL_REPLAY); }
+    } else {
+        int mine = 0;
+        const bool ok = dcs::sp_resolve_chunks_g(slot, grp, (int)A.gv[(size_t)slot * A.g.gstride + grp], A.g, A.S, A.planes, A.desc, P, get,
+                                                 [&](int i, int val) { if ((u32)i == lane) mine = val; });
+        if (!ok) { if (lane == 0) atomicOr(&A.meta[DM_FAIL], (u32)FAIL_REPLAY); }
+        else if (c < nch) A.sv[(size_t)slot * A.g.cstride + c] = (u16)mine;
+    }
+}
+// Resolve step 2: one wavefront per slot walks the slot's group summaries in order, 64 at a time out of the lanes' registers
+__global__ __launch_bounds__(64) void sp_resolve_serial_kernel(SpArgs A)
+{
+    if (A.meta[DM_FAIL] != 0u) return;
+    const int slot = (int)blockIdx.x;
+    if (!((A.slots >> slot) & 1u)) return;
+    const u32 lane = threadIdx.x;
+    const u32 ng = dcs::sp_ngroups(A.g, slot);
+    const dcs::SpParams P = dcs::sp_params(*A.mp, slot);
+    int v = P.init;
+    for (u32 base = 0; base < ng; base += 64) {
+        const u32 cnt = (ng - base < 64u) ? ng - base : 64u;
+        const uint4 g4 = (lane < cnt) ? reinterpret_cast<const uint4*>(A.gsum + (size_t)slot * A.g.gstride)[base + lane] : make_uint4(0, 0, 0, 0);
+        int mine = 0;
+        for (u32 i = 0; i < cnt; ++i) {
+            if (i == lane) mine = v;
+            const u32 x = dc_readlane(g4.x, i), y = dc_readlane(g4.y, i), z = dc_readlane(g4.z, i), ww = dc_readlane(g4.w, i);
+            dcs::SpGroupSum o; o.closed = (u16)(x & 0xffffu); o.value = (u16)(x >> 16); o.cnt = (u16)(y & 0xffffu); o.big = (u16)(y >> 16); o.hist = (u64)z | ((u64)ww << 32);
+            if (!dcs::sp_after_group(&v, o, slot, base + i, A.g, A.S, A.planes, A.desc, P, A.sums + (size_t)slot * A.g.cstride + (size_t)(base + i) * dcs::SP_RG)) {
+                if (lane == 0) atomicOr(&A.meta[DM_FAIL], (u32)FAIL_REPLAY);
+                return;
+            }
+        }
+        if (lane < cnt) A.gv[(size_t)slot * A.g.gstride + base + lane] = (u16)mine;
+    }
+}
+// values: one wavefront per tile, lane = (slot, sub-tile); the tile's 64 records (8 x u16 per run) leave as one 1 KB piece
+__global__ __launch_bounds__(WG) void sp_values_kernel(SpArgs A)
+{
+    __shared__ __attribute__((aligned(16))) u16 rec[WAVES][64][8];
+    __shared__ dcs::SpParams P3[3];                                     // by class: RF, RE, RM
+    if (A.meta[DM_FAIL] != 0u) return;
+    if (threadIdx.x < 3u) P3[threadIdx.x] = dcs::sp_params(*A.mp, threadIdx.x == 0 ? 0 : threadIdx.x == 1 ? 1 : 5);
+    __syncthreads();
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));
+    if (tile >= A.g.ntiles) return;
+    typedef __attribute__((address_space(3))) volatile u16 lds_vu16;
+    lds_vu16* mine = (lds_vu16*)&rec[w][0][0];
+    dcs::sp_values(tile, (int)lane, A.g, A.S, A.planes, A.desc, P3, A.state, [&](int i, int k, int v) { mine[i * 8 + k] = (u16)v; });
+    dc_wave_sync();
+    const u32 j = tile * 64u + lane;
+    if (j < A.g.m) A.rec[j] = *reinterpret_cast<const uint4*>(&rec[w][lane][0]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 4. probability stream, stream order.  Thread per run.
 // ---------------------------------------------------------------------------------------------------------------------
 struct DcGather {
@@ -919,6 +1074,9 @@ struct DcGather {
     const u32 *doff_sp, *doff_ch, *doff_sr, *doff_sn;
     const u32 *pos_sp, *pos_ch, *pos_sr, *pos_sn;
     const u16 *V_sp, *V_ch, *V_sr, *V_sn;
+    // static family in stream order (SPF): the 8 x u16 record of every run's rank side, the runs' offsets in the p stream; doff_sp /
+    // pos_sp / V_sp then belong to the small job that holds the family's NE / NM decisions only (entry kk - 1 of the run's piece)
+    const uint4* sp_rec; const u32* doff_full;
 };
 // pos entries of one run are contiguous but only 4-byte aligned: a packed struct makes the compiler use one dwordx4 load
 // (global memory takes dword-aligned multi-dword accesses) instead of four dword loads
@@ -940,10 +1098,11 @@ typedef __attribute__((address_space(3))) volatile u16 dc_lds_vu16;
 #ifndef DC_PS_MINW
 #define DC_PS_MINW 1            // minimum waves per SIMD the register allocator must leave room for (A/B: 82 VGPRs = 5 waves by default)
 #endif
-template <bool FAST>
+template <bool FAST, bool SPF>
 __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, DcSub S, const ModelParams* __restrict__ mp,
                                                         const u32* __restrict__ meta, u16* __restrict__ out, u16* __restrict__ dbg /*[3][D] or null*/, u32 dbgD)
 {
+    const u32 mrp = dc_maxr_pack(S);                                  // max_rank of the eight sub-blocks, one scalar word
     __shared__ u16 stage[WAVES][DC_PS_STAGE];
     __shared__ short s_lr[NUM_CLS][4];                                // blend weights per class: an LDS read per decision instead of global loads at a per-lane address
     if (meta[DM_FAIL] != 0u) return;
@@ -955,27 +1114,45 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, 
     const u32 lane = threadIdx.x & 63u;
     const bool valid = j < G.m;                                       // (whole wavefronts past the end still take part in the shuffles below)
     const Item it = item_unpack(valid ? G.key_ch[j] : 0ull);
-    const int maxr = (int)S.maxr[it.sb];
+    const int maxr = dc_maxr_of(it.sb, mrp);
     const int n_rank = valid ? count_rank_side(it, maxr) : 0, n_run = valid ? count_run_side(it) : 0, nd = n_rank + n_run;
-    const u32 b_sp = valid ? G.doff_sp[j] : 0u;
+    const u32 b_sp = valid ? (SPF ? G.doff_full[j] : G.doff_sp[j]) : 0u;
     const u32 incl = wave_incl_sum((u32)nd);
     const u32 loc = incl - (u32)nd;                                   // this run's first entry inside the wavefront's piece of the stream
     const u32 wtotal = (u32)__shfl((int)incl, 63, 64);
     const u32 wbase = (u32)__shfl((int)b_sp, 0, 64);                  // lane 0 is valid whenever any lane is
     const bool staged = wtotal <= DC_PS_STAGE;                        // wave-uniform
     dc_lds_vu16* sg = (dc_lds_vu16*)&stage[threadIdx.x >> 6][0];
-    const u32* p_sp = G.pos_sp + b_sp;
+    const u32* p_sp = G.pos_sp + (SPF ? (valid ? G.doff_sp[j] : 0u) : b_sp);
     const u32* p_ch = G.pos_ch + (valid ? G.doff_ch[G.inv_ch[j]] : 0u);
     const u32* p_sr = FAST ? G.pos_ch : G.pos_sr + (valid ? G.doff_sr[G.inv_sr[j]] : 0u);
     const u32* p_sn = FAST ? G.pos_ch : G.pos_sn + (valid ? G.doff_sn[G.inv_sn[j]] : 0u);
     u16* o = out + b_sp;
+    // SPF: the family's values of the run side's NE / NM decisions (entries kk - 1 = 0..3 of the small job's piece of this run: all there
+    // are for runs below 32) are fetched up front — looked up inside the rounds they were two dependent loads in the middle of every
+    // round, and the rounds' other gathers waited behind them
+    u32 vrs[4] = {2048u, 2048u, 2048u, 2048u};
+    if (SPF && !FAST && n_run > 1) {
+        const DcU4 pp = *reinterpret_cast<const DcU4*>(p_sp);
+        vrs[0] = G.V_sp[pp.a];
+        if (n_run > 2) vrs[1] = G.V_sp[pp.b];
+        if (n_run > 3) vrs[2] = G.V_sp[pp.c];
+        if (n_run > 4) vrs[3] = G.V_sp[pp.d];
+    }
+    // SPF: q_sp is the VALUE for a rank-side decision (from the run's record)
     auto emit = [&](int k, u32 q_sp, u32 q_ch, u32 q_st, bool run_side, int cls, u32 bit) {
         const int v_ch = G.V_ch[q_ch];
         u16 e;
         if (FAST) {
             e = (u16)((u32)v_ch | (bit << 13) | (k == 0 ? (u32)PSF_RUN : 0u) | (run_side ? (u32)PSF_SIDE : 0u));
         } else {
-            const int v_sp = G.V_sp[q_sp];
+            int v_sp;
+            if (SPF) {
+                // NF's counter of this family never moves (rate 0, blend weight 0: qlfc_data.inc RUN_FIRST): 2048, as the general path reports it
+                const int kk = k - n_rank;                          // run side: 0 = NF, then NE / NM
+                const u32 pre = kk == 1 ? vrs[0] : kk == 2 ? vrs[1] : kk == 3 ? vrs[2] : vrs[3];
+                v_sp = !run_side ? (int)q_sp : (kk == 0 ? 2048 : kk <= 4 ? (int)pre : (int)G.V_sp[p_sp[kk - 1]]);
+            } else v_sp = G.V_sp[q_sp];
             const int v_st = run_side ? G.V_sn[q_st] : G.V_sr[q_st];
             const int p = blend(v_ch, v_st, v_sp, s_lr[cls]);
             e = (u16)((u32)p | (bit << 12) | (k == 0 ? (u32)PS_RUN : 0u));
@@ -990,7 +1167,11 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, 
     if (valid) {
         const DcU4 c0 = *reinterpret_cast<const DcU4*>(p_ch), c1 = *reinterpret_cast<const DcU4*>(p_ch + 4);
         qch[0] = c0.a; qch[1] = c0.b; qch[2] = c0.c; qch[3] = c0.d; qch[4] = c1.a; qch[5] = c1.b; qch[6] = c1.c; qch[7] = c1.d;
-        if (!FAST) {
+        if (!FAST && SPF) {
+            const uint4 r = G.sp_rec[j];
+            qsp[0] = r.x & 0xffffu; qsp[1] = r.x >> 16; qsp[2] = r.y & 0xffffu; qsp[3] = r.y >> 16;
+            qsp[4] = r.z & 0xffffu; qsp[5] = r.z >> 16; qsp[6] = r.w & 0xffffu; qsp[7] = r.w >> 16;
+        } else if (!FAST) {
             const DcU4 a0 = *reinterpret_cast<const DcU4*>(p_sp), a1 = *reinterpret_cast<const DcU4*>(p_sp + 4);
             qsp[0] = a0.a; qsp[1] = a0.b; qsp[2] = a0.c; qsp[3] = a0.d; qsp[4] = a1.a; qsp[5] = a1.b; qsp[6] = a1.c; qsp[7] = a1.d;
         }
@@ -1025,7 +1206,7 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, 
     for (int k = 8; k < nd; ++k) {
         u32 bit; bool rs;
         const int cls = nth_class(it, maxr, n_rank, k, &bit, &rs);
-        emit(k, FAST ? 0u : p_sp[k], p_ch[k], FAST ? 0u : (rs ? p_sn[k - n_rank] : p_sr[k]), rs, cls, bit);
+        emit(k, (FAST || SPF) ? 0u : p_sp[k], p_ch[k], FAST ? 0u : (rs ? p_sn[k - n_rank] : p_sr[k]), rs, cls, bit);     // (SPF: a rank side has at most 8 decisions, so this is a run-side one)
     }
     if (staged) {
         // the wavefront's piece [wbase, wbase + wtotal) of the stream: 4-byte stores from the first even entry on, the odd ends singly
@@ -1034,6 +1215,120 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, 
         const u32 head = wbase & 1u;                                  // 1: the piece starts on an odd entry
         if (head && lane == 0 && wtotal > 0) ow[0] = sg[0];
         const u32 body = (wtotal - (head < wtotal ? head : wtotal)) >> 1;     // whole 4-byte words after the head
+        u32* ow32 = reinterpret_cast<u32*>(ow + head);
+        for (u32 t = lane; t < body; t += 64) ow32[t] = (u32)sg[head + 2 * t] | ((u32)sg[head + 2 * t + 1] << 16);
+        if (lane == 0 && wtotal > head && ((wtotal - head) & 1u)) ow[wtotal - 1] = sg[wtotal - 1];
+    }
+}
+
+// The p stream with the static family in stream order (devcoder_static.h): rank side and run side as two sets of rounds with STATIC
+// register indices.  What bounds this kernel is the number of dependent memory round trips a wavefront goes through (round 6: taking
+// a third of the gathers away changed nothing; the tail loop's two round trips per decision beyond the eighth were ~10 of them), so
+// everything a run of up to 8 + 9 decisions needs is requested in three waves of loads: per-run words, then all position pieces by
+// 16-byte loads (the char family's positions once from the run's first decision and once from its first run-side decision, so that
+// neither side needs a select chain), then all counter values.  Lanes without a decision in a round read entry 0 (no branch around a load).
+__global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_spf_kernel(DcGather G, DcSub S, const ModelParams* __restrict__ mp,
+                                                        const u32* __restrict__ meta, u16* __restrict__ out, u16* __restrict__ dbg /*[3][D] or null*/, u32 dbgD)
+{
+    const u32 mrp = dc_maxr_pack(S);                                  // max_rank of the eight sub-blocks, one scalar word
+    __shared__ u16 stage[WAVES][DC_PS_STAGE];
+    __shared__ short s_lr[NUM_CLS][4];
+    if (meta[DM_FAIL] != 0u) return;
+    if (threadIdx.x < (u32)NUM_CLS * 3u) s_lr[threadIdx.x / 3u][threadIdx.x % 3u] = mp->lr[threadIdx.x / 3u][threadIdx.x % 3u];
+    __syncthreads();
+    const u32 j = dc_virtual_block() * WG + threadIdx.x;
+    const u32 lane = threadIdx.x & 63u;
+    const bool valid = j < G.m;
+    const u32 jj = valid ? j : 0u;
+    // 1. per-run words (coalesced)
+    const u64 key = G.key_ch[jj];
+    const u32 b_sp = G.doff_full[jj], b_mini = G.doff_sp[jj];
+    const u32 i_ch = G.inv_ch[jj], i_sr = G.inv_sr[jj], i_sn = G.inv_sn[jj];
+    const uint4 rec = G.sp_rec[jj];
+    const Item it = item_unpack(valid ? key : 0ull);
+    const int maxr = dc_maxr_of(it.sb, mrp);
+    const int n_rank = valid ? count_rank_side(it, maxr) : 0, n_run = valid ? count_run_side(it) : 0, nd = n_rank + n_run;
+    const u32 incl = wave_incl_sum((u32)nd);
+    const u32 loc = incl - (u32)nd;
+    const u32 wtotal = (u32)__shfl((int)incl, 63, 64);
+    const u32 wbase = (u32)__shfl((int)b_sp, 0, 64);
+    const bool staged = wtotal <= DC_PS_STAGE;
+    dc_lds_vu16* sg = (dc_lds_vu16*)&stage[threadIdx.x >> 6][0];
+    const u32* p_sp = G.pos_sp + b_mini;
+    const u32* p_ch = G.pos_ch + G.doff_ch[i_ch];
+    const u32* p_sr = G.pos_sr + G.doff_sr[i_sr];
+    const u32* p_sn = G.pos_sn + G.doff_sn[i_sn];
+    u16* o = out + b_sp;
+    // 2. positions (the arrays have slack behind their last entry)
+    const u32* p_chn = p_ch + n_rank;                                  // the char family's positions of the run side
+    const DcU4 cr0 = *reinterpret_cast<const DcU4*>(p_ch), cr1 = *reinterpret_cast<const DcU4*>(p_ch + 4);
+    const DcU4 sr0 = *reinterpret_cast<const DcU4*>(p_sr), sr1 = *reinterpret_cast<const DcU4*>(p_sr + 4);
+    const DcU4 cn0 = *reinterpret_cast<const DcU4*>(p_chn), cn1 = *reinterpret_cast<const DcU4*>(p_chn + 4);
+    const DcU4 sn0 = *reinterpret_cast<const DcU4*>(p_sn), sn1 = *reinterpret_cast<const DcU4*>(p_sn + 4);
+    const DcU4 sp0 = *reinterpret_cast<const DcU4*>(p_sp), sp1 = *reinterpret_cast<const DcU4*>(p_sp + 4);
+    const u32 cn8 = p_chn[8], sn8 = p_sn[8];
+    const u32 qchR[8] = {cr0.a, cr0.b, cr0.c, cr0.d, cr1.a, cr1.b, cr1.c, cr1.d};
+    const u32 qsr[8] = {sr0.a, sr0.b, sr0.c, sr0.d, sr1.a, sr1.b, sr1.c, sr1.d};
+    const u32 qchN[9] = {cn0.a, cn0.b, cn0.c, cn0.d, cn1.a, cn1.b, cn1.c, cn1.d, cn8};
+    const u32 qsn[9] = {sn0.a, sn0.b, sn0.c, sn0.d, sn1.a, sn1.b, sn1.c, sn1.d, sn8};
+    const u32 qsp[8] = {sp0.a, sp0.b, sp0.c, sp0.d, sp1.a, sp1.b, sp1.c, sp1.d};       // the small job's entries kk - 1 = 0..7
+    const u32 vrec[8] = {rec.x & 0xffffu, rec.x >> 16, rec.y & 0xffffu, rec.y >> 16, rec.z & 0xffffu, rec.z >> 16, rec.w & 0xffffu, rec.w >> 16};
+    // 3. values: rank side (at most 8 decisions: RF, <= 3 RE, <= 4 RM with max_rank <= 4)
+    const u32 rank = it.rank;
+    const int B = (valid && rank != 1u) ? bsr(rank) : 0;
+    const int e = B ? (B - 1) + (B < maxr ? 1 : 0) : 0;
+    int vch[8], vst[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const bool on = k < n_rank; vch[k] = G.V_ch[on ? qchR[k] : 0u]; vst[k] = G.V_sr[on ? qsr[k] : 0u]; }
+    // run side: NF, then NE / NM
+    const u32 run = it.run;
+    const int nb = (valid && run != 1u) ? bsr(run) : 0;
+    int wch[5], wst[5], wsp[5];
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) {
+        const bool on = kk < n_run;
+        wch[kk] = G.V_ch[on ? qchN[kk] : 0u]; wst[kk] = G.V_sn[on ? qsn[kk] : 0u];
+        wsp[kk] = (kk == 0) ? 2048 : (int)G.V_sp[on ? qsp[kk - 1] : 0u];       // NF's counter of this family never moves (rate 0, weight 0)
+    }
+    auto put = [&](int k, int p, u32 bit, int v_st, int v_ch, int v_sp) {
+        const u16 en = (u16)((u32)p | (bit << 12) | (k == 0 ? (u32)PS_RUN : 0u));
+        if (dbg) { dbg[b_sp + k] = (u16)v_st; dbg[(size_t)dbgD + b_sp + k] = (u16)v_ch; dbg[2 * (size_t)dbgD + b_sp + k] = (u16)v_sp; }
+        if (staged) sg[loc + (u32)k] = en; else o[k] = en;
+    };
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k < n_rank) {
+            // k = 0: RF; 1..e: RE (bit = more to come); then RM depth k - 1 - e
+            const int cls = k == 0 ? CLS_RF : k <= e ? CLS_RE : CLS_RM;
+            const u32 bit = k == 0 ? (rank != 1u ? 1u : 0u) : k <= e ? (k < B ? 1u : 0u) : (rank >> (B - 1 - (k - 1 - e))) & 1u;
+            put(k, blend(vch[k], vst[k], (int)vrec[k], s_lr[cls]), bit, vst[k], vch[k], (int)vrec[k]);
+        }
+    }
+    auto run_round = [&](int kk, int v_ch, int v_st, int v_sp) {
+        const int cls = kk == 0 ? CLS_NF : kk <= nb ? CLS_NE : (nb <= 5 ? CLS_NM : CLS_NM2);
+        const u32 bit = kk == 0 ? (run != 1u ? 1u : 0u) : kk <= nb ? (kk < nb ? 1u : 0u) : (run >> (nb - 1 - (kk - 1 - nb))) & 1u;
+        put(n_rank + kk, blend(v_ch, v_st, v_sp, s_lr[cls]), bit, v_st, v_ch, v_sp);
+    };
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) if (kk < n_run) run_round(kk, wch[kk], wst[kk], wsp[kk]);
+    if (__ballot(n_run > 5)) {                                          // a run of 8 or more somewhere in the wavefront (a third of them on text)
+        int xch[4], xst[4], xsp[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int kk = 5 + x; const bool on = kk < n_run;
+            xch[x] = G.V_ch[on ? qchN[kk] : 0u]; xst[x] = G.V_sn[on ? qsn[kk] : 0u]; xsp[x] = (int)G.V_sp[on ? qsp[kk - 1] : 0u];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) if (5 + x < n_run) run_round(5 + x, xch[x], xst[x], xsp[x]);
+        for (int kk = 9; kk < n_run; ++kk)                              // runs of 32 and more: from memory, one decision at a time
+            run_round(kk, (int)G.V_ch[p_chn[kk]], (int)G.V_sn[p_sn[kk]], (int)G.V_sp[p_sp[kk - 1]]);
+    }
+    if (staged) {
+        __builtin_amdgcn_wave_barrier();
+        u16* ow = out + wbase;
+        const u32 head = wbase & 1u;
+        if (head && lane == 0 && wtotal > 0) ow[0] = sg[0];
+        const u32 body = (wtotal - (head < wtotal ? head : wtotal)) >> 1;
         u32* ow32 = reinterpret_cast<u32*>(ow + head);
         for (u32 t = lane; t < body; t += 64) ow32[t] = (u32)sg[head + 2 * t] | ((u32)sg[head + 2 * t + 1] << 16);
         if (lane == 0 && wtotal > head && ((wtotal - head) & 1u)) ow[wtotal - 1] = sg[wtotal - 1];
@@ -1150,13 +1445,18 @@ int devcoder_ensure(bscgpu_ctx* c)
         {(void**)&d->pos[0], 4 * D}, {(void**)&d->pos[1], 4 * D}, {(void**)&d->pos[2], 4 * D}, {(void**)&d->pos[3], 4 * D},
         {(void**)&d->V[0], 2 * D}, {(void**)&d->V[1], 2 * D}, {(void**)&d->V[2], 2 * D}, {(void**)&d->V[3], 2 * D},
         {(void**)&d->ps[0], 2 * D}, {(void**)&d->ps[1], 2 * D},
-        {(void**)&d->cnt, (size_t)DC_ROWS * DC_WCH_MAX * 4}, {(void**)&d->rowtot, DC_ROWS * 4}, {(void**)&d->rowstart, 4 * (DC_ROWS + 8) * 4},
+        {(void**)&d->cnt, (size_t)DC_ROWS * DC_WCH_MAX * 4}, {(void**)&d->rowtot, DC_ROWS * 4}, {(void**)&d->rowstart, 6 * (DC_ROWS + 8) * 4},
         {(void**)&d->wdec, (DC_WCH_MAX + 8) * 4}, {(void**)&d->wdecoff, (DC_WCH_MAX + 8) * 4},
         {(void**)&d->elo, 2 * 4 * NCH}, {(void**)&d->ehi, 2 * 4 * NCH}, {(void**)&d->S, 2 * 4 * NCH},
         {(void**)&d->present, (size_t)DC_KIND_WORDS * 4}, {(void**)&d->rounds, 256},
         {(void**)&d->meta, DM_COUNT * 4}, {(void**)&d->poff, 16 * 4},
         {(void**)&d->tab_rank, 32768}, {(void**)&d->tab_run, 8192}, {(void**)&d->mp, sizeof(ModelParams)}, {(void**)&d->mp_fast, sizeof(ModelParams)},
         {(void**)&d->rowbins, DC_ROWS * sizeof(DcRowBins)}, {(void**)&d->sink, 4096},
+        // static family in stream order (devcoder_static.h); T tiles of 64 runs
+        {(void**)&d->sp_planes, (M / 64 + 2) * dcs::SP_PLANES * 8}, {(void**)&d->sp_desc, sizeof d->sp_desc_host},
+        {(void**)&d->sp_sums, (size_t)dcs::SP_SLOTS * (M / 64 / dcs::SP_CT_MIN + 2) * sizeof(dcs::SpSum)}, {(void**)&d->sp_sv, (size_t)dcs::SP_SLOTS * (M / 64 / dcs::SP_CT_MIN + 2) * 2},
+        {(void**)&d->sp_gsum, (size_t)dcs::SP_SLOTS * (M / 64 / dcs::SP_CT_MIN / dcs::SP_RG + 2) * sizeof(dcs::SpGroupSum)}, {(void**)&d->sp_gv, (size_t)dcs::SP_SLOTS * (M / 64 / dcs::SP_CT_MIN / dcs::SP_RG + 2) * 2},
+        {(void**)&d->sp_state, (M / 64 + 16) * dcs::SP_LANES * 2 + 256}, {(void**)&d->sp_rec, 16 * M}, {(void**)&d->doff_full, 4 * M},
     };
     size_t total = 0;
     for (auto& cv : carve) total += dc_align(cv.bytes);
@@ -1180,7 +1480,10 @@ int devcoder_ensure(bscgpu_ctx* c)
     if (!rowbins_ok) { (void)hipFree(d->arena); (void)hipHostFree(d->hmeta); delete d; return ctx_fail(c, BSC_GPU_ERROR, "device coder: bin layout", hipSuccess); }
     const bschost::QlfcTables& QT = bschost::qlfc_tables();
     const uint8_t *rs = QT.rank_state, *ns = QT.run_state;
+    d->sp_ok = true;
+    for (int mr = 0; mr <= dcs::SP_MAXR; ++mr) d->sp_ok = dcs::sp_build_descs(mr, d->sp_desc_host[mr]) && d->sp_ok;
     const bool ok = hipMemcpyAsync(d->mp, &mp, sizeof mp, hipMemcpyHostToDevice, c->stream) == hipSuccess
+                 && hipMemcpyAsync(d->sp_desc, d->sp_desc_host, sizeof d->sp_desc_host, hipMemcpyHostToDevice, c->stream) == hipSuccess
                  && hipMemcpyAsync(d->mp_fast, &mpf, sizeof mpf, hipMemcpyHostToDevice, c->stream) == hipSuccess
                  && hipMemcpyAsync(d->tab_rank, rs, 32768, hipMemcpyHostToDevice, c->stream) == hipSuccess
                  && hipMemcpyAsync(d->tab_run, ns, 8192, hipMemcpyHostToDevice, c->stream) == hipSuccess
@@ -1246,8 +1549,30 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
         hipLaunchKernelGGL(dc_avg_kernel, dim3(((m + DC_AVG_CH - 1) / DC_AVG_CH + WG - 1) / WG), dim3(WG), 0, c->stream, drank, m, S, d->ge32, d->meta);
     else
         HIP_TRY(c, hipMemsetAsync(d->ge32, 0, m, c->stream));
-    hipLaunchKernelGGL(dc_items_kernel, dim3(gm), dim3(WG), 0, c->stream, dsym, drank, dstart, d->ge32, m, n, S, d->key_ch);
+    // Static family in stream order (devcoder_static.h) when no sub-block has more than 32 symbols (then no escape coding either)
+    bool spf = c->dc_spf != 0 && d->sp_ok && !may_escape;
+    u32 sp_slots = 0;
+    for (int b = 0; b < nb && spf; ++b) {
+        if (max_rank[b] < 0 || max_rank[b] > dcs::SP_MAXR) { spf = false; break; }
+        for (int s2 = 0; s2 < dcs::SP_SLOTS; ++s2) if (d->sp_desc_host[max_rank[b]][s2].present) sp_slots |= 1u << s2;
+    }
+    hipLaunchKernelGGL(dc_items_kernel, dim3(gm), dim3(WG), 0, c->stream, dsym, drank, dstart, d->ge32, m, n, S, d->key_ch, spf ? d->sp_planes : (u64*)nullptr);
     prof_end(c);
+    SpArgs SA;
+    if (spf) {
+        SA.g = dcs::sp_geom(m); SA.S = S; SA.slots = sp_slots;
+        SA.uniform = 1u; for (int b = 1; b < nb; ++b) if (max_rank[b] != max_rank[0]) SA.uniform = 0u; SA.planes = d->sp_planes; SA.desc = d->sp_desc; SA.mp = d->mp;
+        SA.sums = d->sp_sums; SA.gsum = d->sp_gsum; SA.gv = d->sp_gv; SA.sv = d->sp_sv; SA.state = d->sp_state; SA.rec = d->sp_rec; SA.meta = d->meta;
+        prof_begin(c, BSCGPU_K_DC_STATIC, (u64)m * 16, m);
+        const dim3 wgrid((SA.g.cstride + WG - 1) / WG, dcs::SP_SLOTS - 1), rgrid((SA.g.gstride + WAVES - 1) / WAVES, dcs::SP_SLOTS - 1);
+        hipLaunchKernelGGL(sp_walk_kernel<false>, wgrid, dim3(WG), 0, c->stream, SA);
+        hipLaunchKernelGGL(sp_resolve_kernel<1>, rgrid, dim3(WG), 0, c->stream, SA);
+        hipLaunchKernelGGL(sp_resolve_serial_kernel, dim3(dcs::SP_SLOTS - 1), dim3(64), 0, c->stream, SA);
+        hipLaunchKernelGGL(sp_resolve_kernel<3>, rgrid, dim3(WG), 0, c->stream, SA);
+        hipLaunchKernelGGL(sp_walk_kernel<true>, wgrid, dim3(WG), 0, c->stream, SA);
+        hipLaunchKernelGGL(sp_values_kernel, dim3((SA.g.ntiles + WAVES - 1) / WAVES), dim3(WG), 0, c->stream, SA);
+        prof_end(c);
+    }
     RadixPass top; top.shift = 56; top.bits = 8;
     int in_alt = 0;
     // one pass: the engine reads `keys` (left intact) and writes the sorted copy to the alt array
@@ -1265,7 +1590,18 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
 
     // families: static (stream order, X ignored), char (symbol-major), state (rank side by rank-state, run side by run-state):
     // four independent partition jobs, then ONE read-back of their sizes, then all chains of the block in one set of launches
-    dc_launch_partition<3>(c, d, d->key_ch, m, S, 0, 1u);
+    if (spf) {
+        // job 0 holds the family's NE / NM decisions only; the runs' offsets in the p stream (all decisions) come from counts and scans alone
+        dc_launch_partition<6>(c, d, d->key_ch, m, S, 0, 1u);
+        const DcGeom g = dc_geom(m);
+        const u32 grid = (g.W + WAVES - 1) / WAVES;
+        prof_begin(c, BSCGPU_K_DC_PART, (u64)m * 8, m);
+        hipLaunchKernelGGL(dc_part_count_kernel<3>, dim3(grid), dim3(WG), 0, c->stream, d->key_ch, g, S, d->rowbins, d->cnt, d->wdec);
+        hipLaunchKernelGGL(dc_scan_rows_kernel, dim3(DC_ROWS), dim3(WG), 0, c->stream, d->cnt, g.W, d->rowtot);     // (the row totals: the block's decision count)
+        hipLaunchKernelGGL(dc_scan_misc_kernel, dim3(1), dim3(WG), 0, c->stream, d->rowtot, d->rowstart + (DC_ROWS + 8) * 5, d->wdec, g.W, d->wdecoff, d->meta, 5, (u32)d->Dcap);
+        hipLaunchKernelGGL(dc_doff_kernel<3>, dim3(grid), dim3(WG), 0, c->stream, d->key_ch, g, S, d->meta, d->wdecoff, d->doff_full);
+        prof_end(c);
+    } else dc_launch_partition<3>(c, d, d->key_ch, m, S, 0, 1u);
     dc_launch_partition<3>(c, d, d->key_ch_s, m, S, 1, 0u);
     dc_launch_partition<1>(c, d, d->key_sr_s, m, S, 2, 0u);
     dc_launch_partition<2>(c, d, d->key_sn_s, m, S, 3, 0u);
@@ -1276,7 +1612,8 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     if (d->hmeta[DM_FAIL] != 0) { c->dc_last_fail = (int)d->hmeta[DM_FAIL]; return BSC_NOT_SUPPORTED; }
     u32 E[4];
     for (int job = 0; job < 4; ++job) E[job] = d->hmeta[DM_D0 + job];
-    if (E[0] != E[1] || E[0] != E[2] + E[3]) return ctx_fail(c, BSC_GPU_ERROR, "device coder: decision counts of the families differ", hipSuccess);
+    const u32 Efull = spf ? d->hmeta[DM_DFULL] : E[0];                 // decisions of the block (spf: job 0 is the small NE / NM job)
+    if (Efull != E[1] || Efull != E[2] + E[3]) return ctx_fail(c, BSC_GPU_ERROR, "device coder: decision counts of the families differ", hipSuccess);
     {
         DcEvalAll A;
         A.wstart[0] = 0; A.cstart[0] = 0; A.sink = d->sink;
@@ -1299,7 +1636,7 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
             A.cstart[job + 1] = A.cstart[job] + (nch + 63) / 64 * 64;           // chunk slots padded to whole wavefronts
         }
         if (A.cstart[4] > 4 * d->nch_cap) return ctx_fail(c, BSC_GPU_ERROR, "device coder: chunk table too small", hipSuccess);
-        prof_begin(c, BSCGPU_K_DC_EVAL, (u64)E[0] * 18, (u64)E[0] * 3);
+        prof_begin(c, BSCGPU_K_DC_EVAL, (u64)(E[0] + E[1] + E[2] + E[3]) * 6, (u64)E[0] + E[1] + E[2] + E[3]);
         if (A.wstart[4] > 0) {
             hipLaunchKernelGGL(dc_mark_rows_kernel, dim3((4 * DC_ROWS + WG - 1) / WG), dim3(WG), 0, c->stream, A);
             hipLaunchKernelGGL(dc_eval_wave_kernel<false>, dim3((A.wstart[4] + DC_EVAL_WAVES - 1) / DC_EVAL_WAVES), dim3(64 * DC_EVAL_WAVES), DC_EVAL_LDS, c->stream, A, d->mp, d->meta, d->elo, d->ehi, (const u16*)nullptr, d->cnt);
@@ -1314,10 +1651,12 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     G.doff_sp = d->doff[0]; G.doff_ch = d->doff[1]; G.doff_sr = d->doff[2]; G.doff_sn = d->doff[3];
     G.pos_sp = d->pos[0]; G.pos_ch = d->pos[1]; G.pos_sr = d->pos[2]; G.pos_sn = d->pos[3];
     G.V_sp = d->V[0]; G.V_ch = d->V[1]; G.V_sr = d->V[2]; G.V_sn = d->V[3];
-    prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)E[0] * 26, E[0]);
+    G.sp_rec = d->sp_rec; G.doff_full = d->doff_full;
+    prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)Efull * 26, Efull);
     if (c->ps_guard[psbuf & 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ps_guard[psbuf & 1], 0));     // the buffer's previous copy-out
-    hipLaunchKernelGGL(dc_pstream_kernel<false>, dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, E[0]);
-    hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, d->doff[0], S, m, d->poff);
+    if (spf) hipLaunchKernelGGL(dc_pstream_spf_kernel, dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, Efull);
+    else     hipLaunchKernelGGL((dc_pstream_kernel<false, false>), dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, Efull);
+    hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, spf ? d->doff_full : d->doff[0], S, m, d->poff);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(d->hmeta, d->meta, DM_COUNT * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1339,8 +1678,8 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
         }
     }
 #endif
-    if (getenv("BSCGPU_DEBUG")) fprintf(stderr, "[devcoder] decisions %u, types %u, rounds %u, chunks replayed %u\n", E[0], d->hmeta[DM_NTYPES], d->hmeta[DM_NROUNDS], d->hmeta[DM_REPLAYS]);
-    *D_out = E[0];
+    if (getenv("BSCGPU_DEBUG")) fprintf(stderr, "[devcoder] decisions %u, types %u, rounds %u, chunks replayed %u, static family %s\n", Efull, d->hmeta[DM_NTYPES], d->hmeta[DM_NROUNDS], d->hmeta[DM_REPLAYS], spf ? "in stream order" : "partitioned");
+    *D_out = Efull;
     for (int b = 0; b <= nb; ++b) poff_out[b] = d->hmeta[32 + b];
     return BSC_NO_ERROR;
 }
@@ -1356,7 +1695,7 @@ static int devcoder_pstream_fast(bscgpu_ctx* c, DevCoder* d, const u8* dsym, con
     const u32 gm8 = (gm + 7u) / 8u * 8u;
     prof_begin(c, BSCGPU_K_DC_CTX, (u64)m * 14, m);
     HIP_TRY(c, hipMemsetAsync(d->ge32, 0, m, c->stream));              // no escape coding in this coder
-    hipLaunchKernelGGL(dc_items_kernel, dim3(gm), dim3(WG), 0, c->stream, dsym, drank, dstart, d->ge32, m, n, S, d->key_ch);
+    hipLaunchKernelGGL(dc_items_kernel, dim3(gm), dim3(WG), 0, c->stream, dsym, drank, dstart, d->ge32, m, n, S, d->key_ch, (u64*)nullptr);
     prof_end(c);
     RadixPass top; top.shift = 56; top.bits = 8;
     int in_alt = 0;
@@ -1413,7 +1752,7 @@ static int devcoder_pstream_fast(bscgpu_ctx* c, DevCoder* d, const u8* dsym, con
     G.V_sp = d->V[1]; G.V_ch = d->V[1]; G.V_sr = d->V[1]; G.V_sn = d->V[1];
     prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)E * 10, E);
     if (c->ps_guard[psbuf & 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ps_guard[psbuf & 1], 0));     // the buffer's previous copy-out
-    hipLaunchKernelGGL(dc_pstream_kernel<true>, dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp_fast, d->meta, d->ps[psbuf & 1], (u16*)nullptr, E);
+    hipLaunchKernelGGL((dc_pstream_kernel<true, false>), dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp_fast, d->meta, d->ps[psbuf & 1], (u16*)nullptr, E);
     hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, d->doff[0], S, m, d->poff);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());

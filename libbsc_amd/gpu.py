@@ -141,7 +141,7 @@ class GpuContext:
         return Pipe(self, depth, reuse_outputs)
 
     # ---- measurement / test knobs (include/bscgpu.h: BSCGPU_OPT_*, BSCGPU_CNT_*) ---------------------------------
-    OPT_RS_ONESWEEP, CNT_OS_RETRIES = 1, 2
+    OPT_RS_ONESWEEP, CNT_OS_RETRIES, OPT_DC_STREAM_STATIC = 1, 2, 3
 
     def option_set(self, key, value):
         return self._check(self.L.bscgpu_option_set(self.h, key, value))

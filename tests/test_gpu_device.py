@@ -535,6 +535,50 @@ def test_device_static_model_matches_oracle_trace(ctx):
         small.close()
 
 
+def test_stream_order_static_family_equals_partitioned_path(ctx):
+    """devcoder_static.h (round 6): for blocks of at most 32 symbols per sub-block the static coder's context-free counter family is
+    walked in stream order instead of being partitioned.  Same probability stream as the general path (BSCGPU_OPT_DC_STREAM_STATIC = 0)
+    and as the oracle's trace of the reference model, on 1 / 2 / 4 sub-blocks, sub-blocks of different alphabet size (max_rank 0..4 and
+    one with 40 symbols, which sends the whole block down the general path), a block of a handful of runs, and constant data (brackets
+    that cannot close: declined or exact, never approximate)."""
+    from libbsc_amd import api
+    from libbsc_amd.gpu import GpuError
+    from oracle.refbind import Oracle, Ref
+    orc, ref = Oracle(), Ref()
+    rng = np.random.default_rng(29)
+    bwt = lambda x: ref.bwt_encode(x)[0]
+    def alpha(n, k, p=0.3):         # k symbols, geometric
+        return (rng.geometric(p, n) % k).astype(np.uint8)
+    parts = [alpha(300_000, 2), alpha(700_000, 4), alpha(900_000, 7, 0.1), alpha(400_000, 32, 0.05), alpha(800_000, 17, 0.08), alpha(1_100_000, 3)]
+    cases = [("text200k", bwt(api.synth_text_v1(12, 200_000))), ("text1m", bwt(api.synth_text_v1(13, 1 << 20))), ("text5m", bwt(api.synth_text_v1(14, 5 << 20))),
+             ("mixed alphabets 4.2m", np.concatenate(parts)), ("mixed + 40 symbols", np.concatenate(parts[:3] + [alpha(500_000, 40, 0.03)] + parts[3:])),
+             ("tiny", np.array([1, 1, 2, 2, 2, 1, 3], np.uint8)), ("one run", np.zeros(70_000, np.uint8)), ("ab", (np.arange(600_000) % 2).astype(np.uint8)),
+             ("dna5m", bwt(rng.integers(0, 4, 5 << 20, dtype=np.uint8))), ("32 symbols uniform", rng.integers(0, 32, 2 << 20, dtype=np.uint8))]
+    assert ctx.option_get(ctx.OPT_DC_STREAM_STATIC) == 0          # off by default (measured slower: profiles/r06)
+    try:
+        for name, L in cases:
+            got = {}
+            for mode in (1, 0):
+                ctx.option_set(ctx.OPT_DC_STREAM_STATIC, mode)
+                try:
+                    got[mode] = ctx.qlfc_static_pstream(L, debug=(L.size <= (1 << 20)))
+                except GpuError as e:
+                    assert e.code == -4, (name, mode, e)            # declined: the block takes the host model
+                    got[mode] = None
+            if got[1] is None or got[0] is None:
+                continue
+            (ps1, st1, sz1, poff1, dbg1), (ps0, st0, sz0, poff0, dbg0) = got[1], got[0]
+            assert st1 == st0 and sz1 == sz0 and poff1 == poff0, name
+            assert np.array_equal(ps1, ps0), (name, int((ps1 != ps0).sum()))
+            if dbg1 is not None:
+                assert np.array_equal(dbg1, dbg0), name                 # the three counter values behind every probability
+            for b in range(len(st1)):
+                tr, _ = orc.static_pstream(L[st1[b]:st1[b] + sz1[b]])
+                assert np.array_equal(tr, ps1[poff1[b]:poff1[b + 1]]), (name, b)
+    finally:
+        ctx.option_set(ctx.OPT_DC_STREAM_STATIC, 0)
+
+
 def test_gpu_inverse_bwt(ctx, ref):
     """bscgpu_unbwt (unbwt.hip): LF mapping from one radix pass with destination positions, the LF cycle cut at ~n/128 marked rows
     and walked in parallel.  Against the texts the reference's forward BWT came from; wrong primary indexes and damaged columns

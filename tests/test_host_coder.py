@@ -235,3 +235,29 @@ def test_fast_coder_chain_model_matches_the_host_coder(tmp_path):
                     "-I", os.path.join(root, "include"), os.path.join(root, "tools/devcoder_fast_sim.cpp"), "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "all equal" in r.stdout, r.stdout + r.stderr
+
+
+def test_stream_order_static_family_lane_functions(tmp_path):
+    """The static coder's context-free counter family evaluated in stream order (devcoder_static.h, round 6): descriptors derived from
+    the model's own case analysis for max_rank 0..4 (checked rank by rank), rank bit planes, bracket walk per (slot, chunk), resolve,
+    exact walk, values per (slot, sub-tile) — every lane function the HIP kernels call, run lane by lane on the CPU against a plain
+    sequential walk of the chains (tools/devcoder_static_sim.cpp): 151 rank sequences incl. one-run blocks, constant ranks (brackets
+    that never close: the path must decline, not approximate), sub-block starts crowded into one tile, on a tile's first lane and on
+    a chunk's first lane, and sub-blocks with different max_rank; then the ranks of a real BWT block through the host front end."""
+    import os
+    import subprocess
+    import numpy as np
+    from libbsc_amd import api
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "static_sim")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-march=x86-64-v3", "-I", os.path.join(root, "libbsc_amd/csrc/host"), "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tools/devcoder_static_sim.cpp"), os.path.join(root, "libbsc_amd/csrc/host/coder.cpp"), "-o", exe, "-lpthread"], check=True)
+    # a BWT-like block: text sorted by its 3 following characters (any byte sequence serves as the coder's input; this one has the
+    # structure of a sorted block: long stretches of few symbols), 5 MiB = 4 sub-blocks
+    T = api.synth_text_v1(9, 5 << 20)
+    key = (T[np.r_[1:T.size, 0]].astype(np.uint32) << 16) | (T[np.r_[2:T.size, 0, 1]].astype(np.uint32) << 8) | T[np.r_[3:T.size, 0, 1, 2]]
+    L = T[np.argsort(key, kind="stable")]
+    f = tmp_path / "block.bin"
+    L.tofile(f)
+    r = subprocess.run([exe, str(f)], capture_output=True, text=True)
+    assert r.returncode == 0 and "static stream-order evaluation OK" in r.stdout and "mismatches 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

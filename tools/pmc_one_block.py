@@ -8,5 +8,7 @@ n = 64 << 20
 T = api.synth_text_v1(2, n)
 ctx = GpuContext(0, max_n=n + 4096)
 d = torch.from_numpy(T).cuda()
-blk = ctx.compress_device(d, n, 1, 1)
+import os
+for _ in range(int(os.environ.get("ONE_BLOCK_REPS", "1"))):
+    blk = ctx.compress_device(d, n, 1, 1)
 print("compressed", blk.size)
