@@ -163,21 +163,26 @@ def main():
     # nothing to do until then (round 3's timeline: first block coded at 144 ms of 340); staggered, the first block reaches them after
     # one GPU stage, and the stages keep ending one at a time.
     use_queue = os.environ.get("BSC_BENCH_QUEUE", "1") != "0"
+    tail_rule = int(os.environ.get("BSC_BENCH_TAILRULE", "0"))      # 0: context k draws only while more than k blocks are left; 1: any context draws; 2: while more than k // 2 are left
+    head_rule = int(os.environ.get("BSC_BENCH_HEADRULE", "0"))      # 0: context k starts after k GPU stages of the run; 1: after k // 2; 2: at once
+    urgent_blocks = int(os.environ.get("BSC_BENCH_URGENT", "0"))    # how many of the job's last blocks are coded as eight single-stream tasks whatever the pool's load
+    URGENT = 0x20000
     queue_lock = threading.Condition()
     queue_state = {"next": 0, "total": 0, "stages_done": 0}
 
     def take_block(k, i_static, steps_static):
         """-> (take it?, is one of the job's last blocks?)"""
         if queue_state["total"] == 0:                     # static split: pipe k's own share
-            return i_static < steps_static, i_static == steps_static - 1
+            return i_static < steps_static, (1 if i_static == steps_static - 1 else 0)
         with queue_lock:
             if i_static == 0:                             # this context's first block of the run
-                queue_lock.wait_for(lambda: queue_state["stages_done"] >= k or queue_state["next"] >= queue_state["total"])
+                need = k if head_rule == 0 else (k // 2 if head_rule == 1 else 0)
+                queue_lock.wait_for(lambda: queue_state["stages_done"] >= need or queue_state["next"] >= queue_state["total"])
             left = queue_state["total"] - queue_state["next"]
-            if left <= k:
+            if left <= (k if tail_rule == 0 else (0 if tail_rule == 1 else k // 2)):
                 return False, False
             queue_state["next"] += 1
-            return True, left <= ll_blocks
+            return True, (0 if announce else 2 if left <= urgent_blocks else 1 if left <= ll_blocks else 0)
 
     def stage_finished():
         if queue_state["total"]:
@@ -198,7 +203,7 @@ def main():
             take, last = take_block(k, i, steps)
             if not take:
                 break
-            feat = 3 | (LOW_LATENCY if (tail_low_latency and last) else 0)
+            feat = 3 | ((LOW_LATENCY if last == 1 else URGENT | LOW_LATENCY) if (tail_low_latency and last) else 0)
             if trace is not None and record: trace.append((k, i, "submit", time.perf_counter() - t_run0[0]))
             tickets.append(pipe.submit_host(host_in, args.sorter, args.coder, lzp[0], lzp[1], feat) if (host_leg[0] or lzp[0]) else pipe.submit(d_in, n, args.sorter, args.coder, feat))
             stage_finished()
@@ -218,8 +223,14 @@ def main():
             with stage_lock:
                 stage[:] += local_stage
 
+    announce = os.environ.get("BSC_BENCH_ANNOUNCE", "1") != "0"       # tell the coder pool how many blocks the job has (bscgpu_coder_pool_expect)
+
     def run(steps, record=False, static=False):
         out = [None] * ncx
+        if announce and not static:
+            import ctypes as C
+            from libbsc_amd import _native as NN
+            NN.lib().bscgpu_coder_pool_expect(C.c_longlong(steps))
         share = [steps // ncx + (1 if k < steps % ncx else 0) for k in range(ncx)]
         queue_state["next"] = 0
         queue_state["stages_done"] = 0
@@ -292,6 +303,22 @@ def main():
     cpu_used = time.process_time() - cpu0               # all threads of this rank
     cg1 = cgroup_cpu_stat()
     if trace is not None and rank == 0:
+        try:                                            # the coder pool's own record of its tasks (BSCGPU_POOL_TRACE=1)
+            import ctypes as C
+            from libbsc_amd import _native as NN
+            L = NN.lib()
+            L.bscgpu_steady_now.restype = C.c_double
+            off = time.perf_counter() - L.bscgpu_steady_now()           # both clocks are monotonic: one offset
+            buf = (C.c_double * (6 * 4096))()
+            cnt = L.bscgpu_coder_pool_trace(buf, 4096, 1)
+            ids = {}
+            for r in range(cnt):
+                a, b, job, sub, shape, feat = (buf[6 * r + x] for x in range(6))
+                if b + off < t0: continue
+                jid = ids.setdefault(job, len(ids))
+                trace.append((-1, jid, f"task sub {int(sub)} x{int(shape)}{' LL' if int(feat) & 0x10000 else ''} ran {(a + off - t0) * 1e3:.1f} .. {(b + off - t0) * 1e3:.1f} ms ({(b - a) * 1e3:.1f})", b + off - t0))
+        except Exception as e:
+            print(f"[trace] pool trace unavailable: {e!r}", file=sys.stderr)
         for k, i, what, t in sorted(trace, key=lambda x: x[3]):
             print(f"[trace] {t * 1e3:8.1f} ms  pipe {k} block {i}: {what}", file=sys.stderr)
         print(f"[trace] {dt * 1e3:8.1f} ms  end of the timed region", file=sys.stderr)

@@ -348,6 +348,7 @@ struct BlockJob {
     bool pipelined = false;        // submitted through a pipe (several blocks in flight): throughput over latency
     int  pipe_workers = 0;         // coder threads of the process-wide pool (0: a synchronous call, which starts its own threads)
     int  pool_free = -1;           // CPUs of the pool's budget with nothing to do when the block was queued (-1: not a pipe's block)
+    int  tail_r = -1;              // blocks of the announced job whose GPU stage was still to END when this one's did (-1: no job announced)
     int  ps_g = 2;                 // device-model sub-blocks per coder task (ps_group), fixed when the block's host work starts
     bool use_ps = false; const uint16_t* ps = nullptr; u32 poff[9]; u32 ndec = 0; int sorter = 0;
     hipEvent_t ps_ready = nullptr;   // the p stream's copy to the host (copy stream), all of it
@@ -585,6 +586,19 @@ static int ps_group(const BlockJob& J)
     static const int adaptive = [] { const char* e = getenv("BSC_RC_ADAPTIVE"); return e ? atoi(e) : 0; }();
     static const int cpus = default_coder_threads();
     const int callers = g_sync_callers.load(std::memory_order_relaxed);
+    if ((J.features & BSCGPU_FEATURE_URGENT) && ps_simd_env() < 0) return 1;       // the caller's word: eight single-stream tasks
+    // An announced job (bscgpu_coder_pool_expect): the shape follows the order in which GPU stages END, which is what decides when a
+    // block's coding can start — not the order in which the caller submitted them (with several contexts interleaving on the GPU the
+    // two differ by 100 ms: round 6's task timeline had blocks submitted 8th..10th from last end their GPU stage 60 ms before the
+    // job's last one, take an eight-lane task of 110-120 ms each, and finish the job).  The last block: eight single-stream tasks
+    // (35 ms); the few before it: pairs (50 ms); everything earlier ends in time as one eight-lane task (half the CPU time).
+    if (J.tail_r >= 0 && ps_simd_env() < 0 && cpu_has_avx512vl()) {
+        static const int tail_singles = [] { const char* e = getenv("BSC_TAIL_SINGLES"); return e ? atoi(e) : 1; }();
+        static const int tail_pairs = [] { const char* e = getenv("BSC_TAIL_PAIRS"); return e ? atoi(e) : 5; }();
+        if (J.tail_r < tail_singles) return 1;
+        if (J.tail_r < tail_singles + tail_pairs) return 2;
+        if (!(J.features & BSCGPU_FEATURE_LOW_LATENCY)) return 8;
+    }
     return bscgpu_coder_task_shape(ps_simd_env(), ((J.features & BSCGPU_FEATURE_LOW_LATENCY) || !J.pipelined) ? 1 : 0, J.pool_free,
                                    cpus / (callers > 1 ? callers : 1), cpu_has_avx512vl() ? 1 : 0, adaptive);
 }
@@ -900,6 +914,27 @@ static int default_coder_threads()
     return n;
 }
 
+// Optional task trace (BSCGPU_POOL_TRACE=1; bench.py BSC_BENCH_TRACE prints it): when each coder task ran — the only way to see where a
+// short job's drain goes, since a pipe's caller learns of a finished block only when it next asks.
+struct PoolTraceRec { double t0, t1; const void* job; int sub, shape, features; };
+static std::mutex g_trace_mu;
+static std::vector<PoolTraceRec> g_trace;
+static const bool g_trace_on = [] { const char* e = getenv("BSCGPU_POOL_TRACE"); return e && e[0] == '1'; }();
+static double trace_now() { return std::chrono::duration<double>(clk::now().time_since_epoch()).count(); }
+extern "C" BSCGPU_API int bscgpu_coder_pool_trace(double* out /* [cap][6]: start, end (seconds, steady clock), job id, sub-block, sub-blocks per task, features */, int cap, int reset)
+{
+    std::lock_guard<std::mutex> g(g_trace_mu);
+    int n = 0;
+    for (const PoolTraceRec& r : g_trace) {
+        if (n >= cap) break;
+        out[6 * n + 0] = r.t0; out[6 * n + 1] = r.t1; out[6 * n + 2] = (double)(uintptr_t)r.job; out[6 * n + 3] = r.sub; out[6 * n + 4] = r.shape; out[6 * n + 5] = r.features;
+        ++n;
+    }
+    if (reset) g_trace.clear();
+    return n;
+}
+extern "C" BSCGPU_API double bscgpu_steady_now() { return trace_now(); }
+
 // ---- pipe: several blocks in flight -------------------------------------------------------------------------
 // submit() runs the GPU stage on the calling thread and queues the block's host work as tasks for the coder pool: ONE pool per
 // process (the CPUs it may use: affinity and cgroup quota, default_coder_threads(); BSCGPU_HOST_THREADS overrides the number of
@@ -913,6 +948,7 @@ struct CoderPool {
     std::deque<Task> queue;
     std::vector<std::thread> workers;
     int active = 0, budget = 0, users = 0;
+    long long to_come = -1;                           // blocks of the announced job not yet queued (bscgpu_coder_pool_expect); -1: none announced
     bool stop = false;
 
     void worker_loop()
@@ -928,11 +964,14 @@ struct CoderPool {
             }
             BlockJob& J = *t.job;
             bool finished = false;
+            const double tr0 = g_trace_on ? trace_now() : 0.0;
+            const int tr_shape = J.use_ps ? J.ps_g : 0, tr_feat = J.features;
             if (t.sub == -1) { host_stage(J); finished = true; }
             else {
                 if (J.use_ps) host_encode_group(J, t.sub); else host_encode_sub(J, t.sub);
                 if (J.remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) { host_finalize(J); finished = true; }
             }
+            if (g_trace_on) { const double tr1 = trace_now(); std::lock_guard<std::mutex> g(g_trace_mu); g_trace.push_back({tr0, tr1, (const void*)&J, t.sub, tr_shape, tr_feat}); }
             { std::lock_guard<std::mutex> lk(mu); --active; if (finished) J.done = true; }
             if (finished) cv_done.notify_all();
         }
@@ -942,7 +981,19 @@ struct CoderPool {
 };
 static std::mutex g_pool_mu;
 static CoderPool* g_pool = nullptr;
+
 static std::atomic<uint64_t> g_pool_mode[4];          // blocks queued as: 8 scalar tasks, 4 pair tasks, one eight-lane task, host-model tasks
+
+// The caller's knowledge of where a job ENDS: `blocks` more blocks will be submitted to this process's pipes (any of them); the pool then
+// shapes the host tasks of the blocks whose GPU stages end last for latency (ps_group).  blocks < 0: no announcement (the default).
+extern "C" BSCGPU_API int bscgpu_coder_pool_expect(long long blocks)
+{
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    if (!g_pool) return LIBBSC_BAD_PARAMETER;
+    std::lock_guard<std::mutex> lk(g_pool->mu);
+    g_pool->to_come = blocks < 0 ? -1 : blocks;
+    return LIBBSC_NO_ERROR;
+}
 
 void bscgpu_coder_pool_stats(uint64_t out[4], int reset)
 {
@@ -1048,6 +1099,9 @@ static int pipe_enqueue(bscgpu_pipe* p, bscgpu_pipe::Lane& L, int ticket)
     {
         std::lock_guard<std::mutex> lk(P->mu);
         L.ticket = ticket; L.joined = false;
+        J.tail_r = -1;
+        if (P->to_come > 0) J.tail_r = (int)(--P->to_come < 0x7fffffff ? P->to_come : 0x7fffffff);
+        else if (P->to_come == 0) P->to_come = -1;               // more blocks than announced: the rule is dropped
         J.done = false;                                          // (with the other fields a peeker reads, under the pool's mutex)
         p->next_ticket = ticket + 1;
         J.pool_free = P->free_cpus();
