@@ -102,7 +102,9 @@ def main():
     rc_x8 = rc_simd == 8 or (rc_simd < 0 and has_avx512vl)
     if args.depth <= 0:                                 # blocks in flight per context
         args.depth = max(2, min(4, 8 // ncx))
-        if rc_x8: args.depth = max(2, min(4, 18 // ncx))      # one longer task per block: 16-18 blocks in flight per GPU
+        if rc_x8: args.depth = max(2, min(4, 24 // ncx))      # one longer task per block (~105 ms of a CPU against ~12 ms of the GPU): 24 blocks in
+                                                              # flight per GPU (round 6: with 18 a pipe regularly sat in wait() on its oldest block
+                                                              # while the GPU had nothing to do — 3991 -> 4089 MB/s at the driver's 20 steps, 5 runs each)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
@@ -230,7 +232,7 @@ def main():
         if announce and not static:
             import ctypes as C
             from libbsc_amd import _native as NN
-            NN.lib().bscgpu_coder_pool_expect(C.c_longlong(steps))
+            NN.lib().bscgpu_coder_pool_expect(C.c_longlong(steps), 1)
         share = [steps // ncx + (1 if k < steps % ncx else 0) for k in range(ncx)]
         queue_state["next"] = 0
         queue_state["stages_done"] = 0
@@ -634,45 +636,66 @@ def baseline_configs(torch, dev, local, ctx64, d_in64, n64, GpuContext, api):
                 "against tests/golden/golden_big.json (the reference's libsais path took 2.6 s on 8 threads, SURVEY 8a)"}
     del out
 
-    # config 5: 128 MiB blocks (seed 3) through ST5 and ST6 + QLFC static, 4 blocks each through one pipe of depth 2
+    # config 5: 128 MiB blocks (seed 3) through ST5 and ST6 + QLFC static, 8 blocks each through two contexts with two blocks in flight
     n5 = 128 << 20
     T3 = api.synth_text_v1(3, n5)
     d3 = torch.from_numpy(T3).to(dev)
-    cx = GpuContext(local, max_n=n5 + 4096)
+    cxs = [GpuContext(local, max_n=n5 + 4096) for _ in range(2)]
     try:
-        pipe = cx.pipe(2, reuse_outputs=True)
-        for k in (5, 6):
-            e5 = next(e for e in big if e["tag"] == "config5" and e["sorter"] == k)
-            pipe.wait(pipe.submit(d3, n5, k, 1, 3))                      # every buffer of the path once
-            pipe.wait(pipe.submit(d3, n5, k, 1, 3))
-            cx.profile(True); cx.profile_reset()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
+        import threading
+        pps = [cx.pipe(2, reuse_outputs=True) for cx in cxs]
+        from libbsc_amd import _native as NN
+        import ctypes as C
+
+        def through(pipe, nblocks, k, out, slot):
             tickets, b5 = [], None
-            for _ in range(4):
+            for _ in range(nblocks):
                 tickets.append(pipe.submit(d3, n5, k, 1, 3))
                 if len(tickets) >= 2:
                     b5 = pipe.wait(tickets.pop(0))
             while tickets:
                 b5 = pipe.wait(tickets.pop(0))
+            out[slot] = b5
+        for k in (5, 6):
+            e5 = next(e for e in big if e["tag"] == "config5" and e["sorter"] == k)
+            out = [None, None]
+            for i, pp in enumerate(pps):
+                through(pp, 2, k, out, i)                                # every buffer of the path once
+            for cx in cxs:
+                cx.profile(True); cx.profile_reset()
+            torch.cuda.synchronize()
+            NN.lib().bscgpu_coder_pool_expect(C.c_longlong(8), 1)
+            t0 = time.perf_counter()
+            ths = [threading.Thread(target=through, args=(pp, 4, k, out, i)) for i, pp in enumerate(pps)]
+            for t in ths: t.start()
+            for t in ths: t.join()
             dt5 = time.perf_counter() - t0
-            cx.profile(False)
-            st = cx.profile_get()
-            launches = cx.scatter_launches(65536)
+            b5 = out[0]
+            st = None
+            launches = []
+            for cx in cxs:
+                cx.profile(False)
+                g = cx.profile_get()
+                launches += cx.scatter_launches(65536)
+                if st is None: st = g
+                else:
+                    for kk, vv in g.items():
+                        for f in ("ms", "launches", "bytes", "records"): st[kk][f] += vv[f]
             ms_sort = sum(st[x]["ms"] for x in ("radix_hist_all", "radix_hist", "radix_scan", "radix_scatter") if x in st)
             full = [(ms, rec) for ms, rec in launches if rec == n5]
             b_sort = sum(16 * rec for _, rec in full) + 8 * n5 * max(st.get("radix_hist_all", {}).get("launches", 0), 0)
             res[f"config5_128MiB_st{k}_qlfc_static"] = {
-                "MBps": round(4 * n5 / 1e6 / dt5, 1), "ms_per_block": round(dt5 / 4 * 1e3, 2), "blocks": 4,
+                "MBps": round(8 * n5 / 1e6 / dt5, 1), "ms_per_block": round(dt5 / 8 * 1e3, 2), "blocks": 8,
                 "sort_frac": round(b_sort / 1e6 / max(ms_sort, 1e-9) / HBM_PEAK_GBPS, 4),
                 "digit_pass_frac": round(sum(16 * rec for _, rec in full) / 1e6 / max(sum(ms for ms, _ in full), 1e-9) / HBM_PEAK_GBPS, 4),
-                "digit_passes_per_block": len(full) // 4,
-                "compressed_bytes": int(b5.size), "verified": (int(b5.size), md5(b5)) == (e5["size"], e5["md5"]),
-                "what": f"4 x 128 MiB synth-text v1 blocks (seed 3) through bscgpu_pipe_submit(ST{k}, QLFC static), one context, two blocks in flight, fill and "
-                        f"drain included; sort_frac = SURVEY 8d's B_sort (m*8 + {k}*2*m*8) over the time of every radix kernel; checked against golden_big.json"}
-        pipe.close()
+                "digit_passes_per_block": len(full) // 8,
+                "compressed_bytes": int(b5.size), "verified": all((int(b.size), md5(b)) == (e5["size"], e5["md5"]) for b in out),
+                "what": f"8 x 128 MiB synth-text v1 blocks (seed 3) through bscgpu_pipe_submit(ST{k}, QLFC static), two contexts x two blocks in flight, fill and "
+                        f"drain included (a short job: the steady rate is higher); sort_frac = SURVEY 8d's B_sort (m*8 + {k}*2*m*8) over the time of every radix kernel "
+                        f"(two contexts share the GPU while they are measured); checked against golden_big.json"}
+        for pp in pps: pp.close()
     finally:
-        cx.close()
+        for cx in cxs: cx.close()
     res["leg_seconds"] = round(time.perf_counter() - t_leg, 2)
     return res
 

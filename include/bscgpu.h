@@ -118,12 +118,12 @@ BSCGPU_API int  bscgpu_pipe_create(bscgpu_ctx* ctx, int depth, bscgpu_pipe** out
 /* How the pool has coded the pipes' blocks so far: out[0] blocks as eight scalar tasks, [1] as four pair tasks, [2] as one eight-lane
  * task, [3] blocks on the host model (one task per sub-block).  reset != 0 clears the counts.  (bench.py reports them.) */
 BSCGPU_API void bscgpu_coder_pool_stats(uint64_t out[4], int reset);
-/* Where a job ends: `blocks` more blocks will be submitted to the pipes of this process (all pipes together; a pipe must exist).  The blocks
- * whose GPU stages END last are then coded as short tasks — the last one as eight single-stream tasks, the five before it as pairs —
- * whatever their order of submission (several contexts interleave on the GPU, so the two orders differ), everything earlier as one
- * eight-lane task.  Replaces marking blocks BSCGPU_FEATURE_LOW_LATENCY at submission for callers that know the total; blocks < 0
- * withdraws the announcement.  Output is identical either way. */
-BSCGPU_API int  bscgpu_coder_pool_expect(long long blocks);
+/* Where a job ends: `blocks` more blocks will be submitted to the pipes of this process (all pipes together), which drive `gpus` GPUs.
+ * The blocks whose GPU stages END last are then coded as short tasks — per GPU the last one as eight single-stream tasks, the five
+ * before it as pairs (BSC_TAIL_SINGLES / BSC_TAIL_PAIRS) — whatever their order of submission (several contexts interleave on a GPU,
+ * so the two orders differ by up to 100 ms), everything earlier as one eight-lane task.  For callers that know the total, instead of
+ * marking blocks BSCGPU_FEATURE_LOW_LATENCY at submission; blocks < 0 withdraws the announcement.  Output is identical either way. */
+BSCGPU_API int  bscgpu_coder_pool_expect(long long blocks, int gpus);
 /* The rule behind those shapes as a pure function (unit-tested on CPU): sub-blocks per coder task — 8 (one SIMD task), 2 or 1 — from
  * forced (-1 none, 8 or 0: BSC_RC_SIMD), low_latency (synchronous call or BSCGPU_FEATURE_LOW_LATENCY), pool_free (idle CPUs of the
  * pool's budget; -1: a synchronous call), sync_cpus (CPUs / synchronous callers running), wide_simd (AVX-512VL), adaptive. */

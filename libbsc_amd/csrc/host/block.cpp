@@ -349,6 +349,7 @@ struct BlockJob {
     int  pipe_workers = 0;         // coder threads of the process-wide pool (0: a synchronous call, which starts its own threads)
     int  pool_free = -1;           // CPUs of the pool's budget with nothing to do when the block was queued (-1: not a pipe's block)
     int  tail_r = -1;              // blocks of the announced job whose GPU stage was still to END when this one's did (-1: no job announced)
+    int  tail_gpus = 1;            // ... and how many GPUs feed the pool in that job
     int  ps_g = 2;                 // device-model sub-blocks per coder task (ps_group), fixed when the block's host work starts
     bool use_ps = false; const uint16_t* ps = nullptr; u32 poff[9]; u32 ndec = 0; int sorter = 0;
     hipEvent_t ps_ready = nullptr;   // the p stream's copy to the host (copy stream), all of it
@@ -595,8 +596,9 @@ static int ps_group(const BlockJob& J)
     if (J.tail_r >= 0 && ps_simd_env() < 0 && cpu_has_avx512vl()) {
         static const int tail_singles = [] { const char* e = getenv("BSC_TAIL_SINGLES"); return e ? atoi(e) : 1; }();
         static const int tail_pairs = [] { const char* e = getenv("BSC_TAIL_PAIRS"); return e ? atoi(e) : 5; }();
-        if (J.tail_r < tail_singles) return 1;
-        if (J.tail_r < tail_singles + tail_pairs) return 2;
+        const int gp = J.tail_gpus > 0 ? J.tail_gpus : 1;               // GPUs feeding the pool: that many GPU stages end per block time
+        if (J.tail_r < tail_singles * gp) return 1;
+        if (J.tail_r < (tail_singles + tail_pairs) * gp) return 2;
         if (!(J.features & BSCGPU_FEATURE_LOW_LATENCY)) return 8;
     }
     return bscgpu_coder_task_shape(ps_simd_env(), ((J.features & BSCGPU_FEATURE_LOW_LATENCY) || !J.pipelined) ? 1 : 0, J.pool_free,
@@ -949,6 +951,7 @@ struct CoderPool {
     std::vector<std::thread> workers;
     int active = 0, budget = 0, users = 0;
     long long to_come = -1;                           // blocks of the announced job not yet queued (bscgpu_coder_pool_expect); -1: none announced
+    int to_come_gpus = 1;
     bool stop = false;
 
     void worker_loop()
@@ -986,12 +989,15 @@ static std::atomic<uint64_t> g_pool_mode[4];          // blocks queued as: 8 sca
 
 // The caller's knowledge of where a job ENDS: `blocks` more blocks will be submitted to this process's pipes (any of them); the pool then
 // shapes the host tasks of the blocks whose GPU stages end last for latency (ps_group).  blocks < 0: no announcement (the default).
-extern "C" BSCGPU_API int bscgpu_coder_pool_expect(long long blocks)
+static long long g_pending_expect = -1; static int g_pending_gpus = 1;      // an announcement made before the first pipe exists (under g_pool_mu)
+extern "C" BSCGPU_API int bscgpu_coder_pool_expect(long long blocks, int gpus)
 {
+    if (gpus < 1) gpus = 1;
     std::lock_guard<std::mutex> g(g_pool_mu);
-    if (!g_pool) return LIBBSC_BAD_PARAMETER;
+    if (!g_pool) { g_pending_expect = blocks < 0 ? -1 : blocks; g_pending_gpus = gpus; return LIBBSC_NO_ERROR; }
     std::lock_guard<std::mutex> lk(g_pool->mu);
     g_pool->to_come = blocks < 0 ? -1 : blocks;
+    g_pool->to_come_gpus = gpus;
     return LIBBSC_NO_ERROR;
 }
 
@@ -1021,6 +1027,7 @@ static CoderPool* pool_acquire()
         P->budget = (forced && nworkers < cpus) ? nworkers : cpus;
         if (const char* e = getenv("BSCGPU_HOST_CPUS")) { int v = atoi(e); if (v >= 1 && v <= 256) P->budget = v; }
         for (int i = 0; i < nworkers; ++i) P->workers.emplace_back([P] { P->worker_loop(); });
+        P->to_come = g_pending_expect; P->to_come_gpus = g_pending_gpus; g_pending_expect = -1;
         g_pool = P;
     }
     ++g_pool->users;
@@ -1100,6 +1107,7 @@ static int pipe_enqueue(bscgpu_pipe* p, bscgpu_pipe::Lane& L, int ticket)
         std::lock_guard<std::mutex> lk(P->mu);
         L.ticket = ticket; L.joined = false;
         J.tail_r = -1;
+        J.tail_gpus = P->to_come_gpus;
         if (P->to_come > 0) J.tail_r = (int)(--P->to_come < 0x7fffffff ? P->to_come : 0x7fffffff);
         else if (P->to_come == 0) P->to_come = -1;               // more blocks than announced: the rule is dropped
         J.done = false;                                          // (with the other fields a peeker reads, under the pool's mutex)

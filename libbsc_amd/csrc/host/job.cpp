@@ -61,6 +61,7 @@ struct Job {
     long long expected = -1;            // blocks the caller has announced (bscgpu_job_expect); -1: unknown
     std::vector<unsigned> stages_done;  // per device: GPU stages (submits) that have returned in the current burst
     size_t active = 0;                  // blocks taken and not finished yet
+    size_t in_gpu_stage = 0;            // blocks taken whose submit (GPU stage) has not returned yet
     unsigned burst = 0;                 // a burst begins when a block is taken while nothing is in flight anywhere (job start, or the caller let it run dry)
 
     // Which blocks a worker may take (caller holds mu).  Steady state wants every context busy — kernels of different blocks interleave on
@@ -123,11 +124,13 @@ void Job::run(Worker& w)
             // another thread appends is a race on its block map)
             if (may_take(w)) {
                 if (active == 0) { ++burst; for (auto& sd : stages_done) sd = 0; }
-                ++active; w.burst_seen = burst;
+                ++active; ++in_gpu_stage; w.burst_seen = burst;
                 b = next++; Bp = &blocks[b]; Bp->worker = w.id; have = true; ++w.blocks;
                 features = Bp->features;
-                // the job's last blocks: short host tasks whatever the coder pool's load — the drain of the pipeline is the caller's time
-                if (expected >= 0 && (long long)blocks.size() <= expected && expected - (long long)b <= (long long)workers.size())
+                // the job's last blocks: short host tasks whatever the coder pool's load — the drain of the pipeline is the caller's time.
+                // With the library's own pipes the coder pool knows the total and decides by the order in which GPU stages END
+                // (bscgpu_job_expect -> bscgpu_coder_pool_expect); another executor gets the mark at submission.
+                if (!own_pipes && expected >= 0 && (long long)blocks.size() <= expected && expected - (long long)b <= (long long)workers.size())
                     features |= BSCGPU_FEATURE_LOW_LATENCY;
             } else if (inflight.empty()) {
                 if (all_taken()) break;
@@ -137,7 +140,7 @@ void Job::run(Worker& w)
         if (have) {
             Block& B = *Bp;
             const int ticket = be.pipe_submit_host(be.user, w.pipe, B.input, B.output, B.n, B.lzpHashSize, B.lzpMinLen, B.sorter, B.coder, features);
-            { std::lock_guard<std::mutex> lk(mu); ++stages_done[(size_t)w.dev_index]; if (ticket < 0) { B.result = ticket; B.done = true; --active; } else B.ticket = ticket; }
+            { std::lock_guard<std::mutex> lk(mu); ++stages_done[(size_t)w.dev_index]; --in_gpu_stage; if (ticket < 0) { B.result = ticket; B.done = true; --active; } else B.ticket = ticket; }
             cv_work.notify_all();                             // a context waiting for this device's k-th stage may start now
             cv_done.notify_all();                             // a collector waiting for this block: it failed, or it has a ticket to look at now
             if (ticket >= 0) inflight.emplace_back(ticket, b);
@@ -224,7 +227,9 @@ int bscgpu_job_expect(bscgpu_job* J, int total_blocks)
 {
     if (!J || total_blocks < 0) return LIBBSC_BAD_PARAMETER;
     Job& j = J->j;
-    { std::lock_guard<std::mutex> lk(j.mu); j.expected = total_blocks; }
+    long long to_come;
+    { std::lock_guard<std::mutex> lk(j.mu); j.expected = total_blocks; to_come = total_blocks - (long long)j.next + (long long)j.in_gpu_stage; }
+    if (j.own_pipes) (void)bscgpu_coder_pool_expect(to_come > 0 ? to_come : -1, j.ndev);      // blocks whose host work has not been queued yet
     j.cv_work.notify_all();
     return LIBBSC_NO_ERROR;
 }

@@ -84,7 +84,7 @@ double cpu_seconds() { rusage u; getrusage(RUSAGE_SELF, &u); return u.ru_utime.t
 
 int main(int argc, char** argv)
 {
-    int steps = 320, warmup = 4, contexts = 6, depth = 3, gpus = 1, sorter = 1, coder = 1, lzpH = 0, lzpM = 0;
+    int steps = 320, warmup = 4, contexts = 6, depth = 4, gpus = 1, sorter = 1, coder = 1, lzpH = 0, lzpM = 0;
     long long n = 64ll << 20; unsigned long long seed = 2; const char* dump = nullptr;
     bool pin_input = false, upfront = false;
     for (int a = 1; a < argc; ++a) {

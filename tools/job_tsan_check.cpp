@@ -2,6 +2,7 @@
 //   g++ -std=c++17 -O1 -g -fsanitize=thread -I include tools/job_tsan_check.cpp -o /tmp/job_tsan_check -lpthread && /tmp/job_tsan_check
 // (run by tests/test_job_driver.py).  The default executor's entry points are stubbed: this program only ever uses bscgpu_job_create_ex.
 #include "../libbsc_amd/csrc/host/job.cpp"
+extern "C" int bscgpu_coder_pool_expect(long long, int) { return 0; }      // (block.cpp is not linked here: the stand-in executor has no coder pool)
 #include <chrono>
 #include <cstdio>
 #include <random>
