@@ -31,7 +31,10 @@ typedef unsigned char      u8;
 // ---------------------------------------------------------------------------------------------
 constexpr int   WG          = 256;      // threads per workgroup (4 wave64)
 constexpr int   WAVES       = WG / 64;
-constexpr int   MAX_CHUNKS  = 1024;
+#ifndef BSC_MAX_CHUNKS
+#define BSC_MAX_CHUNKS 1024
+#endif
+constexpr int   MAX_CHUNKS  = BSC_MAX_CHUNKS;
 
 struct Chunking {
     u32 num_tiles;     // total tiles
