@@ -208,22 +208,35 @@ __device__ __forceinline__ u64 lanemask_lt() {
     return (l == 0) ? 0ull : (~0ull >> (64 - l));
 }
 
-// inclusive wave scan (sum) over 64 lanes
+// Inclusive wave64 scans on the DPP network (row shifts inside the rows of 16, then the two row broadcasts): six dependent VALU operations.
+// ALL 64 LANES MUST BE ACTIVE (every caller scans whole wavefronts).  Round 6: the ds_bpermute form these replace (kept below as *_bperm)
+// is six LDS round trips, each waited for — ~700 cycles per scan on the critical path of every tile of the device coder's partition kernels
+// (four wavefronts per SIMD: nothing to hide it behind) and of every block scan of the chunked kernels.
 __device__ __forceinline__ u32 wave_incl_sum(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);      // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);      // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1 and 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ u32 wave_incl_max(u32 v) {
+    auto mx = [](u32 a, u32 b) { return a > b ? a : b; };                         // (lanes without a source read 0: the identity of an unsigned max)
+    v = mx(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+    v = mx(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+    v = mx(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+    v = mx(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+    v = mx(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = mx(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+__device__ __forceinline__ u32 wave_incl_sum_bperm(u32 v) {
     u32 l = lane_id();
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         u32 t = __shfl_up(v, d, 64);
         if (l >= (u32)d) v += t;
-    }
-    return v;
-}
-__device__ __forceinline__ u32 wave_incl_max(u32 v) {
-    u32 l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 t = __shfl_up(v, d, 64);
-        if (l >= (u32)d) v = (t > v) ? t : v;
     }
     return v;
 }

@@ -608,7 +608,7 @@ __global__ __launch_bounds__(WG) void dc_part_scatter_kernel(const u64* __restri
         const u32 incl = wave_incl_sum(nd);
         const u32 loc = incl - nd;                                    // first decision of this item inside the tile
         if (valid) doff[i] = running + loc;
-        const u32 tile_total = (u32)__builtin_amdgcn_readfirstlane(__shfl((int)incl, 63, 64));      // a scalar: `staged` below is then a scalar
+        const u32 tile_total = (u32)__builtin_amdgcn_readlane((int)incl, 63);      // a scalar: `staged` below is then a scalar
         const bool staged = tile_total <= DC_POS_STAGE;               // branch around every round's position store, not an exec-mask dance
         const u32 sig = (ignoreX ? 0u : item_X(key)) | (it.sb << 8);
         u32* mypos = pos + running + loc;
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(WG) void dc_doff_kernel(const u64* __restrict__ ite
         if (valid) { if (SIDES & 1) nd += (u32)count_rank_side(it, maxr); if (SIDES & 2) nd += (u32)count_run_side(it); }
         const u32 incl = wave_incl_sum(nd);
         if (valid) doff[i] = running + incl - nd;
-        running += (u32)__shfl((int)incl, 63, 64);
+        running += (u32)__builtin_amdgcn_readlane((int)incl, 63);
     }
     if (wc == g.W - 1 && lane == 0) doff[g.m] = running;
 }
@@ -1119,8 +1119,8 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, 
     const u32 b_sp = valid ? (SPF ? G.doff_full[j] : G.doff_sp[j]) : 0u;
     const u32 incl = wave_incl_sum((u32)nd);
     const u32 loc = incl - (u32)nd;                                   // this run's first entry inside the wavefront's piece of the stream
-    const u32 wtotal = (u32)__shfl((int)incl, 63, 64);
-    const u32 wbase = (u32)__shfl((int)b_sp, 0, 64);                  // lane 0 is valid whenever any lane is
+    const u32 wtotal = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+    const u32 wbase = (u32)__builtin_amdgcn_readfirstlane((int)b_sp);                  // lane 0 is valid whenever any lane is
     const bool staged = wtotal <= DC_PS_STAGE;                        // wave-uniform
     dc_lds_vu16* sg = (dc_lds_vu16*)&stage[threadIdx.x >> 6][0];
     const u32* p_sp = G.pos_sp + (SPF ? (valid ? G.doff_sp[j] : 0u) : b_sp);
@@ -1250,8 +1250,8 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_spf_kernel(DcGather
     const int n_rank = valid ? count_rank_side(it, maxr) : 0, n_run = valid ? count_run_side(it) : 0, nd = n_rank + n_run;
     const u32 incl = wave_incl_sum((u32)nd);
     const u32 loc = incl - (u32)nd;
-    const u32 wtotal = (u32)__shfl((int)incl, 63, 64);
-    const u32 wbase = (u32)__shfl((int)b_sp, 0, 64);
+    const u32 wtotal = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+    const u32 wbase = (u32)__builtin_amdgcn_readfirstlane((int)b_sp);
     const bool staged = wtotal <= DC_PS_STAGE;
     dc_lds_vu16* sg = (dc_lds_vu16*)&stage[threadIdx.x >> 6][0];
     const u32* p_sp = G.pos_sp + b_mini;

@@ -16,17 +16,8 @@ typedef __attribute__((address_space(3))) volatile u32 lds_vu32;
 #endif
 constexpr int RS_WAVES_DEFAULT = 4;
 
-// Inclusive wave64 sum scan on the DPP network (row shifts inside the rows of 16, then the two row broadcasts): six
-// v_add_u32_dpp, no lane-address registers (the ds_bpermute form of wave_incl_sum keeps six of them live).  All 64 lanes active.
-__device__ __forceinline__ u32 wave_incl_sum_dpp(u32 v) {
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);      // row_shr:4
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);      // row_shr:8
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1 and 3
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2 and 3
-    return v;
-}
+// (the DPP form of the wave scan lives in dev_common.h since round 6: wave_incl_sum)
+__device__ __forceinline__ u32 wave_incl_sum_dpp(u32 v) { return wave_incl_sum(v); }
 
 // Exclusive sum over the first 256 threads' values (one per digit); every thread of the workgroup calls it
 // (threads >= 256 pass 0).  scr: RS_WAVES u32.
