@@ -118,6 +118,10 @@ BSCGPU_API int  bscgpu_pipe_create(bscgpu_ctx* ctx, int depth, bscgpu_pipe** out
 /* How the pool has coded the pipes' blocks so far: out[0] blocks as eight scalar tasks, [1] as four pair tasks, [2] as one eight-lane
  * task, [3] blocks on the host model (one task per sub-block).  reset != 0 clears the counts.  (bench.py reports them.) */
 BSCGPU_API void bscgpu_coder_pool_stats(uint64_t out[4], int reset);
+/* ... of the eight-lane blocks, how many were coded two at a time in the sixteen lanes of 512-bit registers (round 6: half the CPU time per
+ * block at equal throughput on long jobs, a few per cent slower on 20-block jobs: opt-in with BSC_RC_X16=1 on AVX-512F/VL/BW hosts;
+ * BSC_RC_X16_WAIT_MS is how long a block waits for a partner: 15) */
+BSCGPU_API uint64_t bscgpu_coder_pool_x16_blocks(int reset);
 /* Where a job ends: `blocks` more blocks will be submitted to the pipes of this process (all pipes together), which drive `gpus` GPUs.
  * The blocks whose GPU stages END last are then coded as short tasks — per GPU the last one as eight single-stream tasks, the five
  * before it as pairs (BSC_TAIL_SINGLES / BSC_TAIL_PAIRS) — whatever their order of submission (several contexts interleave on a GPU,

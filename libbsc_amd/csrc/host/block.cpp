@@ -629,6 +629,34 @@ static void host_encode_group(BlockJob& J, int b)
     }
 }
 
+// All eight sub-blocks of TWO device-model blocks in the sixteen lanes of one SIMD range-coder loop (qlfc.cpp: encode_pstream_x16): half
+// the CPU time per block.  Both blocks were queued as one eight-lane task each (ps_g = 8) and use the same coder.
+static void host_encode_x16(BlockJob& A, BlockJob& B)
+{
+    BlockJob* JJ[2] = {&A, &B};
+    PstreamJob P[16];
+    for (int h = 0; h < 2; ++h) {
+        BlockJob& J = *JJ[h];
+        for (int q = 0; q < 8; ++q) {
+            const size_t need = (size_t)J.size[q] + 64;
+            if (J.scratch_cap[q] < need) { J.scratch[q].reset(new uint8_t[need + need / 8]); J.scratch_cap[q] = need + need / 8; }
+            P[8 * h + q] = PstreamJob{J.views[q].first_seen, J.views[q].nsym, J.size[q], J.ps + J.poff[q], (size_t)(J.poff[q + 1] - J.poff[q]), J.scratch[q].get(), J.size[q]};
+        }
+    }
+    bool landed = true;
+    for (int h = 0; h < 2; ++h) if (hipEventSynchronize(JJ[h]->ps_part[7]) != hipSuccess) landed = false;
+    int r[16];
+    if (!landed || !(A.coder == LIBBSC_CODER_QLFC_FAST ? qlfc_encode_fast_pstream_x16(P, r) : qlfc_encode_static_pstream_x16(P, r))) {
+        host_encode_group(A, 0); host_encode_group(B, 0);            // a copy that failed, or a stream near its budget: each block on its own (eight lanes, then the exact scalar coders)
+        return;
+    }
+    for (int h = 0; h < 2; ++h) for (int q = 0; q < 8; ++q) {
+        BlockJob& J = *JJ[h];
+        if (r[8 * h + q] < 0) J.redo.store(true, std::memory_order_relaxed);
+        J.sub_res[q] = r[8 * h + q] < 0 ? J.size[q] : r[8 * h + q];
+    }
+}
+
 static void write_stored(BlockJob& J)
 {
     uint8_t* output = J.output; const int n = J.n_orig;
@@ -944,12 +972,19 @@ extern "C" BSCGPU_API double bscgpu_steady_now() { return trace_now(); }
 // shared by every pipe — several contexts per GPU, as bench.py runs them, draw on the same threads, so a block whose own pipe
 // is momentarily quiet is coded by whoever is free, and the pool knows how busy the process's CPUs are (ps_group).  FIFO; the
 // worker that finishes a block's last task frames it.
+static std::atomic<uint64_t> g_pool_x16{0};           // blocks coded two at a time in sixteen lanes
 struct CoderPool {
     struct Task { BlockJob* job; int sub; };          // sub = -1: whole host stage of the block as one task; else first sub-block of the task
     std::mutex mu; std::condition_variable cv_work, cv_done;
     std::deque<Task> queue;
     std::vector<std::thread> workers;
     int active = 0, budget = 0, users = 0;
+    // Pairing of eight-lane blocks into sixteen-lane tasks (host_encode_x16): a worker that draws an eight-lane block and finds another
+    // one HELD takes both; else it holds its own for up to x16_wait_ms (asleep: no CPU) while more blocks are to come, and codes it alone
+    // when nobody came.  At most one block is held at a time.
+    Task held{nullptr, 0};
+    std::condition_variable cv_hold;
+    bool x16 = false; int x16_wait_ms = 15;
     long long to_come = -1;                           // blocks of the announced job not yet queued (bscgpu_coder_pool_expect); -1: none announced
     int to_come_gpus = 1;
     bool stop = false;
@@ -964,6 +999,32 @@ struct CoderPool {
                 if (queue.empty()) return;
                 t = queue.front(); queue.pop_front();
                 ++active;
+                // an eight-lane block: with a partner it is half the CPU time
+                BlockJob* partner = nullptr;
+                if (x16 && t.sub == 0 && t.job->use_ps && t.job->ps_g == 8 && t.job->nblocks == 8) {
+                    if (held.job && held.job->coder == t.job->coder) { partner = held.job; held.job = nullptr; cv_hold.notify_all(); }
+                    else if (!held.job && (t.job->tail_r < 0 || t.job->tail_r >= 8 * t.job->tail_gpus)) {
+                        // (a block of the job's tail is not held: its eight-lane task has to start now to end in time)
+                        held = t; --active;
+                        cv_hold.wait_for(lk, std::chrono::milliseconds(x16_wait_ms), [&] { return stop || held.job != t.job; });
+                        if (held.job == t.job) { held.job = nullptr; ++active; }          // nobody came: alone after all
+                        else continue;                                                     // taken: the worker that took it reports both blocks
+                    }
+                }
+                if (partner) {
+                    lk.unlock();
+                    BlockJob& A = *partner; BlockJob& B = *t.job;
+                    const double tr0 = g_trace_on ? trace_now() : 0.0;
+                    host_encode_x16(A, B);
+                    bool fa = false, fb = false;
+                    if (A.remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) { host_finalize(A); fa = true; }
+                    if (B.remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) { host_finalize(B); fb = true; }
+                    g_pool_x16.fetch_add(2, std::memory_order_relaxed);
+                    if (g_trace_on) { const double tr1 = trace_now(); std::lock_guard<std::mutex> g(g_trace_mu); g_trace.push_back({tr0, tr1, (const void*)&A, 0, 16, A.features}); g_trace.push_back({tr0, tr1, (const void*)&B, 0, 16, B.features}); }
+                    { std::lock_guard<std::mutex> lk2(mu); --active; if (fa) A.done = true; if (fb) B.done = true; }
+                    cv_done.notify_all();
+                    continue;
+                }
             }
             BlockJob& J = *t.job;
             bool finished = false;
@@ -1001,6 +1062,13 @@ extern "C" BSCGPU_API int bscgpu_coder_pool_expect(long long blocks, int gpus)
     return LIBBSC_NO_ERROR;
 }
 
+extern "C" BSCGPU_API uint64_t bscgpu_coder_pool_x16_blocks(int reset)
+{
+    const uint64_t v = g_pool_x16.load(std::memory_order_relaxed);
+    if (reset) g_pool_x16.store(0, std::memory_order_relaxed);
+    return v;
+}
+
 void bscgpu_coder_pool_stats(uint64_t out[4], int reset)
 {
     for (int i = 0; i < 4; ++i) { out[i] = g_pool_mode[i].load(std::memory_order_relaxed); if (reset) g_pool_mode[i].store(0, std::memory_order_relaxed); }
@@ -1028,6 +1096,8 @@ static CoderPool* pool_acquire()
         if (const char* e = getenv("BSCGPU_HOST_CPUS")) { int v = atoi(e); if (v >= 1 && v <= 256) P->budget = v; }
         for (int i = 0; i < nworkers; ++i) P->workers.emplace_back([P] { P->worker_loop(); });
         P->to_come = g_pending_expect; P->to_come_gpus = g_pending_gpus; g_pending_expect = -1;
+        P->x16 = qlfc_x16_available() && ps_simd_env() < 0;
+        if (const char* e = getenv("BSC_RC_X16_WAIT_MS")) { const int v = atoi(e); if (v >= 0 && v <= 1000) P->x16_wait_ms = v; }
         g_pool = P;
     }
     ++g_pool->users;

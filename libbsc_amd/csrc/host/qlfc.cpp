@@ -1237,6 +1237,164 @@ static bool encode_pstream_x8(const PstreamJob* J, int* res)
     return false;
 #endif
 }
+// ------------------------------------------------------------------------------------------------
+// Sixteen sub-blocks — TWO device-model blocks — in the 32-bit lanes of 512-bit registers (round 6).  A step of the eight-lane coder
+// above costs about the same micro-ops whatever its width (that is why a four-lane version lost), and the EPYC hosts of the MI355X
+// boxes execute 512-bit integer operations at the rate of 256-bit ones: the same step on sixteen lanes codes two blocks in the time
+// of one, i.e. HALF the CPU time per block (the range coder is the whole of the host's work behind the device model: ~0.10 CPU-s per
+// 64 MiB block, 75-105 cores for an 8-GPU node by DESIGN.md 7's budget).  Latency per task is unchanged (~100 ms: 23 M dependent steps), and a
+// task needs two blocks at once: the coder pool pairs eight-lane blocks that are waiting together (block.cpp).
+// The step is the mask-register form of x8_steps_avx512 (VSEL = 0) — the vector-mask trick of round 5's step has no 512-bit encoding.
+// Log records carry a 4-bit lane number; replay, tails and the give-up rule are those of the eight-lane coder.
+// ------------------------------------------------------------------------------------------------
+#if defined(__AVX2__)
+struct alignas(64) X16State { uint32_t R[16], LO[16], CY[16]; };
+
+template <bool FAST>
+__attribute__((target("avx512f,avx512vl,avx512bw")))
+static uint32_t* x16_steps_avx512(X16State& S, const uint16_t* const* ps, size_t i, size_t end, uint32_t* logp, size_t pf)
+{
+    __m512i R = _mm512_load_si512((const void*)S.R), LO = _mm512_load_si512((const void*)S.LO), CY = _mm512_load_si512((const void*)S.CY);
+    const __m512i m12 = _mm512_set1_epi32(FAST ? 0x1fff : 0xfff), one = _mm512_set1_epi32(1), lim = _mm512_set1_epi32(0x10000), b12 = _mm512_set1_epi32(FAST ? 0x2000 : 0x1000);
+    const __m512i c13 = _mm512_set1_epi32(13), c16 = _mm512_set1_epi32(16);
+    const __m512i lane_id = _mm512_setr_epi32(0 << 17, 1 << 17, 2 << 17, 3 << 17, 4 << 17, 5 << 17, 6 << 17, 7 << 17,
+                                              8 << 17, 9 << 17, 10 << 17, 11 << 17, 12 << 17, 13 << 17, 14 << 17, 15 << 17);
+#define BSC_X16_STEP(xv) do {                                                                                                      \
+        const __m512i x = (xv);                                                                                                    \
+        const __mmask16 need = _mm512_cmplt_epu32_mask(R, lim);                                        /* range < 2^16 */          \
+        const __m512i rec = _mm512_ternarylogic_epi32(_mm512_srli_epi32(LO, 16), _mm512_slli_epi32(CY, 16), lane_id, 0xfe);         \
+        _mm512_storeu_si512((void*)logp, _mm512_maskz_compress_epi32(need, rec));                                                  \
+        logp += __builtin_popcount((unsigned)need);                                                                                \
+        LO = _mm512_mask_slli_epi32(LO, need, LO, 16);                                                                             \
+        CY = _mm512_maskz_mov_epi32((__mmask16)~need, CY);                                                                         \
+        const __m512i p = _mm512_and_si512(x, m12);                                                                                \
+        const __m512i sh = _mm512_sub_epi32(c13, _mm512_slli_epi32(_mm512_srli_epi32(x, 15), 1));                                  \
+        const __m512i ra = FAST ? _mm512_mullo_epi32(_mm512_srlv_epi32(R, sh), p) : _mm512_mullo_epi32(_mm512_srli_epi32(R, 12), p); \
+        const __m512i rb = FAST ? _mm512_mullo_epi32(_mm512_sllv_epi32(R, _mm512_sub_epi32(c16, sh)), p) : _mm512_mullo_epi32(_mm512_slli_epi32(R, 4), p); \
+        R  = _mm512_mask_slli_epi32(R, need, R, 16);                                                                               \
+        const __mmask16 kb = _mm512_test_epi32_mask(x, b12);                                           /* the coded bit */         \
+        const __m512i r = _mm512_mask_mov_epi32(ra, need, rb);                                                                     \
+        const __m512i lo2 = _mm512_mask_add_epi32(LO, kb, LO, r);                                                                  \
+        CY = _mm512_mask_add_epi32(CY, _mm512_cmplt_epu32_mask(lo2, LO), CY, one);                     /* wrapped: carry out */    \
+        LO = lo2;                                                                                                                  \
+        R = _mm512_mask_sub_epi32(r, kb, R, r);                                                        /* bit ? range - r : r */   \
+    } while (0)
+    const uint16_t* const* pa = ps; const uint16_t* const* pb = ps + 8;
+    for (; i < end; i += 8) {
+        if (pf) {
+            const unsigned l2 = ((unsigned)(i >> 3) & 3u) * 2u;
+            _mm_prefetch((const char*)(pa[l2] + i + pf), _MM_HINT_T0); _mm_prefetch((const char*)(pa[l2 + 1] + i + pf), _MM_HINT_T0);
+            _mm_prefetch((const char*)(pb[l2] + i + pf), _MM_HINT_T0); _mm_prefetch((const char*)(pb[l2 + 1] + i + pf), _MM_HINT_T0);
+        }
+        __m512i xs[8];
+        {
+            BSC_X8_TRANSPOSE(pa, i);
+            xs[0] = _mm512_castsi256_si512(_mm256_cvtepu16_epi32(t0)); xs[1] = _mm512_castsi256_si512(_mm256_cvtepu16_epi32(t1));
+            xs[2] = _mm512_castsi256_si512(_mm256_cvtepu16_epi32(t2)); xs[3] = _mm512_castsi256_si512(_mm256_cvtepu16_epi32(t3));
+            xs[4] = _mm512_castsi256_si512(_mm256_cvtepu16_epi32(t4)); xs[5] = _mm512_castsi256_si512(_mm256_cvtepu16_epi32(t5));
+            xs[6] = _mm512_castsi256_si512(_mm256_cvtepu16_epi32(t6)); xs[7] = _mm512_castsi256_si512(_mm256_cvtepu16_epi32(t7));
+        }
+        {
+            BSC_X8_TRANSPOSE(pb, i);
+            xs[0] = _mm512_inserti64x4(xs[0], _mm256_cvtepu16_epi32(t0), 1); xs[1] = _mm512_inserti64x4(xs[1], _mm256_cvtepu16_epi32(t1), 1);
+            xs[2] = _mm512_inserti64x4(xs[2], _mm256_cvtepu16_epi32(t2), 1); xs[3] = _mm512_inserti64x4(xs[3], _mm256_cvtepu16_epi32(t3), 1);
+            xs[4] = _mm512_inserti64x4(xs[4], _mm256_cvtepu16_epi32(t4), 1); xs[5] = _mm512_inserti64x4(xs[5], _mm256_cvtepu16_epi32(t5), 1);
+            xs[6] = _mm512_inserti64x4(xs[6], _mm256_cvtepu16_epi32(t6), 1); xs[7] = _mm512_inserti64x4(xs[7], _mm256_cvtepu16_epi32(t7), 1);
+        }
+        BSC_X16_STEP(xs[0]); BSC_X16_STEP(xs[1]); BSC_X16_STEP(xs[2]); BSC_X16_STEP(xs[3]);
+        BSC_X16_STEP(xs[4]); BSC_X16_STEP(xs[5]); BSC_X16_STEP(xs[6]); BSC_X16_STEP(xs[7]);
+    }
+#undef BSC_X16_STEP
+    _mm512_store_si512((void*)S.R, R); _mm512_store_si512((void*)S.LO, LO); _mm512_store_si512((void*)S.CY, CY);
+    return logp;
+}
+#endif
+
+bool qlfc_x16_available()
+{
+#if defined(__AVX2__)
+    static const bool ok = [] {
+        // Opt-in (BSC_RC_X16=1).  Measured on the pool's EPYC 9575F hosts (profiles/r06/sixteen_lane_coder.txt): 0.114 -> 0.093 CPU-s per
+        // block at the same throughput over 160 blocks (the step costs ~1.5 x the eight-lane step for twice the lanes there, not 1 x), but a
+        // 20-block job is ~4 % slower: a block waits up to 15 ms for its partner, and that work then sits in the job's tail.
+        const char* e = getenv("BSC_RC_X16");
+        if (!e || atoi(e) == 0) return false;
+        return (bool)(__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512bw"));
+    }();
+    return ok;
+#else
+    return false;
+#endif
+}
+
+template <bool FAST>
+static bool encode_pstream_x16(const PstreamJob* J, int* res)
+{
+#if defined(__AVX2__)
+    if (!qlfc_x16_available()) return false;
+    RunView H;
+    RangeEncoder rc[16];
+    size_t common = ~(size_t)0;
+    for (int l = 0; l < 16; ++l) {
+        H.nsym = J[l].nsym; memcpy(H.first_seen, J[l].first_seen, (size_t)J[l].nsym);
+        rc[l].init(J[l].out, J[l].out_size);
+        rc[l].encode_word((uint32_t)J[l].in_size);
+        if (FAST) (void)encode_alphabet(H, [&](unsigned b) { rc[l].template encode<1>(b, 1); });
+        else      (void)encode_alphabet(H, [&](unsigned b) { rc[l].encode_half(b); });
+        if (J[l].count < common) common = J[l].count;
+    }
+    X16State S;
+    for (int l = 0; l < 16; ++l) { const RangeEncoder::Live L = rc[l].enter(); S.R[l] = L.range; S.LO[l] = (uint32_t)L.low; S.CY[l] = (uint32_t)(L.low >> 32); }
+    const size_t pf = (size_t)x8_prefetch_entries();
+    constexpr size_t CHUNK = 32768;                                  // steps between two replays of the log (2 MiB of records at most)
+    static thread_local std::unique_ptr<uint32_t[]> log_mem;
+    if (!log_mem) log_mem.reset(new uint32_t[CHUNK * 16 + 32]);
+    uint32_t* const log0 = log_mem.get();
+    const uint16_t* ps[16];
+    for (int l = 0; l < 16; ++l) ps[l] = J[l].ps;
+    size_t i = 0;
+    while (i + 8 <= common) {
+        size_t end = i + CHUNK; if (end > common) end = common;
+        end = i + ((end - i) & ~(size_t)7);
+        uint32_t* const logp = x16_steps_avx512<FAST>(S, ps, i, end, log0, pf);
+        i = end;
+        for (const uint32_t* q = log0; q < logp; ++q) {              // replay: the only code that touches the outputs
+            const uint32_t rec = *q;
+            RangeEncoder& e = rc[rec >> 17];
+            if (e.full()) return false;
+            e.emit_unit(rec & 0xffffu, (rec >> 16) & 1u);
+        }
+    }
+    for (int l = 0; l < 16; ++l) if (rc[l].full()) return false;
+    // the rest of every stream on its own, with the run-start test of the scalar coder (as in the eight-lane coder; the two blocks'
+    // sub-blocks differ in length by a few per cent)
+    for (int l = 0; l < 16; ++l) {
+        RangeEncoder::Live L{(uint64_t)S.LO[l] | ((uint64_t)S.CY[l] << 32), S.R[l]};
+        bool failed = false;
+        const uint16_t* q = ps[l];
+        unsigned is_full = (unsigned)rc[l].full();
+        for (size_t k = i; k < J[l].count; ++k) {
+            const unsigned x = q[k];
+            if (FAST) {
+                if (__builtin_expect(((x >> 14) & is_full) != 0u, 0)) { failed = true; break; }
+                rc[l].encode_live_var(L, (x >> 13) & 1u, x & 0x1fffu, psf_prec(x), is_full);
+            } else {
+                if (__builtin_expect(((x >> 13) & is_full) != 0u, 0)) { failed = true; break; }
+                rc[l].template encode_live_f<12>(L, (x >> 12) & 1u, (int)(x & 0xfffu), is_full);
+            }
+        }
+        rc[l].leave(L);
+        res[l] = failed ? NOT_COMPRESSIBLE : rc[l].finish();
+    }
+    return true;
+#else
+    (void)J; (void)res;
+    return false;
+#endif
+}
+bool qlfc_encode_static_pstream_x16(const PstreamJob* J, int* res) { return encode_pstream_x16<false>(J, res); }
+bool qlfc_encode_fast_pstream_x16(const PstreamJob* J, int* res) { return encode_pstream_x16<true>(J, res); }
+
 bool qlfc_encode_static_pstream_x8(const PstreamJob* J, int* res) { return encode_pstream_x8<false>(J, res); }
 bool qlfc_encode_fast_pstream_x8(const PstreamJob* J, int* res) { return encode_pstream_x8<true>(J, res); }
 

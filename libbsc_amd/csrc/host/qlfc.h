@@ -73,6 +73,10 @@ bool qlfc_encode_static_pstream_x8(const PstreamJob* J, int* res);
 // decision of a run, [15] run side = 11-bit precision, else 13} (devcoder_model.h PSF_*); header and alphabet as encode_model2 writes them.
 int qlfc_encode_fast_pstream(const uint8_t* first_seen, int nsym, int in_size, const uint16_t* ps, size_t count, uint8_t* out, int out_size);
 void qlfc_encode_fast_pstream_pair(const PstreamJob& A, const PstreamJob& B, int* resA, int* resB);
+// sixteen sub-blocks = two blocks in the lanes of 512-bit registers (AVX-512F/VL/BW; false: not available or a stream near its budget)
+bool qlfc_x16_available();
+bool qlfc_encode_static_pstream_x16(const PstreamJob* J /*[16]*/, int* res /*[16]*/);
+bool qlfc_encode_fast_pstream_x16(const PstreamJob* J /*[16]*/, int* res /*[16]*/);
 bool qlfc_encode_fast_pstream_x8(const PstreamJob* J, int* res);      // eight sub-blocks in SIMD lanes, per-lane precision (as qlfc_encode_static_pstream_x8)
 // Encode one sub-block (what coder.cpp:61 dispatches to).  Returns bytes written or NOT_COMPRESSIBLE.
 int qlfc_encode_block(const uint8_t* in, uint8_t* out, int in_size, int out_size, int coder);

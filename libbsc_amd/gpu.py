@@ -178,7 +178,11 @@ def coder_pool_stats(reset=False):
     """how the process's coder pool has coded the pipes' blocks: {scalar x8 tasks, pairs x4 tasks, eight_lanes x1 task, host_model}"""
     out = (C.c_uint64 * 4)()
     N.lib().bscgpu_coder_pool_stats(out, 1 if reset else 0)
-    return {"scalar_tasks": int(out[0]), "pair_tasks": int(out[1]), "eight_lane_task": int(out[2]), "host_model": int(out[3])}
+    L = N.lib()
+    L.bscgpu_coder_pool_x16_blocks.restype = C.c_uint64
+    x16 = int(L.bscgpu_coder_pool_x16_blocks(1 if reset else 0))
+    return {"scalar_tasks": int(out[0]), "pair_tasks": int(out[1]), "eight_lane_task": int(out[2]), "host_model": int(out[3]),
+            "of_the_eight_lane_blocks_coded_in_pairs_of_sixteen_lanes": x16}
 
 
 class Pipe:

@@ -16,7 +16,7 @@ def assign_blocks(num_blocks: int, world: int) -> List[List[int]]:
     return [list(range(r, num_blocks, world)) for r in range(world)]
 
 
-def gather_blocks_to_rank0(payload: np.ndarray, rank: int, world: int, device, staging=None) -> Optional[List[np.ndarray]]:
+def gather_blocks_to_rank0(payload: np.ndarray, rank: int, world: int, device, staging=None, always_collective: bool = False) -> Optional[List[np.ndarray]]:
     """Every rank contributes one compressed block (np.uint8).  Rank 0 returns them (np.uint8 arrays) in rank order
     (= block order for one block per rank), other ranks return None.
     One all_gather of the sizes, then the peers' payloads arrive concurrently (all receives are posted before the first
@@ -24,7 +24,7 @@ def gather_blocks_to_rank0(payload: np.ndarray, rank: int, world: int, device, s
     the host once."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not always_collective:        # (always_collective: the one-rank smoke test of the RCCL branch on a 1-GPU box)
         return [payload]
     n = int(payload.size)
     mine = torch.tensor([n], dtype=torch.int64, device=device)

@@ -146,6 +146,11 @@ def test_avx2_eight_lane_range_coder_matches_scalar(tmp_path):
                 assert r.returncode == 0 and "all equal" in r.stdout and "fast coder, eight lanes: equal" in r.stdout, (cxx, extra, size, r.stdout + r.stderr)
                 if size == "400000":
                     assert "gave up" in r.stdout            # the budget case bails out to the scalar coders
+        # round 6: two blocks in the sixteen lanes of 512-bit registers (opt-in: BSC_RC_X16=1), static and fast entries, roomy and budget cases
+        for size in ("9", "400000"):
+            r = subprocess.run([exe, size], capture_output=True, text=True, env={**os.environ, "BSC_RC_X16": "1"})
+            assert r.returncode == 0 and "all equal" in r.stdout, (cxx, size, r.stdout + r.stderr)
+            assert "sixteen lanes: equal" in r.stdout or "sixteen lanes: not available" in r.stdout, r.stdout
 
 
 @pytest.mark.parametrize("nphys", [1, 2, 4, 8])

@@ -89,6 +89,55 @@ int main(int argc, char** argv)
             if (ra[l] != rb[l] || memcmp(oa[l].data(), ob[l].data(), (size_t)(ra[l] > 0 ? ra[l] : 0)) != 0) { printf("FAIL fast lane %d: scalar %d bytes, x8 %d bytes\n", l, ra[l], rb[l]); ++bad; }
         printf("fast coder, eight lanes: %s\n", bad ? "differs" : "equal");
     }
+    // sixteen lanes (two blocks per task, 512-bit registers): static and fast entries against the scalar coders
+    if (qlfc_x16_available()) {
+        for (int fast = 0; fast < 2; ++fast) {
+            std::vector<uint16_t> st[16];
+            uint8_t fs16[16][256]; int ns16[16];
+            for (int l = 0; l < 16; ++l) {
+                const size_t cnt = base + (rng() % (base / 20 + 1)) - (l == 11 ? base / 40 : 0);
+                st[l].resize(cnt);
+                for (size_t i = 0; i < cnt; ++i) {
+                    if (!fast) {
+                        unsigned p = 1 + (unsigned)(rng() % 4095);
+                        if (rng() & 3) p = (rng() & 1) ? 1 + p / 16 : 4095 - p / 16;
+                        const unsigned bit = ((rng() % 4096) >= p) ? 1u : 0u;
+                        st[l][i] = (uint16_t)(p | (bit << 12) | ((i % 7 == 0) ? 0x2000u : 0u));
+                    } else {
+                        const unsigned side = (unsigned)(rng() & 1), sh = 13u - 2u * side;
+                        unsigned pv = 1 + (unsigned)(rng() % ((1u << sh) - 1));
+                        if (rng() & 3) pv = (rng() & 1) ? 1 + pv / 16 : ((1u << sh) - 1) - pv / 16;
+                        const unsigned bit = ((rng() % (1u << sh)) >= pv) ? 1u : 0u;
+                        st[l][i] = (uint16_t)(pv | (bit << 13) | ((rng() % 3 == 0) ? 0x4000u : 0u) | (side << 15));
+                    }
+                }
+                ns16[l] = 18 + l;
+                for (int q = 0; q < ns16[l]; ++q) fs16[l][q] = (uint8_t)(q * 5 + l);
+            }
+            for (int mode = 0; mode < 2; ++mode) {                     // 0: roomy outputs, 1: lane 13 too small (must give up)
+                std::vector<uint8_t> oa[16], ob[16];
+                PstreamJob J[16]; int ra[16], rb[16];
+                for (int l = 0; l < 16; ++l) {
+                    const int osz = (mode == 1 && l == 13) ? 4096 : (int)st[l].size() * 2 + 1024;
+                    oa[l].assign(osz + 64, 0); ob[l].assign(osz + 64, 0);
+                    J[l] = PstreamJob{fs16[l], ns16[l], (int)st[l].size(), st[l].data(), st[l].size(), ob[l].data(), osz};
+                    ra[l] = fast ? qlfc_encode_fast_pstream(fs16[l], ns16[l], (int)st[l].size(), st[l].data(), st[l].size(), oa[l].data(), osz)
+                                 : qlfc_encode_static_pstream(fs16[l], ns16[l], (int)st[l].size(), st[l].data(), st[l].size(), oa[l].data(), osz);
+                }
+                auto t0 = std::chrono::steady_clock::now();
+                const bool ok = fast ? qlfc_encode_fast_pstream_x16(J, rb) : qlfc_encode_static_pstream_x16(J, rb);
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                size_t total = 0; for (int l = 0; l < 16; ++l) total += st[l].size();
+                printf("%s coder, sixteen lanes, mode %d: %s, %.1f ms, %.3f ns/decision\n", fast ? "fast" : "static", mode, ok ? "done" : "gave up", ms, ms * 1e6 / total);
+                if (mode == 0) {
+                    if (!ok) { printf("FAIL: x16 gave up with roomy outputs\n"); ++bad; }
+                    else for (int l = 0; l < 16; ++l)
+                        if (ra[l] != rb[l] || memcmp(oa[l].data(), ob[l].data(), (size_t)(ra[l] > 0 ? ra[l] : 0)) != 0) { printf("FAIL x16 lane %d: scalar %d bytes, x16 %d bytes\n", l, ra[l], rb[l]); ++bad; }
+                } else if (ok && rb[13] != ra[13]) { printf("FAIL: x16 budget case, scalar %d x16 %d\n", ra[13], rb[13]); ++bad; }
+            }
+        }
+        printf("sixteen lanes: %s\n", bad ? "differs" : "equal");
+    } else printf("sixteen lanes: not available on this CPU (needs AVX-512F/VL/BW)\n");
     printf(bad ? "FAILED\n" : "all equal\n");
     return bad != 0;
 }
