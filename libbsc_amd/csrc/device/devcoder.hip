@@ -95,6 +95,7 @@ struct DevCoder {
     // values, sub-tile values, the 8 x u16 record of every run, and the runs' offsets in the p stream
     u64* sp_planes = nullptr; dcs::SpDesc* sp_desc = nullptr; dcs::SpSum* sp_sums = nullptr; dcs::SpGroupSum* sp_gsum = nullptr; u16* sp_gv = nullptr; u16* sp_sv = nullptr; u16* sp_state = nullptr;
     uint4* sp_rec = nullptr; u32* doff_full = nullptr;
+    char* sp_arena = nullptr; bool sp_alloc_failed = false;     // (own allocation, made when BSCGPU_OPT_DC_STREAM_STATIC is first used: dc_sp_ensure)
     dcs::SpDesc sp_desc_host[5][dcs::SP_SLOTS]; bool sp_ok = false;   // descriptors by max_rank (built once; sp_ok: every type representable)
     u32 *hmeta = nullptr;                                      // pinned: meta + poff
 };
@@ -202,8 +203,17 @@ __global__ __launch_bounds__(WG) void dc_ctx_kernel(const u64* __restrict__ key_
         // after nine)
         constexpr int NP = 9;
         u64 pk[NP];
+        if (q >= 10u) {
+            // the nine predecessors are 72 consecutive bytes: five 16-byte loads instead of nine 8-byte ones (round 6: the kernel is bound by
+            // the lines its gathers touch per instruction, and these nine touched the same one or two lines nine times)
+            struct __attribute__((packed, aligned(8))) U2 { u64 a, b; };
+            const U2* w = reinterpret_cast<const U2*>(key_ch_s + (q - 10u));
+            const U2 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];            // elements q-10 .. q-1
+            pk[8] = w0.b; pk[7] = w1.a; pk[6] = w1.b; pk[5] = w2.a; pk[4] = w2.b; pk[3] = w3.a; pk[2] = w3.b; pk[1] = w4.a; pk[0] = w4.b;
+        } else {
 #pragma unroll
-        for (int t = 1; t <= NP; ++t) pk[t - 1] = key_ch_s[q >= (u32)t ? q - (u32)t : 0u];
+            for (int t = 1; t <= NP; ++t) pk[t - 1] = key_ch_s[q >= (u32)t ? q - (u32)t : 0u];
+        }
         u32 prun[NP], prank0 = 0; int np = 0; bool at_start = false;
 #pragma unroll
         for (int t = 1; t <= NP; ++t) {
@@ -1393,6 +1403,7 @@ void devcoder_destroy(bscgpu_ctx* c)
     DevCoder* d = c->dc;
     if (!d) return;
     if (d->arena) hipFree(d->arena);
+    if (d->sp_arena) (void)hipFree(d->sp_arena);
     if (d->hmeta) hipHostFree(d->hmeta);
     delete d;
     c->dc = nullptr;
@@ -1452,11 +1463,7 @@ int devcoder_ensure(bscgpu_ctx* c)
         {(void**)&d->meta, DM_COUNT * 4}, {(void**)&d->poff, 16 * 4},
         {(void**)&d->tab_rank, 32768}, {(void**)&d->tab_run, 8192}, {(void**)&d->mp, sizeof(ModelParams)}, {(void**)&d->mp_fast, sizeof(ModelParams)},
         {(void**)&d->rowbins, DC_ROWS * sizeof(DcRowBins)}, {(void**)&d->sink, 4096},
-        // static family in stream order (devcoder_static.h); T tiles of 64 runs
-        {(void**)&d->sp_planes, (M / 64 + 2) * dcs::SP_PLANES * 8}, {(void**)&d->sp_desc, sizeof d->sp_desc_host},
-        {(void**)&d->sp_sums, (size_t)dcs::SP_SLOTS * (M / 64 / dcs::SP_CT_MIN + 2) * sizeof(dcs::SpSum)}, {(void**)&d->sp_sv, (size_t)dcs::SP_SLOTS * (M / 64 / dcs::SP_CT_MIN + 2) * 2},
-        {(void**)&d->sp_gsum, (size_t)dcs::SP_SLOTS * (M / 64 / dcs::SP_CT_MIN / dcs::SP_RG + 2) * sizeof(dcs::SpGroupSum)}, {(void**)&d->sp_gv, (size_t)dcs::SP_SLOTS * (M / 64 / dcs::SP_CT_MIN / dcs::SP_RG + 2) * 2},
-        {(void**)&d->sp_state, (M / 64 + 16) * dcs::SP_LANES * 2 + 256}, {(void**)&d->sp_rec, 16 * M}, {(void**)&d->doff_full, 4 * M},
+        {(void**)&d->sp_desc, sizeof d->sp_desc_host},
     };
     size_t total = 0;
     for (auto& cv : carve) total += dc_align(cv.bytes);
@@ -1495,6 +1502,28 @@ int devcoder_ensure(bscgpu_ctx* c)
 }
 
 int64_t devcoder_arena_bytes(const bscgpu_ctx* c) { return c->dc ? (int64_t)c->dc->arena_bytes : 0; }
+
+// The buffers of the stream-order evaluation of the static family (devcoder_static.h; ~23 bytes per block byte): allocated when the
+// option is first used — it is off by default, and six contexts' worth of them would be 9 GB of HBM nobody reads.
+static bool dc_sp_ensure(DevCoder* d)
+{
+    if (d->sp_arena) return true;
+    if (d->sp_alloc_failed) return false;
+    const size_t M = d->Mcap + 64;
+    struct Carve { void** p; size_t bytes; };
+    Carve carve[] = {
+        {(void**)&d->sp_planes, (M / 64 + 2) * dcs::SP_PLANES * 8},
+        {(void**)&d->sp_sums, (size_t)dcs::SP_SLOTS * (M / 64 / dcs::SP_CT_MIN + 2) * sizeof(dcs::SpSum)}, {(void**)&d->sp_sv, (size_t)dcs::SP_SLOTS * (M / 64 / dcs::SP_CT_MIN + 2) * 2},
+        {(void**)&d->sp_gsum, (size_t)dcs::SP_SLOTS * (M / 64 / dcs::SP_CT_MIN / dcs::SP_RG + 2) * sizeof(dcs::SpGroupSum)}, {(void**)&d->sp_gv, (size_t)dcs::SP_SLOTS * (M / 64 / dcs::SP_CT_MIN / dcs::SP_RG + 2) * 2},
+        {(void**)&d->sp_state, (M / 64 + 16) * dcs::SP_LANES * 2 + 256}, {(void**)&d->sp_rec, 16 * M}, {(void**)&d->doff_full, 4 * M},
+    };
+    size_t total = 0;
+    for (auto& cv : carve) total += dc_align(cv.bytes);
+    if (hipMalloc((void**)&d->sp_arena, total) != hipSuccess) { (void)hipGetLastError(); d->sp_arena = nullptr; d->sp_alloc_failed = true; return false; }
+    size_t off = 0;
+    for (auto& cv : carve) { *cv.p = d->sp_arena + off; off += dc_align(cv.bytes); }
+    return true;
+}
 
 template <int SIDES>
 static void dc_launch_partition(bscgpu_ctx* c, DevCoder* d, const u64* items, u32 m, const DcSub& S, int job, u32 ignoreX)
@@ -1550,7 +1579,7 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     else
         HIP_TRY(c, hipMemsetAsync(d->ge32, 0, m, c->stream));
     // Static family in stream order (devcoder_static.h) when no sub-block has more than 32 symbols (then no escape coding either)
-    bool spf = c->dc_spf != 0 && d->sp_ok && !may_escape;
+    bool spf = c->dc_spf != 0 && d->sp_ok && !may_escape && dc_sp_ensure(d);
     u32 sp_slots = 0;
     for (int b = 0; b < nb && spf; ++b) {
         if (max_rank[b] < 0 || max_rank[b] > dcs::SP_MAXR) { spf = false; break; }
