@@ -128,6 +128,10 @@ BSCGPU_API uint64_t bscgpu_coder_pool_x16_blocks(int reset);
  * so the two orders differ by up to 100 ms), everything earlier as one eight-lane task.  For callers that know the total, instead of
  * marking blocks BSCGPU_FEATURE_LOW_LATENCY at submission; blocks < 0 withdraws the announcement.  Output is identical either way. */
 BSCGPU_API int  bscgpu_coder_pool_expect(long long blocks, int gpus);
+/* 1 when a block's probability stream leaves the device through the HSA runtime's DMA copy (csrc/device/dma_copy.h) in this process,
+ * 0 when it goes through hipMemcpyAsync (BSC_D2H_DMA=0, or no usable HSA runtime in the process).  Which engine that is depends on the
+ * HIP runtime: a DMA engine on ROCm 7.2's, a 256-workgroup copy kernel on the one torch 2.10 carries (profiles/r06/d2h_copy_path.txt). */
+BSCGPU_API int  bscgpu_d2h_dma_available(void);
 /* The rule behind those shapes as a pure function (unit-tested on CPU): sub-blocks per coder task — 8 (one SIMD task), 2 or 1 — from
  * forced (-1 none, 8 or 0: BSC_RC_SIMD), low_latency (synchronous call or BSCGPU_FEATURE_LOW_LATENCY), pool_free (idle CPUs of the
  * pool's budget; -1: a synchronous call), sync_cpus (CPUs / synchronous callers running), wide_simd (AVX-512VL), adaptive. */

@@ -3,6 +3,7 @@
 // Mirrors the role of libcubwt's device storage object (libcubwt.cu:2239-2395) but is sized for
 // 288 GB of HBM3E: one hipMalloc of ~60 bytes per block byte, carved once, reused for every block.
 #include "dev_common.h"
+#include "dma_copy.h"
 #include <sys/mman.h>
 #include <system_error>
 #include <thread>
@@ -51,6 +52,8 @@ int ctx_ensure_slots(bscgpu_ctx* c, int count)
         if (hipEventCreateWithFlags(&s.copy_ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) return BSC_NOT_ENOUGH_MEMORY;
         for (int b = 0; b < 8; ++b)
             if (hipEventCreateWithFlags(&s.part_ev[b], hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) return BSC_NOT_ENOUGH_MEMORY;
+        if (dma_available())
+            for (int b = 0; b < 8; ++b) s.part_sig[b] = dma_signal_create();       // (0 if the runtime has no more: that slot's copies then go through HIP)
     }
     return BSC_NO_ERROR;
 }
@@ -127,13 +130,17 @@ int ctx_ensure_pstream_slot(bscgpu_ctx* c, HostSlot& slot, size_t entries)
 {
     (void)c;
     if (slot.hps_cap >= entries) return BSC_NO_ERROR;
-    if (slot.hps) { pinned_free(slot.hps, slot.hps_cap * 2); slot.hps = nullptr; slot.hps_cap = 0; }
+    if (slot.hps) { pinned_free(slot.hps, slot.hps_cap * 2); slot.hps = nullptr; slot.hps_cap = 0; slot.hps_dev = nullptr; }
     entries += entries / 16;                                    // a little room: the next block's stream is rarely exactly this long
     slot.hps = (u16*)pinned_alloc(entries * 2);
     if (!slot.hps) return BSC_NOT_ENOUGH_MEMORY;
     slot.hps_cap = entries;
+    slot.hps_dev = nullptr;
+    if (hipHostGetDevicePointer(&slot.hps_dev, slot.hps, 0) != hipSuccess) { (void)hipGetLastError(); slot.hps_dev = nullptr; }
     return BSC_NO_ERROR;
 }
+
+extern "C" int bscgpu_d2h_dma_available(void) { return dma_available(); }
 
 extern "C" int bscgpu_device_count(void)
 {
@@ -232,9 +239,11 @@ extern "C" void bscgpu_destroy(bscgpu_ctx* c)
     for (int i = 0; i < MAX_SLOTS; ++i) {
         HostSlot& s = c->slots[i];
         if (s.run_base) pinned_free(s.run_base, s.run_bytes);
+        for (int b = 0; b < 8; ++b) if (s.part_sig[b]) (void)dma_wait(s.part_sig[b]);     // (a signal that was never armed reads 0)
         if (s.hps) pinned_free(s.hps, s.hps_cap * 2);
         if (s.copy_ev) hipEventDestroy(s.copy_ev);
         for (int b = 0; b < 8; ++b) if (s.part_ev[b]) hipEventDestroy(s.part_ev[b]);
+        for (int b = 0; b < 8; ++b) if (s.part_sig[b]) dma_signal_destroy(s.part_sig[b]);
     }
     devcoder_destroy(c);
     if (c->arena) hipFree(c->arena);

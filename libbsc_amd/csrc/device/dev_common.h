@@ -66,6 +66,9 @@ struct HostSlot {
     hipEvent_t copy_ev = nullptr;   // recorded on the copy stream behind the block's p-stream copy (its last piece); guards the device buffer's reuse
     hipEvent_t part_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // behind the piece of each sub-block: a coder task waits
                                     // for its own sub-blocks only (the stream leaves sub-block by sub-block, 366 MB in all for a 64 MiB text block)
+    // the same pieces through the DMA engine directly (dma_copy.h): one HSA signal per piece, the landing zone's device address
+    uint64_t part_sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void* hps_dev = nullptr;
 };
 constexpr int MAX_SLOTS = 8;
 
@@ -76,6 +79,7 @@ struct bscgpu_ctx {
     hipStream_t  stream      = nullptr;
     hipStream_t  copy_stream = nullptr;   // D2H of the device coder's p stream, overlapped with the next block's GPU stage
     hipEvent_t   ps_guard[2] = {nullptr, nullptr};   // last copy out of each device p-stream buffer (not owned: a slot's copy_ev)
+    uint64_t     ps_guard_sig[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};   // ... or, when the copy went through dma_copy.h, the signals of its pieces (host-side wait)
     int          ps_toggle   = 0;
     hipEvent_t   sync_ev     = nullptr;   // blocking-sync event: waiting threads sleep instead of spinning (host CPUs are the scarce resource)
     int64_t      max_n       = 0;

@@ -28,6 +28,7 @@
 // handles exactly (more than 256 distinct decision types in a block, an avg_rank bracket that does not decide, capacity),
 // a flag is raised and the caller falls back to the host model; nothing approximate is ever emitted.
 #include "dev_common.h"
+#include "dma_copy.h"
 #include <thread>
 #include <system_error>
 #include "devcoder_model.h"
@@ -1683,6 +1684,7 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     G.sp_rec = d->sp_rec; G.doff_full = d->doff_full;
     prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)Efull * 26, Efull);
     if (c->ps_guard[psbuf & 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ps_guard[psbuf & 1], 0));     // the buffer's previous copy-out
+    for (int b = 0; b < 8; ++b) if (c->ps_guard_sig[psbuf & 1][b]) (void)dma_wait(c->ps_guard_sig[psbuf & 1][b]);   // ... when it went through the DMA engine directly (two blocks ago: long landed)
     if (spf) hipLaunchKernelGGL(dc_pstream_spf_kernel, dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, Efull);
     else     hipLaunchKernelGGL((dc_pstream_kernel<false, false>), dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, Efull);
     hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, spf ? d->doff_full : d->doff[0], S, m, d->poff);
@@ -1781,6 +1783,7 @@ static int devcoder_pstream_fast(bscgpu_ctx* c, DevCoder* d, const u8* dsym, con
     G.V_sp = d->V[1]; G.V_ch = d->V[1]; G.V_sr = d->V[1]; G.V_sn = d->V[1];
     prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)E * 10, E);
     if (c->ps_guard[psbuf & 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ps_guard[psbuf & 1], 0));     // the buffer's previous copy-out
+    for (int b = 0; b < 8; ++b) if (c->ps_guard_sig[psbuf & 1][b]) (void)dma_wait(c->ps_guard_sig[psbuf & 1][b]);   // ... when it went through the DMA engine directly (two blocks ago: long landed)
     hipLaunchKernelGGL((dc_pstream_kernel<true, false>), dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp_fast, d->meta, d->ps[psbuf & 1], (u16*)nullptr, E);
     hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, d->doff[0], S, m, d->poff);
     prof_end(c);

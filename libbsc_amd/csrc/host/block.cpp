@@ -24,6 +24,7 @@
 #include "../../../include/libbsc.h"
 #include "../../../include/bscgpu.h"
 #include "../device/dev_common.h"
+#include "../device/dma_copy.h"
 #include "qlfc.h"
 #include "lzp.h"
 #include "par.h"
@@ -354,6 +355,8 @@ struct BlockJob {
     bool use_ps = false; const uint16_t* ps = nullptr; u32 poff[9]; u32 ndec = 0; int sorter = 0;
     hipEvent_t ps_ready = nullptr;   // the p stream's copy to the host (copy stream), all of it
     hipEvent_t ps_part[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ... up to and including sub-block b: what a coder task waits on
+    bool ps_dma = false; uint64_t ps_sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the pieces went through the DMA engine directly (dma_copy.h): signals instead of events
+    bool ps_landed(int b) const { return ps_dma ? dma_wait(ps_sig[b]) == 0 : hipEventSynchronize(ps_part[b]) == hipSuccess; }
     std::atomic<bool> redo{false};   // a sub-block did not compress: the block goes through the host model again (raw sub-blocks need the run arrays)
     bool stored_small = false;       // n <= header size: finished in the GPU stage
     int  result = 0;
@@ -450,7 +453,30 @@ static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
                 // here: the next block's sort overlaps it, the coder tasks wait on the event
                 // (sub-block by sub-block, an event behind each piece: the task that codes sub-blocks b.. starts when ITS entries have landed —
                 // 366 MB take 7-14 ms over PCIe, which the last block of a job and every synchronous call used to wait out in full)
-                {
+                // Which engine moves them: hipMemcpyAsync is a DMA-engine copy on the system's HIP runtime but a 256-workgroup copy KERNEL on
+                // the runtime a torch process carries (dma_copy.h), so the pieces are handed to the HSA runtime's DMA copy directly and
+                // complete HSA signals; hipMemcpyAsync + events remain for a process where that is not possible (or BSC_D2H_DMA=0).
+                bool dma = dma_available() && J.slot->hps_dev != nullptr;
+                for (int b = 0; b < 8 && dma; ++b) dma = J.slot->part_sig[b] != 0;
+                J.ps_dma = false;
+                if (dma) {
+                    const uint16_t* dps = devcoder_pstream_ptr(c, pb);
+                    uint16_t* hdev = (uint16_t*)J.slot->hps_dev;
+                    int issued = 0;
+                    for (; issued < J.nblocks; ++issued) {
+                        const size_t lo = J.poff[issued], hi = J.poff[issued + 1];
+                        if (dma_d2h(hdev + lo, dps + lo, (hi - lo) * 2, J.slot->part_sig[issued]) != 0) break;
+                        J.ps_sig[issued] = J.slot->part_sig[issued];
+                    }
+                    if (issued == J.nblocks) {
+                        J.ps_dma = true;
+                        for (int b = 0; b < 8; ++b) c->ps_guard_sig[pb][b] = b < J.nblocks ? J.slot->part_sig[b] : 0;
+                        c->ps_guard[pb] = nullptr; J.ps_ready = nullptr;
+                    } else {
+                        for (int b = 0; b < issued; ++b) (void)dma_wait(J.slot->part_sig[b]);       // what was queued lands first; then the whole stream again through HIP
+                    }
+                }
+                if (!J.ps_dma) {
                     const uint16_t* dps = devcoder_pstream_ptr(c, pb);
                     for (int b = 0; b < J.nblocks; ++b) {
                         const size_t lo = J.poff[b], hi = J.poff[b + 1];
@@ -459,9 +485,10 @@ static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
                         J.ps_part[b] = J.slot->part_ev[b];
                     }
                     if (hipEventRecord(J.slot->copy_ev, c->copy_stream) != hipSuccess) return LIBBSC_GPU_ERROR;
+                    c->ps_guard[pb] = J.slot->copy_ev; J.ps_ready = J.slot->copy_ev;
+                    for (int b = 0; b < 8; ++b) c->ps_guard_sig[pb][b] = 0;
                 }
-                c->ps_guard[pb] = J.slot->copy_ev; c->ps_toggle = pb ^ 1;
-                J.ps_ready = J.slot->copy_ev;
+                c->ps_toggle = pb ^ 1;
                 J.use_ps = true; J.ps = J.slot->hps; J.ndec = ndec; ok = true;
                 g_count_devmodel.fetch_add(1, std::memory_order_relaxed);
                 if (J.lz) g_count_devmodel_lzp.fetch_add(1, std::memory_order_relaxed);
@@ -503,7 +530,7 @@ static void host_encode_sub(BlockJob& J, int b)
     const size_t need = (size_t)J.size[b] + 64;
     if (J.scratch_cap[b] < need) { J.scratch[b].reset(new uint8_t[need + need / 8]); J.scratch_cap[b] = need + need / 8; }
     if (J.use_ps) {
-        if (hipEventSynchronize(J.ps_part[b]) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); J.sub_res[b] = J.size[b]; return; }
+        if (!J.ps_landed(b)) { J.redo.store(true, std::memory_order_relaxed); J.sub_res[b] = J.size[b]; return; }
         const int r = (J.coder == LIBBSC_CODER_QLFC_FAST ? qlfc_encode_fast_pstream : qlfc_encode_static_pstream)(
                           J.views[b].first_seen, J.views[b].nsym, J.size[b], J.ps + J.poff[b], (size_t)(J.poff[b + 1] - J.poff[b]), J.scratch[b].get(), J.size[b]);
         if (r < 0) J.redo.store(true, std::memory_order_relaxed);      // would be stored raw: that needs the run arrays
@@ -525,7 +552,7 @@ static void host_encode_pair(BlockJob& J, int b)
         if (J.scratch_cap[q] < need) { J.scratch[q].reset(new uint8_t[need + need / 8]); J.scratch_cap[q] = need + need / 8; }
         P[k] = PstreamJob{J.views[q].first_seen, J.views[q].nsym, J.size[q], J.ps + J.poff[q], (size_t)(J.poff[q + 1] - J.poff[q]), J.scratch[q].get(), J.size[q]};
     }
-    if (hipEventSynchronize(J.ps_part[b + 1]) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); J.sub_res[b] = J.size[b]; J.sub_res[b + 1] = J.size[b + 1]; return; }
+    if (!J.ps_landed(b + 1)) { J.redo.store(true, std::memory_order_relaxed); J.sub_res[b] = J.size[b]; J.sub_res[b + 1] = J.size[b + 1]; return; }
     int r0, r1;
     if (J.coder == LIBBSC_CODER_QLFC_FAST) qlfc_encode_fast_pstream_pair(P[0], P[1], &r0, &r1);
     else qlfc_encode_static_pstream_pair(P[0], P[1], &r0, &r1);
@@ -617,7 +644,7 @@ static void host_encode_group(BlockJob& J, int b)
         if (J.scratch_cap[q] < need) { J.scratch[q].reset(new uint8_t[need + need / 8]); J.scratch_cap[q] = need + need / 8; }
         P[k] = PstreamJob{J.views[q].first_seen, J.views[q].nsym, J.size[q], J.ps + J.poff[q], (size_t)(J.poff[q + 1] - J.poff[q]), J.scratch[q].get(), J.size[q]};
     }
-    if (hipEventSynchronize(J.ps_part[b + g - 1]) != hipSuccess) { J.redo.store(true, std::memory_order_relaxed); for (int k = 0; k < g; ++k) J.sub_res[b + k] = J.size[b + k]; return; }
+    if (!J.ps_landed(b + g - 1)) { J.redo.store(true, std::memory_order_relaxed); for (int k = 0; k < g; ++k) J.sub_res[b + k] = J.size[b + k]; return; }
     int r[8];
     if (!(J.coder == LIBBSC_CODER_QLFC_FAST ? qlfc_encode_fast_pstream_x8(P, r) : qlfc_encode_static_pstream_x8(P, r))) {
         for (int k = 0; k < g; k += 2) host_encode_pair(J, b + k);      // a stream near its budget: the exact scalar coders
@@ -644,7 +671,7 @@ static void host_encode_x16(BlockJob& A, BlockJob& B)
         }
     }
     bool landed = true;
-    for (int h = 0; h < 2; ++h) if (hipEventSynchronize(JJ[h]->ps_part[7]) != hipSuccess) landed = false;
+    for (int h = 0; h < 2; ++h) if (!JJ[h]->ps_landed(7)) landed = false;
     int r[16];
     if (!landed || !(A.coder == LIBBSC_CODER_QLFC_FAST ? qlfc_encode_fast_pstream_x16(P, r) : qlfc_encode_static_pstream_x16(P, r))) {
         host_encode_group(A, 0); host_encode_group(B, 0);            // a copy that failed, or a stream near its budget: each block on its own (eight lanes, then the exact scalar coders)

@@ -545,6 +545,22 @@ def test_landing_zones_fall_back_to_hiphostmalloc_when_registration_is_refused(t
     _rerun_with_env("eight_sub_block_inputs or pipe_matches_sync_path or sub_block_count_boundaries", BSC_PIN_REGISTER_FAIL="1")
 
 
+def test_p_stream_copies_through_the_hip_runtime_when_the_dma_path_is_off(torch_cuda):
+    """The p stream normally leaves the device through the HSA runtime's DMA copy (dma_copy.h: HSA signals, host-side waits, host-side
+    guard of the device buffer's reuse); BSC_D2H_DMA=0 keeps hipMemcpyAsync + events.  Both must give the same bytes on the synchronous
+    path, the pipelined path (buffer reuse two blocks later) and the 64 MiB golden block."""
+    _rerun_with_env("eight_sub_block_inputs or pipe_matches_sync_path or full_size_64m_block_golden", BSC_D2H_DMA="0")
+
+
+def test_p_stream_dma_path_is_the_one_in_use(torch_cuda):
+    """In this process (torch's HIP runtime) the DMA path must be available — a silent decline would put the copy kernels back."""
+    import ctypes
+    from libbsc_amd import _native
+    lib = _native.lib()
+    lib.bscgpu_d2h_dma_available.restype = ctypes.c_int
+    assert lib.bscgpu_d2h_dma_available() == 1
+
+
 def test_c_job_bench_verifies_against_the_committed_reference_output(torch_cuda):
     """tools/job_bench.cpp (built next to the library): bench.py's workload through bscgpu_job_* from a C++ caller — announced total,
     tapered head and tail, low-latency last blocks; its last block must be the committed reference output (its own md5 check, exit code 3
