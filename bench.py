@@ -431,13 +431,17 @@ def main():
     # where every block of this workload has 183.2 M decisions = 366.4 MB)
     dps = stats.get("dc_pstream", {})
     decisions_per_block = dps.get("records", 0) / max(dps.get("launches", 0), 1)
-    d2h_bytes = 2.0 * decisions_per_block * args.steps
+    # (round 6: the static coder's stream crosses as 13 bits per decision, each sub-block's padded to 64 decisions — BSCGPU_OPT_DC_PACKED_STREAM)
+    ps_packed = args.coder == 1 and ctxs[0].option_get(ctxs[0].OPT_DC_PACKED_STREAM) == 1
+    bytes_per_decision = 13.0 / 8.0 if ps_packed else 2.0
+    d2h_bytes = bytes_per_decision * decisions_per_block * args.steps
     mine = {"rank": rank, "verified": verified, "gpu_stage_total_ms": round(float(stage[0] + stage[1] + stage[2]) / args.steps, 2),
             "pcie_d2h_MBps": round(d2h_bytes / 1e6 / dt, 1), "pcie_d2h_MB_per_block": round(d2h_bytes / 1e6 / args.steps, 1),
             "host_dram_MBps_estimate": round(2 * d2h_bytes / 1e6 / dt, 1),
             # host DRAM traffic of one block (8 ranks per node share the host's memory system, not xGMI): the p stream is written once by the
             # DMA engine and read once by the range coder; the compressed block is written once; a host-resident input is read once for the H2D
-            "host_dram_bytes_per_block": {"pstream_dma_write": int(2 * decisions_per_block), "pstream_coder_read": int(2 * decisions_per_block),
+            "pstream_bits_per_decision": 13 if ps_packed else 16,
+            "host_dram_bytes_per_block": {"pstream_dma_write": int(bytes_per_decision * decisions_per_block), "pstream_coder_read": int(bytes_per_decision * decisions_per_block),
                                           "compressed_block_write": int(blk.size), "input_read_for_h2d": int(n if (lzp[0] or host_leg[0]) else 0)},
             "sorter_only_MBps": round(n / 1e6 / max(stage[1] / args.steps / 1e3, 1e-9), 1),
             "cpu_seconds_per_block": round(cpu_used / args.steps, 3), "coder_threads": coder_threads,

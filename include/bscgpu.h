@@ -86,6 +86,14 @@ BSCGPU_API int bscgpu_radix_sort_u64(bscgpu_ctx* ctx, void* keys, void* keys_alt
  * dbg (optional, [3][cap]): the state- / char- / static-counter value behind every decision. */
 BSCGPU_API int64_t bscgpu_qlfc_static_pstream(bscgpu_ctx* ctx, const uint8_t* L, int n, uint16_t* out, int64_t cap, int* nblocks,
                                    int* sub_start /*[8]*/, int* sub_size /*[8]*/, int64_t* poff /*[9]*/, uint16_t* dbg);
+/* The same stage with the stream in the form that crosses PCIe since round 6 (BSCGPU_OPT_DC_PACKED_STREAM): 13 bits per decision
+ * {[11:0] probability, [12] coded bit}, eight decisions in 13 bytes (field e of a group at bits [13 e, 13 e + 13), little endian); sub-block
+ * b's fields start at decision pbase[b] of the packed space — a multiple of 64, i.e. at byte pbase[b] / 8 * 13 — and its last group is
+ * zero-padded.  out takes pbase[nblocks] / 8 * 13 bytes (cap_bytes).  Returns the number of decisions; LIBBSC_NOT_SUPPORTED also when
+ * the packed form was not produced for this block (option off; 64 consecutive runs with more decisions than a wavefront stages —
+ * bsc_compress then moves that block's stream as 16-bit entries). */
+BSCGPU_API int64_t bscgpu_qlfc_static_pstream_packed(bscgpu_ctx* ctx, const uint8_t* L, int n, uint8_t* out, int64_t cap_bytes, int* nblocks,
+                                   int* sub_start /*[8]*/, int* sub_size /*[8]*/, int64_t* poff /*[9]*/, int64_t* pbase /*[9]*/);
 
 /* ---- full block compression with the BWT/ST + coder split across GPU and host ------------- */
 /* bsc_compress semantics (libbsc.cpp:213) for input already in HBM: Adler-32 + sort transform on
@@ -246,8 +254,13 @@ BSCGPU_API const char* bscgpu_last_error(const bscgpu_ctx* ctx);
  *                          counter family in stream order for blocks of at most 32 symbols per sub-block (devcoder_static.h);
  *                          0 (default) sends it through partition / evaluation / gather like the other two families.  Same
  *                          output either way; round 6 measured the stream-order form slower (profiles/r06/static_family_stream_order.txt).
+ * BSCGPU_OPT_DC_PACKED_STREAM  1 (default; BSC_PS13=0 in the environment turns it off): the static coder's probability stream crosses
+ *                          PCIe as 13 bits per decision — 12-bit probability + coded bit, eight decisions in 13 bytes — instead of
+ *                          16-bit entries (298 instead of 366 MB per 64 MiB text block).  The run-start mark of the 16-bit entry only
+ *                          placed the reference's output-budget test; a stream that reaches its budget is redone on the host model
+ *                          either way.  Same output.
  * set returns the previous value or a negative libbsc error code; get the value or a negative error code. */
-enum { BSCGPU_OPT_RS_ONESWEEP = 1, BSCGPU_CNT_OS_RETRIES = 2, BSCGPU_OPT_DC_STREAM_STATIC = 3 };
+enum { BSCGPU_OPT_RS_ONESWEEP = 1, BSCGPU_CNT_OS_RETRIES = 2, BSCGPU_OPT_DC_STREAM_STATIC = 3, BSCGPU_OPT_DC_PACKED_STREAM = 4 };
 BSCGPU_API int bscgpu_option_set(bscgpu_ctx* ctx, int key, int value);
 BSCGPU_API int bscgpu_option_get(bscgpu_ctx* ctx, int key);
 /* Process-wide counts since start (tests, reports): blocks whose static model ran on the GPU, how many of those were LZP-preprocessed,

@@ -170,6 +170,7 @@ extern "C" int bscgpu_create(bscgpu_ctx** out, int device, int64_t max_n)
     c->device = device;
     c->max_n  = max_n;
     { const char* e = getenv("BSC_DC_SPF"); c->dc_spf = (e && e[0] == '1') ? 1 : 0; }     // BSCGPU_OPT_DC_STREAM_STATIC (off by default: measured slower, profiles/r06)
+    { const char* e = getenv("BSC_PS13"); c->dc_p13 = (e && e[0] == '0') ? 0 : 1; }       // BSCGPU_OPT_DC_PACKED_STREAM
     memset(c->kstat, 0, sizeof c->kstat);
     auto tm_streams = std::make_unique<CtxTimer>("  streams + events");
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BSC_GPU_ERROR; }
@@ -316,6 +317,7 @@ extern "C" int bscgpu_option_set(bscgpu_ctx* c, int key, int value)
     if (!c) return BSC_BAD_PARAMETER;
     if (key == BSCGPU_OPT_RS_ONESWEEP && value >= 0 && value <= 3 && (value == 0 || c->os_available)) { const int old = c->os_mode; c->os_mode = value; return old; }
     if (key == BSCGPU_OPT_DC_STREAM_STATIC && (value == 0 || value == 1)) { const int old = c->dc_spf; c->dc_spf = value; return old; }
+    if (key == BSCGPU_OPT_DC_PACKED_STREAM && (value == 0 || value == 1)) { const int old = c->dc_p13; c->dc_p13 = value; return old; }
     return BSC_BAD_PARAMETER;
 }
 extern "C" int bscgpu_option_get(bscgpu_ctx* c, int key)
@@ -324,6 +326,7 @@ extern "C" int bscgpu_option_get(bscgpu_ctx* c, int key)
     if (key == BSCGPU_OPT_RS_ONESWEEP) return c->os_mode;
     if (key == BSCGPU_CNT_OS_RETRIES) return c->os_retries;
     if (key == BSCGPU_OPT_DC_STREAM_STATIC) return c->dc_spf;
+    if (key == BSCGPU_OPT_DC_PACKED_STREAM) return c->dc_p13;
     return BSC_BAD_PARAMETER;
 }
 extern "C" int bscgpu_last_stage_ms(bscgpu_ctx* c, double* out6)

@@ -120,6 +120,7 @@ struct bscgpu_ctx {
     bool os_available = true;        // the single-read kernels could be set up on this device (radix_onesweep_setup)
     int  os_retries = 0;             // transforms redone through the three-kernel passes after a give-up (bscgpu_debug_counter)
     int  dc_spf = 0;                 // BSCGPU_OPT_DC_STREAM_STATIC (context.hip reads BSC_DC_SPF at creation)
+    int  dc_p13 = 1;                 // BSCGPU_OPT_DC_PACKED_STREAM: the static coder's p stream leaves as 13 bits per decision (BSC_PS13=0: 16-bit entries)
     bool os_gave_up = false;         // radix_onesweep_check found a give-up: the caller may redo its sorts through the three-kernel passes
     // pinned host
     u32* hscal  = nullptr;   // 1024 u32 (slot map: the users' comments; OS_ERR_SLOT = 1000)
@@ -195,7 +196,8 @@ int ctx_ensure_pstream_slot(bscgpu_ctx* c, HostSlot& slot, size_t entries);     
 int ctx_ensure_run_slot(bscgpu_ctx* c, HostSlot& slot);                           // pinned landing zone for a block's run arrays
 // device-side model of the static QLFC coder (devcoder.hip): probability stream of a whole block from the front end's run arrays
 int  devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* dstart, u32 m, u32 n, int nb, const u32* run_first,
-                      const int* max_rank, u32* D_out, u32* poff_out, u16* dbg, int psbuf = 0, int coder = 1 /* 1 static (-e1), 3 fast (-e0) */);
+                      const int* max_rank, u32* D_out, u32* poff_out, u16* dbg, int psbuf = 0, int coder = 1 /* 1 static (-e1), 3 fast (-e0) */,
+                      int* packed_out = nullptr /* non-null: the caller takes the 13-bit packed stream (devcoder.hip DcP13); *packed_out = 1 if that is what was written */);
 const u16* devcoder_pstream_ptr(const bscgpu_ctx* c, int psbuf = 0);
 void devcoder_destroy(bscgpu_ctx* c);
 int64_t devcoder_arena_bytes(const bscgpu_ctx* c);

@@ -66,7 +66,7 @@ constexpr u32 DC_SIGMASK  = 0x7ffu;    // event = X | sub-block << 8 | bit << 11
 constexpr int DC_ROWS     = 1088;      // rows of the chain-major layout = decision types (NUM_TAU = 1080), padded to whole wavefronts
 
 // meta scalars (device u32 array)
-enum { DM_FAIL = 0, DM_NTYPES, DM_NROUNDS, DM_AVG_UND, DM_REPLAYS, DM_D0, DM_D1, DM_D2, DM_D3, DM_HIST_FAIL, DM_DFULL /* = DM_D0 + 5 */, DM_SP_OPEN, DM_SP_REWALKS, DM_COUNT = 16 };
+enum { DM_FAIL = 0, DM_NTYPES, DM_NROUNDS, DM_AVG_UND, DM_REPLAYS, DM_D0, DM_D1, DM_D2, DM_D3, DM_HIST_FAIL, DM_DFULL /* = DM_D0 + 5 */, DM_SP_OPEN, DM_SP_REWALKS, DM_P13_OVER /* a wavefront's piece did not fit the staging buffer: the packed stream is void */, DM_COUNT = 16 };
 enum { FAIL_TYPES = 1, FAIL_AVG = 2, FAIL_HIST = 4, FAIL_CAP = 8, FAIL_REPLAY = 16 };
 
 typedef dcs::SpSub DcSub;                                       // { u32 nb; u32 first[9]; u32 maxr[8]; }: run index range and max_rank of each sub-block
@@ -96,6 +96,7 @@ struct DevCoder {
     // values, sub-tile values, the 8 x u16 record of every run, and the runs' offsets in the p stream
     u64* sp_planes = nullptr; dcs::SpDesc* sp_desc = nullptr; dcs::SpSum* sp_sums = nullptr; dcs::SpGroupSum* sp_gsum = nullptr; u16* sp_gv = nullptr; u16* sp_sv = nullptr; u16* sp_state = nullptr;
     uint4* sp_rec = nullptr; u32* doff_full = nullptr;
+    struct DcFrag* frag = nullptr;                              // packed stream: two fragment records per wavefront of dc_pstream (DcP13)
     char* sp_arena = nullptr; bool sp_alloc_failed = false;     // (own allocation, made when BSCGPU_OPT_DC_STREAM_STATIC is first used: dc_sp_ensure)
     dcs::SpDesc sp_desc_host[5][dcs::SP_SLOTS]; bool sp_ok = false;   // descriptors by max_rank (built once; sp_ok: every type representable)
     u32 *hmeta = nullptr;                                      // pinned: meta + poff
@@ -1104,14 +1105,122 @@ struct __attribute__((packed, aligned(4))) DcU4 { u32 a, b, c, d; };
 constexpr u32 DC_PS_STAGE = DC_PS_STAGE_N;
 typedef __attribute__((address_space(3))) volatile u16 dc_lds_vu16;
 
+// ---- the packed stream (round 6): 13 bits per decision ---------------------------------------------------------------------------
+// What the host's range coder needs of a static-coder entry is the probability (12 bits) and the coded bit; the run-start mark only
+// placed the reference's budget test (qlfc.cpp:894), and a stream that reaches its budget is redone from the run arrays anyway.
+// P13: field = entry & 0x1fff, eight decisions in 13 bytes (field e of a group at bits [13 e, 13 e + 13), little endian); a sub-block's
+// stream starts at a multiple of 64 decisions (104 bytes) and is zero-padded to a whole group: 366 -> 298 MB per 64 MiB block over PCIe
+// and through the host's DRAM.  The entries of a wavefront's runs are contiguous in the stream, but its piece starts and ends anywhere,
+// so a wavefront writes the groups that lie wholly inside its piece (13 bytes per lane and trip) and leaves the fragment of a group
+// at either end of it as a 24-byte record; dc_p13_join_kernel then writes the group between every two neighbouring wavefronts from
+// the tail record of the one and the head record of the other — no atomics, no zeroed buffer.
+struct DcFrag { u32 gidx; u32 slot_count; u16 e[8]; };               // group index (decisions / 8), first slot | count << 8 (count 0: none), the entries
+struct DcP13 { u32 pad[8]; u8* out; DcFrag* frag; };                 // pad[sb]: packed index of a decision = its index in the block's stream + pad[its sub-block]
+struct __attribute__((packed)) DcGroup13 { u32 a, b, c; u8 d; };
+__device__ __forceinline__ DcGroup13 dc_pack13(const u32 (&f)[8])
+{
+    const u64 lo = (u64)f[0] | ((u64)f[1] << 13) | ((u64)f[2] << 26) | ((u64)f[3] << 39) | ((u64)f[4] << 52);
+    const u64 hi = (u64)(f[4] >> 12) | ((u64)f[5] << 1) | ((u64)f[6] << 14) | ((u64)f[7] << 27);
+    DcGroup13 g; g.a = (u32)lo; g.b = (u32)(lo >> 32); g.c = (u32)hi; g.d = (u8)(hi >> 32);
+    return g;
+}
+// The wavefront's staged entries sg[0 .. wtotal) are the decisions wbase .. of the block's stream; loc / nd / sb / valid: this lane's run.
+__device__ __forceinline__ void dc_flush13(dc_lds_vu16* sg, const u32 wbase, const u32 lane, const u32 loc, const u32 nd, const u32 sb, const bool valid,
+                                           const DcP13& Q, const u32 wave_global)
+{
+    const u64 vmask = __ballot(valid);
+    DcFrag head, tail; head.slot_count = 0; tail.slot_count = 0; head.gidx = 0; tail.gidx = 0;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) { head.e[x] = 0; tail.e[x] = 0; }
+    if (vmask != 0ull) {
+        const u32 lastv = 63u - (u32)__builtin_clzll(vmask);
+        const u32 sb_first = (u32)__builtin_amdgcn_readfirstlane((int)sb), sb_last = (u32)__builtin_amdgcn_readlane((int)sb, (int)lastv);
+        for (u32 s2 = sb_first; s2 <= sb_last; ++s2) {                    // one trip, except where sub-blocks meet inside the wavefront
+            const u64 mk = __ballot(valid && sb == s2);
+            if (mk == 0ull) continue;
+            const u32 l0 = (u32)__builtin_ctzll(mk), l1 = 63u - (u32)__builtin_clzll(mk);
+            const u32 k0 = (u32)__builtin_amdgcn_readlane((int)loc, (int)l0), k1 = (u32)__builtin_amdgcn_readlane((int)(loc + nd), (int)l1);
+            const u32 len = k1 - k0;
+            if (len == 0u) continue;
+            const u32 P0 = wbase + k0 + Q.pad[s2];
+            const u32 g_full0 = (P0 + 7u) >> 3, g_full1 = (P0 + len) >> 3;         // groups [g_full0, g_full1) lie wholly inside
+            for (u32 g = g_full0 + lane; g < g_full1; g += 64u) {
+                const u32 k = k0 + (g * 8u - P0);
+                u32 f[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) f[x] = (u32)sg[k + (u32)x] & 0x1fffu;
+                *reinterpret_cast<DcGroup13*>(Q.out + (size_t)g * 13u) = dc_pack13(f);
+            }
+            // the fragment before the first group boundary: only the wavefront's first piece can have one (a sub-block starts on a group)
+            u32 hcount = 0;
+            if ((P0 & 7u) != 0u) {
+                hcount = 8u - (P0 & 7u); if (hcount > len) hcount = len;
+                head.gidx = P0 >> 3; head.slot_count = (P0 & 7u) | (hcount << 8);
+#pragma unroll
+                for (int x = 0; x < 8; ++x) head.e[x] = (u32)x < hcount ? (u16)(sg[k0 + (u32)x] & 0x1fffu) : (u16)0;
+            }
+            // the fragment behind the last one: the next wavefront completes it — unless the sub-block ends here, then it is a whole (padded) group
+            if (((P0 + len) & 7u) != 0u && (g_full1 << 3) >= P0) {
+                const u32 tcount = (P0 + len) & 7u, tk = k0 + ((g_full1 << 3) - P0);
+                u32 f[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) f[x] = (u32)x < tcount ? ((u32)sg[tk + (u32)x] & 0x1fffu) : 0u;
+                if (s2 != sb_last) { if (lane == 0u) *reinterpret_cast<DcGroup13*>(Q.out + (size_t)g_full1 * 13u) = dc_pack13(f); }
+                else {
+                    tail.gidx = g_full1; tail.slot_count = tcount << 8;
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) tail.e[x] = (u16)f[x];
+                }
+            }
+        }
+    }
+    // both records (every lane holds the same two: they were read from LDS at wave-uniform addresses) as ONE 48-byte store: lane t writes word t
+    if (lane < 12u) {
+        const DcFrag& r = lane < 6u ? head : tail;
+        const u32 q = lane < 6u ? lane : lane - 6u;
+        const u32 w = q == 0u ? r.gidx : q == 1u ? r.slot_count
+                    : q == 2u ? ((u32)r.e[0] | ((u32)r.e[1] << 16)) : q == 3u ? ((u32)r.e[2] | ((u32)r.e[3] << 16))
+                    : q == 4u ? ((u32)r.e[4] | ((u32)r.e[5] << 16)) : ((u32)r.e[6] | ((u32)r.e[7] << 16));
+        reinterpret_cast<u32*>(Q.frag + 2u * wave_global)[lane] = w;
+    }
+}
+// thread w: the group between wavefront w and w + 1 (tail of w, head of w + 1), and a head nobody's tail belongs to (never on blocks whose
+// wavefronts hold 64 runs; written for completeness)
+__global__ __launch_bounds__(WG) void dc_p13_join_kernel(const DcFrag* __restrict__ frag, u32 nwaves, u8* __restrict__ out, const u32* __restrict__ meta)
+{
+    if (meta[DM_FAIL] != 0u) return;
+    const u32 w = blockIdx.x * WG + threadIdx.x;
+    if (w >= nwaves) return;
+    const DcFrag T = frag[2u * w + 1u];
+    DcFrag H; H.slot_count = 0; H.gidx = 0;
+    if (w + 1u < nwaves) H = frag[2u * (w + 1u)];
+    const u32 tc = T.slot_count >> 8, hc = H.slot_count >> 8, hs = H.slot_count & 0xffu;
+    if (tc != 0u) {
+        u32 f[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) f[x] = (u32)x < tc ? (u32)T.e[x] : 0u;
+        if (hc != 0u && H.gidx == T.gidx) {
+#pragma unroll
+            for (int x = 0; x < 8; ++x) if ((u32)x >= hs && (u32)x < hs + hc) f[x] = (u32)H.e[(u32)x - hs];
+        }
+        *reinterpret_cast<DcGroup13*>(out + (size_t)T.gidx * 13u) = dc_pack13(f);
+    }
+    if (hc != 0u && !(tc != 0u && H.gidx == T.gidx)) {
+        u32 f[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) f[x] = ((u32)x >= hs && (u32)x < hs + hc) ? (u32)H.e[(u32)x - hs] : 0u;
+        *reinterpret_cast<DcGroup13*>(out + (size_t)H.gidx * 13u) = dc_pack13(f);
+    }
+}
+
 // FAST: the fast coder's stream — one counter per decision (the char family's value IS the probability, 13 / 11 bits), entries
 // {value, bit << 13, run start << 14, run side << 15} (devcoder_model.h PSF_*).
 #ifndef DC_PS_MINW
 #define DC_PS_MINW 1            // minimum waves per SIMD the register allocator must leave room for (A/B: 82 VGPRs = 5 waves by default)
 #endif
-template <bool FAST, bool SPF>
+template <bool FAST, bool SPF, bool P13>
 __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, DcSub S, const ModelParams* __restrict__ mp,
-                                                        const u32* __restrict__ meta, u16* __restrict__ out, u16* __restrict__ dbg /*[3][D] or null*/, u32 dbgD)
+                                                        u32* __restrict__ meta, u16* __restrict__ out, u16* __restrict__ dbg /*[3][D] or null*/, u32 dbgD, DcP13 Q)
 {
     const u32 mrp = dc_maxr_pack(S);                                  // max_rank of the eight sub-blocks, one scalar word
     __shared__ u16 stage[WAVES][DC_PS_STAGE];
@@ -1169,7 +1278,7 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, 
             e = (u16)((u32)p | (bit << 12) | (k == 0 ? (u32)PS_RUN : 0u));
             if (dbg) { dbg[b_sp + k] = (u16)v_st; dbg[(size_t)dbgD + b_sp + k] = (u16)v_ch; dbg[2 * (size_t)dbgD + b_sp + k] = (u16)v_sp; }
         }
-        if (staged) sg[loc + (u32)k] = e; else o[k] = e;
+        if (staged) sg[loc + (u32)k] = e; else if (!P13) o[k] = e;
     };
     // first 8 decisions: positions by wide loads (the arrays have slack behind their last entry), static register indices
     u32 qsp[8], qch[8];
@@ -1219,7 +1328,13 @@ __global__ __launch_bounds__(WG, DC_PS_MINW) void dc_pstream_kernel(DcGather G, 
         const int cls = nth_class(it, maxr, n_rank, k, &bit, &rs);
         emit(k, (FAST || SPF) ? 0u : p_sp[k], p_ch[k], FAST ? 0u : (rs ? p_sn[k - n_rank] : p_sr[k]), rs, cls, bit);     // (SPF: a rank side has at most 8 decisions, so this is a run-side one)
     }
-    if (staged) {
+    if (P13) {
+        // (a piece that does not fit the staging buffer voids the packed stream: the host launches the 2-byte form for this block)
+        if (!staged) { if (lane == 0u) atomicOr(&meta[DM_P13_OVER], 1u); }
+        __builtin_amdgcn_wave_barrier();
+        if (staged) dc_flush13(sg, wbase, lane, loc, (u32)nd, (u32)it.sb, valid, Q, j >> 6);
+        else if (lane < 12u) reinterpret_cast<u32*>(Q.frag + 2u * (j >> 6))[lane] = 0u;
+    } else if (staged) {
         // the wavefront's piece [wbase, wbase + wtotal) of the stream: 4-byte stores from the first even entry on, the odd ends singly
         __builtin_amdgcn_wave_barrier();
         u16* ow = out + wbase;
@@ -1461,7 +1576,7 @@ int devcoder_ensure(bscgpu_ctx* c)
         {(void**)&d->wdec, (DC_WCH_MAX + 8) * 4}, {(void**)&d->wdecoff, (DC_WCH_MAX + 8) * 4},
         {(void**)&d->elo, 2 * 4 * NCH}, {(void**)&d->ehi, 2 * 4 * NCH}, {(void**)&d->S, 2 * 4 * NCH},
         {(void**)&d->present, (size_t)DC_KIND_WORDS * 4}, {(void**)&d->rounds, 256},
-        {(void**)&d->meta, DM_COUNT * 4}, {(void**)&d->poff, 16 * 4},
+        {(void**)&d->meta, DM_COUNT * 4}, {(void**)&d->poff, 16 * 4}, {(void**)&d->frag, (M / 64 + 64) * 2 * sizeof(DcFrag)},
         {(void**)&d->tab_rank, 32768}, {(void**)&d->tab_run, 8192}, {(void**)&d->mp, sizeof(ModelParams)}, {(void**)&d->mp_fast, sizeof(ModelParams)},
         {(void**)&d->rowbins, DC_ROWS * sizeof(DcRowBins)}, {(void**)&d->sink, 4096},
         {(void**)&d->sp_desc, sizeof d->sp_desc_host},
@@ -1554,8 +1669,9 @@ static int devcoder_pstream_fast(bscgpu_ctx* c, DevCoder* d, const u8* dsym, con
                                  const u32* run_first, u32* D_out, u32* poff_out, int psbuf);
 
 int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* dstart, u32 m, u32 n, int nb, const u32* run_first,
-                     const int* max_rank, u32* D_out, u32* poff_out, u16* dbg, int psbuf, int coder)
+                     const int* max_rank, u32* D_out, u32* poff_out, u16* dbg, int psbuf, int coder, int* packed_out)
 {
+    if (packed_out) *packed_out = 0;
     int rc = devcoder_ensure(c);
     if (rc < 0) return rc;
     DevCoder* d = c->dc;
@@ -1635,11 +1751,16 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     dc_launch_partition<3>(c, d, d->key_ch_s, m, S, 1, 0u);
     dc_launch_partition<1>(c, d, d->key_sr_s, m, S, 2, 0u);
     dc_launch_partition<2>(c, d, d->key_sn_s, m, S, 3, 0u);
+    // (the sub-blocks' offsets in the stream are known from here on: the packed stream's layout is made of them)
+    hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, spf ? d->doff_full : d->doff[0], S, m, d->poff);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(d->hmeta, d->meta, DM_COUNT * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d->hmeta + 32, d->poff, 16 * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, ctx_sync(c));
     prof_collect(c);
     if (d->hmeta[DM_FAIL] != 0) { c->dc_last_fail = (int)d->hmeta[DM_FAIL]; return BSC_NOT_SUPPORTED; }
+    u32 poff_h[9];
+    for (int b = 0; b <= nb; ++b) poff_h[b] = d->hmeta[32 + b];
     u32 E[4];
     for (int job = 0; job < 4; ++job) E[job] = d->hmeta[DM_D0 + job];
     const u32 Efull = spf ? d->hmeta[DM_DFULL] : E[0];                 // decisions of the block (spf: job 0 is the small NE / NM job)
@@ -1685,15 +1806,35 @@ int devcoder_pstream(bscgpu_ctx* c, const u8* dsym, const u8* drank, const u32* 
     prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)Efull * 26, Efull);
     if (c->ps_guard[psbuf & 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ps_guard[psbuf & 1], 0));     // the buffer's previous copy-out
     for (int b = 0; b < 8; ++b) if (c->ps_guard_sig[psbuf & 1][b]) (void)dma_wait(c->ps_guard_sig[psbuf & 1][b]);   // ... when it went through the DMA engine directly (two blocks ago: long landed)
-    if (spf) hipLaunchKernelGGL(dc_pstream_spf_kernel, dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, Efull);
-    else     hipLaunchKernelGGL((dc_pstream_kernel<false, false>), dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, Efull);
-    hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, spf ? d->doff_full : d->doff[0], S, m, d->poff);
+    // 13 bits per decision (DcP13) when the caller can take it: not with the debug planes, not with the stream-order static family
+    bool packed = packed_out != nullptr && c->dc_p13 != 0 && !spf && dbg == nullptr;
+    DcP13 Q{};
+    if (packed) {
+        u32 pbase = 0;
+        for (int b = 0; b < nb; ++b) { Q.pad[b] = pbase - poff_h[b]; pbase += (poff_h[b + 1] - poff_h[b] + 63u) / 64u * 64u; }
+        Q.out = reinterpret_cast<u8*>(d->ps[psbuf & 1]); Q.frag = d->frag;
+        if ((u64)pbase / 8u * 13u > 2ull * (u64)(d->Dcap + 64)) packed = false;        // (cannot happen: 13 / 8 of D + 8 x 64 decisions of padding against 2 D)
+    }
+    if (spf)         hipLaunchKernelGGL(dc_pstream_spf_kernel, dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, Efull);
+    else if (packed) {
+        hipLaunchKernelGGL((dc_pstream_kernel<false, false, true>), dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, Efull, Q);
+        hipLaunchKernelGGL(dc_p13_join_kernel, dim3((gm8 * WAVES + WG - 1) / WG), dim3(WG), 0, c->stream, d->frag, gm8 * WAVES, Q.out, d->meta);
+    } else           hipLaunchKernelGGL((dc_pstream_kernel<false, false, false>), dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, Efull, Q);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(d->hmeta, d->meta, DM_COUNT * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(d->hmeta + 32, d->poff, 16 * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, ctx_sync(c));
     if (d->hmeta[DM_FAIL] != 0) { c->dc_last_fail = (int)d->hmeta[DM_FAIL]; return BSC_NOT_SUPPORTED; }
+    if (packed && d->hmeta[DM_P13_OVER] != 0) {
+        // 64 consecutive runs with more decisions than a wavefront's staging buffer holds (runs of thousands): this block's stream in the 2-byte form
+        packed = false;
+        prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)Efull * 26, Efull);
+        hipLaunchKernelGGL((dc_pstream_kernel<false, false, false>), dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp, d->meta, d->ps[psbuf & 1], dbg, Efull, Q);
+        prof_end(c);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, ctx_sync(c));
+    }
+    if (packed_out) *packed_out = packed ? 1 : 0;
     c->dc_last_fail = 0;
     c->dc_replays = (int)d->hmeta[DM_REPLAYS];
 #if DC_EVAL_TIMING
@@ -1784,7 +1925,7 @@ static int devcoder_pstream_fast(bscgpu_ctx* c, DevCoder* d, const u8* dsym, con
     prof_begin(c, BSCGPU_K_DC_PSTREAM, (u64)E * 10, E);
     if (c->ps_guard[psbuf & 1]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ps_guard[psbuf & 1], 0));     // the buffer's previous copy-out
     for (int b = 0; b < 8; ++b) if (c->ps_guard_sig[psbuf & 1][b]) (void)dma_wait(c->ps_guard_sig[psbuf & 1][b]);   // ... when it went through the DMA engine directly (two blocks ago: long landed)
-    hipLaunchKernelGGL((dc_pstream_kernel<true, false>), dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp_fast, d->meta, d->ps[psbuf & 1], (u16*)nullptr, E);
+    hipLaunchKernelGGL((dc_pstream_kernel<true, false, false>), dim3(gm8), dim3(WG), 0, c->stream, G, S, d->mp_fast, d->meta, d->ps[psbuf & 1], (u16*)nullptr, E, DcP13{});
     hipLaunchKernelGGL(dc_poff_kernel, dim3(1), dim3(16), 0, c->stream, d->doff[0], S, m, d->poff);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
@@ -1807,8 +1948,9 @@ const u16* devcoder_pstream_ptr(const bscgpu_ctx* c, int psbuf) { return c->dc ?
 // oracle's trace of the reference model: sub-block split (coder.cpp:70-109), run / rank front end and the model on the GPU.
 // Returns the number of decisions (their 16-bit entries are in out[0..)), BSC_NOT_SUPPORTED when the block needs the host
 // model (bscgpu_last_error tells why), or another negative libbsc code.
-extern "C" int64_t bscgpu_qlfc_static_pstream(bscgpu_ctx* c, const uint8_t* L, int n, uint16_t* out, int64_t cap, int* nblocks_out,
-                                              int* sub_start /*[8]*/, int* sub_size /*[8]*/, int64_t* poff_out /*[9]*/, uint16_t* dbg_out /*[3][cap] or NULL*/)
+static int64_t qlfc_static_pstream_stage(bscgpu_ctx* c, const uint8_t* L, int n, uint16_t* out, int64_t cap, int* nblocks_out,
+                                         int* sub_start /*[8]*/, int* sub_size /*[8]*/, int64_t* poff_out /*[9]*/, uint16_t* dbg_out /*[3][cap] or NULL*/,
+                                         bool want_packed, int64_t* pbase_out /*[9], packed only*/)
 {
     if (!c || !L || !out || n <= 0 || !nblocks_out || !sub_start || !sub_size || !poff_out) return BSC_BAD_PARAMETER;
     if (n > c->max_n) return BSC_GPU_NOT_ENOUGH_MEMORY;
@@ -1830,15 +1972,24 @@ extern "C" int64_t bscgpu_qlfc_static_pstream(bscgpu_ctx* c, const uint8_t* L, i
     u16* ddbg = nullptr;
     if (dbg_out) { rc = devcoder_ensure(c); if (rc < 0) return rc; if (hipMalloc((void**)&ddbg, (size_t)c->dc->Dcap * 6) != hipSuccess) return BSC_GPU_NOT_ENOUGH_MEMORY; }
     u32 D = 0, poff[9];
-    rc = devcoder_pstream(c, reinterpret_cast<const u8*>(c->vA), reinterpret_cast<const u8*>(c->vB), c->SA, m, (u32)n, nb, run_first, max_rank, &D, poff, ddbg);
-    if (rc == BSC_NOT_SUPPORTED) {
+    int packed = 0;
+    rc = devcoder_pstream(c, reinterpret_cast<const u8*>(c->vA), reinterpret_cast<const u8*>(c->vB), c->SA, m, (u32)n, nb, run_first, max_rank, &D, poff, ddbg, 0, 1,
+                          want_packed ? &packed : nullptr);
+    if (rc == BSC_NO_ERROR && want_packed && !packed) { c->err = "the packed stream was not produced (option off, or a wavefront's piece beyond the staging buffer)"; rc = BSC_NOT_SUPPORTED; }
+    else if (rc == BSC_NOT_SUPPORTED) {
         char buf[96]; snprintf(buf, sizeof buf, "device coder declined the block (reason mask %d)", c->dc_last_fail);
         c->err = buf;
     }
     if (rc < 0) { if (ddbg) hipFree(ddbg); return rc; }
     *nblocks_out = nb;
     for (int b = 0; b <= nb; ++b) poff_out[b] = poff[b];
-    if ((int64_t)D <= cap) {
+    if (want_packed) {
+        int64_t pb = 0;
+        for (int b = 0; b < nb; ++b) { pbase_out[b] = pb; pb += ((int64_t)(poff[b + 1] - poff[b]) + 63) / 64 * 64; }
+        pbase_out[nb] = pb;
+        const int64_t bytes = pb / 8 * 13;
+        if (bytes <= cap) { HIP_TRY(c, hipMemcpyAsync(out, devcoder_pstream_ptr(c), (size_t)bytes, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(c, ctx_sync(c)); }
+    } else if ((int64_t)D <= cap) {
         HIP_TRY(c, hipMemcpyAsync(out, devcoder_pstream_ptr(c), (size_t)D * 2, hipMemcpyDeviceToHost, c->stream));
         if (dbg_out) for (int f = 0; f < 3; ++f) HIP_TRY(c, hipMemcpyAsync(dbg_out + (size_t)f * cap, ddbg + (size_t)f * D, (size_t)D * 2, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, ctx_sync(c));
@@ -1846,4 +1997,19 @@ extern "C" int64_t bscgpu_qlfc_static_pstream(bscgpu_ctx* c, const uint8_t* L, i
     if (ddbg) hipFree(ddbg);
     prof_collect(c);
     return (int64_t)D;
+}
+extern "C" int64_t bscgpu_qlfc_static_pstream(bscgpu_ctx* c, const uint8_t* L, int n, uint16_t* out, int64_t cap, int* nblocks_out,
+                                              int* sub_start /*[8]*/, int* sub_size /*[8]*/, int64_t* poff_out /*[9]*/, uint16_t* dbg_out /*[3][cap] or NULL*/)
+{
+    return qlfc_static_pstream_stage(c, L, n, out, cap, nblocks_out, sub_start, sub_size, poff_out, dbg_out, false, nullptr);
+}
+// The same stage with the stream as it crosses PCIe since round 6 (DcP13): out[0 .. pbase[nb] / 8 * 13) bytes (cap in BYTES), sub-block b's
+// fields from decision pbase[b] of the packed space on (13 bits each, eight in 13 bytes); poff as above.  BSC_NOT_SUPPORTED also when the
+// packed form was not produced for this block (BSCGPU_OPT_DC_PACKED_STREAM off, or 64 consecutive runs with more decisions than a
+// wavefront stages: bsc_compress then takes the 16-bit form for that block).
+extern "C" int64_t bscgpu_qlfc_static_pstream_packed(bscgpu_ctx* c, const uint8_t* L, int n, uint8_t* out, int64_t cap_bytes, int* nblocks_out,
+                                                     int* sub_start /*[8]*/, int* sub_size /*[8]*/, int64_t* poff_out /*[9]*/, int64_t* pbase_out /*[9]*/)
+{
+    if (!pbase_out) return BSC_BAD_PARAMETER;
+    return qlfc_static_pstream_stage(c, L, n, reinterpret_cast<uint16_t*>(out), cap_bytes, nblocks_out, sub_start, sub_size, poff_out, nullptr, true, pbase_out);
 }

@@ -353,6 +353,9 @@ struct BlockJob {
     int  tail_gpus = 1;            // ... and how many GPUs feed the pool in that job
     int  ps_g = 2;                 // device-model sub-blocks per coder task (ps_group), fixed when the block's host work starts
     bool use_ps = false; const uint16_t* ps = nullptr; u32 poff[9]; u32 ndec = 0; int sorter = 0;
+    bool ps_packed = false; u32 pbase[9];          // the stream is the 13-bit packed form (devcoder.hip DcP13): sub-block b's starts at decision pbase[b] of the packed space (a multiple of 64)
+    // sub-block b's stream as the coders take it: 16-bit entries, or the packed bytes behind the same pointer type
+    const uint16_t* ps_of(int b) const { return ps_packed ? reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(ps) + (size_t)pbase[b] / 8u * 13u) : ps + poff[b]; }
     hipEvent_t ps_ready = nullptr;   // the p stream's copy to the host (copy stream), all of it
     hipEvent_t ps_part[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ... up to and including sub-block b: what a coder task waits on
     bool ps_dma = false; uint64_t ps_sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the pieces went through the DMA engine directly (dma_copy.h): signals instead of events
@@ -381,7 +384,7 @@ static std::atomic<uint64_t> g_count_devmodel{0}, g_count_redo{0}, g_count_devmo
 static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
 {
     CtxTimer tm_stage("gpu_stage of one block");
-    J.sorter = blockSorter; J.use_ps = false; J.redo.store(false, std::memory_order_relaxed);
+    J.sorter = blockSorter; J.use_ps = false; J.ps_packed = false; J.redo.store(false, std::memory_order_relaxed);
     bscgpu_ctx* c = J.c;
     const int n = J.n;
     if (hipSetDevice(c->device) != hipSuccess) return LIBBSC_GPU_ERROR;
@@ -445,10 +448,25 @@ static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
             }
             u32 ndec = 0;
             const int pb = c->ps_toggle;
+            int packed = 0;
             const int r2 = devcoder_pstream(c, reinterpret_cast<const u8*>(c->vA), reinterpret_cast<const u8*>(c->vB), c->SA, m, (u32)n, J.nblocks,
-                                            J.run_first, maxr, &ndec, J.poff, nullptr, pb, J.coder);
+                                            J.run_first, maxr, &ndec, J.poff, nullptr, pb, J.coder, &packed);
+            // byte range of every sub-block's piece in the device buffer = in the landing zone (the same layout on both sides)
+            size_t piece_lo[8], piece_hi[8], zone_entries = (size_t)ndec + 64;
+            J.ps_packed = packed != 0;
+            if (r2 == LIBBSC_NO_ERROR) {
+                u32 pb13 = 0;
+                for (int b = 0; b < J.nblocks; ++b) {
+                    const u32 cnt = J.poff[b + 1] - J.poff[b];
+                    J.pbase[b] = pb13;
+                    if (J.ps_packed) { piece_lo[b] = (size_t)pb13 / 8u * 13u; piece_hi[b] = piece_lo[b] + ((size_t)cnt + 7u) / 8u * 13u; pb13 += (cnt + 63u) / 64u * 64u; }
+                    else             { piece_lo[b] = (size_t)J.poff[b] * 2u; piece_hi[b] = (size_t)J.poff[b + 1] * 2u; }
+                }
+                J.pbase[J.nblocks] = pb13;
+                if (J.ps_packed) zone_entries = ((size_t)pb13 / 8u * 13u + 1u) / 2u + 64;
+            }
             // (a pinned landing zone that cannot be had is a reason to take the host model, like an arena that does not fit)
-            if (r2 == LIBBSC_NO_ERROR && ctx_ensure_pstream_slot(c, *J.slot, (size_t)ndec + 64) == LIBBSC_NO_ERROR) {
+            if (r2 == LIBBSC_NO_ERROR && ctx_ensure_pstream_slot(c, *J.slot, zone_entries) == LIBBSC_NO_ERROR) {
                 // the stream has been synchronised behind the last kernel; the copy goes to the copy stream and is NOT waited for
                 // here: the next block's sort overlaps it, the coder tasks wait on the event
                 // (sub-block by sub-block, an event behind each piece: the task that codes sub-blocks b.. starts when ITS entries have landed —
@@ -460,12 +478,12 @@ static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
                 for (int b = 0; b < 8 && dma; ++b) dma = J.slot->part_sig[b] != 0;
                 J.ps_dma = false;
                 if (dma) {
-                    const uint16_t* dps = devcoder_pstream_ptr(c, pb);
-                    uint16_t* hdev = (uint16_t*)J.slot->hps_dev;
+                    const uint8_t* dps = reinterpret_cast<const uint8_t*>(devcoder_pstream_ptr(c, pb));
+                    uint8_t* hdev = (uint8_t*)J.slot->hps_dev;
                     int issued = 0;
                     for (; issued < J.nblocks; ++issued) {
-                        const size_t lo = J.poff[issued], hi = J.poff[issued + 1];
-                        if (dma_d2h(hdev + lo, dps + lo, (hi - lo) * 2, J.slot->part_sig[issued]) != 0) break;
+                        const size_t lo = piece_lo[issued], hi = piece_hi[issued];
+                        if (dma_d2h(hdev + lo, dps + lo, hi - lo, J.slot->part_sig[issued]) != 0) break;
                         J.ps_sig[issued] = J.slot->part_sig[issued];
                     }
                     if (issued == J.nblocks) {
@@ -477,10 +495,10 @@ static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
                     }
                 }
                 if (!J.ps_dma) {
-                    const uint16_t* dps = devcoder_pstream_ptr(c, pb);
+                    const uint8_t* dps = reinterpret_cast<const uint8_t*>(devcoder_pstream_ptr(c, pb));
                     for (int b = 0; b < J.nblocks; ++b) {
-                        const size_t lo = J.poff[b], hi = J.poff[b + 1];
-                        if ((hi > lo && hipMemcpyAsync(J.slot->hps + lo, dps + lo, (hi - lo) * 2, hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess) ||
+                        const size_t lo = piece_lo[b], hi = piece_hi[b];
+                        if ((hi > lo && hipMemcpyAsync((uint8_t*)J.slot->hps + lo, dps + lo, hi - lo, hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess) ||
                             hipEventRecord(J.slot->part_ev[b], c->copy_stream) != hipSuccess) return LIBBSC_GPU_ERROR;
                         J.ps_part[b] = J.slot->part_ev[b];
                     }
@@ -531,7 +549,9 @@ static void host_encode_sub(BlockJob& J, int b)
     if (J.scratch_cap[b] < need) { J.scratch[b].reset(new uint8_t[need + need / 8]); J.scratch_cap[b] = need + need / 8; }
     if (J.use_ps) {
         if (!J.ps_landed(b)) { J.redo.store(true, std::memory_order_relaxed); J.sub_res[b] = J.size[b]; return; }
-        const int r = (J.coder == LIBBSC_CODER_QLFC_FAST ? qlfc_encode_fast_pstream : qlfc_encode_static_pstream)(
+        const int r = J.ps_packed ? qlfc_encode_static_p13(J.views[b].first_seen, J.views[b].nsym, J.size[b], reinterpret_cast<const uint8_t*>(J.ps_of(b)),
+                                                           (size_t)(J.poff[b + 1] - J.poff[b]), J.scratch[b].get(), J.size[b])
+                    : (J.coder == LIBBSC_CODER_QLFC_FAST ? qlfc_encode_fast_pstream : qlfc_encode_static_pstream)(
                           J.views[b].first_seen, J.views[b].nsym, J.size[b], J.ps + J.poff[b], (size_t)(J.poff[b + 1] - J.poff[b]), J.scratch[b].get(), J.size[b]);
         if (r < 0) J.redo.store(true, std::memory_order_relaxed);      // would be stored raw: that needs the run arrays
         J.sub_res[b] = (r < 0) ? J.size[b] : r;
@@ -550,11 +570,12 @@ static void host_encode_pair(BlockJob& J, int b)
         const int q = b + k;
         const size_t need = (size_t)J.size[q] + 64;
         if (J.scratch_cap[q] < need) { J.scratch[q].reset(new uint8_t[need + need / 8]); J.scratch_cap[q] = need + need / 8; }
-        P[k] = PstreamJob{J.views[q].first_seen, J.views[q].nsym, J.size[q], J.ps + J.poff[q], (size_t)(J.poff[q + 1] - J.poff[q]), J.scratch[q].get(), J.size[q]};
+        P[k] = PstreamJob{J.views[q].first_seen, J.views[q].nsym, J.size[q], J.ps_of(q), (size_t)(J.poff[q + 1] - J.poff[q]), J.scratch[q].get(), J.size[q]};
     }
     if (!J.ps_landed(b + 1)) { J.redo.store(true, std::memory_order_relaxed); J.sub_res[b] = J.size[b]; J.sub_res[b + 1] = J.size[b + 1]; return; }
     int r0, r1;
-    if (J.coder == LIBBSC_CODER_QLFC_FAST) qlfc_encode_fast_pstream_pair(P[0], P[1], &r0, &r1);
+    if (J.ps_packed) qlfc_encode_static_p13_pair(P[0], P[1], &r0, &r1);
+    else if (J.coder == LIBBSC_CODER_QLFC_FAST) qlfc_encode_fast_pstream_pair(P[0], P[1], &r0, &r1);
     else qlfc_encode_static_pstream_pair(P[0], P[1], &r0, &r1);
     if (r0 < 0 || r1 < 0) J.redo.store(true, std::memory_order_relaxed);
     J.sub_res[b] = r0 < 0 ? J.size[b] : r0;
@@ -642,11 +663,11 @@ static void host_encode_group(BlockJob& J, int b)
         const int q = b + k;
         const size_t need = (size_t)J.size[q] + 64;
         if (J.scratch_cap[q] < need) { J.scratch[q].reset(new uint8_t[need + need / 8]); J.scratch_cap[q] = need + need / 8; }
-        P[k] = PstreamJob{J.views[q].first_seen, J.views[q].nsym, J.size[q], J.ps + J.poff[q], (size_t)(J.poff[q + 1] - J.poff[q]), J.scratch[q].get(), J.size[q]};
+        P[k] = PstreamJob{J.views[q].first_seen, J.views[q].nsym, J.size[q], J.ps_of(q), (size_t)(J.poff[q + 1] - J.poff[q]), J.scratch[q].get(), J.size[q]};
     }
     if (!J.ps_landed(b + g - 1)) { J.redo.store(true, std::memory_order_relaxed); for (int k = 0; k < g; ++k) J.sub_res[b + k] = J.size[b + k]; return; }
     int r[8];
-    if (!(J.coder == LIBBSC_CODER_QLFC_FAST ? qlfc_encode_fast_pstream_x8(P, r) : qlfc_encode_static_pstream_x8(P, r))) {
+    if (!(J.ps_packed ? qlfc_encode_static_p13_x8(P, r) : J.coder == LIBBSC_CODER_QLFC_FAST ? qlfc_encode_fast_pstream_x8(P, r) : qlfc_encode_static_pstream_x8(P, r))) {
         for (int k = 0; k < g; k += 2) host_encode_pair(J, b + k);      // a stream near its budget: the exact scalar coders
         return;
     }
@@ -667,7 +688,7 @@ static void host_encode_x16(BlockJob& A, BlockJob& B)
         for (int q = 0; q < 8; ++q) {
             const size_t need = (size_t)J.size[q] + 64;
             if (J.scratch_cap[q] < need) { J.scratch[q].reset(new uint8_t[need + need / 8]); J.scratch_cap[q] = need + need / 8; }
-            P[8 * h + q] = PstreamJob{J.views[q].first_seen, J.views[q].nsym, J.size[q], J.ps + J.poff[q], (size_t)(J.poff[q + 1] - J.poff[q]), J.scratch[q].get(), J.size[q]};
+            P[8 * h + q] = PstreamJob{J.views[q].first_seen, J.views[q].nsym, J.size[q], J.ps_of(q), (size_t)(J.poff[q + 1] - J.poff[q]), J.scratch[q].get(), J.size[q]};
         }
     }
     bool landed = true;
@@ -1028,7 +1049,7 @@ struct CoderPool {
                 ++active;
                 // an eight-lane block: with a partner it is half the CPU time
                 BlockJob* partner = nullptr;
-                if (x16 && t.sub == 0 && t.job->use_ps && t.job->ps_g == 8 && t.job->nblocks == 8) {
+                if (x16 && t.sub == 0 && t.job->use_ps && !t.job->ps_packed && t.job->ps_g == 8 && t.job->nblocks == 8) {     // (the sixteen-lane coder reads 16-bit entries: BSC_PS13=0)
                     if (held.job && held.job->coder == t.job->coder) { partner = held.job; held.job = nullptr; cv_hold.notify_all(); }
                     else if (!held.job && (t.job->tail_r < 0 || t.job->tail_r >= 8 * t.job->tail_gpus)) {
                         // (a block of the job's tail is not held: its eight-lane task has to start now to end in time)

@@ -908,6 +908,75 @@ void qlfc_encode_static_pstream_pair(const PstreamJob& A, const PstreamJob& B, i
     *resB = fb ? NOT_COMPRESSIBLE : rb.finish();
 }
 
+// ---- the packed stream (round 6; devcoder.hip DcP13): 13 bits per decision, eight decisions in 13 bytes -------------------------------
+// field i at bits [13 i, 13 i + 13) of the sub-block's stream, little endian: {probability[11:0], coded bit}.  There is no run-start mark:
+// the reference tests its output budget at run starts only (qlfc.cpp:894), here a stream whose budget is reached at ANY decision gives up
+// (NOT_COMPRESSIBLE), and the caller redoes the block on the host model from the run arrays — which is what it does for every sub-block that
+// does not compress, and which reproduces the reference's decision exactly.  (A 4-byte read at the last field reaches 3 bytes past the
+// stream: the landing zones have that slack.)
+static inline unsigned p13_get(const uint8_t* b, size_t i)
+{
+    const size_t bit = i * 13u;
+    uint32_t w; memcpy(&w, b + (bit >> 3), 4);
+    return (w >> (bit & 7u)) & 0x1fffu;
+}
+void qlfc_pack_p13(const uint16_t* ps, size_t count, uint8_t* out)
+{
+    const size_t bytes = (count + 7) / 8 * 13;
+    memset(out, 0, bytes);
+    for (size_t i = 0; i < count; ++i) {
+        const size_t bit = i * 13u;
+        const uint32_t f = ((uint32_t)ps[i] & 0x1fffu) << (bit & 7u);
+        out[bit >> 3] |= (uint8_t)f; out[(bit >> 3) + 1] |= (uint8_t)(f >> 8); if (f >> 16) out[(bit >> 3) + 2] |= (uint8_t)(f >> 16);
+    }
+}
+int qlfc_encode_static_p13(const uint8_t* first_seen, int nsym, int in_size, const uint8_t* ps, size_t count, uint8_t* out, int out_size)
+{
+    if (in_size <= 0 || nsym <= 0) return BAD_PARAMETER;
+    RunView H; H.nsym = nsym; memcpy(H.first_seen, first_seen, (size_t)nsym);
+    RangeEncoder rc;
+    rc.init(out, out_size);
+    rc.encode_word((uint32_t)in_size);
+    (void)encode_alphabet(H, [&](unsigned b) { rc.encode_half(b); });
+    RangeEncoder::Live L = rc.enter();
+    unsigned is_full = (unsigned)rc.full();
+    for (size_t i = 0; i < count; ++i) {
+        if (__builtin_expect(is_full != 0u, 0)) return NOT_COMPRESSIBLE;
+        const unsigned x = p13_get(ps, i);
+        rc.encode_live_f<12>(L, x >> 12, (int)(x & 0xfffu), is_full);
+    }
+    rc.leave(L);
+    return rc.finish();
+}
+void qlfc_encode_static_p13_pair(const PstreamJob& A, const PstreamJob& B, int* resA, int* resB)
+{
+    RunView HA, HB;
+    HA.nsym = A.nsym; memcpy(HA.first_seen, A.first_seen, (size_t)A.nsym);
+    HB.nsym = B.nsym; memcpy(HB.first_seen, B.first_seen, (size_t)B.nsym);
+    RangeEncoder ra, rb;
+    ra.init(A.out, A.out_size); rb.init(B.out, B.out_size);
+    ra.encode_word((uint32_t)A.in_size); rb.encode_word((uint32_t)B.in_size);
+    (void)encode_alphabet(HA, [&](unsigned b) { ra.encode_half(b); });
+    (void)encode_alphabet(HB, [&](unsigned b) { rb.encode_half(b); });
+    RangeEncoder::Live La = ra.enter(), Lb = rb.enter();
+    const uint8_t* pa = (const uint8_t*)A.ps; const uint8_t* pb = (const uint8_t*)B.ps;
+    const size_t both = A.count < B.count ? A.count : B.count;
+    size_t i = 0;
+    bool fa = false, fb = false;
+    unsigned fulla = (unsigned)ra.full(), fullb = (unsigned)rb.full();
+    for (; i < both; ++i) {
+        if (__builtin_expect((fulla | fullb) != 0u, 0)) { if (fulla) fa = true; else fb = true; break; }
+        const unsigned x = p13_get(pa, i), y = p13_get(pb, i);
+        ra.encode_live_f<12>(La, x >> 12, (int)(x & 0xfffu), fulla);
+        rb.encode_live_f<12>(Lb, y >> 12, (int)(y & 0xfffu), fullb);
+    }
+    if (!fa) for (size_t k = i; k < A.count; ++k) { if (fulla) { fa = true; break; } const unsigned x = p13_get(pa, k); ra.encode_live_f<12>(La, x >> 12, (int)(x & 0xfffu), fulla); }
+    if (!fb) for (size_t k = i; k < B.count; ++k) { if (fullb) { fb = true; break; } const unsigned y = p13_get(pb, k); rb.encode_live_f<12>(Lb, y >> 12, (int)(y & 0xfffu), fullb); }
+    ra.leave(La); rb.leave(Lb);
+    *resA = fa ? NOT_COMPRESSIBLE : ra.finish();
+    *resB = fb ? NOT_COMPRESSIBLE : rb.finish();
+}
+
 // The fast coder (-e0) behind the device model: one counter per decision, so an entry IS the probability; what differs from the
 // static coder's stream is the precision, which follows the side of the run the decision belongs to (bit 15), and the alphabet header,
 // whose bits go out at precision 1 (qlfc.cpp:1174).  The budget test sits on the run-start mark as in encode_model2 (qlfc.cpp:1191).
@@ -1009,6 +1078,31 @@ struct alignas(32) X8State { uint32_t R[8], LO[8], CY[8]; };
     const __m128i t0 = _mm_unpacklo_epi64(c0, c4), t1 = _mm_unpackhi_epi64(c0, c4), t2 = _mm_unpacklo_epi64(c1, c5), t3 = _mm_unpackhi_epi64(c1, c5); \
     const __m128i t4 = _mm_unpacklo_epi64(c2, c6), t5 = _mm_unpackhi_epi64(c2, c6), t6 = _mm_unpacklo_epi64(c3, c7), t7 = _mm_unpackhi_epi64(c3, c7)
 
+// The packed stream (13 bits per decision): 8 decisions of a stream are 13 bytes; a 16-byte load, a byte shuffle that puts the 3-4 bytes of
+// every field into a 32-bit lane and a per-lane shift give r_l = the 8 fields of stream l (with bits of the neighbouring field above bit
+// 12, which the static coder's steps never look at: they mask the probability with 0xfff and test bit 12), then an 8 x 8 transpose of
+// 32-bit words.  3 operations per stream and 24 for the transpose against 1 load, 24 + 8 widenings for the 16-bit entries.
+#define BSC_X8_LOAD13(ps, i, l) _mm256_srlv_epi32(_mm256_shuffle_epi8(_mm256_broadcastsi128_si256(_mm_loadu_si128((const __m128i*)((const uint8_t*)(ps)[l] + ((i) >> 3) * 13))), shuf13), shift13)
+#define BSC_X8_TRANSPOSE13(ps, i)                                                                                                 \
+    const __m256i r0 = BSC_X8_LOAD13(ps, i, 0), r1 = BSC_X8_LOAD13(ps, i, 1), r2 = BSC_X8_LOAD13(ps, i, 2), r3 = BSC_X8_LOAD13(ps, i, 3); \
+    const __m256i r4 = BSC_X8_LOAD13(ps, i, 4), r5 = BSC_X8_LOAD13(ps, i, 5), r6 = BSC_X8_LOAD13(ps, i, 6), r7 = BSC_X8_LOAD13(ps, i, 7); \
+    const __m256i u0 = _mm256_unpacklo_epi32(r0, r1), u1 = _mm256_unpackhi_epi32(r0, r1), u2 = _mm256_unpacklo_epi32(r2, r3), u3 = _mm256_unpackhi_epi32(r2, r3); \
+    const __m256i u4 = _mm256_unpacklo_epi32(r4, r5), u5 = _mm256_unpackhi_epi32(r4, r5), u6 = _mm256_unpacklo_epi32(r6, r7), u7 = _mm256_unpackhi_epi32(r6, r7); \
+    const __m256i v0 = _mm256_unpacklo_epi64(u0, u2), v1 = _mm256_unpackhi_epi64(u0, u2), v2 = _mm256_unpacklo_epi64(u1, u3), v3 = _mm256_unpackhi_epi64(u1, u3); \
+    const __m256i v4 = _mm256_unpacklo_epi64(u4, u6), v5 = _mm256_unpackhi_epi64(u4, u6), v6 = _mm256_unpacklo_epi64(u5, u7), v7 = _mm256_unpackhi_epi64(u5, u7); \
+    const __m256i w0 = _mm256_permute2x128_si256(v0, v4, 0x20), w1 = _mm256_permute2x128_si256(v1, v5, 0x20), w2 = _mm256_permute2x128_si256(v2, v6, 0x20), w3 = _mm256_permute2x128_si256(v3, v7, 0x20); \
+    const __m256i w4 = _mm256_permute2x128_si256(v0, v4, 0x31), w5 = _mm256_permute2x128_si256(v1, v5, 0x31), w6 = _mm256_permute2x128_si256(v2, v6, 0x31), w7 = _mm256_permute2x128_si256(v3, v7, 0x31)
+#define BSC_X8_CONST13                                                                                                            \
+    const __m256i shuf13 = _mm256_setr_epi8(0, 1, 2, 3, 1, 2, 3, 4, 3, 4, 5, 6, 4, 5, 6, 7, 6, 7, 8, 9, 8, 9, 10, 11, 9, 10, 11, 12, 11, 12, 13, 14); \
+    const __m256i shift13 = _mm256_setr_epi32(0, 5, 2, 7, 4, 1, 6, 3)
+#define BSC_X8_PREFETCH13(ps, i, pf) do {                                                                                          \
+        if (pf) {                                                                                                                  \
+            const unsigned l2 = ((unsigned)((i) >> 3) & 3u) * 2u;                                                                  \
+            _mm_prefetch((const char*)(ps)[l2] + (((i) + (pf)) >> 3) * 13, _MM_HINT_T0);                                             \
+            _mm_prefetch((const char*)(ps)[l2 + 1] + (((i) + (pf)) >> 3) * 13, _MM_HINT_T0);                                         \
+        }                                                                                                                          \
+    } while (0)
+
 // A step reads 16 bytes of each stream, i.e. every stream crosses a cache line every fourth step and a 4 KiB page every 256th; the
 // entries were written by the GPU's DMA engine, so every line comes from DRAM.  Two of the eight streams per step get a software
 // prefetch `pf` entries ahead (each stream one per line): it runs across page boundaries, where the hardware stream prefetchers stop.
@@ -1023,9 +1117,11 @@ struct alignas(32) X8State { uint32_t R[8], LO[8], CY[8]; };
 
 // steps [i, end) (end - i a multiple of 8) of all eight streams; appends the renormalisation records, returns the log's new end
 // FAST: entries of the fast coder (13-bit value, bit at 13, precision 13 - 2 * bit 15: a per-lane shift count instead of the constant 12)
-template <bool FAST>
+template <bool FAST, bool P13 = false>
 static uint32_t* x8_steps_avx2(X8State& S, const uint16_t* const* ps, size_t i, size_t end, uint32_t* logp, size_t pf)
 {
+    static_assert(!(FAST && P13), "the packed stream is the static coder's");
+    BSC_X8_CONST13;
     __m256i R = _mm256_load_si256((const __m256i*)S.R), LO = _mm256_load_si256((const __m256i*)S.LO), CY = _mm256_load_si256((const __m256i*)S.CY);
     const __m256i zero = _mm256_setzero_si256(), m12 = _mm256_set1_epi32(FAST ? 0x1fff : 0xfff), one = _mm256_set1_epi32(1);
     const __m256i c13 = _mm256_set1_epi32(13);
@@ -1052,6 +1148,13 @@ static uint32_t* x8_steps_avx2(X8State& S, const uint16_t* const* ps, size_t i, 
         LO = lo2;
         R = _mm256_add_epi32(r, _mm256_and_si256(m, _mm256_sub_epi32(_mm256_sub_epi32(R, r), r)));
     };
+    if (P13) {
+        for (; i < end; i += 8) {
+            BSC_X8_PREFETCH13(ps, i, pf);
+            BSC_X8_TRANSPOSE13(ps, i);
+            step(w0); step(w1); step(w2); step(w3); step(w4); step(w5); step(w6); step(w7);
+        }
+    } else
     for (; i < end; i += 8) {
         BSC_X8_PREFETCH(ps, i, pf);
         BSC_X8_TRANSPOSE(ps, i);
@@ -1066,10 +1169,12 @@ static uint32_t* x8_steps_avx2(X8State& S, const uint16_t* const* ps, size_t i, 
 // two directions of the update are masked shifts / adds / subtracts, and the records are left-packed by vpcompressd: ~24
 // micro-ops per step instead of ~45.
 // VSEL: 0 the round-4 step (BSC_RC_VSEL=0), 2 round 5's
-template <bool FAST, int VSEL>
+template <bool FAST, int VSEL, bool P13 = false>
 __attribute__((target("avx512f,avx512vl")))
 static uint32_t* x8_steps_avx512(X8State& S, const uint16_t* const* ps, size_t i, size_t end, uint32_t* logp, size_t pf)
 {
+    static_assert(!(FAST && P13), "the packed stream is the static coder's");
+    BSC_X8_CONST13;
     __m256i R = _mm256_load_si256((const __m256i*)S.R), LO = _mm256_load_si256((const __m256i*)S.LO), CY = _mm256_load_si256((const __m256i*)S.CY);
     const __m256i m12 = _mm256_set1_epi32(FAST ? 0x1fff : 0xfff), one = _mm256_set1_epi32(1), lim = _mm256_set1_epi32(0x10000), b12 = _mm256_set1_epi32(FAST ? 0x2000 : 0x1000);
     const __m256i c13 = _mm256_set1_epi32(13), c16 = _mm256_set1_epi32(16), zero = _mm256_setzero_si256();
@@ -1135,6 +1240,14 @@ static uint32_t* x8_steps_avx512(X8State& S, const uint16_t* const* ps, size_t i
         CY = _mm256_mask_add_epi32(CY, _mm256_cmplt_epu32_mask(lo2, LO), CY, one);                     /* wrapped: carry out */    \
         LO = lo2;                                                                                                                  \
     } while (0)
+    if (P13) {
+        for (; i < end; i += 8) {
+            BSC_X8_PREFETCH13(ps, i, pf);
+            BSC_X8_TRANSPOSE13(ps, i);
+            if (VSEL == 2) { BSC_X8_STEP512W(w0); BSC_X8_STEP512W(w1); BSC_X8_STEP512W(w2); BSC_X8_STEP512W(w3); BSC_X8_STEP512W(w4); BSC_X8_STEP512W(w5); BSC_X8_STEP512W(w6); BSC_X8_STEP512W(w7); }
+            else           { BSC_X8_STEP512(w0); BSC_X8_STEP512(w1); BSC_X8_STEP512(w2); BSC_X8_STEP512(w3); BSC_X8_STEP512(w4); BSC_X8_STEP512(w5); BSC_X8_STEP512(w6); BSC_X8_STEP512(w7); }
+        }
+    } else
     for (; i < end; i += 8) {
         BSC_X8_PREFETCH(ps, i, pf);
         BSC_X8_TRANSPOSE(ps, i);
@@ -1166,7 +1279,7 @@ static int x8_prefetch_entries()
     static const int env = [] { const char* e = getenv("BSC_RC_PREFETCH"); return e ? atoi(e) : 256; }();      // 512 bytes ahead: -2 % (104 -> 102 -> 96 ms per block with the new step)
     return g_x8_prefetch_override >= 0 ? g_x8_prefetch_override : env;
 }
-template <bool FAST>
+template <bool FAST, bool P13 = false>
 static bool encode_pstream_x8(const PstreamJob* J, int* res)
 {
 #if defined(__AVX2__)
@@ -1201,8 +1314,8 @@ static bool encode_pstream_x8(const PstreamJob* J, int* res)
     while (i + 8 <= common) {
         size_t end = i + CHUNK; if (end > common) end = common;
         end = i + ((end - i) & ~(size_t)7);
-        uint32_t* const logp = !use512 ? x8_steps_avx2<FAST>(S, ps, i, end, log0, pf)
-                             : vsel != 0 ? x8_steps_avx512<FAST, 2>(S, ps, i, end, log0, pf) : x8_steps_avx512<FAST, 0>(S, ps, i, end, log0, pf);
+        uint32_t* const logp = !use512 ? x8_steps_avx2<FAST, P13>(S, ps, i, end, log0, pf)
+                             : vsel != 0 ? x8_steps_avx512<FAST, 2, P13>(S, ps, i, end, log0, pf) : x8_steps_avx512<FAST, 0, P13>(S, ps, i, end, log0, pf);
         i = end;
         for (const uint32_t* q = log0; q < logp; ++q) {              // replay: the only code that touches the outputs
             const uint32_t rec = *q;
@@ -1218,6 +1331,13 @@ static bool encode_pstream_x8(const PstreamJob* J, int* res)
         bool failed = false;
         const uint16_t* q = ps[l];
         unsigned is_full = (unsigned)rc[l].full();
+        if (P13) {
+            for (size_t k = i; k < J[l].count; ++k) {
+                if (__builtin_expect(is_full != 0u, 0)) { failed = true; break; }
+                const unsigned x = p13_get((const uint8_t*)q, k);
+                rc[l].template encode_live_f<12>(L, x >> 12, (int)(x & 0xfffu), is_full);
+            }
+        } else
         for (size_t k = i; k < J[l].count; ++k) {
             const unsigned x = q[k];
             if (FAST) {
@@ -1396,6 +1516,7 @@ bool qlfc_encode_static_pstream_x16(const PstreamJob* J, int* res) { return enco
 bool qlfc_encode_fast_pstream_x16(const PstreamJob* J, int* res) { return encode_pstream_x16<true>(J, res); }
 
 bool qlfc_encode_static_pstream_x8(const PstreamJob* J, int* res) { return encode_pstream_x8<false>(J, res); }
+bool qlfc_encode_static_p13_x8(const PstreamJob* J, int* res) { return encode_pstream_x8<false, true>(J, res); }
 bool qlfc_encode_fast_pstream_x8(const PstreamJob* J, int* res) { return encode_pstream_x8<true>(J, res); }
 
 int qlfc_encode_runs(const RunView& R, int in_size, uint8_t* out, int out_size, int coder)

@@ -69,6 +69,13 @@ void qlfc_encode_static_pstream_pair(const PstreamJob& A, const PstreamJob& B, i
 // Eight sub-blocks, one per AVX2 lane (J[8], res[8]).  false = not done (a stream reached its output budget, or no AVX2):
 // the caller codes the sub-blocks with the functions above.
 bool qlfc_encode_static_pstream_x8(const PstreamJob* J, int* res);
+// The packed stream (devcoder.hip DcP13): 13 bits per decision {probability[11:0], coded bit}, eight decisions in 13 bytes, no run-start
+// mark (a stream that reaches its budget anywhere returns NOT_COMPRESSIBLE / false and the block is redone on the host model).  PstreamJob::ps
+// then points at the packed bytes.  qlfc_pack_p13 makes the packed form of a 16-bit stream (tests, tools): out has (count + 7) / 8 * 13 bytes.
+int  qlfc_encode_static_p13(const uint8_t* first_seen, int nsym, int in_size, const uint8_t* ps, size_t count, uint8_t* out, int out_size);
+void qlfc_encode_static_p13_pair(const PstreamJob& A, const PstreamJob& B, int* resA, int* resB);
+bool qlfc_encode_static_p13_x8(const PstreamJob* J, int* res);
+void qlfc_pack_p13(const uint16_t* ps, size_t count, uint8_t* out);
 // The fast coder's back half (-e0, qlfc.cpp:1135-1336) behind the device model: entries {[12:0] probability, [13] bit, [14] first
 // decision of a run, [15] run side = 11-bit precision, else 13} (devcoder_model.h PSF_*); header and alphabet as encode_model2 writes them.
 int qlfc_encode_fast_pstream(const uint8_t* first_seen, int nsym, int in_size, const uint16_t* ps, size_t count, uint8_t* out, int out_size);

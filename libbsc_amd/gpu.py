@@ -132,6 +132,33 @@ class GpuContext:
         k = nb.value
         return out[:D], list(st[:k]), list(sz[:k]), list(poff[:k + 1]), (dbg[:, :D] if debug else None)
 
+    def qlfc_static_pstream_packed(self, L):
+        """bscgpu_qlfc_static_pstream_packed: (fields u16[D] unpacked from the 13-bit stream, sub_start, sub_size, poff, pbase, packed bytes);
+        raises GpuError -4 when the block takes the host model or the packed form was not produced."""
+        a = np.ascontiguousarray(L, dtype=np.uint8)
+        cap = 26 * a.size + 65536 + 8 * 104
+        out = np.zeros(cap + 8, np.uint8)
+        nb = C.c_int(0); st = (C.c_int * 8)(); sz = (C.c_int * 8)(); poff = (C.c_int64 * 9)(); pbase = (C.c_int64 * 9)()
+        f = self.L.bscgpu_qlfc_static_pstream_packed
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        D = f(self.h, N.np_ptr(a), a.size, out.ctypes.data, cap, C.byref(nb), st, sz, poff, pbase)
+        self._check(D)
+        k = nb.value
+        po, pb = list(poff[:k + 1]), list(pbase[:k + 1])
+        nbytes = pb[k] // 8 * 13
+        if nbytes > cap:
+            raise GpuError(-2, f"{nbytes} bytes exceed the buffer of {cap}")
+        fields = np.empty(D, np.uint16)
+        for b in range(k):                                         # field i of sub-block b: bits [13 i, 13 i + 13) from byte pbase[b] / 8 * 13 on
+            cnt = po[b + 1] - po[b]
+            base = pb[b] // 8 * 13
+            bit = np.arange(cnt, dtype=np.int64) * 13
+            byte = base + (bit >> 3)
+            w = out[byte].astype(np.uint32) | (out[byte + 1].astype(np.uint32) << 8) | (out[byte + 2].astype(np.uint32) << 16)
+            fields[po[b]:po[b + 1]] = ((w >> (bit & 7).astype(np.uint32)) & 0x1fff).astype(np.uint16)
+        return fields, list(st[:k]), list(sz[:k]), po, pb, out[:nbytes]
+
     def compress_device(self, dInput, n, sorter=1, coder=1, features=3):
         out = np.empty(n + 28, np.uint8)
         rc = self._check(self.L.bscgpu_compress_device(self.h, _dptr(dInput), N.np_ptr(out), n, sorter, coder, features))
@@ -141,7 +168,7 @@ class GpuContext:
         return Pipe(self, depth, reuse_outputs)
 
     # ---- measurement / test knobs (include/bscgpu.h: BSCGPU_OPT_*, BSCGPU_CNT_*) ---------------------------------
-    OPT_RS_ONESWEEP, CNT_OS_RETRIES, OPT_DC_STREAM_STATIC = 1, 2, 3
+    OPT_RS_ONESWEEP, CNT_OS_RETRIES, OPT_DC_STREAM_STATIC, OPT_DC_PACKED_STREAM = 1, 2, 3, 4
 
     def option_set(self, key, value):
         return self._check(self.L.bscgpu_option_set(self.h, key, value))

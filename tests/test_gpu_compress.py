@@ -545,6 +545,35 @@ def test_landing_zones_fall_back_to_hiphostmalloc_when_registration_is_refused(t
     _rerun_with_env("eight_sub_block_inputs or pipe_matches_sync_path or sub_block_count_boundaries", BSC_PIN_REGISTER_FAIL="1")
 
 
+def test_packed_stream_falls_back_to_16_bit_entries_for_runs_of_thousands(ref, torch_cuda):
+    """A periodic block of 200 distinct symbols has a BWT of 200 runs of 16 384 bytes: ~44 decisions per run, 64 runs of a wavefront
+    beyond the staging buffer of dc_pstream — the 13-bit packed stream is void for such a block (DM_P13_OVER) and the block's stream is
+    written again as 16-bit entries.  Same bytes as the reference, on the device-model path (process counter) and without a redo."""
+    import ctypes as C
+    from libbsc_amd import GpuContext, _native
+    torch = torch_cuda
+    L = _native.lib()
+    L.bscgpu_process_counter.restype = C.c_longlong
+    L.bscgpu_process_counter.argtypes = [C.c_int]
+    T = np.tile(np.arange(1, 201, dtype=np.uint8), 1 << 14)
+    ctx = GpuContext(0, max_n=T.size + 4096)
+    try:
+        c0 = [L.bscgpu_process_counter(k) for k in (1, 2)]
+        got = ctx.compress_device(torch.from_numpy(T).cuda(), T.size, 1, 1).tobytes()
+        assert got == ref.compress(T, 1, 1)
+        c1 = [L.bscgpu_process_counter(k) for k in (1, 2)]
+        assert c1[0] == c0[0] + 1 and c1[1] == c0[1], (c0, c1)        # on the device model, not redone on the host model
+    finally:
+        ctx.close()
+
+
+def test_p_stream_as_16_bit_entries_when_the_packed_form_is_off(torch_cuda):
+    """BSC_PS13=0 (BSCGPU_OPT_DC_PACKED_STREAM = 0): the stream crosses as 16-bit entries with run-start marks, as before round 6 — same bytes
+    on the synchronous path, the pipelined path and the 64 MiB golden block (the coders for that form stay in use for the fast coder and for
+    blocks whose packed stream is void)."""
+    _rerun_with_env("eight_sub_block_inputs or pipe_matches_sync_path or full_size_64m_block_golden or sub_block_count_boundaries", BSC_PS13="0")
+
+
 def test_p_stream_copies_through_the_hip_runtime_when_the_dma_path_is_off(torch_cuda):
     """The p stream normally leaves the device through the HSA runtime's DMA copy (dma_copy.h: HSA signals, host-side waits, host-side
     guard of the device buffer's reuse); BSC_D2H_DMA=0 keeps hipMemcpyAsync + events.  Both must give the same bytes on the synchronous

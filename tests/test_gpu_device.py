@@ -535,6 +535,54 @@ def test_device_static_model_matches_oracle_trace(ctx):
         small.close()
 
 
+def test_packed_probability_stream_equals_the_16_bit_entries(ctx):
+    """Round 6 (BSCGPU_OPT_DC_PACKED_STREAM): the static coder's stream crosses PCIe as 13 bits per decision, eight decisions in 13 bytes,
+    written by the wavefronts of dc_pstream (whole groups inside a wavefront's piece) and dc_p13_join_kernel (the group between two
+    wavefronts).  Unpacked, it must be the 16-bit stream without its run-start marks — on one to eight sub-blocks, sub-block boundaries
+    inside a wavefront (a block of a handful of runs), padding between sub-blocks zero, and it must be refused (not mis-written) where a
+    wavefront's 64 runs have more decisions than its staging buffer holds."""
+    from libbsc_amd import api
+    from libbsc_amd.gpu import GpuError
+    from oracle.refbind import Ref
+    ref = Ref()
+    rng = np.random.default_rng(41)
+    bwt = lambda x: ref.bwt_encode(x)[0]
+    cases = [("text300k", bwt(api.synth_text_v1(3, 300_000))), ("text1m", bwt(api.synth_text_v1(1, 1 << 20))), ("text5m", bwt(api.synth_text_v1(14, 5 << 20))),
+             ("low1m", bwt(rng.integers(0, 3, 1 << 20, dtype=np.uint8))), ("tiny", np.array([1, 1, 2, 2, 2, 1, 3], np.uint8)),
+             ("ab", (np.arange(600_000) % 2).astype(np.uint8)), ("sym40", bwt((rng.geometric(0.15, 700_000) % 40).astype(np.uint8))),
+             ("rand600k", rng.integers(0, 256, 600_000, dtype=np.uint8)), ("skew3m", bwt((rng.geometric(0.02, 3 << 20) % 256).astype(np.uint8))),
+             ("runs of tens", np.repeat(rng.integers(0, 6, 60_000, dtype=np.uint8), rng.integers(1, 40, 60_000)).astype(np.uint8))]
+    assert ctx.option_get(ctx.OPT_DC_PACKED_STREAM) == 1
+    for name, L in cases:
+        ps, st, sz, poff, _ = ctx.qlfc_static_pstream(L)
+        f, st2, sz2, poff2, pbase, raw = ctx.qlfc_static_pstream_packed(L)
+        assert st == st2 and sz == sz2 and poff == poff2, name
+        assert np.array_equal(f, ps & 0x1fff), (name, int(np.argmax(f != (ps & 0x1fff))))
+        for b in range(len(st)):                                   # layout: 64-decision alignment of every sub-block, zero padding behind its last field
+            assert pbase[b] % 64 == 0 and pbase[b + 1] - pbase[b] == (poff[b + 1] - poff[b] + 63) // 64 * 64, (name, b)
+            cnt = poff[b + 1] - poff[b]
+            end_bit = pbase[b] // 8 * 13 * 8 + cnt * 13
+            tail = raw[(end_bit + 7) // 8: (pbase[b] // 8 + (cnt + 7) // 8) * 13]
+            assert not tail.any(), (name, b)
+            if end_bit % 8:
+                assert raw[end_bit // 8] >> (end_bit % 8) == 0, (name, b)
+    # runs of thousands: a wavefront's 64 runs hold more decisions than its staging buffer -> the packed form is refused for the block,
+    # and bsc_compress (which then moves 16-bit entries) still gives the reference's bytes
+    long_runs = np.repeat(rng.integers(0, 6, 3000, dtype=np.uint8), rng.integers(2000, 9000, 3000)).astype(np.uint8)
+    with pytest.raises(GpuError) as e:
+        ctx.qlfc_static_pstream_packed(long_runs)
+    assert e.value.code == -4
+    ps, *_ = ctx.qlfc_static_pstream(long_runs)
+    assert len(ps) > 0
+    # option off: refused as well, the 16-bit stage unaffected
+    ctx.option_set(ctx.OPT_DC_PACKED_STREAM, 0)
+    try:
+        with pytest.raises(GpuError):
+            ctx.qlfc_static_pstream_packed(cases[0][1])
+    finally:
+        ctx.option_set(ctx.OPT_DC_PACKED_STREAM, 1)
+
+
 def test_stream_order_static_family_equals_partitioned_path(ctx):
     """devcoder_static.h (round 6): for blocks of at most 32 symbols per sub-block the static coder's context-free counter family is
     walked in stream order instead of being partitioned.  Same probability stream as the general path (BSCGPU_OPT_DC_STREAM_STATIC = 0)

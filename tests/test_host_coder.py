@@ -144,6 +144,7 @@ def test_avx2_eight_lane_range_coder_matches_scalar(tmp_path):
             for size in ("1", "9", "400000"):
                 r = subprocess.run([exe, size], capture_output=True, text=True, env={**os.environ, **extra})
                 assert r.returncode == 0 and "all equal" in r.stdout and "fast coder, eight lanes: equal" in r.stdout, (cxx, extra, size, r.stdout + r.stderr)
+                assert "packed stream: equal" in r.stdout, (cxx, extra, size, r.stdout + r.stderr)       # round 6: 13 bits per decision (single, pair, eight lanes)
                 if size == "400000":
                     assert "gave up" in r.stdout            # the budget case bails out to the scalar coders
         # round 6: two blocks in the sixteen lanes of 512-bit registers (opt-in: BSC_RC_X16=1), static and fast entries, roomy and budget cases

@@ -136,6 +136,43 @@ int main(int argc, char** argv)
             printf("  eight single-stream tasks, one after the other: %7.1f ms per block  (%.3f ns per decision; a task %.1f ms)\n", best, best * 1e6 / D, best / 8);
         }
     }
+#ifndef RC_HOST_BENCH_OLD_CODER
+    // round 6: the same block's stream in its packed form (13 bits per decision, eight decisions in 13 bytes), in a pinned landing zone written
+    // by DMA before every run: the three task shapes again
+    {
+        const int64_t cap13 = (int64_t)D * 13 / 8 + 8 * 104 + 64;
+        uint8_t* pin13 = nullptr; uint8_t* d13 = nullptr;
+        int nb2 = 0, st2[8], sz2[8]; int64_t poff2[9], pbase[9];
+        if (hipHostMalloc((void**)&pin13, (size_t)cap13 + 64, hipHostMallocDefault) != hipSuccess) { fprintf(stderr, "no pinned memory\n"); return 1; }
+        const int64_t D2 = bscgpu_qlfc_static_pstream_packed(c, L.data(), n, pin13, cap13, &nb2, st2, sz2, poff2, pbase);
+        if (D2 != D || nb2 != 8) { fprintf(stderr, "packed pstream failed: %lld (%s)\n", (long long)D2, bscgpu_last_error(c)); return 1; }
+        const size_t bytes13 = (size_t)pbase[8] / 8 * 13;
+        if (hipMalloc((void**)&d13, bytes13) != hipSuccess || hipMemcpy(d13, pin13, bytes13, hipMemcpyHostToDevice) != hipSuccess) return 1;
+        printf("== packed stream (13 bits per decision): %zu bytes against %lld as 16-bit entries; pinned landing zone, written by DMA before every run\n", bytes13, (long long)D * 2);
+        auto jobs13 = [&](PstreamJob* J, std::vector<uint8_t>* o) {
+            for (int b = 0; b < 8; ++b) J[b] = PstreamJob{first_seen, 96, sub_size[b], reinterpret_cast<const uint16_t*>(pin13 + (size_t)pbase[b] / 8 * 13), (size_t)(poff[b + 1] - poff[b]), o[b].data(), sub_size[b]};
+        };
+        auto cold13 = [&] { if (hipMemcpy(pin13, d13, bytes13, hipMemcpyDeviceToHost) != hipSuccess) exit(1); };
+        for (int shape = 8; shape >= 1; shape = shape == 8 ? 2 : shape == 2 ? 1 : 0) {
+            double best = 1e30;
+            for (int rep = 0; rep < 3; ++rep) {
+                PstreamJob J[8]; jobs13(J, out); int r[8];
+                cold13();
+                g_x8_prefetch_override = 256; g_x8_vsel_override = -1;
+                const double t0 = now_ms();
+                if (shape == 8) { if (!qlfc_encode_static_p13_x8(J, r)) { printf("packed x8 gave up\n"); ++bad; break; } }
+                else if (shape == 2) for (int b = 0; b < 8; b += 2) qlfc_encode_static_p13_pair(J[b], J[b + 1], &r[b], &r[b + 1]);
+                else for (int b = 0; b < 8; ++b) r[b] = qlfc_encode_static_p13(J[b].first_seen, J[b].nsym, J[b].in_size, reinterpret_cast<const uint8_t*>(J[b].ps), J[b].count, J[b].out, J[b].out_size);
+                const double ms = now_ms() - t0;
+                if (rep == 0) check(shape == 8 ? "packed x8" : shape == 2 ? "packed pairs" : "packed singles", r);
+                if (ms < best) best = ms;
+            }
+            printf("  packed, %s: %7.1f ms per block  (%.3f ns per decision)\n", shape == 8 ? "eight-lane task                " : shape == 2 ? "four two-stream tasks          " : "eight single-stream tasks      ", best, best * 1e6 / D);
+        }
+        g_x8_prefetch_override = -1;
+        hipFree(d13); hipHostFree(pin13);
+    }
+#endif
     // six eight-lane tasks at once, every one on its own landing zone (the steady state of a six-context job: the tasks share the
     // memory system, not the entries)
     if (!quick) {

@@ -89,6 +89,54 @@ int main(int argc, char** argv)
             if (ra[l] != rb[l] || memcmp(oa[l].data(), ob[l].data(), (size_t)(ra[l] > 0 ? ra[l] : 0)) != 0) { printf("FAIL fast lane %d: scalar %d bytes, x8 %d bytes\n", l, ra[l], rb[l]); ++bad; }
         printf("fast coder, eight lanes: %s\n", bad ? "differs" : "equal");
     }
+    // the packed stream (13 bits per decision, eight decisions in 13 bytes; round 6): single, pair and eight-lane coders on the packed
+    // form of the static streams above against the scalar coder on the 16-bit entries — same bytes; and the give-up rule (no run-start
+    // mark: a stream whose budget is reached anywhere reports NOT_COMPRESSIBLE / the eight-lane coder gives up)
+    {
+        int pbad = 0;
+        std::vector<uint8_t> pk[8];
+        for (int l = 0; l < 8; ++l) { pk[l].assign((ps[l].size() + 7) / 8 * 13 + 64, 0xa5); qlfc_pack_p13(ps[l].data(), ps[l].size(), pk[l].data()); }
+        std::vector<uint8_t> oa[8], ob[8], oc[8];
+        PstreamJob J[8]; int ra[8], rb[8], rc1[8];
+        for (int l = 0; l < 8; ++l) {
+            const int osz = (int)ps[l].size() * 2 + 1024;
+            oa[l].assign(osz + 64, 0); ob[l].assign(osz + 64, 0); oc[l].assign(osz + 64, 0);
+            J[l] = PstreamJob{first_seen[l], nsym[l], (int)ps[l].size(), reinterpret_cast<const uint16_t*>(pk[l].data()), ps[l].size(), ob[l].data(), osz};
+            ra[l] = qlfc_encode_static_pstream(first_seen[l], nsym[l], (int)ps[l].size(), ps[l].data(), ps[l].size(), oa[l].data(), osz);
+            rc1[l] = qlfc_encode_static_p13(first_seen[l], nsym[l], (int)ps[l].size(), pk[l].data(), ps[l].size(), oc[l].data(), osz);
+            if (ra[l] != rc1[l] || memcmp(oa[l].data(), oc[l].data(), (size_t)(ra[l] > 0 ? ra[l] : 0)) != 0) { printf("FAIL packed single, stream %d: %d against %d bytes\n", l, rc1[l], ra[l]); ++pbad; }
+        }
+        auto t0 = std::chrono::steady_clock::now();
+        const bool ok = qlfc_encode_static_p13_x8(J, rb);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        size_t total = 0; for (int l = 0; l < 8; ++l) total += ps[l].size();
+        printf("packed stream, eight lanes: %s, %.1f ms, %.3f ns/decision\n", ok ? "done" : "gave up", ms, ms * 1e6 / total);
+        if (!ok) { printf("FAIL: packed x8 gave up with roomy outputs\n"); ++pbad; }
+        else for (int l = 0; l < 8; ++l)
+            if (ra[l] != rb[l] || memcmp(oa[l].data(), ob[l].data(), (size_t)(ra[l] > 0 ? ra[l] : 0)) != 0) { printf("FAIL packed x8 lane %d: scalar %d bytes, x8 %d bytes\n", l, ra[l], rb[l]); ++pbad; }
+        for (int a = 0; a < 8; a += 2) {
+            std::vector<uint8_t> o0(oa[a].size(), 0), o1(oa[a + 1].size(), 0);
+            PstreamJob A = J[a], B = J[a + 1]; A.out = o0.data(); B.out = o1.data();
+            int r0, r1;
+            qlfc_encode_static_p13_pair(A, B, &r0, &r1);
+            if (r0 != ra[a] || r1 != ra[a + 1] || memcmp(o0.data(), oa[a].data(), (size_t)(r0 > 0 ? r0 : 0)) != 0 || memcmp(o1.data(), oa[a + 1].data(), (size_t)(r1 > 0 ? r1 : 0)) != 0) { printf("FAIL packed pair %d\n", a); ++pbad; }
+        }
+        // budget: stream 5 into 4096 bytes
+        {
+            std::vector<uint8_t> small(4096 + 64, 0);
+            const int r = qlfc_encode_static_p13(first_seen[5], nsym[5], (int)ps[5].size(), pk[5].data(), ps[5].size(), small.data(), 4096);
+            const int rs = qlfc_encode_static_pstream(first_seen[5], nsym[5], (int)ps[5].size(), ps[5].data(), ps[5].size(), oa[5].data(), 4096);
+            if (ps[5].size() > 40000 && r >= 0) { printf("FAIL: packed single coded %zu decisions into 4096 bytes (%d)\n", ps[5].size(), r); ++pbad; }
+            if (rs >= 0 && r != rs) { printf("FAIL: packed single %d where the scalar coder fits (%d)\n", r, rs); ++pbad; }
+            PstreamJob K[8]; for (int l = 0; l < 8; ++l) K[l] = J[l];
+            K[5].out = small.data(); K[5].out_size = 4096;
+            int rr[8];
+            const bool ok2 = qlfc_encode_static_p13_x8(K, rr);
+            if (ps[5].size() > 40000 && ok2 && rr[5] >= 0) { printf("FAIL: packed x8 did not give up on the small lane\n"); ++pbad; }
+        }
+        printf("packed stream: %s\n", pbad ? "differs" : "equal");
+        bad += pbad;
+    }
     // sixteen lanes (two blocks per task, 512-bit registers): static and fast entries against the scalar coders
     if (qlfc_x16_available()) {
         for (int fast = 0; fast < 2; ++fast) {
