@@ -1349,10 +1349,13 @@ static bool encode_pstream_x8(const PstreamJob* J, int* res)
         return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl");
     }();
 
-    // (BSC_RC_VBMI=0: the AVX2 unpacking of the packed stream inside the AVX-512 step — A/B and tests)
+    // The VBMI form of the packed stream's unpacking: on by default on AMD hosts that have it (EPYC 9575F: the eight-lane task 101.6 -> 96.0 ms
+    // per block, against 94.3 on 16-bit entries); off by default elsewhere — on the Xeon of the build container the 512-bit permutes
+    // among 256-bit steps cost 40 % (1.03 -> 1.46 ns per decision).  BSC_RC_VBMI=1 / 0 overrides.
     static const bool use_vbmi = [] {
-        if (const char* e = getenv("BSC_RC_VBMI")) if (atoi(e) == 0) return false;
-        return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vbmi");
+        const bool have = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vbmi");
+        if (const char* e = getenv("BSC_RC_VBMI")) return atoi(e) != 0 && have;
+        return have && __builtin_cpu_is("amd");
     }();
     const size_t pf = (size_t)x8_prefetch_entries();
     const int vsel = x8_vector_select();
