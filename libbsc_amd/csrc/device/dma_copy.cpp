@@ -6,12 +6,15 @@
 #include <hsa/hsa_ext_amd.h>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 
 namespace {
 struct Hsa {
     bool ok = false;
-    int engine = 0;                 // BSC_D2H_ENGINE: 0 = the runtime's device-to-host engine (hsa_amd_memory_async_copy); else an engine mask for ..._on_engine
+    int engines[4] = {0, 0, 0, 0}; int nengines = 0;   // BSC_D2H_ENGINE: empty = the runtime's device-to-host engine (hsa_amd_memory_async_copy); else up to
+                                                       // four engine masks for ..._on_engine, taken in turn by successive copies ("2,4": two engines side by side)
+    std::atomic<unsigned> turn{0};
     hsa_agent_t cpu{};
     decltype(&hsa_init) init = nullptr;
     decltype(&hsa_iterate_agents) iterate_agents = nullptr;
@@ -38,7 +41,9 @@ hsa_status_t find_cpu(hsa_agent_t a, void* out)
 void resolve()
 {
     if (const char* e = getenv("BSC_D2H_DMA")) if (atoi(e) == 0) return;
-    if (const char* e = getenv("BSC_D2H_ENGINE")) g.engine = (int)strtol(e, nullptr, 0);
+    if (const char* e = getenv("BSC_D2H_ENGINE")) {
+        while (*e && g.nengines < 4) { char* end = nullptr; const long v = strtol(e, &end, 0); if (end == e) break; if (v > 0) g.engines[g.nengines++] = (int)v; e = (*end == ',') ? end + 1 : end; }
+    }
     void* h = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_NOLOAD);
     if (!h) return;                                                     // no HSA runtime in the process: not a ROCm HIP runtime we know
 #define SYM(field, name) g.field = (decltype(g.field))dlsym(h, name); if (!g.field) return
@@ -48,7 +53,7 @@ void resolve()
     SYM(pointer_info, "hsa_amd_pointer_info"); SYM(memory_async_copy, "hsa_amd_memory_async_copy");
 #undef SYM
     g.memory_async_copy_on_engine = (decltype(g.memory_async_copy_on_engine))dlsym(h, "hsa_amd_memory_async_copy_on_engine");
-    if (g.engine != 0 && !g.memory_async_copy_on_engine) g.engine = 0;
+    if (g.nengines != 0 && !g.memory_async_copy_on_engine) g.nengines = 0;
     if (g.init() != HSA_STATUS_SUCCESS) return;                         // reference counted: the HIP runtime's own initialisation stands
     hsa_agent_t cpu{}; cpu.handle = 0;
     const hsa_status_t st = g.iterate_agents(find_cpu, &cpu);
@@ -83,8 +88,10 @@ int dma_d2h(void* dst_dev, const void* src, size_t bytes, uint64_t sig)
     const hsa_agent_t gpu = info.agentOwner;
     g.signal_store_relaxed(s, 1);
     hsa_status_t st;
-    if (g.engine != 0) st = g.memory_async_copy_on_engine(dst_dev, g.cpu, src, gpu, bytes, 0, nullptr, s, (hsa_amd_sdma_engine_id_t)g.engine, true);
-    else               st = g.memory_async_copy(dst_dev, g.cpu, src, gpu, bytes, 0, nullptr, s);
+    if (g.nengines != 0) {
+        const int engine = g.engines[g.turn.fetch_add(1, std::memory_order_relaxed) % (unsigned)g.nengines];
+        st = g.memory_async_copy_on_engine(dst_dev, g.cpu, src, gpu, bytes, 0, nullptr, s, (hsa_amd_sdma_engine_id_t)engine, true);
+    } else st = g.memory_async_copy(dst_dev, g.cpu, src, gpu, bytes, 0, nullptr, s);
     if (st != HSA_STATUS_SUCCESS) { g.signal_store_screlease(s, 0); return -1; }
     return 0;
 }

@@ -8,6 +8,7 @@
 // it directly: hsa_amd_memory_async_copy from the device buffer to the (registered) landing zone's device address, one HSA signal per
 // piece, the coder tasks wait on the signals.  Everything else (small copies, H2D of host-resident input) stays with the HIP runtime.
 // Internal.  The path is optional at run time (BSC_D2H_DMA=0, or HSA not usable): then the copies are hipMemcpyAsync as before.
+// BSC_D2H_ENGINE=<mask>[,<mask>..]: explicit engine(s) for hsa_amd_memory_async_copy_on_engine, taken in turn (experiments).
 #pragma once
 #include <cstddef>
 #include <cstdint>
