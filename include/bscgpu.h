@@ -136,6 +136,12 @@ BSCGPU_API uint64_t bscgpu_coder_pool_x16_blocks(int reset);
  * so the two orders differ by up to 100 ms), everything earlier as one eight-lane task.  For callers that know the total, instead of
  * marking blocks BSCGPU_FEATURE_LOW_LATENCY at submission; blocks < 0 withdraws the announcement.  Output is identical either way. */
 BSCGPU_API int  bscgpu_coder_pool_expect(long long blocks, int gpus);
+/* The pool's own record of its tasks (recorded when BSCGPU_POOL_TRACE=1 is in the environment): up to cap rows of six doubles — start, end
+ * (seconds on the clock bscgpu_steady_now reads), the block's id inside its pipe, first sub-block, sub-blocks per task (1, 2, 8; 16 for a
+ * sixteen-lane task), the block's features.  Returns the number of rows; reset != 0 clears the record.  (bench.py prints it with
+ * BSC_BENCH_TRACE=1: where a short job's last 100 ms go.) */
+BSCGPU_API int    bscgpu_coder_pool_trace(double* out, int cap, int reset);
+BSCGPU_API double bscgpu_steady_now(void);
 /* 1 when a block's probability stream leaves the device through the HSA runtime's DMA copy (csrc/device/dma_copy.h) in this process,
  * 0 when it goes through hipMemcpyAsync (BSC_D2H_DMA=0, or no usable HSA runtime in the process).  Which engine that is depends on the
  * HIP runtime: a DMA engine on ROCm 7.2's, a 256-workgroup copy kernel on the one torch 2.10 carries (profiles/r06/d2h_copy_path.txt). */
