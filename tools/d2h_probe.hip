@@ -12,6 +12,9 @@
 // hipcc -O3 --offload-arch=gfx950 tools/d2h_probe.hip -o tools/bin/d2h_probe
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <sched.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -38,6 +41,14 @@ __global__ __launch_bounds__(1024) void k_copy(const u64* __restrict__ kin, cons
     for (u64 i = (u64)blockIdx.x * 1024 + threadIdx.x; i < n; i += (u64)gridDim.x * 1024) { kout[i] = __builtin_nontemporal_load(&kin[i]); vout[i] = __builtin_nontemporal_load(&vin[i]); }
 }
 
+// NUMA node a page lives on (move_pages in query mode), -1 if unknown
+static int node_of(void* p)
+{
+    void* page = (void*)((uintptr_t)p & ~(uintptr_t)4095); int status = -1;
+    if (syscall(SYS_move_pages, 0, 1ul, &page, nullptr, &status, 0) != 0) return -1;
+    return status;
+}
+
 int main(int argc, char** argv)
 {
     const size_t piece = (size_t)45 << 20, total = piece * 8;
@@ -57,6 +68,7 @@ int main(int argc, char** argv)
         for (int k = 0; k < 8; ++k) CHECK(hipMemcpyAsync((char*)host + k * piece + off, dev + k * piece + off, piece - off - cut, hipMemcpyDeviceToHost, s));
     };
     if (part == 0 || part == 1) {
+        printf("this thread runs on CPU %d; host buffers live on NUMA node %d (hipHostMalloc) and %d (registered mmap; its last page: %d)\n", sched_getcpu(), node_of(hm), node_of(hr), node_of((char*)hr + total - 4096));
         for (int rep = 0; rep < 3; ++rep) {
             double t0 = now(); if (which != 2) copy8(hm); CHECK(hipStreamSynchronize(s)); double t1 = now();
             if (which != 1) copy8(hr); CHECK(hipStreamSynchronize(s)); double t2 = now();
