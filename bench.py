@@ -42,9 +42,11 @@ def main():
     ap.add_argument("--sorter", type=int, default=1)
     ap.add_argument("--coder", type=int, default=1)
     ap.add_argument("--depth", type=int, default=0, help="blocks in flight per GPU (0 = from the coder pool size); their sub-blocks feed the pool of coder threads")
-    ap.add_argument("--contexts", type=int, default=6, help="GPU contexts (own stream, arena and pipe each) driven concurrently on every GPU: "
+    ap.add_argument("--contexts", type=int, default=5, help="GPU contexts (own stream, arena and pipe each) driven concurrently on every GPU: "
                     "kernels of different blocks interleave on the device, which fills what one block's latency-bound kernels leave idle "
-                    "(one box, 320 / 20 steps: 3 x 4 4834, 4 x 4 4882 / 3655, 6 x 3 5054 / 3903, 5 x 3 - / 3640, 8 x 2 - / 3513 MB/s)")
+                    "(round 4, one box, 320 / 20 steps: 3 x 4 4834, 4 x 4 4882 / 3655, 6 x 3 5054 / 3903, 5 x 3 - / 3640, 8 x 2 - / 3513 MB/s; "
+                    "round 6, with the p-stream copies off the CUs, 160 / 20 steps, means of 3 / 5 interleaved runs: 4 x 4 5963, 5 x 4 5975 / 4466, "
+                    "6 x 4 5980 / 4377, another box 5 x 4 6076, 6 x 4 5885, 7 x 4 5843, 8 x 4 5929: profiles/r06/contexts.txt)")
     ap.add_argument("--lzp", default="", help="H,M: LZP preprocessing as the reference CLI's default has it (-H15 -M128: --lzp 15,128).  The block then enters through "
                     "bscgpu_pipe_submit_host from host memory (LZP is host code); a separate, labelled line — BASELINE's configs have LZP off")
     ap.add_argument("--input", default="synth-text-v1", choices=["synth-text-v1", "python-source", "binary"],
