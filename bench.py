@@ -33,6 +33,17 @@ BLOCK = 64 << 20
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
+def _dma_in_use():
+    import ctypes
+    from libbsc_amd import _native
+    try:
+        f = _native.lib().bscgpu_d2h_dma_available
+        f.restype = ctypes.c_int
+        return f() == 1
+    except Exception:
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -443,6 +454,7 @@ def main():
             # host DRAM traffic of one block (8 ranks per node share the host's memory system, not xGMI): the p stream is written once by the
             # DMA engine and read once by the range coder; the compressed block is written once; a host-resident input is read once for the H2D
             "pstream_bits_per_decision": 13 if ps_packed else 16,
+            "pstream_copy": "HSA DMA copy, one signal per sub-block piece (csrc/device/dma_copy.cpp)" if _dma_in_use() else "hipMemcpyAsync (a copy kernel on torch's HIP runtime)",
             "host_dram_bytes_per_block": {"pstream_dma_write": int(bytes_per_decision * decisions_per_block), "pstream_coder_read": int(bytes_per_decision * decisions_per_block),
                                           "compressed_block_write": int(blk.size), "input_read_for_h2d": int(n if (lzp[0] or host_leg[0]) else 0)},
             "sorter_only_MBps": round(n / 1e6 / max(stage[1] / args.steps / 1e3, 1e-9), 1),

@@ -131,8 +131,8 @@ BSCGPU_API void bscgpu_coder_pool_stats(uint64_t out[4], int reset);
  * BSC_RC_X16_WAIT_MS is how long a block waits for a partner: 15) */
 BSCGPU_API uint64_t bscgpu_coder_pool_x16_blocks(int reset);
 /* Where a job ends: `blocks` more blocks will be submitted to the pipes of this process (all pipes together), which drive `gpus` GPUs.
- * The blocks whose GPU stages END last are then coded as short tasks — per GPU the last one as eight single-stream tasks, the five
- * before it as pairs (BSC_TAIL_SINGLES / BSC_TAIL_PAIRS) — whatever their order of submission (several contexts interleave on a GPU,
+ * The blocks whose GPU stages END last are then coded as short tasks — per GPU the last one as eight single-stream tasks, the few
+ * before it as pairs (two fewer than the contexts that interleave on a GPU) (BSC_TAIL_SINGLES / BSC_TAIL_PAIRS) — whatever their order of submission (several contexts interleave on a GPU,
  * so the two orders differ by up to 100 ms), everything earlier as one eight-lane task.  For callers that know the total, instead of
  * marking blocks BSCGPU_FEATURE_LOW_LATENCY at submission; blocks < 0 withdraws the announcement.  Output is identical either way. */
 BSCGPU_API int  bscgpu_coder_pool_expect(long long blocks, int gpus);

@@ -351,6 +351,7 @@ struct BlockJob {
     int  pool_free = -1;           // CPUs of the pool's budget with nothing to do when the block was queued (-1: not a pipe's block)
     int  tail_r = -1;              // blocks of the announced job whose GPU stage was still to END when this one's did (-1: no job announced)
     int  tail_gpus = 1;            // ... and how many GPUs feed the pool in that job
+    int  tail_pipes = 6;           // ... and how many pipes (GPU contexts) per GPU: that many blocks' GPU stages overlap
     int  ps_g = 2;                 // device-model sub-blocks per coder task (ps_group), fixed when the block's host work starts
     bool use_ps = false; const uint16_t* ps = nullptr; u32 poff[9]; u32 ndec = 0; int sorter = 0;
     bool ps_packed = false; u32 pbase[9];          // the stream is the 13-bit packed form (devcoder.hip DcP13): sub-block b's starts at decision pbase[b] of the packed space (a multiple of 64)
@@ -643,7 +644,10 @@ static int ps_group(const BlockJob& J)
     // (35 ms); the few before it: pairs (50 ms); everything earlier ends in time as one eight-lane task (half the CPU time).
     if (J.tail_r >= 0 && ps_simd_env() < 0 && cpu_has_avx512vl()) {
         static const int tail_singles = [] { const char* e = getenv("BSC_TAIL_SINGLES"); return e ? atoi(e) : 1; }();
-        static const int tail_pairs = [] { const char* e = getenv("BSC_TAIL_PAIRS"); return e ? atoi(e) : 5; }();
+        // how many blocks before the last as pairs: two fewer than the contexts that interleave on a GPU (measured: 5 contexts: 3 > 4 > 5 pair-blocks;
+        // 6 contexts: 4 = 5 > 3 — profiles/r06/pool_affinity.txt, short_job_tail.txt); BSC_TAIL_PAIRS sets it by hand
+        static const int tail_pairs_env = [] { const char* e = getenv("BSC_TAIL_PAIRS"); return e ? atoi(e) : -1; }();
+        const int tail_pairs = tail_pairs_env >= 0 ? tail_pairs_env : (J.tail_pipes - 2 < 2 ? 2 : J.tail_pipes - 2 > 6 ? 6 : J.tail_pipes - 2);
         const int gp = J.tail_gpus > 0 ? J.tail_gpus : 1;               // GPUs feeding the pool: that many GPU stages end per block time
         if (J.tail_r < tail_singles * gp) return 1;
         if (J.tail_r < (tail_singles + tail_pairs) * gp) return 2;
@@ -992,6 +996,75 @@ static int default_coder_threads()
     return n;
 }
 
+// Where the pool's threads may run (round 6, profiles/r06/pool_affinity.txt).  The 1-GPU boxes grant 16 CPUs of CPU TIME on a machine of
+// 2 x 64 cores x 2 hardware threads, and leave the process free to run anywhere: coder threads then share cores with their SMT siblings
+// and read a landing zone on the other socket whenever the scheduler says so.  Kept to one hardware thread per core of the GPU's own NUMA
+// node a 20-block job runs 4472 MB/s against 4228 left alone (means of five interleaved runs, spread 4286-4663 against 3980-4553);
+// long jobs are level.  Rule: of the CPUs the process may use, the first hardware thread of every core — on the GPU's node when the
+// process sees ONE GPU (several GPUs: all nodes) — provided that still leaves at least as many CPUs as the pool's budget; else no
+// restriction.  BSCGPU_HOST_AFFINITY=0 turns it off, =<cpu list> (e.g. 0-31,64-95) sets it by hand.
+static bool parse_cpu_list(const char* t, cpu_set_t* out)
+{
+    CPU_ZERO(out);
+    int n = 0;
+    while (*t) {
+        char* end = nullptr;
+        const long a = strtol(t, &end, 10);
+        if (end == t || a < 0 || a >= CPU_SETSIZE) return false;
+        long b = a;
+        if (*end == '-') { t = end + 1; b = strtol(t, &end, 10); if (end == t || b < a || b >= CPU_SETSIZE) return false; }
+        for (long c = a; c <= b; ++c) { CPU_SET((int)c, out); ++n; }
+        t = (*end == ',') ? end + 1 : end;
+        if (*end != ',' && *end != 0 && *end != '\n') return false;
+        if (*end == '\n') break;
+    }
+    return n > 0;
+}
+static bool read_cpu_list_file(const char* path, cpu_set_t* out)
+{
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    char buf[4096]; const bool got = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    return got && parse_cpu_list(buf, out);
+}
+static bool pool_cpu_set(int budget, int device, cpu_set_t* out)
+{
+    const char* e = getenv("BSCGPU_HOST_AFFINITY");
+    if (e && e[0] == '0' && e[1] == 0) return false;
+    if (e && e[0] && !(e[0] == '1' && e[1] == 0)) return parse_cpu_list(e, out);
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+    // the GPU's NUMA node, if the process sees exactly one GPU
+    cpu_set_t node; bool have_node = false;
+    int ndev = 0;
+    if (device >= 0 && hipGetDeviceCount(&ndev) == hipSuccess && ndev == 1) {
+        char bus[64];
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) == hipSuccess) {
+            for (char* q = bus; *q; ++q) if (*q >= 'A' && *q <= 'F') *q = (char)(*q - 'A' + 'a');
+            char path[160]; snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+            int nd = -1;
+            if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &nd) != 1) nd = -1; fclose(f); }
+            if (nd >= 0) { snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", nd); have_node = read_cpu_list_file(path, &node); }
+        }
+    } else (void)hipGetLastError();
+    for (int pass = have_node ? 0 : 1; pass < 2; ++pass) {              // pass 0: the GPU's node only; pass 1: every node
+        CPU_ZERO(out);
+        int n = 0;
+        for (int c = 0; c < CPU_SETSIZE; ++c) {
+            if (!CPU_ISSET(c, &allowed) || (pass == 0 && !CPU_ISSET(c, &node))) continue;
+            char path[128]; snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+            cpu_set_t sib;
+            if (!read_cpu_list_file(path, &sib)) return false;           // no topology: leave the threads alone
+            int first = -1;
+            for (int k = 0; k < CPU_SETSIZE; ++k) if (CPU_ISSET(k, &sib) && CPU_ISSET(k, &allowed)) { first = k; break; }
+            if (first == c) { CPU_SET(c, out); ++n; }
+        }
+        if (n >= budget && n < CPU_COUNT(&allowed)) return true;        // (n == allowed: nothing to restrict)
+    }
+    return false;
+}
+
 // Optional task trace (BSCGPU_POOL_TRACE=1; bench.py BSC_BENCH_TRACE prints it): when each coder task ran — the only way to see where a
 // short job's drain goes, since a pipe's caller learns of a finished block only when it next asks.
 struct PoolTraceRec { double t0, t1; const void* job; int sub, shape, features; };
@@ -1122,7 +1195,7 @@ void bscgpu_coder_pool_stats(uint64_t out[4], int reset)
     for (int i = 0; i < 4; ++i) { out[i] = g_pool_mode[i].load(std::memory_order_relaxed); if (reset) g_pool_mode[i].store(0, std::memory_order_relaxed); }
 }
 
-static CoderPool* pool_acquire()
+static CoderPool* pool_acquire(int device = -1)
 {
     std::lock_guard<std::mutex> g(g_pool_mu);
     if (!g_pool) {
@@ -1143,6 +1216,9 @@ static CoderPool* pool_acquire()
         P->budget = (forced && nworkers < cpus) ? nworkers : cpus;
         if (const char* e = getenv("BSCGPU_HOST_CPUS")) { int v = atoi(e); if (v >= 1 && v <= 256) P->budget = v; }
         for (int i = 0; i < nworkers; ++i) P->workers.emplace_back([P] { P->worker_loop(); });
+        cpu_set_t where;
+        if (pool_cpu_set(P->budget, device, &where))
+            for (auto& t : P->workers) (void)pthread_setaffinity_np(t.native_handle(), sizeof where, &where);
         P->to_come = g_pending_expect; P->to_come_gpus = g_pending_gpus; g_pending_expect = -1;
         P->x16 = qlfc_x16_available() && ps_simd_env() < 0;
         if (const char* e = getenv("BSC_RC_X16_WAIT_MS")) { const int v = atoi(e); if (v >= 0 && v <= 1000) P->x16_wait_ms = v; }
@@ -1200,7 +1276,7 @@ int bscgpu_pipe_create(bscgpu_ctx* c, int depth, bscgpu_pipe** out)
     bscgpu_pipe* p = new bscgpu_pipe;
     p->c = c; p->depth = depth;
     for (int i = 0; i < depth; ++i) p->lanes[i].job.reset(new BlockJob);
-    p->pool = pool_acquire();
+    p->pool = pool_acquire(c->device);
     *out = p;
     return LIBBSC_NO_ERROR;
 }
@@ -1226,6 +1302,7 @@ static int pipe_enqueue(bscgpu_pipe* p, bscgpu_pipe::Lane& L, int ticket)
         L.ticket = ticket; L.joined = false;
         J.tail_r = -1;
         J.tail_gpus = P->to_come_gpus;
+        J.tail_pipes = P->users / (P->to_come_gpus > 0 ? P->to_come_gpus : 1);
         if (P->to_come > 0) J.tail_r = (int)(--P->to_come < 0x7fffffff ? P->to_come : 0x7fffffff);
         else if (P->to_come == 0) P->to_come = -1;               // more blocks than announced: the rule is dropped
         J.done = false;                                          // (with the other fields a peeker reads, under the pool's mutex)
