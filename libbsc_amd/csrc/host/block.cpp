@@ -978,19 +978,26 @@ int bscgpu_compress_device(bscgpu_ctx* c, const void* dInput, uint8_t* output, i
 
 // CPUs this process can actually use: min(affinity mask, cgroup v2 cpu.max quota), clamped to [4, 64].  The coder pool of a
 // pipe defaults to this (a multi-rank driver divides it between its ranks through BSCGPU_HOST_THREADS).
+// CPUs of CPU time the cgroup grants (cgroup v2 cpu.max), 0 if unlimited or unknown
+static int cgroup_quota_cpus()
+{
+    int c = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; long long period = 0;
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long long quota = atoll(q);
+            if (quota > 0) c = (int)(quota / period);
+        }
+        fclose(f);
+    }
+    return c;
+}
 static int default_coder_threads()
 {
     int n = (int)std::thread::hardware_concurrency();
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = c; }
-    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        char q[64]; long long period = 0;
-        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
-            const long long quota = atoll(q);
-            if (quota > 0) { const int c = (int)(quota / period); if (c >= 1 && c < n) n = c; }
-        }
-        fclose(f);
-    }
+    { const int c = cgroup_quota_cpus(); if (c >= 1 && c < n) n = c; }
     if (n < 4) n = 4;
     if (n > 64) n = 64;
     return n;
@@ -1001,8 +1008,10 @@ static int default_coder_threads()
 // and read a landing zone on the other socket whenever the scheduler says so.  Kept to one hardware thread per core of the GPU's own NUMA
 // node a 20-block job runs 4472 MB/s against 4228 left alone (means of five interleaved runs, spread 4286-4663 against 3980-4553);
 // long jobs are level.  Rule: of the CPUs the process may use, the first hardware thread of every core — on the GPU's node when the
-// process sees ONE GPU (several GPUs: all nodes) — provided that still leaves at least as many CPUs as the pool's budget; else no
-// restriction.  BSCGPU_HOST_AFFINITY=0 turns it off, =<cpu list> (e.g. 0-31,64-95) sets it by hand.
+// process sees ONE GPU (several GPUs: all nodes) — provided the machine is NOT meant to be filled: the cgroup grants a quota of CPU time
+// and the whole quota fits on the chosen CPUs (every process of the cgroup can then follow the same rule: eight ranks of a node share
+// one quota).  Without a quota the hardware threads are all the process's to use, and nothing is restricted.
+// BSCGPU_HOST_AFFINITY=0 turns it off, =<cpu list> (e.g. 0-31,64-95) sets it by hand.
 static bool parse_cpu_list(const char* t, cpu_set_t* out)
 {
     CPU_ZERO(out);
@@ -1033,6 +1042,8 @@ static bool pool_cpu_set(int budget, int device, cpu_set_t* out)
     const char* e = getenv("BSCGPU_HOST_AFFINITY");
     if (e && e[0] == '0' && e[1] == 0) return false;
     if (e && e[0] && !(e[0] == '1' && e[1] == 0)) return parse_cpu_list(e, out);
+    const int quota = cgroup_quota_cpus();
+    if (quota <= 0) return false;                                       // no CPU-time limit: every hardware thread is there to be used
     cpu_set_t allowed;
     if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
     // the GPU's NUMA node, if the process sees exactly one GPU
@@ -1060,7 +1071,7 @@ static bool pool_cpu_set(int budget, int device, cpu_set_t* out)
             for (int k = 0; k < CPU_SETSIZE; ++k) if (CPU_ISSET(k, &sib) && CPU_ISSET(k, &allowed)) { first = k; break; }
             if (first == c) { CPU_SET(c, out); ++n; }
         }
-        if (n >= budget && n < CPU_COUNT(&allowed)) return true;        // (n == allowed: nothing to restrict)
+        if (n >= budget && n >= quota && n < CPU_COUNT(&allowed)) return true;        // (n == allowed: nothing to restrict)
     }
     return false;
 }
