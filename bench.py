@@ -436,7 +436,7 @@ def main():
             other_configs = baseline_configs(torch, dev, local, ctxs[0], d_in, n, GpuContext, api)
         except Exception as e:                            # reporting only
             print(f"[bench] configs leg failed: {e!r}", file=sys.stderr)
-    # what leaves this rank's GPU over PCIe in the timed region: 16 bits per binary decision of the device model (run arrays instead
+    # what leaves this rank's GPU over PCIe in the timed region: 13 (until round 6: 16) bits per binary decision of the device model (run arrays instead
     # for blocks on the host model: not counted) + nothing else of size (the input is resident, the sorted block never crosses);
     # the host's DRAM sees those bytes twice (DMA write, coder read) — with 8 ranks per node this, not xGMI, is the shared resource
     # (decisions per block from the p-stream kernel's own launches: the profile of the timed region folds a launch in at the context's next
@@ -566,7 +566,7 @@ def main():
                                     f"NOT BASELINE's workload: {world} x {n >> 20} MiB block(s) of the image's own {args.input} files per step (libbsc_amd.synth.image_corpus), ") +
                                    (f"bsc_compress(lzp off, sorter={args.sorter}, coder={args.coder}); input resident in HBM; " if not lzp[0] else
                                     f"bsc_compress(lzp -H{lzp[0]} -M{lzp[1]}, sorter={args.sorter}, coder={args.coder}); input in HOST memory (LZP is host code: bscgpu_pipe_submit_host), one H2D of the LZP output per block; ") +
-                                   "Adler-32 + sorter + QLFC run/rank front end" + (" + the static coder's whole adaptive model on the GPU, 16 bits per binary decision over PCIe, "
+                                   "Adler-32 + sorter + QLFC run/rank front end" + (" + the static coder's whole adaptive model on the GPU, " + ("13" if ps_packed else "16") + " bits per binary decision over PCIe, "
                                    "range coding on host threads (" + coder_desc + ")" if args.coder == 1 else
                                    " + the fast coder's model on the GPU (one counter per decision: the static coder's char family with shift updates), 16 bits per binary decision "
                                    "over PCIe, range coding on host threads (" + coder_desc + ")" if args.coder == 3 else
