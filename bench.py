@@ -44,6 +44,43 @@ def _dma_in_use():
         return False
 
 
+def _process_affinity():
+    """The WHOLE process (not only the library's coder pool, which does this by itself: block.cpp pool_cpu_set) on one hardware thread per core, of
+    the GPUs' NUMA node if they all sit on one — when a cgroup CPU-time quota says the machine is not meant to be filled (the 1-GPU boxes: 16 CPUs
+    of time on 256 hardware threads).  What numactl / taskset would do for any caller; BSC_BENCH_AFFINITY=0 leaves the process alone.
+    profiles/r06/pool_affinity.txt: 20-step means 4472 against 4228 (call 40), 4291 against 4107 / 4221 (call 44) — at the edge of the spread."""
+    if os.environ.get("BSC_BENCH_AFFINITY", "1") == "0":
+        return
+    import glob
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q == "max":
+            return
+        quota = int(q) // int(period)
+        allowed = os.sched_getaffinity(0)
+        nodes = set()
+        for f in glob.glob("/sys/bus/pci/drivers/amdgpu/*/numa_node"):
+            nodes.add(int(open(f).read()))
+        def cpulist(t):
+            out = set()
+            for part in t.strip().split(","):
+                a, _, b = part.partition("-")
+                out.update(range(int(a), int(b or a) + 1))
+            return out
+        cand = allowed
+        if len(nodes) == 1 and min(nodes) >= 0:
+            cand = allowed & cpulist(open(f"/sys/devices/system/node/node{min(nodes)}/cpulist").read())
+        keep = set()
+        for c in cand:
+            sib = cpulist(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read()) & allowed
+            if c == min(sib):
+                keep.add(c)
+        if quota >= 1 and len(keep) >= quota and len(keep) < len(allowed):
+            os.sched_setaffinity(0, keep)
+    except Exception as e:
+        print(f"[bench] process affinity not set: {e!r}", file=sys.stderr)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +104,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    _process_affinity()            # (BSC_BENCH_AFFINITY=0: off)
     import torch
     import torch.distributed as dist
     from libbsc_amd import GpuContext, api
