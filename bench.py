@@ -81,6 +81,32 @@ def _process_affinity():
         print(f"[bench] process affinity not set: {e!r}", file=sys.stderr)
 
 
+def _narrow_affinity_to_gpu_node(torch, local):
+    """After _process_affinity: the box's sysfs lists every GPU of the machine, on both NUMA nodes, although the process sees one; now that HIP says
+    which one, the main thread (and every thread it starts from here on: the pipes' threads, the library's pool) keeps to that GPU's node."""
+    if os.environ.get("BSC_BENCH_AFFINITY", "1") == "0":
+        return
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] == "max":
+            return
+        quota = int(q[0]) // int(q[1])
+        pr = torch.cuda.get_device_properties(local)
+        bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bus}/numa_node").read())
+        if node < 0:
+            return
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        keep = os.sched_getaffinity(0) & cpus
+        if len(keep) >= max(quota, 1):
+            os.sched_setaffinity(0, keep)
+    except Exception as e:
+        print(f"[bench] affinity not narrowed to the GPU's node: {e!r}", file=sys.stderr)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +183,8 @@ def main():
                                                               # flight per GPU (round 6: with 18 a pipe regularly sat in wait() on its oldest block
                                                               # while the GPU had nothing to do — 3991 -> 4089 MB/s at the driver's 20 steps, 5 runs each)
     torch.cuda.set_device(local)
+    if world == 1:
+        _narrow_affinity_to_gpu_node(torch, local)
     dev = torch.device("cuda", local)
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
     n = args.block
