@@ -67,7 +67,10 @@ __global__ __launch_bounds__(WG) void bwt_bytehist_kernel(const u8* __restrict__
 // that raw bytes spend on 8, which removes most of the first doubling round's work.
 // Suffixes whose window crosses the end ("tails", i + w > n, at most w-1 of them) go FIRST in input order, shortest
 // first: the stable sort then leaves them first inside any group of equal padded keys, already in final order.
-struct PackParams { u32 cb; u32 w; u32 tc; u32 low_shift; u32 pred_shift; };   // pred_shift: 0 = values are plain suffix indexes,
+#ifndef BWT_RADIX_DEFAULT
+#define BWT_RADIX_DEFAULT 0
+#endif
+struct PackParams { u32 cb; u32 w; u32 tc; u32 low_shift; u32 pred_shift; u32 radix; u64 top; };   // radix != 0: the key is the number with digits c_0 .. c_{w-1} in base `radix` (top = radix^(w-1)): one more character than 64 / cb where radix^(w) < 2^64 (28 symbols: 13 instead of 12);   // pred_shift: 0 = values are plain suffix indexes,
                                                                                // else value = index | code(T[i-1]) << pred_shift
 
 __global__ __launch_bounds__(WG) void bwt_pack_kernel(const u8* __restrict__ T, u32 n, PackParams pp,
@@ -96,13 +99,28 @@ __global__ __launch_bounds__(WG) void bwt_pack_kernel(const u8* __restrict__ T, 
             const u32 c = (wds[t >> 2] >> (8 * (t & 3))) & 0xffu;
             cd[t] = (i0 + t < n) ? (u64)lut[c] : 0ull;
         }
+        u64 rkey = 0;
 #pragma unroll
         for (u32 j = 0; j < 4; ++j) {
             const u32 i = i0 + j;
             if (i < n) {
                 u64 key = 0;
+                if (pp.radix) {
+                    // base-K number of the w characters: rolled from the previous suffix's key (drop its first digit, shift, append one)
+                    if (j == 0) {
+#pragma unroll
+                        for (u32 t = 0; t < 16; ++t) if (t < pp.w) key = key * pp.radix + cd[t];
+                    } else {
+                        u64 nxt = 0;                                   // (static register indices: cd[j + w - 1] by a select chain)
+#pragma unroll
+                        for (u32 t = 0; t < 16; ++t) if (t + 1 == pp.w) nxt = cd[j + t];
+                        key = (rkey - cd[j - 1] * pp.top) * pp.radix + nxt;
+                    }
+                    rkey = key;
+                } else {
 #pragma unroll
                 for (u32 t = 0; t < 16; ++t) if (t < pp.w) key |= cd[j + t] << (64 - pp.cb * (t + 1));
+                }
                 const u32 val = pp.pred_shift ? (i | (pcode << pp.pred_shift)) : i;
                 const bool tail = (u64)i + pp.w > (u64)n;
                 if (tail) { keys[n - 1 - i] = key; vals[n - 1 - i] = val; }
@@ -1012,8 +1030,22 @@ static int bwt_device_once(bscgpu_ctx* c, const u8* dT_user, u8* dL_user, int64_
     if (pp.cb < 4) pp.cb = 4;                                   // at most 16 characters per key
     pp.w = 64 / pp.cb;
     { static const int wmax = [] { const char* e = getenv("BSC_BWT_W"); return e ? atoi(e) : 0; }(); if (wmax >= 2 && (u32)wmax < pp.w) pp.w = (u32)wmax; }   // experiment: shorter first-sort keys
+    // Mixed-radix keys (round 6, BSC_BWT_RADIX=1): with K symbols the base-K number of w' characters fits 64 bits for w' = floor(64 / log2 K),
+    // which is one character more than 64 / cb for K = 17..19, 24..30 (text: 28 symbols -> 13 characters instead of 12; same eight digit passes).
+    // Measured and NOT the default (profiles/r06/first_sort_keys.txt): on the bench block 20.9 M instead of 27.8 M suffixes are unsorted after the
+    // first sort and the text round takes 0.78 instead of 1.13 ms — but the bytes of a base-28 number are uniform digits, where the bytes of
+    // the 5-bit packing are skewed ones (long runs per bucket), and the eight digit passes take 3.65 instead of 3.07 ms (0.44 against 0.53 of 8 TB/s).
+    pp.radix = 0; pp.top = 0;
+    {
+        static const int radix_on = [] { const char* e = getenv("BSC_BWT_RADIX"); return e ? atoi(e) : BWT_RADIX_DEFAULT; }();
+        if (radix_on && K >= 3 && getenv("BSC_BWT_W") == nullptr) {            // (BSC_BWT_W, the other key-width experiment, keeps the bit-packed keys)
+            u32 wr = 0; unsigned __int128 pw = 1;
+            while (pw * K <= ((unsigned __int128)1 << 64) - 1 && wr < 16) { pw *= K; ++wr; }      // K^wr <= 2^64 - 1
+            if (wr > pp.w && wr <= 16) { pp.radix = K; pp.w = wr; u64 t = 1; for (u32 x = 1; x < wr; ++x) t *= K; pp.top = t; }
+        }
+    }
     pp.tc = n < pp.w - 1 ? n : pp.w - 1;
-    pp.low_shift = 64 - pp.cb * pp.w;
+    pp.low_shift = pp.radix ? 0u : 64 - pp.cb * pp.w;
     // The sort's values have spare high bits when the block is not huge: carry the code of the character in FRONT of the
     // suffix there, so that the final L = T[SA - 1] needs no random gather from the text (BSC_BWT_PRED=0 keeps the gather)
     const int idx_bits = bit_length(n - 1);
