@@ -574,6 +574,14 @@ def test_p_stream_as_16_bit_entries_when_the_packed_form_is_off(torch_cuda):
     _rerun_with_env("eight_sub_block_inputs or pipe_matches_sync_path or full_size_64m_block_golden or sub_block_count_boundaries", BSC_PS13="0")
 
 
+def test_mixed_radix_first_sort_keys_variant(torch_cuda):
+    """BSC_BWT_RADIX=1 (round 6, off by default: profiles/r06/first_sort_keys.txt): the BWT's first-sort key as the base-K number of one more
+    character than bit packing holds (28 symbols: 13 instead of 12; 17-19 and 24-30 symbols likewise) — other digits, other group structure
+    behind the first sort, same BWT: the 16 MiB text block, the edge corpus against the reference, alphabets of 17 .. 200 symbols and the
+    64 MiB golden block."""
+    _rerun_with_env("bwt_device_resident_16m or full_size_64m_block_golden or bwt_matches_reference or front_end_rank_paths", BSC_BWT_RADIX="1")
+
+
 def test_p_stream_copies_through_the_hip_runtime_when_the_dma_path_is_off(torch_cuda):
     """The p stream normally leaves the device through the HSA runtime's DMA copy (dma_copy.h: HSA signals, host-side waits, host-side
     guard of the device buffer's reuse); BSC_D2H_DMA=0 keeps hipMemcpyAsync + events.  Both must give the same bytes on the synchronous
