@@ -382,6 +382,20 @@ static int  devcoder_min_n() { static const int v = [] { const char* e = getenv(
 
 static std::atomic<uint64_t> g_count_devmodel{0}, g_count_redo{0}, g_count_devmodel_lzp{0};     // bscgpu_process_counter
 
+// Experiment (round 6, profiles/r06/sort_slots.txt): the sort is the HBM-bound half of a block's GPU stage, the device model the
+// latency / VALU-bound half; contexts whose sorts overlap only share HBM, a sort beside another block's model overlaps for real.
+// BSC_SORT_SLOTS=k lets at most k contexts of the process be inside their sort at once (0 = no limit, the default).
+struct SortSlot {
+    static int limit() { static const int v = [] { const char* e = getenv("BSC_SORT_SLOTS"); return e ? atoi(e) : 0; }(); return v; }
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static std::condition_variable& cv() { static std::condition_variable c; return c; }
+    static int& busy() { static int b = 0; return b; }
+    bool held = false;
+    SortSlot() { if (limit() > 0) { std::unique_lock<std::mutex> lk(mu()); cv().wait(lk, [] { return busy() < limit(); }); ++busy(); held = true; } }
+    void release() { if (held) { { std::lock_guard<std::mutex> lk(mu()); --busy(); } cv().notify_one(); held = false; } }
+    ~SortSlot() { release(); }
+};
+
 static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
 {
     CtxTimer tm_stage("gpu_stage of one block");
@@ -403,6 +417,7 @@ static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
 
     t0 = clk::now();
     J.num_indexes = 0;
+    SortSlot sort_slot;                                       // (experiment, BSC_SORT_SLOTS=k: at most k contexts of the process inside their sort at once)
     if (blockSorter == LIBBSC_BLOCKSORTER_BWT) {
         const int r = aux_rate(n);
         uint32_t I[256];
@@ -417,6 +432,7 @@ static int gpu_stage(BlockJob& J, int blockSorter, bool allow_devcoder = true)
         if (rc < 0) return rc;
     }
     if (J.n_orig < 64 * 1024) J.num_indexes = 0;              // libbsc.cpp:290 (the original size decides)
+    sort_slot.release();
     c->stage_ms[1] = ms_since(t0);
 
     // QLFC front half on the GPU (sub-block split, runs, ranks); only the run arrays (+ L for the rare raw
