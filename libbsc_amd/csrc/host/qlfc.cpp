@@ -1268,39 +1268,48 @@ static uint32_t* x8_steps_avx512(X8State& S, const uint16_t* const* ps, size_t i
 // (8 loads), and ONE vpermt2b per pair of steps puts bytes o_k .. o_k + 3 of every stream's chunk into the 32-bit lane of that stream for
 // field k (low half) and field k + 1 (high half); a per-lane shift finishes it: 8 + 4 + 4 + 4 (the high halves) operations per 8 steps
 // against 48 for the AVX2 form above and 40 for the 16-bit entries.
-template <int VSEL>
+// P13 = false: the same for 16-bit entries (static and fast coder): the permute zero-extends every entry into its 32-bit lane, no shift — 8 + 4 + 4
+// operations against 8 loads, a 24-operation transpose and 8 widenings.
+template <bool FAST, int VSEL, bool P13>
 __attribute__((target("avx512f,avx512vl,avx512bw,avx512vbmi")))
-static uint32_t* x8_steps_avx512_vbmi13(X8State& S, const uint16_t* const* ps, size_t i, size_t end, uint32_t* logp, size_t pf)
+static uint32_t* x8_steps_avx512_vbmi(X8State& S, const uint16_t* const* ps, size_t i, size_t end, uint32_t* logp, size_t pf)
 {
-    constexpr bool FAST = false;
+    static_assert(!(FAST && P13), "the packed stream is the static coder's");
     __m256i R = _mm256_load_si256((const __m256i*)S.R), LO = _mm256_load_si256((const __m256i*)S.LO), CY = _mm256_load_si256((const __m256i*)S.CY);
-    const __m256i m12 = _mm256_set1_epi32(0xfff), one = _mm256_set1_epi32(1), lim = _mm256_set1_epi32(0x10000), b12 = _mm256_set1_epi32(0x1000);
+    const __m256i m12 = _mm256_set1_epi32(FAST ? 0x1fff : 0xfff), one = _mm256_set1_epi32(1), lim = _mm256_set1_epi32(0x10000), b12 = _mm256_set1_epi32(FAST ? 0x2000 : 0x1000);
     const __m256i c13 = _mm256_set1_epi32(13), c16 = _mm256_set1_epi32(16), zero = _mm256_setzero_si256();
     const __m256i lane_id = _mm256_setr_epi32(0 << 17, 1 << 17, 2 << 17, 3 << 17, 4 << 17, 5 << 17, 6 << 17, 7 << 17);
     (void)c13; (void)c16;
     // index / shift tables: output register q holds field 2 q of the eight streams in its low half, field 2 q + 1 in its high half
     alignas(64) static const struct Tab { uint8_t idx[4][64]; uint32_t sh[4][16]; } T = [] {
         Tab t;
-        static const int off[8] = {0, 1, 3, 4, 6, 8, 9, 11}, shf[8] = {0, 5, 2, 7, 4, 1, 6, 3};
+        static const int off13[8] = {0, 1, 3, 4, 6, 8, 9, 11}, shf13[8] = {0, 5, 2, 7, 4, 1, 6, 3};
         for (int q = 0; q < 4; ++q)
             for (int d = 0; d < 16; ++d) {
                 const int l = d & 7, k = 2 * q + (d >> 3);
-                for (int b = 0; b < 4; ++b) t.idx[q][4 * d + b] = (uint8_t)(64 * (l >> 2) + 16 * (l & 3) + off[k] + b);
-                t.sh[q][d] = (uint32_t)shf[k];
+                for (int b = 0; b < 4; ++b) t.idx[q][4 * d + b] = (uint8_t)(64 * (l >> 2) + 16 * (l & 3) + (P13 ? off13[k] + b : 2 * k + (b & 1)));   // (16-bit entries: bytes 2, 3 of a lane are masked to zero)
+                t.sh[q][d] = P13 ? (uint32_t)shf13[k] : 0u;
             }
         return t;
     }();
     const __m512i ix0 = _mm512_load_si512(T.idx[0]), ix1 = _mm512_load_si512(T.idx[1]), ix2 = _mm512_load_si512(T.idx[2]), ix3 = _mm512_load_si512(T.idx[3]);
     const __m512i sh0 = _mm512_load_si512(T.sh[0]), sh1 = _mm512_load_si512(T.sh[1]), sh2 = _mm512_load_si512(T.sh[2]), sh3 = _mm512_load_si512(T.sh[3]);
-#define BSC_X8_CHUNK13(l) _mm_loadu_si128((const __m128i*)((const uint8_t*)ps[l] + (i >> 3) * 13))
+#define BSC_X8_CHUNK13(l) (P13 ? _mm_loadu_si128((const __m128i*)((const uint8_t*)ps[l] + (i >> 3) * 13)) : _mm_loadu_si128((const __m128i*)(ps[l] + i)))
+    const __mmask64 low2 = 0x3333333333333333ull;
     for (; i < end; i += 8) {
-        BSC_X8_PREFETCH13(ps, i, pf);
+        if (P13) BSC_X8_PREFETCH13(ps, i, pf); else BSC_X8_PREFETCH(ps, i, pf);
         __m512i z0 = _mm512_castsi128_si512(BSC_X8_CHUNK13(0)), z1 = _mm512_castsi128_si512(BSC_X8_CHUNK13(4));
         z0 = _mm512_inserti32x4(z0, BSC_X8_CHUNK13(1), 1); z1 = _mm512_inserti32x4(z1, BSC_X8_CHUNK13(5), 1);
         z0 = _mm512_inserti32x4(z0, BSC_X8_CHUNK13(2), 2); z1 = _mm512_inserti32x4(z1, BSC_X8_CHUNK13(6), 2);
         z0 = _mm512_inserti32x4(z0, BSC_X8_CHUNK13(3), 3); z1 = _mm512_inserti32x4(z1, BSC_X8_CHUNK13(7), 3);
-        const __m512i q0 = _mm512_srlv_epi32(_mm512_permutex2var_epi8(z0, ix0, z1), sh0), q1 = _mm512_srlv_epi32(_mm512_permutex2var_epi8(z0, ix1, z1), sh1);
-        const __m512i q2 = _mm512_srlv_epi32(_mm512_permutex2var_epi8(z0, ix2, z1), sh2), q3 = _mm512_srlv_epi32(_mm512_permutex2var_epi8(z0, ix3, z1), sh3);
+        __m512i q0, q1, q2, q3;
+        if (P13) {
+            q0 = _mm512_srlv_epi32(_mm512_permutex2var_epi8(z0, ix0, z1), sh0); q1 = _mm512_srlv_epi32(_mm512_permutex2var_epi8(z0, ix1, z1), sh1);
+            q2 = _mm512_srlv_epi32(_mm512_permutex2var_epi8(z0, ix2, z1), sh2); q3 = _mm512_srlv_epi32(_mm512_permutex2var_epi8(z0, ix3, z1), sh3);
+        } else {
+            q0 = _mm512_maskz_permutex2var_epi8(low2, z0, ix0, z1); q1 = _mm512_maskz_permutex2var_epi8(low2, z0, ix1, z1);
+            q2 = _mm512_maskz_permutex2var_epi8(low2, z0, ix2, z1); q3 = _mm512_maskz_permutex2var_epi8(low2, z0, ix3, z1);
+        }
         const __m256i w0 = _mm512_castsi512_si256(q0), w1 = _mm512_extracti64x4_epi64(q0, 1), w2 = _mm512_castsi512_si256(q1), w3 = _mm512_extracti64x4_epi64(q1, 1);
         const __m256i w4 = _mm512_castsi512_si256(q2), w5 = _mm512_extracti64x4_epi64(q2, 1), w6 = _mm512_castsi512_si256(q3), w7 = _mm512_extracti64x4_epi64(q3, 1);
         if (VSEL == 2) { BSC_X8_STEP512W(w0); BSC_X8_STEP512W(w1); BSC_X8_STEP512W(w2); BSC_X8_STEP512W(w3); BSC_X8_STEP512W(w4); BSC_X8_STEP512W(w5); BSC_X8_STEP512W(w6); BSC_X8_STEP512W(w7); }
@@ -1357,6 +1366,12 @@ static bool encode_pstream_x8(const PstreamJob* J, int* res)
         if (const char* e = getenv("BSC_RC_VBMI")) return atoi(e) != 0 && have;
         return have && __builtin_cpu_is("amd");
     }();
+    // (16-bit entries through the same permute: measured SLOWER than the 128-bit transpose on the EPYC 9575F — 96.7 against 95.0 ms per block —
+    // so only on request: BSC_RC_VBMI16=1)
+    static const bool use_vbmi16 = [] {
+        const char* e = getenv("BSC_RC_VBMI16");
+        return e && atoi(e) != 0 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vbmi");
+    }();
     const size_t pf = (size_t)x8_prefetch_entries();
     const int vsel = x8_vector_select();
     constexpr size_t CHUNK = 32768;                                  // steps between two replays of the log (1 MiB of records at most)
@@ -1371,7 +1386,7 @@ static bool encode_pstream_x8(const PstreamJob* J, int* res)
         size_t end = i + CHUNK; if (end > common) end = common;
         end = i + ((end - i) & ~(size_t)7);
         uint32_t* const logp = !use512 ? x8_steps_avx2<FAST, P13>(S, ps, i, end, log0, pf)
-                             : (P13 && use_vbmi) ? (vsel != 0 ? x8_steps_avx512_vbmi13<2>(S, ps, i, end, log0, pf) : x8_steps_avx512_vbmi13<0>(S, ps, i, end, log0, pf))
+                             : (P13 ? use_vbmi : use_vbmi16) ? (vsel != 0 ? x8_steps_avx512_vbmi<FAST, 2, P13>(S, ps, i, end, log0, pf) : x8_steps_avx512_vbmi<FAST, 0, P13>(S, ps, i, end, log0, pf))
                              : vsel != 0 ? x8_steps_avx512<FAST, 2, P13>(S, ps, i, end, log0, pf) : x8_steps_avx512<FAST, 0, P13>(S, ps, i, end, log0, pf);
         i = end;
         for (const uint32_t* q = log0; q < logp; ++q) {              // replay: the only code that touches the outputs

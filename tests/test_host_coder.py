@@ -141,7 +141,8 @@ def test_avx2_eight_lane_range_coder_matches_scalar(tmp_path):
         subprocess.run([cxx, *flags, "-std=c++17", "-march=x86-64-v3", "-I", os.path.join(root, "libbsc_amd/csrc/host"), "-I", os.path.join(root, "include"),
                         os.path.join(root, "tools/rc_x8_check.cpp"), "-o", exe], check=True)
         # (BSC_RC_VBMI: the packed stream's unpack + transpose by one byte permute across two 512-bit registers; on by default on AMD hosts only)
-        for extra in ({}, {"BSC_RC_VSEL": "0"}, {"BSC_RC_AVX512": "0"}, {"BSC_RC_PREFETCH": "0"}, {"BSC_RC_VBMI": "1"}, {"BSC_RC_VBMI": "1", "BSC_RC_VSEL": "0"}, {"BSC_RC_VBMI": "0"}):
+        for extra in ({}, {"BSC_RC_VSEL": "0"}, {"BSC_RC_AVX512": "0"}, {"BSC_RC_PREFETCH": "0"}, {"BSC_RC_VBMI": "1"}, {"BSC_RC_VBMI": "1", "BSC_RC_VSEL": "0"}, {"BSC_RC_VBMI": "0"},
+                      {"BSC_RC_VBMI16": "1"}, {"BSC_RC_VBMI16": "1", "BSC_RC_VSEL": "0"}):
             for size in ("1", "9", "400000"):
                 r = subprocess.run([exe, size], capture_output=True, text=True, env={**os.environ, **extra})
                 assert r.returncode == 0 and "all equal" in r.stdout and "fast coder, eight lanes: equal" in r.stdout, (cxx, extra, size, r.stdout + r.stderr)
